@@ -1,0 +1,169 @@
+/*
+ * eben_hip.h -- C ABI of libeben_hip.so: the MI355X (gfx950) kernels of the EBEN
+ * bandwidth-extension GAN train step (vibravox: EBENGenerator +
+ * DiscriminatorEBENMultiScales forward/backward, PQMF, feature/hinge/MRSTFT losses, Adam).
+ *
+ * The reference has no native code: every "kernel" on its hot path is
+ * an ATen call site inside a Python nn.Module.  Each entry point below therefore cites the
+ * reference *call site* it replaces (file:line relative to the vibravox checkout); the
+ * binding a maintainer adds on the reference side is a ctypes stub.
+ *
+ * Conventions
+ *   - all tensors are contiguous float32 (batch, channel, time) device buffers; pointers are
+ *     raw device pointers (tensor.data_ptr()); `stream` is a hipStream_t passed as void*.
+ *   - every call is asynchronous on `stream`, re-entrant, allocates nothing and never
+ *     synchronises; scratch comes from a caller-provided workspace.
+ *   - return 0 on success, a negative EBEN_E* code on a bad argument, or a positive
+ *     hipError_t from the launch.  eben_last_error() returns a thread-local message.
+ *     Nothing throws across the ABI.
+ */
+#ifndef EBEN_HIP_H
+#define EBEN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#if defined(EBEN_BUILDING)
+#define EBEN_API __attribute__((visibility("default")))
+#else
+#define EBEN_API
+#endif
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EBEN_OK 0
+#define EBEN_EINVAL (-1)      /* inconsistent descriptor / null pointer */
+#define EBEN_EWORKSPACE (-2)  /* workspace too small */
+#define EBEN_EUNSUPPORTED (-3)
+
+#define EBEN_PAD_ZERO 0
+#define EBEN_PAD_REFLECT 1
+
+/* One Conv1d / ConvTranspose1d layer (nn.Conv1d / nn.ConvTranspose1d semantics).
+ * Replaces the F.conv1d / F.conv_transpose1d call sites behind
+ *   vibravox/torch_modules/dnn/eben_generator.py:112-166,241-249,272-280,295-312
+ *   vibravox/torch_modules/dnn/eben_discriminator.py:66-157
+ *   vibravox/torch_modules/dnn/melgan_discriminator.py:89-156
+ * weight layout: Conv1d (Cout, Cin/groups, k); ConvTranspose1d (Cin, Cout/groups, k). */
+typedef struct EbenConv1dDesc {
+  int32_t batch;
+  int32_t c_in, c_out;
+  int32_t l_in, l_out;      /* l_out must equal the nn.Module's output length */
+  int32_t ksize, stride, dilation, groups;
+  int32_t pad_l, pad_r;     /* padding on the input (Conv1d) / `padding` of ConvTranspose1d in pad_l */
+  int32_t pad_mode;         /* EBEN_PAD_ZERO | EBEN_PAD_REFLECT (Conv1d only) */
+  int32_t transposed;       /* 0 Conv1d, 1 ConvTranspose1d */
+  float in_slope;           /* LeakyReLU slope fused on the input load (1.0f = none) */
+  float out_slope;          /* LeakyReLU slope fused on the output (1.0f = none) */
+} EbenConv1dDesc;
+
+EBEN_API const char* eben_last_error(void);
+EBEN_API int eben_version(void);
+/* fills name with the device's gcnArchName; returns compute-unit count (or negative) */
+EBEN_API int eben_device_info(char* name, size_t name_bytes);
+
+/* ---- weight-norm (torch_modules/utils.py:4-9 -> torch._weight_norm, dim=0) -------------- */
+/* scale[r] = g[r]/||v[r,:]||, norm[r] = ||v[r,:]||  for r < rows */
+EBEN_API int eben_wn_scale(const float* g, const float* v, int rows, int cols, float* scale, float* norm, void* stream);
+/* dw given as `nslab` partial slabs of (rows, row_stride) floats (first `cols` of each row are
+ * the weight gradient, column `cols` -- if has_bias -- the bias gradient).
+ *   g != NULL: dg[r] = sum(dw*v)/norm, dv = (g/norm) dw - (g dg/norm^2) v     (weight-norm)
+ *   g == NULL: dv = sum of slabs                                                (plain weight)
+ * dbias (nullable) = summed bias column. */
+EBEN_API int eben_wn_bwd(const float* dw_slabs, int nslab, size_t slab_stride, int rows, int cols, int row_stride,
+                const float* g, const float* v, const float* norm, float* dg, float* dv, float* dbias, void* stream);
+
+/* ---- conv layers ------------------------------------------------------------------------ */
+/* floats needed for the packed weights of the forward (which=0) / input-gradient (which=1) pass */
+EBEN_API size_t eben_conv1d_packed_floats(const EbenConv1dDesc* d, int which);
+/* pack v (optionally scaled per dim-0 row: weight-norm) into the MFMA-friendly layouts */
+EBEN_API int eben_conv1d_pack(const EbenConv1dDesc* d, const float* v, const float* scale, float* wp_fwd, float* wp_bwd, void* stream);
+/* y = lrelu_out( conv(lrelu_in(x)) + bias ) [+ residual] */
+EBEN_API int eben_conv1d_fwd(const EbenConv1dDesc* d, const float* x, const float* wp_fwd, const float* bias,
+                    const float* residual, float* y, void* stream);
+/* workspace bytes for bwd_dx (reflect padding only) and bwd_dw (partial slabs) */
+EBEN_API size_t eben_conv1d_bwd_dx_workspace(const EbenConv1dDesc* d);
+EBEN_API size_t eben_conv1d_bwd_dw_workspace(const EbenConv1dDesc* d, int* nslab, int* row_stride);
+/* dx = conv^T( dy * lrelu_out'(y) ) * lrelu_in'(x).  y may be NULL when out_slope==1, x when in_slope==1.
+ * accumulate!=0 adds into dx instead of overwriting. */
+EBEN_API int eben_conv1d_bwd_dx(const EbenConv1dDesc* d, const float* dy, const float* y, const float* wp_bwd,
+                       const float* x, float* dx, int accumulate, void* workspace, size_t ws_bytes, void* stream);
+/* partial weight (+bias) gradients into `slabs` (layout reported by bwd_dw_workspace);
+ * finish with eben_wn_bwd. */
+EBEN_API int eben_conv1d_bwd_dw(const EbenConv1dDesc* d, const float* dy, const float* y, const float* x, int has_bias,
+                       float* slabs, size_t ws_bytes, void* stream);
+
+/* ---- PQMF (vibravox/torch_modules/dsp/pqmf.py:194-213, eben_generator.py:209-211) ---------- */
+/* decimating FIR bank: y[b,k,t] = sum_j w[k*ntaps+j] * x[b,0,t*stride+off0+j], zero outside [0,lx) */
+EBEN_API int eben_fir_decimate(const float* x, const float* w, float* y, int batch, int lx, int ly, int bands, int ntaps,
+                      int stride, int off0, void* stream);
+/* interpolating FIR bank summed over bands (adjoint of the above):
+ *   x[b,0,u] (+)= sum_k sum_{t,j : t*stride+off0+j == u} w[k*ntaps+j] * y[b,k,t] */
+EBEN_API int eben_fir_interp_sum(const float* y, const float* w, float* x, int batch, int lx, int ly, int bands, int ntaps,
+                        int stride, int off0, void* stream);
+
+/* ---- elementwise ------------------------------------------------------------------------ */
+EBEN_API int eben_lrelu_fwd(const float* x, float* y, size_t n, float slope, void* stream);
+EBEN_API int eben_lrelu_bwd(const float* dy, const float* x_or_y, float* dx, size_t n, float slope, void* stream);
+EBEN_API int eben_add(const float* a, const float* b, float* out, size_t n, void* stream);
+EBEN_API int eben_axpby(const float* a, float alpha, const float* b, float beta, float* out, size_t n, void* stream);
+/* bands = tanh(x + lift) where lift has `c_lift` leading channels (eben_generator.py:203-208) */
+EBEN_API int eben_tanh_lift_fwd(const float* x, const float* lift, float* out, int batch, int channels, int c_lift, int length, void* stream);
+EBEN_API int eben_tanh_bwd(const float* dout, const float* out, float* dx, size_t n, void* stream);
+/* nn.ReflectionPad1d (eben_discriminator.py:69, melgan_discriminator.py:92) and its adjoint */
+EBEN_API int eben_reflect_pad_fwd(const float* x, float* y, int rows, int lx, int pad_l, int pad_r, void* stream);
+EBEN_API int eben_reflect_pad_bwd(const float* dy, float* dx, int rows, int lx, int pad_l, int pad_r, void* stream);
+
+/* ---- losses ----------------------------------------------------------------------------- */
+/* feature matching (vibravox/torch_modules/losses/feature_loss.py:37-50): per pair i
+ * sums[2i] = sum|a-b|, sums[2i+1] = sum|a| (device floats).  ptrs = HOST array of 2*npairs device
+ * pointers (a0,b0,a1,b1,...), numel = HOST array of npairs element counts; they travel to the
+ * kernels by value in the kernel-argument segment (no device table, no copy). */
+EBEN_API int eben_fm_sums(const void* const* ptrs, const int64_t* numel, int npairs, float* partial_ws, size_t ws_bytes,
+                 float* sums, void* stream);
+EBEN_API size_t eben_fm_sums_workspace(int npairs);
+/* da_i = gout * inv_count * ( sign(a-b)/S2 - S1*sign(a)/S2^2 ); gout is a device scalar */
+EBEN_API int eben_fm_bwd(const void* const* ptrs, void* const* da_ptrs, const int64_t* numel, int npairs, const float* sums,
+                const float* gout, float inv_count, void* stream);
+/* hinge (losses/hinge_loss.py:35-43): out[i] = mean(relu(1 - target*x_i)) ; bwd adds nothing else */
+EBEN_API int eben_hinge_fwd(const float* x, size_t n, float target, float* out, void* stream);
+EBEN_API int eben_hinge_bwd(const float* x, size_t n, float target, const float* gout, float scale, float* dx, void* stream);
+/* STFT magnitude losses (auraloss.freq.STFTLoss as configured by multi_stft.yaml; call site
+ * vibravox/lightning_modules/eben.py:195-198).  spec_* hold (rows, 2*bins_pad, frames) with re in
+ * channels [0,bins) and im in [bins_pad, bins_pad+bins); |.| = sqrt(clamp(re^2+im^2, eps)).
+ * per row r: out[3r] = sum (|Y|-|X|)^2, out[3r+1] = sum |Y|^2, out[3r+2] = sum |log|X| - log|Y|| */
+EBEN_API int eben_stft_loss_sums(const float* spec_x, const float* spec_y, int rows, int bins, int bins_pad, int frames,
+                        float eps, float* out, void* stream);
+/* dspec_x from d(loss) with loss = mean_rows(sqrt(s0/s1)) + mean(|log X - log Y|); gout device scalar * scale */
+EBEN_API int eben_stft_loss_bwd(const float* spec_x, const float* spec_y, int rows, int bins, int bins_pad, int frames,
+                       float eps, const float* sums, const float* gout, float scale, float* dspec_x, void* stream);
+
+/* adjoint of framing a (reflect-)padded signal: x[b,u] (+)= fold( sum_f buf[b, u+pad-f*hop, f] ) with
+ * buf (batch, win, frames).  Used by the STFT backward: d(frames) = basis^T . d(spec) is a dense
+ * pointwise conv (eben_conv1d_fwd, ksize 1), this kernel scatters it back onto the waveform. */
+EBEN_API int eben_overlap_add(const float* frames_buf, float* x, int batch, int lx, int win, int frames, int hop, int pad,
+                     int reflect, int accumulate, void* stream);
+
+/* ---- optimiser (torch.optim.Adam as configured by configs/lightning_module/optimizer/adam.yaml) --- */
+typedef struct EbenAdamTensor {
+  float* param;
+  const float* grad;
+  float* exp_avg;
+  float* exp_avg_sq;
+  int64_t numel;
+} EbenAdamTensor;
+/* `table` is a HOST array of ntensors entries (device pointers inside); it is passed to the
+ * kernel by value, 48 tensors per launch. */
+EBEN_API int eben_adam_step(const EbenAdamTensor* table, int ntensors, int64_t max_numel, float lr, float beta1, float beta2,
+                   float eps, float weight_decay, int step, float grad_scale, void* stream);
+
+/* ---- misc ------------------------------------------------------------------------------- */
+/* out[0] = sqrt(sum x^2) (torch.norm at eben.py:226); `out` must hold 257 floats (scratch) */
+EBEN_API int eben_l2norm(const float* x, size_t n, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EBEN_HIP_H */

@@ -142,6 +142,21 @@ def _residual_unit(sd: SD, prefix: str, x: Tensor, dilation: int) -> Tensor:
     return x + F.leaky_relu(h, 0.01)
 
 
+def conv_layer(x: Tensor, v: Tensor, g: Optional[Tensor], bias: Optional[Tensor], *, stride=1, dilation=1, groups=1,
+               pad_l=0, pad_r=0, reflect=False, transposed=False, output_padding=0, in_slope=1.0, out_slope=1.0) -> Tensor:
+    """Reference semantics of one product conv layer (vibravox_amd.ops.conv_layer): used by the
+    per-op parity tests.  lrelu_out(conv(lrelu_in(x); weight_norm(g, v)) + bias)."""
+    w = weight_norm(g, v) if g is not None else v
+    h = F.leaky_relu(x, in_slope) if in_slope != 1.0 else x
+    if transposed:
+        y = F.conv_transpose1d(h, w, bias, stride=stride, padding=pad_l, output_padding=output_padding, groups=groups, dilation=dilation)
+    else:
+        if pad_l or pad_r:
+            h = F.pad(h, (pad_l, pad_r), mode="reflect" if reflect else "constant")
+        y = F.conv1d(h, w, bias, stride=stride, dilation=dilation, groups=groups)
+    return F.leaky_relu(y, out_slope) if out_slope != 1.0 else y
+
+
 # --------------------------------------------------------------------------
 # generator -- eben_generator.py:93-213
 # --------------------------------------------------------------------------

@@ -250,6 +250,12 @@ def main():
     out["check:disc_grad_fp64_floor"] = np.array(floor)
     print("  (reference fp32 vs reference fp64 worst rel-L2:", floor, ")")
 
+    # ---- the state_dict contract (key order + shapes) of both networks
+    for tag, mod in (("G", gen), ("D", disc)):
+        sd = mod.state_dict()
+        out[f"contract/{tag}/keys"] = np.array(list(sd.keys()))
+        out[f"contract/{tag}/shapes"] = np.array([",".join(map(str, v.shape)) for v in sd.values()])
+
     # ---- two train steps without MRSTFT
     gen = R["G"](m=4, n=32, p=2)
     load_formula(gen, "G2")

@@ -1,0 +1,254 @@
+"""GPU: every HIP kernel family through the C ABI against the CPU oracle (float64) on seeded inputs.
+
+Tolerances (fp32 kernels vs an fp64 reference): max-abs error <= 3e-5 * max|ref| for the conv
+GEMMs (K up to ~5k fp32 accumulations), 1e-5 for elementwise / FIR ops.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from formula import formula_tensor
+from oracle import eben_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_err(got: torch.Tensor, ref: torch.Tensor) -> float:
+    got, ref = got.detach().double().cpu(), ref.detach().double()
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    assert torch.isfinite(got).all()
+    return float((got - ref).abs().max() / (ref.abs().max() + 1e-30))
+
+
+CONV_CASES = {
+    # name: (kwargs of ConvSpec, batch, length, weight_norm, bias)
+    "plain_k3_bias_act": (dict(c_in=8, c_out=24, ksize=3, pad_l=1, pad_r=1, out_slope=0.2), 3, 700, True, True),
+    "melgan_l1_like": (dict(c_in=16, c_out=64, ksize=41, stride=4, pad_l=20, pad_r=20, groups=4, out_slope=0.2), 2, 1500, True, True),
+    "melgan_l2_like": (dict(c_in=64, c_out=256, ksize=41, stride=4, pad_l=20, pad_r=20, groups=4, out_slope=0.2), 2, 1100, True, True),
+    "dense_k5_chunks": (dict(c_in=256, c_out=384, ksize=5, pad_l=2, pad_r=2, out_slope=0.2), 2, 300, True, True),
+    "pqmf_disc_d3": (dict(c_in=24, c_out=48, ksize=7, stride=2, dilation=3, pad_l=3, pad_r=3, groups=4, out_slope=0.2), 3, 1001, True, True),
+    "pqmf_disc_d2_even": (dict(c_in=12, c_out=24, ksize=7, stride=2, dilation=2, pad_l=3, pad_r=3, groups=4, out_slope=0.2), 3, 1000, True, True),
+    "pqmf_disc_wide": (dict(c_in=384, c_out=768, ksize=7, stride=2, dilation=2, pad_l=3, pad_r=3, groups=4, out_slope=0.2), 2, 260, True, True),
+    "ru_dilated_reflect": (dict(c_in=32, c_out=32, ksize=3, dilation=9, pad_l=9, pad_r=9, reflect=True, in_slope=0.01), 3, 600, True, False),
+    "ru_pointwise": (dict(c_in=64, c_out=64, ksize=1, out_slope=0.01), 3, 517, True, False),
+    "enc_s4_reflect": (dict(c_in=64, c_out=128, ksize=8, stride=4, pad_l=3, pad_r=3, reflect=True), 2, 1000, True, False),
+    "enc_s8_reflect": (dict(c_in=128, c_out=256, ksize=16, stride=8, pad_l=7, pad_r=7, reflect=True), 2, 1000, True, False),
+    "latent_k7_reflect": (dict(c_in=256, c_out=64, ksize=7, pad_l=3, pad_r=3, reflect=True, out_slope=0.01), 2, 125, True, False),
+    "dec_convT_s8": (dict(c_in=256, c_out=128, ksize=16, stride=8, pad_l=4, transposed=True, out_slope=0.01), 2, 125, True, False),
+    "dec_convT_s2": (dict(c_in=64, c_out=32, ksize=4, stride=2, pad_l=1, transposed=True, in_slope=0.01, out_slope=0.01), 2, 500, True, False),
+    "logits_m1": (dict(c_in=96, c_out=1, ksize=3, pad_l=1, pad_r=1), 3, 251, True, True),
+    "first_conv_plain": (dict(c_in=2, c_out=32, ksize=3, pad_l=1, pad_r=1, reflect=True), 3, 1000, False, False),
+    "last_conv_plain": (dict(c_in=32, c_out=4, ksize=3, pad_l=1, pad_r=1, reflect=True), 3, 1000, False, False),
+    "melgan_l0_k15": (dict(c_in=1, c_out=16, ksize=15, out_slope=0.2), 2, 2014, True, True),
+    "stft_like": (dict(c_in=1, c_out=66, ksize=24, stride=5, pad_l=12, pad_r=12, reflect=True), 4, 1003, False, False),
+    "tiny_l": (dict(c_in=8, c_out=8, ksize=3, pad_l=1, pad_r=1), 1, 5, True, True),
+}
+
+
+@pytest.mark.parametrize("name", list(CONV_CASES))
+def test_conv_layer_fwd_bwd(hip, name):
+    from vibravox_amd import ops
+
+    kw, batch, length, wn, has_bias = CONV_CASES[name]
+    spec = ops.ConvSpec(**kw)
+    wshape = spec.weight_shape()
+    fan_in = wshape[1] * wshape[2]
+    v = formula_tensor(f"{name}/v", wshape, 1 / math.sqrt(fan_in))
+    g = (v.reshape(wshape[0], -1).norm(dim=1).reshape(-1, 1, 1) * (1 + 0.3 * formula_tensor(f"{name}/g", (wshape[0], 1, 1)))) if wn else None
+    bias = formula_tensor(f"{name}/b", (spec.c_out,), 0.1) if has_bias else None
+    x = formula_tensor(f"{name}/x", (batch, spec.c_in, length))
+    l_out = spec.out_len(length)
+    seed = formula_tensor(f"{name}/dy", (batch, spec.c_out, l_out))
+
+    # CPU float64 reference
+    rx, rv = x.double().requires_grad_(True), v.double().requires_grad_(True)
+    rg = g.double().requires_grad_(True) if wn else None
+    rb = bias.double().requires_grad_(True) if has_bias else None
+    okw = {k: val for k, val in kw.items() if k not in ("c_in", "c_out", "ksize")}
+    ry = O.conv_layer(rx, rv, rg, rb, **okw)
+    assert ry.shape[2] == l_out
+    (ry * seed.double()).sum().backward()
+
+    dev = torch.device("cuda")
+    dx_, dv_ = x.to(dev).requires_grad_(True), v.to(dev).requires_grad_(True)
+    dg_ = g.to(dev).requires_grad_(True) if wn else None
+    db_ = bias.to(dev).requires_grad_(True) if has_bias else None
+    y = ops.conv_layer(dx_, dv_, dg_, db_, spec)
+    (y * seed.to(dev)).sum().backward()
+    torch.cuda.synchronize()
+
+    tol = 3e-5
+    assert rel_err(y, ry) < tol, f"forward {rel_err(y, ry)}"
+    assert rel_err(dx_.grad, rx.grad) < tol, f"dx {rel_err(dx_.grad, rx.grad)}"
+    assert rel_err(dv_.grad, rv.grad) < 2 * tol, f"dv {rel_err(dv_.grad, rv.grad)}"
+    if wn:
+        assert rel_err(dg_.grad, rg.grad) < 2 * tol, f"dg {rel_err(dg_.grad, rg.grad)}"
+    if has_bias:
+        assert rel_err(db_.grad, rb.grad) < 2 * tol, f"dbias {rel_err(db_.grad, rb.grad)}"
+
+
+def test_conv_bad_descriptor_raises(hip):
+    from vibravox_amd import _lib, ops
+
+    spec = ops.ConvSpec(c_in=8, c_out=8, ksize=3, pad_l=1, pad_r=1)
+    x = torch.zeros(1, 4, 10, device="cuda")
+    v = torch.zeros(8, 8, 3, device="cuda")
+    with pytest.raises(_lib.EbenError):
+        ops.conv_layer(x, v, None, None, spec)
+    with pytest.raises(_lib.EbenError):
+        ops.conv_layer(torch.zeros(1, 8, 10), v, None, None, spec)  # CPU tensor: no fallback
+
+
+@pytest.mark.parametrize("bands,length", [(4, 8160), (2, 1000), (4, 224), (1, 37)])
+def test_pqmf_analysis_synthesis(hip, golden, bands, length):
+    from vibravox_amd import ops
+
+    ana = torch.from_numpy(golden["pqmf/analysis_4_32"])
+    syn = torch.from_numpy(golden["pqmf/synthesis_4_32"])
+    x = formula_tensor(f"pq/{length}", (3, 1, length))
+    ref = O.pqmf_analysis(x.double(), ana.double(), bands=bands)
+    dev = torch.device("cuda")
+    xd = x.to(dev).requires_grad_(True)
+    got = ops.fir_decimate(xd, ana[:bands].reshape(bands, 32).to(dev), ref.shape[2], 4, -31)
+    assert rel_err(got, ref) < 1e-5
+    # adjoint: <A x, s> gradient equals interp_sum
+    s = formula_tensor(f"pq/s/{length}", tuple(ref.shape))
+    (got * s.to(dev)).sum().backward()
+    rx = x.double().requires_grad_(True)
+    (O.pqmf_analysis(rx, ana.double(), bands=bands) * s.double()).sum().backward()
+    assert rel_err(xd.grad, rx.grad) < 1e-5
+    if bands == 4 and length > 64:
+        b4 = formula_tensor(f"pq/b/{length}", (3, 4, ref.shape[2])).requires_grad_(True)
+        rsyn = O.pqmf_synthesis(b4.double(), syn.double()).sum(1, keepdim=True)
+        bd = b4.detach().to(dev).requires_grad_(True)
+        gsyn = ops.fir_interp_sum(bd, syn.reshape(4, 32).to(dev), rsyn.shape[2], 4, -31)
+        assert rel_err(gsyn, rsyn) < 1e-5
+        w = formula_tensor(f"pq/w/{length}", tuple(rsyn.shape))
+        (gsyn * w.to(dev)).sum().backward()
+        (rsyn * w.double()).sum().backward()
+        assert rel_err(bd.grad, b4.grad) < 1e-5
+
+
+def test_pqmf_roundtrip_snr_on_device(hip, golden):
+    """size-independent property at full length: analysis -> synthesis reconstructs (> 50 dB)."""
+    from vibravox_amd import ops
+
+    dev = torch.device("cuda")
+    ana = torch.from_numpy(golden["pqmf/analysis_4_32"]).reshape(4, 32).to(dev)
+    syn = torch.from_numpy(golden["pqmf/synthesis_4_32"]).reshape(4, 32).to(dev)
+    g = torch.Generator().manual_seed(1)
+    x = torch.rand(32, 1, 31968, generator=g).to(dev)
+    bands = ops.fir_decimate(x, ana, 8000, 4, -31)
+    rec = ops.fir_interp_sum(bands, syn, 31968, 4, -31)
+    snr = 10 * torch.log10((rec ** 2).mean() / ((x - rec) ** 2).mean()).item()
+    assert snr > 50.0
+
+
+def test_elementwise_and_pad(hip):
+    from vibravox_amd import ops
+
+    dev = torch.device("cuda")
+    x = formula_tensor("ew/x", (3, 5, 1001))
+    y = formula_tensor("ew/y", (3, 5, 1001))
+    s = formula_tensor("ew/s", (3, 5, 1001))
+    for slope in (0.01, 0.2):
+        xd = x.to(dev).requires_grad_(True)
+        out = ops.leaky_relu(xd, slope)
+        (out * s.to(dev)).sum().backward()
+        rx = x.double().requires_grad_(True)
+        ro = torch.nn.functional.leaky_relu(rx, slope)
+        (ro * s.double()).sum().backward()
+        assert rel_err(out, ro) < 1e-6 and rel_err(xd.grad, rx.grad) < 1e-6
+    assert rel_err(ops.add(x.to(dev), y.to(dev)), x.double() + y.double()) < 1e-6
+    lift = formula_tensor("ew/l", (3, 2, 1001))
+    xd = x.to(dev).requires_grad_(True)
+    out = ops.tanh_lift(xd, lift.to(dev))
+    (out * s.to(dev)).sum().backward()
+    rx = x.double().requires_grad_(True)
+    ro = torch.tanh(rx + torch.cat((lift.double(), torch.zeros(3, 3, 1001, dtype=torch.float64)), 1))
+    (ro * s.double()).sum().backward()
+    assert rel_err(out, ro) < 1e-5 and rel_err(xd.grad, rx.grad) < 1e-5
+    for pad in (1, 7):
+        xd = x.to(dev).requires_grad_(True)
+        out = ops.reflect_pad(xd, pad, pad)
+        sp = formula_tensor(f"ew/p{pad}", tuple(out.shape))
+        (out * sp.to(dev)).sum().backward()
+        rx = x.double().requires_grad_(True)
+        ro = torch.nn.functional.pad(rx, (pad, pad), mode="reflect")
+        (ro * sp.double()).sum().backward()
+        assert rel_err(out, ro) == 0.0 and rel_err(xd.grad, rx.grad) < 1e-6
+
+
+def test_feature_and_hinge_losses(hip):
+    from vibravox_amd.torch_modules.losses.feature_loss import FeatureLossForDiscriminatorMelganMultiScales
+    from vibravox_amd.torch_modules.losses.hinge_loss import HingeLossForDiscriminatorMelganMultiScales
+
+    dev = torch.device("cuda")
+    shapes = [[(2, 4, 300), (2, 24, 302), (2, 48, 151), (2, 1, 151)], [(2, 1, 1000), (2, 16, 1000), (2, 64, 250), (2, 256, 63), (2, 1, 63)]]
+    ea = [[formula_tensor(f"fl/a{i}{j}", s) for j, s in enumerate(sc)] for i, sc in enumerate(shapes)]
+    eb = [[formula_tensor(f"fl/b{i}{j}", s) for j, s in enumerate(sc)] for i, sc in enumerate(shapes)]
+    ra = [[t.double().requires_grad_(True) for t in sc] for sc in ea]
+    rb = [[t.double() for t in sc] for sc in eb]
+    r_fm, r_hp, r_hm = O.feature_loss(ra, rb), O.hinge_loss(ra, 1), O.hinge_loss(ra, -1)
+    (r_fm * 0.7 + r_hp * 1.3 + r_hm * 0.4).backward()
+    da = [[t.to(dev).requires_grad_(True) for t in sc] for sc in ea]
+    db = [[t.to(dev) for t in sc] for sc in eb]
+    fm, hinge = FeatureLossForDiscriminatorMelganMultiScales(), HingeLossForDiscriminatorMelganMultiScales()
+    g_fm, g_hp, g_hm = fm(da, db), hinge(embeddings=da, target=1), hinge(embeddings=da, target=-1)
+    assert g_fm.dim() == 0 and g_hp.dim() == 0  # reference tests: loss is a 0-dim tensor
+    (g_fm * 0.7 + g_hp * 1.3 + g_hm * 0.4).backward()
+    np.testing.assert_allclose(g_fm.item(), r_fm.item(), rtol=1e-5)
+    np.testing.assert_allclose(g_hp.item(), r_hp.item(), rtol=1e-5)
+    np.testing.assert_allclose(g_hm.item(), r_hm.item(), rtol=1e-5)
+    for sa, sr in zip(da, ra):
+        for i, (t, r) in enumerate(zip(sa, sr)):
+            if r.grad is None:
+                assert t.grad is None
+            else:
+                assert rel_err(t.grad, r.grad) < 1e-5
+
+
+@pytest.mark.parametrize("perceptual", [True, False])
+def test_mrstft_loss_and_grad(hip, perceptual):
+    from vibravox_amd.torch_modules.losses.mrstft_loss import MultiResolutionSTFTLoss
+
+    dev = torch.device("cuda")
+    from formula import formula_audio
+
+    x, y = formula_audio("mr_x", 2, 4000), formula_audio("mr_y", 2, 4000)
+    loss = MultiResolutionSTFTLoss(fft_sizes=(512, 1024, 2048), hop_sizes=(50, 120, 240), win_lengths=(240, 600, 1200),
+                                   sample_rate=16000, perceptual_weighting=perceptual).to(dev)
+    xd = x.to(dev).requires_grad_(True)
+    got = loss(xd, y.to(dev))
+    got.backward()
+    rx = x.double().requires_grad_(True)
+    fir = O.a_weighting_fir(16000).double() if perceptual else None
+    ref = O.mrstft_loss(rx, y.double(), perceptual_weighting=perceptual, fir=fir)
+    ref.backward()
+    np.testing.assert_allclose(got.item(), ref.item(), rtol=2e-5)
+    err = float((xd.grad.double().cpu() - rx.grad).norm() / rx.grad.norm())
+    assert err < 1e-3, err  # sign(log X - log Y) flips at fp32 noise: compare in L2
+
+
+def test_adam_matches_torch(hip):
+    from vibravox_amd.optim import FusedAdam
+
+    dev = torch.device("cuda")
+    shapes = [(7,), (33, 5, 3), (1, 1, 1), (1024, 64)]
+    ps = [formula_tensor(f"ad/p{i}", s) for i, s in enumerate(shapes)]
+    ref = [p.clone().double().requires_grad_(True) for p in ps]
+    got = [p.clone().to(dev).requires_grad_(True) for p in ps]
+    o_ref = torch.optim.Adam(ref, lr=3e-4, betas=(0.5, 0.9))
+    o_got = FusedAdam(got, lr=3e-4, betas=(0.5, 0.9))
+    for step in range(3):
+        for i, (r, g) in enumerate(zip(ref, got)):
+            gr = formula_tensor(f"ad/g{step}/{i}", shapes[i], 0.01)
+            r.grad, g.grad = gr.double(), gr.to(dev)
+        o_ref.step()
+        o_got.step()
+    for r, g in zip(ref, got):
+        assert rel_err(g, r) < 1e-6
+    sd = o_got.state_dict()
+    assert set(sd["state"][0].keys()) >= {"step", "exp_avg", "exp_avg_sq"}

@@ -1,0 +1,138 @@
+"""ctypes binding of ``libeben_hip.so`` (C ABI declared in ``include/eben_hip.h``).
+
+There is deliberately NO fallback: if the shared library is missing, or a tensor handed to an
+op is not a contiguous float32 tensor on a HIP device, the call raises.  The CPU oracle under
+``oracle/`` is test infrastructure and is never imported from here.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libeben_hip.so")
+
+
+class EbenError(RuntimeError):
+    pass
+
+
+class EbenConv1dDesc(ctypes.Structure):
+    _fields_ = [
+        ("batch", c_int32),
+        ("c_in", c_int32),
+        ("c_out", c_int32),
+        ("l_in", c_int32),
+        ("l_out", c_int32),
+        ("ksize", c_int32),
+        ("stride", c_int32),
+        ("dilation", c_int32),
+        ("groups", c_int32),
+        ("pad_l", c_int32),
+        ("pad_r", c_int32),
+        ("pad_mode", c_int32),
+        ("transposed", c_int32),
+        ("in_slope", c_float),
+        ("out_slope", c_float),
+    ]
+
+
+class EbenAdamTensor(ctypes.Structure):
+    _fields_ = [
+        ("param", c_void_p),
+        ("grad", c_void_p),
+        ("exp_avg", c_void_p),
+        ("exp_avg_sq", c_void_p),
+        ("numel", c_int64),
+    ]
+
+
+_P = c_void_p
+_D = POINTER(EbenConv1dDesc)
+
+# name -> (restype, argtypes); mirrors include/eben_hip.h one to one
+SIGNATURES = {
+    "eben_last_error": (c_char_p, []),
+    "eben_version": (c_int, []),
+    "eben_device_info": (c_int, [ctypes.c_char_p, c_size_t]),
+    "eben_wn_scale": (c_int, [_P, _P, c_int, c_int, _P, _P, _P]),
+    "eben_wn_bwd": (c_int, [_P, c_int, c_size_t, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P]),
+    "eben_conv1d_packed_floats": (c_size_t, [_D, c_int]),
+    "eben_conv1d_pack": (c_int, [_D, _P, _P, _P, _P, _P]),
+    "eben_conv1d_fwd": (c_int, [_D, _P, _P, _P, _P, _P, _P]),
+    "eben_conv1d_bwd_dx_workspace": (c_size_t, [_D]),
+    "eben_conv1d_bwd_dw_workspace": (c_size_t, [_D, POINTER(c_int), POINTER(c_int)]),
+    "eben_conv1d_bwd_dx": (c_int, [_D, _P, _P, _P, _P, _P, c_int, _P, c_size_t, _P]),
+    "eben_conv1d_bwd_dw": (c_int, [_D, _P, _P, _P, c_int, _P, c_size_t, _P]),
+    "eben_fir_decimate": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "eben_fir_interp_sum": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "eben_lrelu_fwd": (c_int, [_P, _P, c_size_t, c_float, _P]),
+    "eben_lrelu_bwd": (c_int, [_P, _P, _P, c_size_t, c_float, _P]),
+    "eben_add": (c_int, [_P, _P, _P, c_size_t, _P]),
+    "eben_axpby": (c_int, [_P, c_float, _P, c_float, _P, c_size_t, _P]),
+    "eben_tanh_lift_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "eben_tanh_bwd": (c_int, [_P, _P, _P, c_size_t, _P]),
+    "eben_reflect_pad_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
+    "eben_reflect_pad_bwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
+    "eben_fm_sums": (c_int, [POINTER(c_void_p), POINTER(c_int64), c_int, _P, c_size_t, _P, _P]),
+    "eben_fm_sums_workspace": (c_size_t, [c_int]),
+    "eben_fm_bwd": (c_int, [POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int64), c_int, _P, _P, c_float, _P]),
+    "eben_hinge_fwd": (c_int, [_P, c_size_t, c_float, _P, _P]),
+    "eben_hinge_bwd": (c_int, [_P, c_size_t, c_float, _P, c_float, _P, _P]),
+    "eben_stft_loss_sums": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_float, _P, _P]),
+    "eben_stft_loss_bwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_float, _P, _P, c_float, _P, _P]),
+    "eben_overlap_add": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "eben_adam_step": (c_int, [POINTER(EbenAdamTensor), c_int, c_int64, c_float, c_float, c_float, c_float, c_float, c_int, c_float, _P]),
+    "eben_l2norm": (c_int, [_P, c_size_t, _P, _P]),
+}
+
+_lib: Optional[ctypes.CDLL] = None
+
+
+def load(path: Optional[str] = None) -> ctypes.CDLL:
+    """dlopen the library and attach the prototypes.  Works without a GPU (symbols only)."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or os.environ.get("EBEN_HIP_LIB", LIB_PATH)
+    if not os.path.exists(p):
+        raise EbenError(
+            f"{p} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"or `vibravox_amd/csrc/build.sh` (there is no CPU fallback)."
+        )
+    lib = ctypes.CDLL(p)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().eben_last_error()
+        raise EbenError(f"{what or 'libeben_hip'} failed (code {rc}): {msg.decode() if msg else '?'}")
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    """Device pointer of a tensor the kernels may touch (contiguous float32 on a HIP device)."""
+    if t is None:
+        return None
+    if t.device.type != "cuda":
+        raise EbenError(
+            f"vibravox_amd ops run only on an MI355X HIP device (got a tensor on '{t.device}'); "
+            "there is no CPU path -- the CPU oracle lives under oracle/ and is test-only."
+        )
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        raise EbenError(f"expected a contiguous float32 tensor, got {t.dtype} contiguous={t.is_contiguous()}")
+    return t.data_ptr()
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream

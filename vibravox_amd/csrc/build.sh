@@ -1,0 +1,15 @@
+#!/usr/bin/env bash
+# Build libeben_hip.so for gfx950 (cross-compiles without a GPU).  Usage: build.sh [outdir]
+set -euo pipefail
+here="$(cd "$(dirname "$0")" && pwd)"
+root="$(cd "$here/../.." && pwd)"
+out="${1:-$here/../lib}"
+mkdir -p "$out"
+HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+"$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -fvisibility=hidden \
+  -Wall -Wno-unused-function \
+  -I"$root/include" -I"$here" \
+  -DEBEN_BUILDING=1 \
+  "$here/tapconv.hip" "$here/conv_dw.hip" "$here/direct.hip" \
+  -o "$out/libeben_hip.so" "${@:2}"
+echo "built $out/libeben_hip.so"

@@ -1,0 +1,82 @@
+// Shared host/device helpers for libeben_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "eben_hip.h"
+
+namespace eben {
+
+// ---- error plumbing ------------------------------------------------------------------
+char* tls_error_buffer();
+inline int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(tls_error_buffer(), 512, fmt, ap);
+  va_end(ap);
+  return code;
+}
+inline int hip_fail(hipError_t e, const char* what) {
+  snprintf(tls_error_buffer(), 512, "%s: %s", what, hipGetErrorString(e));
+  return (int)e;
+}
+#define EBEN_CHECK_LAUNCH(what)                         \
+  do {                                                  \
+    hipError_t e__ = hipGetLastError();                 \
+    if (e__ != hipSuccess) return hip_fail(e__, what);  \
+  } while (0)
+#define EBEN_REQUIRE(cond, ...) \
+  do {                          \
+    if (!(cond)) return fail(EBEN_EINVAL, __VA_ARGS__); \
+  } while (0)
+
+inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+inline int round_up(int a, int b) { return ceil_div(a, b) * b; }
+inline size_t ceil_div_z(size_t a, size_t b) { return (a + b - 1) / b; }
+
+// ---- device helpers ------------------------------------------------------------------
+__device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
+__device__ __forceinline__ float dlrelu(float ref, float slope) { return ref > 0.f ? 1.f : slope; }
+
+// MI355X: 8 XCDs, block b is dispatched to XCD b%8 (speed-only assumption).  Remap the linear
+// block id so that each XCD works on a contiguous range of tiles (they share weight panels in
+// that XCD's private L2).  Bijective for any grid size.
+__device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblocks) {
+  const unsigned nx = 8;
+  const unsigned q = nblocks / nx, r = nblocks % nx;
+  const unsigned xcd = bid % nx, idx = bid / nx;
+  const unsigned start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return start + idx;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// block-wide sum for 256-thread blocks; result valid in every thread
+__device__ __forceinline__ float block_sum_256(float v, float* red /* >= 4 floats of LDS */) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[w] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Canonical strided convolution behind a Conv1d (as is) or a ConvTranspose1d (its adjoint):
+// big side X (B,Cin,Lin), small side Y (B,Cout,Lout), weight (Cout, Cin/g, k).
+struct Canon {
+  int B, Cin, Cout, Lin, Lout, k, s, d, g, pl, pr, reflect;
+};
+int canon_from_desc(const EbenConv1dDesc* d, Canon* c);
+
+}  // namespace eben

@@ -1,0 +1,304 @@
+// conv_dw.hip -- weight gradients of Conv1d / ConvTranspose1d and the weight-norm kernels.
+//
+//   dw[co, c, j] = sum_{b,t} A(b, co, t) * X(b, c, t*S + off0 + j*d)
+//
+// GEMM view per group: M = Cout/g rows, N = (c, j) flattened (+ one "ones" column that yields the
+// bias gradient for free), K = (batch, time) -- a 10^4..10^6-long reduction, so the K range is
+// split over `nsplit` blocks that each write a private slab; eben_wn_bwd sums the slabs in a fixed
+// order (deterministic, no float atomics) and applies the weight-norm chain rule
+// (torch_modules/utils.py:4-9 -> torch._weight_norm backward).
+// A = dy * lrelu'(y) (Conv1d) or lrelu(x) (ConvTranspose1d); X = lrelu(x) or dy * lrelu'(y).
+#include "common.h"
+
+namespace eben {
+
+struct DwArgs {
+  const float* a; const float* amask; int a_mode; float a_slope;
+  const float* x; const float* xmask; int x_mode; float x_slope;
+  float* slabs;
+  int B, G, Cg, Mg, Ca, Cx, La, Lx;
+  int S, d, off0, J, Ng, has_bias, row_stride, reflect;
+  int nsplit, nct, nchunks, nnt, nmt, XSTR;
+  long long slab_stride;
+};
+
+constexpr int DW_BK = 32;
+constexpr int DW_DSTR = DW_BK + 2;  // 16 rows x 2 k-lanes of a half-wave -> 32 distinct banks
+
+__device__ __forceinline__ float load_op(const float* p, const float* mask, long long idx, int mode, float slope) {
+  float v = p[idx];
+  return mode == 0 ? lrelu(v, slope) : v * dlrelu(mask[idx], slope);
+}
+
+template <int WAVES_M, int WAVES_N, int FM, int FN>
+__global__ __launch_bounds__(256) void conv_dw_kernel(const DwArgs P) {
+  constexpr int BM = WAVES_M * FM * 16;
+  constexpr int BN = WAVES_N * FN * 16;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Ds = smem;                  // [BM][DW_DSTR]
+  float* Xs = Ds + BM * DW_DSTR;     // [nch][XSTR] then {0.f, 1.f}
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, kk = lane >> 4;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+  unsigned id = blockIdx.x;
+  const int nti = id % P.nnt; id /= P.nnt;
+  const int mt = id % P.nmt; id /= P.nmt;
+  const int g = id % P.G;
+  const int z = id / P.G;
+  const int n0 = nti * BN, m0 = mt * BM;
+
+  const int c_lo = n0 / P.J;
+  int nch = (BN - 1) / P.J + 2;
+  if (nch > P.Cg - c_lo) nch = P.Cg - c_lo;
+  if (nch < 0) nch = 0;
+  const int span = (DW_BK - 1) * P.S + (P.J - 1) * P.d + 1;
+  const int cell_zero = nch * P.XSTR, cell_one = cell_zero + 1;
+  if (tid == 0) { Xs[cell_zero] = 0.f; Xs[cell_one] = 1.f; }
+
+  int xoff[FN], xstep[FN];
+#pragma unroll
+  for (int n = 0; n < FN; ++n) {
+    const int col = n0 + wn * FN * 16 + n * 16 + l15;
+    if (col < P.Ng) {
+      const int c = col / P.J, j = col - c * P.J;
+      xoff[n] = (c - c_lo) * P.XSTR + j * P.d + kk * P.S;
+      xstep[n] = P.S;
+    } else {
+      xoff[n] = (col == P.Ng && P.has_bias) ? cell_one : cell_zero;
+      xstep[n] = 0;
+    }
+  }
+
+  f32x4 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int n = 0; n < FN; ++n) acc[i][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int q = z; q < P.nchunks; q += P.nsplit) {
+    const int b = q / P.nct;
+    const int t0 = (q - b * P.nct) * DW_BK;
+    __syncthreads();
+    // A tile: BM rows x 32 time steps
+    for (int i = tid; i < BM * DW_BK; i += 256) {
+      const int r = i / DW_BK, tt = i - r * DW_BK;
+      const int m = m0 + r, t = t0 + tt;
+      float v = 0.f;
+      if (m < P.Mg && t < P.La) {
+        const long long idx = ((long long)b * P.Ca + (long long)g * P.Mg + m) * P.La + t;
+        v = load_op(P.a, P.amask, idx, P.a_mode, P.a_slope);
+      }
+      Ds[r * DW_DSTR + tt] = v;
+    }
+    // X tile: nch channels x span positions
+    const int qbase = t0 * P.S + P.off0;
+    for (int c = 0; c < nch; ++c) {
+      const long long row = ((long long)b * P.Cx + (long long)g * P.Cg + c_lo + c) * P.Lx;
+      for (int r = tid; r < span; r += 256) {
+        int p = qbase + r;
+        if (P.reflect) {
+          p = p < 0 ? -p : p;
+          p = p >= P.Lx ? 2 * (P.Lx - 1) - p : p;
+        }
+        float v = 0.f;
+        if (p >= 0 && p < P.Lx) v = load_op(P.x, P.xmask, row + p, P.x_mode, P.x_slope);
+        Xs[c * P.XSTR + r] = v;
+      }
+    }
+    __syncthreads();
+    const float* drow = Ds + (wm * FM * 16 + l15) * DW_DSTR + kk;
+#pragma unroll
+    for (int ks = 0; ks < DW_BK; ks += 4) {
+      float a[FM], bv[FN];
+#pragma unroll
+      for (int i = 0; i < FM; ++i) a[i] = drow[i * 16 * DW_DSTR + ks];
+#pragma unroll
+      for (int n = 0; n < FN; ++n) bv[n] = Xs[xoff[n] + ks * xstep[n]];
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int n = 0; n < FN; ++n)
+          acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], bv[n], acc[i][n], 0, 0, 0);
+    }
+  }
+
+  float* slab = P.slabs + (long long)z * P.slab_stride;
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = m0 + wm * FM * 16 + i * 16 + kk * 4 + r;
+      if (m >= P.Mg) continue;
+      float* orow = slab + ((long long)g * P.Mg + m) * P.row_stride;
+#pragma unroll
+      for (int n = 0; n < FN; ++n) {
+        const int col = n0 + wn * FN * 16 + n * 16 + l15;
+        if (col < P.row_stride) orow[col] = acc[i][n][r];
+      }
+    }
+}
+
+struct DwPlan {
+  int Cg, Mg, G, J, Ng, row_stride, cfg, BM, BN, nnt, nmt, nct, nchunks, nsplit, XSTR, nch_max;
+  size_t lds_bytes;
+  long long slab_stride;
+};
+
+static void make_dw_plan(const Canon& c, DwPlan* p) {
+  p->G = c.g; p->Cg = c.Cin / c.g; p->Mg = c.Cout / c.g; p->J = c.k;
+  p->Ng = p->Cg * c.k; p->row_stride = p->Ng + 1;
+  if (p->Mg > 64) { p->cfg = 0; p->BM = 128; p->BN = 128; }
+  else if (p->Mg > 32) { p->cfg = 1; p->BM = 64; p->BN = 128; }
+  else if (p->Mg > 16) { p->cfg = 2; p->BM = 32; p->BN = 256; }
+  else { p->cfg = 3; p->BM = 16; p->BN = 256; }
+  p->nnt = ceil_div(p->row_stride, p->BN);
+  p->nmt = ceil_div(p->Mg, p->BM);
+  p->nct = ceil_div(c.Lout, DW_BK);
+  p->nchunks = c.B * p->nct;
+  const int tiles = p->nnt * p->nmt * p->G;
+  int ns = ceil_div(1024, tiles);
+  if (ns > 512) ns = 512;
+  if (ns > p->nchunks) ns = p->nchunks;
+  if (ns < 1) ns = 1;
+  p->nsplit = ns;
+  const int span = (DW_BK - 1) * c.s + (c.k - 1) * c.d + 1;
+  p->XSTR = span | 1;  // odd row stride
+  p->nch_max = (p->BN - 1) / c.k + 2;
+  if (p->nch_max > p->Cg) p->nch_max = p->Cg;
+  p->lds_bytes = 4ull * ((size_t)p->BM * DW_DSTR + (size_t)p->nch_max * p->XSTR + 2);
+  p->slab_stride = (long long)c.Cout * p->row_stride;
+}
+
+template <int WM, int WN, int FM, int FN>
+static int launch_dw_cfg(const DwArgs& a, int nblocks, size_t lds, hipStream_t st) {
+  static bool attr_set = false;
+  auto kern = conv_dw_kernel<WM, WN, FM, FN>;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(conv_dw)");
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), lds, st, a);
+  EBEN_CHECK_LAUNCH("conv_dw_kernel");
+  return EBEN_OK;
+}
+
+// ---- weight norm ----------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void wn_scale_kernel(const float* __restrict__ g, const float* __restrict__ v, int cols,
+                                                       float* __restrict__ scale, float* __restrict__ norm) {
+  __shared__ float red[4];
+  const int r = blockIdx.x;
+  const float* row = v + (long long)r * cols;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < cols; i += 256) { const float t = row[i]; s += t * t; }
+  s = block_sum_256(s, red);
+  if (threadIdx.x == 0) {
+    const float n = sqrtf(s);
+    norm[r] = n;
+    scale[r] = g[r] / n;
+  }
+}
+
+__global__ __launch_bounds__(256) void wn_bwd_kernel(const float* __restrict__ slabs, int nslab, long long slab_stride, int cols,
+                                                     int row_stride, const float* __restrict__ g, const float* __restrict__ v,
+                                                     const float* __restrict__ norm, float* __restrict__ dg, float* __restrict__ dv,
+                                                     float* __restrict__ dbias) {
+  __shared__ float red[4];
+  const int r = blockIdx.x;
+  const float* srow = slabs + (long long)r * row_stride;
+  const float* vrow = v + (long long)r * cols;
+  float* orow = dv + (long long)r * cols;
+  // pass 1: dw = sum of slabs (kept in dv), dot = <dw, v>
+  float dot = 0.f;
+  for (int i = threadIdx.x; i < cols; i += 256) {
+    float s = 0.f;
+    for (int z = 0; z < nslab; ++z) s += srow[(long long)z * slab_stride + i];
+    orow[i] = s;
+    dot += s * vrow[i];
+  }
+  if (dbias && threadIdx.x == 0) {
+    float s = 0.f;
+    for (int z = 0; z < nslab; ++z) s += srow[(long long)z * slab_stride + cols];
+    dbias[r] = s;
+  }
+  if (!g) return;
+  dot = block_sum_256(dot, red);
+  const float n = norm[r], gr = g[r];
+  const float dgr = dot / n;
+  if (threadIdx.x == 0) dg[r] = dgr;
+  const float c1 = gr / n, c2 = gr * dgr / (n * n);
+  for (int i = threadIdx.x; i < cols; i += 256) orow[i] = c1 * orow[i] - c2 * vrow[i];
+}
+
+}  // namespace eben
+
+using namespace eben;
+
+extern "C" int eben_wn_scale(const float* g, const float* v, int rows, int cols, float* scale, float* norm, void* stream) {
+  EBEN_REQUIRE(g && v && scale && norm && rows > 0 && cols > 0, "bad wn_scale arguments");
+  hipLaunchKernelGGL(wn_scale_kernel, dim3(rows), dim3(256), 0, as_stream(stream), g, v, cols, scale, norm);
+  EBEN_CHECK_LAUNCH("wn_scale_kernel");
+  return EBEN_OK;
+}
+
+extern "C" int eben_wn_bwd(const float* dw_slabs, int nslab, size_t slab_stride, int rows, int cols, int row_stride,
+                           const float* g, const float* v, const float* norm, float* dg, float* dv, float* dbias, void* stream) {
+  EBEN_REQUIRE(dw_slabs && dv && nslab > 0 && rows > 0 && cols > 0 && row_stride >= cols, "bad wn_bwd arguments");
+  EBEN_REQUIRE(!g || (v && norm && dg), "weight-norm backward needs v, norm and dg");
+  EBEN_REQUIRE(!dbias || row_stride > cols, "no bias column in the slabs");
+  hipLaunchKernelGGL(wn_bwd_kernel, dim3(rows), dim3(256), 0, as_stream(stream), dw_slabs, nslab, (long long)slab_stride, cols,
+                     row_stride, g, v ? v : dw_slabs, norm, dg, dv, dbias);
+  EBEN_CHECK_LAUNCH("wn_bwd_kernel");
+  return EBEN_OK;
+}
+
+extern "C" size_t eben_conv1d_bwd_dw_workspace(const EbenConv1dDesc* d, int* nslab, int* row_stride) {
+  Canon c;
+  if (canon_from_desc(d, &c) != EBEN_OK) return 0;
+  DwPlan p;
+  make_dw_plan(c, &p);
+  if (nslab) *nslab = p.nsplit;
+  if (row_stride) *row_stride = p.row_stride;
+  return sizeof(float) * (size_t)p.slab_stride * p.nsplit;
+}
+
+extern "C" int eben_conv1d_bwd_dw(const EbenConv1dDesc* d, const float* dy, const float* y, const float* x, int has_bias,
+                                  float* slabs, size_t ws_bytes, void* stream) {
+  Canon c;
+  int rc = canon_from_desc(d, &c);
+  if (rc) return rc;
+  EBEN_REQUIRE(dy && x && slabs, "null pointer in conv1d_bwd_dw");
+  EBEN_REQUIRE(d->out_slope == 1.f || y, "y is required to differentiate the fused output activation");
+  EBEN_REQUIRE(!(d->transposed && has_bias), "ConvTranspose1d bias gradient is not provided by this kernel");
+  DwPlan p;
+  make_dw_plan(c, &p);
+  const size_t need = sizeof(float) * (size_t)p.slab_stride * p.nsplit;
+  if (ws_bytes < need) return fail(EBEN_EWORKSPACE, "bwd_dw needs %zu workspace bytes, got %zu", need, ws_bytes);
+  if (p.lds_bytes > 160 * 1024) return fail(EBEN_EUNSUPPORTED, "conv_dw tile needs %zu B of LDS", p.lds_bytes);
+  DwArgs a;
+  if (!d->transposed) {
+    a.a = dy; a.amask = y; a.a_mode = d->out_slope != 1.f ? 1 : 0; a.a_slope = d->out_slope;
+    a.x = x; a.xmask = nullptr; a.x_mode = 0; a.x_slope = d->in_slope;
+  } else {
+    a.a = x; a.amask = nullptr; a.a_mode = 0; a.a_slope = d->in_slope;
+    a.x = dy; a.xmask = y; a.x_mode = d->out_slope != 1.f ? 1 : 0; a.x_slope = d->out_slope;
+  }
+  if (a.a_mode == 0 && a.a == dy) a.a_slope = 1.f;
+  if (a.x_mode == 0 && a.x == dy) a.x_slope = 1.f;
+  a.slabs = slabs;
+  a.B = c.B; a.G = c.g; a.Cg = p.Cg; a.Mg = p.Mg; a.Ca = c.Cout; a.Cx = c.Cin; a.La = c.Lout; a.Lx = c.Lin;
+  a.S = c.s; a.d = c.d; a.off0 = -c.pl; a.J = c.k; a.Ng = p.Ng; a.has_bias = has_bias ? 1 : 0; a.row_stride = p.row_stride;
+  a.reflect = c.reflect;
+  a.nsplit = p.nsplit; a.nct = p.nct; a.nchunks = p.nchunks; a.nnt = p.nnt; a.nmt = p.nmt; a.XSTR = p.XSTR;
+  a.slab_stride = p.slab_stride;
+  const int nb = p.nnt * p.nmt * p.G * p.nsplit;
+  hipStream_t st = as_stream(stream);
+  switch (p.cfg) {
+    case 0: return launch_dw_cfg<2, 2, 4, 4>(a, nb, p.lds_bytes, st);
+    case 1: return launch_dw_cfg<1, 4, 4, 2>(a, nb, p.lds_bytes, st);
+    case 2: return launch_dw_cfg<1, 4, 2, 4>(a, nb, p.lds_bytes, st);
+    default: return launch_dw_cfg<1, 4, 1, 4>(a, nb, p.lds_bytes, st);
+  }
+}

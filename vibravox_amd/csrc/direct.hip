@@ -1,0 +1,557 @@
+// direct.hip -- the HBM-bound kernels of libeben_hip.so (gfx950): PQMF analysis / synthesis FIR
+// banks, the A-weighting FIR, elementwise ops, reflection pads, feature-matching / hinge / STFT
+// loss reductions and their gradients, multi-tensor Adam.  All of them stream (batch, channel,
+// time) float32 rows with coalesced accesses; reductions are two-level and order-deterministic.
+#include "common.h"
+
+namespace eben {
+
+// ---------------------------------------------------------------------------------------------
+// FIR banks (pqmf.py:194-213; auraloss FIRFilter).  One block = 256 consecutive outputs of one
+// batch item, input span and taps staged in LDS.
+// ---------------------------------------------------------------------------------------------
+constexpr int FIR_MAX_W = 1024;  // bands * ntaps
+
+__global__ __launch_bounds__(256) void fir_decimate_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                           float* __restrict__ y, int lx, int ly, int bands, int ntaps,
+                                                           int stride, int off0) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* ws = smem;                  // bands*ntaps
+  float* xs = smem + FIR_MAX_W;      // 255*stride + ntaps
+  const int b = blockIdx.y, t0 = blockIdx.x * 256, tid = threadIdx.x;
+  for (int i = tid; i < bands * ntaps; i += 256) ws[i] = w[i];
+  const int span = 255 * stride + ntaps;
+  const long long q0 = (long long)t0 * stride + off0;
+  const float* xr = x + (long long)b * lx;
+  for (int r = tid; r < span; r += 256) {
+    const long long q = q0 + r;
+    xs[r] = (q >= 0 && q < lx) ? xr[q] : 0.f;
+  }
+  __syncthreads();
+  const int t = t0 + tid;
+  if (t >= ly) return;
+  const float* xp = xs + tid * stride;
+  for (int k = 0; k < bands; ++k) {
+    const float* wk = ws + k * ntaps;
+    float acc = 0.f;
+    for (int j = 0; j < ntaps; ++j) acc = fmaf(wk[j], xp[j], acc);
+    y[((long long)b * bands + k) * ly + t] = acc;
+  }
+}
+
+__global__ __launch_bounds__(256) void fir_interp_sum_kernel(const float* __restrict__ y, const float* __restrict__ w,
+                                                             float* __restrict__ x, int lx, int ly, int bands, int ntaps,
+                                                             int stride, int off0, int tile_t) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* ws = smem;                 // bands*ntaps
+  float* ys = smem + FIR_MAX_W;     // bands*tile_t
+  const int b = blockIdx.y, u0 = blockIdx.x * 256, tid = threadIdx.x;
+  for (int i = tid; i < bands * ntaps; i += 256) ws[i] = w[i];
+  // t = (u - off0 - j)/stride for j in [0, ntaps): floor-division lower bound of the tile
+  long long lo = (long long)u0 - off0 - (ntaps - 1);
+  const int t_min = (int)(lo >= 0 ? lo / stride : -((-lo + stride - 1) / stride));
+  for (int i = tid; i < bands * tile_t; i += 256) {
+    const int k = i / tile_t, tl = i - k * tile_t;
+    const int t = t_min + tl;
+    ys[i] = (t >= 0 && t < ly) ? y[((long long)b * bands + k) * ly + t] : 0.f;
+  }
+  __syncthreads();
+  const int u = u0 + tid;
+  if (u >= lx) return;
+  const int rel = u - off0;                 // = t*stride + j
+  int j0 = rel % stride;
+  if (j0 < 0) j0 += stride;
+  float acc = 0.f;
+  for (int j = j0; j < ntaps; j += stride) {
+    const int t = (rel - j) / stride;       // exact
+    const int tl = t - t_min;
+    if (tl < 0 || tl >= tile_t) continue;
+    for (int k = 0; k < bands; ++k) acc = fmaf(ws[k * ntaps + j], ys[k * tile_t + tl], acc);
+  }
+  x[(long long)b * lx + u] = acc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// elementwise
+// ---------------------------------------------------------------------------------------------
+#define EBEN_GRID_STRIDE(i, n) \
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (n); i += (size_t)gridDim.x * 256)
+
+__global__ __launch_bounds__(256) void lrelu_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n, float s) {
+  EBEN_GRID_STRIDE(i, n) y[i] = lrelu(x[i], s);
+}
+__global__ __launch_bounds__(256) void lrelu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ ref,
+                                                        float* __restrict__ dx, size_t n, float s) {
+  EBEN_GRID_STRIDE(i, n) dx[i] = dy[i] * dlrelu(ref[i], s);
+}
+__global__ __launch_bounds__(256) void axpby_kernel(const float* __restrict__ a, float alpha, const float* __restrict__ b,
+                                                    float beta, float* __restrict__ out, size_t n) {
+  EBEN_GRID_STRIDE(i, n) out[i] = alpha * a[i] + beta * b[i];
+}
+__global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, size_t n) {
+  EBEN_GRID_STRIDE(i, n) out[i] = a[i] + b[i];
+}
+__global__ __launch_bounds__(256) void tanh_lift_kernel(const float* __restrict__ x, const float* __restrict__ lift,
+                                                        float* __restrict__ out, int channels, int c_lift, int length, size_t n) {
+  EBEN_GRID_STRIDE(i, n) {
+    const size_t row = i / length;
+    const int t = (int)(i - row * length);
+    const int c = (int)(row % channels);
+    const size_t b = row / channels;
+    float v = x[i];
+    if (c < c_lift) v += lift[(b * c_lift + c) * (size_t)length + t];
+    out[i] = tanhf(v);
+  }
+}
+__global__ __launch_bounds__(256) void tanh_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ out,
+                                                       float* __restrict__ dx, size_t n) {
+  EBEN_GRID_STRIDE(i, n) { const float o = out[i]; dx[i] = dout[i] * (1.f - o * o); }
+}
+__global__ __launch_bounds__(256) void reflect_pad_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, size_t rows,
+                                                              int lx, int pl, int pr) {
+  const int ly = lx + pl + pr;
+  const size_t n = rows * ly;
+  EBEN_GRID_STRIDE(i, n) {
+    const size_t row = i / ly;
+    int q = (int)(i - row * ly) - pl;
+    q = q < 0 ? -q : q;
+    q = q >= lx ? 2 * (lx - 1) - q : q;
+    y[i] = x[row * lx + q];
+  }
+}
+__global__ __launch_bounds__(256) void reflect_pad_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, size_t rows,
+                                                              int lx, int pl, int pr) {
+  const int ly = lx + pl + pr;
+  const size_t n = rows * lx;
+  EBEN_GRID_STRIDE(i, n) {
+    const size_t row = i / lx;
+    const int u = (int)(i - row * lx);
+    const float* d = dy + row * ly;
+    float v = d[u + pl];
+    if (u >= 1 && u <= pl) v += d[pl - u];
+    if (u >= lx - 1 - pr && u <= lx - 2) v += d[pl + 2 * (lx - 1) - u];
+    dx[i] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// feature matching (feature_loss.py:37-50)
+// ---------------------------------------------------------------------------------------------
+constexpr int FM_MAX_PAIRS = 32;
+constexpr int FM_BLOCKS = 64;
+struct FmTable {
+  const float* a[FM_MAX_PAIRS];
+  const float* b[FM_MAX_PAIRS];
+  float* da[FM_MAX_PAIRS];
+  long long n[FM_MAX_PAIRS];
+};
+
+__global__ __launch_bounds__(256) void fm_partial_kernel(const FmTable T, float* __restrict__ partial) {
+  __shared__ float red[4];
+  const int p = blockIdx.y;
+  const float* a = T.a[p];
+  const float* b = T.b[p];
+  const long long n = T.n[p];
+  float s1 = 0.f, s2 = 0.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)FM_BLOCKS * 256) {
+    const float av = a[i];
+    s1 += fabsf(av - b[i]);
+    s2 += fabsf(av);
+  }
+  s1 = block_sum_256(s1, red);
+  s2 = block_sum_256(s2, red);
+  if (threadIdx.x == 0) {
+    partial[(p * FM_BLOCKS + blockIdx.x) * 2 + 0] = s1;
+    partial[(p * FM_BLOCKS + blockIdx.x) * 2 + 1] = s2;
+  }
+}
+__global__ __launch_bounds__(64) void fm_final_kernel(const float* __restrict__ partial, float* __restrict__ sums) {
+  const int p = blockIdx.x, l = threadIdx.x;
+  float s1 = partial[(p * FM_BLOCKS + l) * 2 + 0], s2 = partial[(p * FM_BLOCKS + l) * 2 + 1];
+  s1 = wave_sum(s1);
+  s2 = wave_sum(s2);
+  if (l == 0) { sums[2 * p] = s1; sums[2 * p + 1] = s2; }
+}
+__global__ __launch_bounds__(256) void fm_bwd_kernel(const FmTable T, const float* __restrict__ sums, const float* __restrict__ gout,
+                                                     float inv_count) {
+  const int p = blockIdx.y;
+  const float* a = T.a[p];
+  const float* b = T.b[p];
+  float* da = T.da[p];
+  const long long n = T.n[p];
+  const float s1 = sums[2 * p], s2 = sums[2 * p + 1];
+  const float gs = gout[0] * inv_count;
+  const float c1 = gs / s2, c2 = gs * s1 / (s2 * s2);
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const float av = a[i], dv = av - b[i];
+    const float sg1 = (dv > 0.f) - (dv < 0.f), sg2 = (av > 0.f) - (av < 0.f);
+    da[i] = c1 * sg1 - c2 * sg2;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// hinge (hinge_loss.py:35-43) and L2 norm
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void hinge_fwd_kernel(const float* __restrict__ x, size_t n, float target, float* __restrict__ out) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (size_t i = threadIdx.x; i < n; i += 256) s += fmaxf(1.f - target * x[i], 0.f);
+  s = block_sum_256(s, red);
+  if (threadIdx.x == 0) out[0] = s / (float)n;
+}
+__global__ __launch_bounds__(256) void hinge_bwd_kernel(const float* __restrict__ x, size_t n, float target,
+                                                        const float* __restrict__ gout, float scale, float* __restrict__ dx) {
+  const float g = gout[0] * scale / (float)n;
+  EBEN_GRID_STRIDE(i, n) dx[i] = (1.f - target * x[i] > 0.f) ? -target * g : 0.f;
+}
+__global__ __launch_bounds__(256) void l2_partial_kernel(const float* __restrict__ x, size_t n, float* __restrict__ partial) {
+  __shared__ float red[4];
+  float s = 0.f;
+  EBEN_GRID_STRIDE(i, n) { const float v = x[i]; s += v * v; }
+  s = block_sum_256(s, red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(64) void l2_final_kernel(const float* __restrict__ partial, int np, float* __restrict__ out) {
+  float s = 0.f;
+  for (int i = threadIdx.x; i < np; i += 64) s += partial[i];
+  s = wave_sum(s);
+  if (threadIdx.x == 0) out[0] = sqrtf(s);
+}
+
+// ---------------------------------------------------------------------------------------------
+// STFT magnitude losses (auraloss STFTLoss: spectral convergence + log-magnitude L1)
+// spec: (rows, 2*bins_pad, frames), re in channel k, im in channel bins_pad+k.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float stft_mag(float re, float im, float eps) { return sqrtf(fmaxf(re * re + im * im, eps)); }
+
+__global__ __launch_bounds__(256) void stft_sums_kernel(const float* __restrict__ sx, const float* __restrict__ sy, int bins,
+                                                        int bins_pad, int frames, float eps, float* __restrict__ out) {
+  __shared__ float red[4];
+  const int r = blockIdx.x;
+  const long long base = (long long)r * 2 * bins_pad * frames;
+  const long long im_off = (long long)bins_pad * frames;
+  const int n = bins * frames;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const float xm = stft_mag(sx[base + i], sx[base + im_off + i], eps);
+    const float ym = stft_mag(sy[base + i], sy[base + im_off + i], eps);
+    const float d = ym - xm;
+    s0 += d * d;
+    s1 += ym * ym;
+    s2 += fabsf(logf(xm) - logf(ym));
+  }
+  s0 = block_sum_256(s0, red);
+  s1 = block_sum_256(s1, red);
+  s2 = block_sum_256(s2, red);
+  if (threadIdx.x == 0) { out[3 * r] = s0; out[3 * r + 1] = s1; out[3 * r + 2] = s2; }
+}
+
+__global__ __launch_bounds__(256) void stft_bwd_kernel(const float* __restrict__ sx, const float* __restrict__ sy, int rows, int bins,
+                                                       int bins_pad, int frames, float eps, const float* __restrict__ sums,
+                                                       const float* __restrict__ gout, float scale, float* __restrict__ dsx) {
+  const int r = blockIdx.y;
+  const long long base = (long long)r * 2 * bins_pad * frames;
+  const long long im_off = (long long)bins_pad * frames;
+  const int n = bins * frames;
+  const float g = gout[0] * scale;
+  const float c_sc = g / ((float)rows * sqrtf(sums[3 * r]) * sqrtf(sums[3 * r + 1]));
+  const float c_lg = g / ((float)rows * (float)bins * (float)frames);
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const float re = sx[base + i], im = sx[base + im_off + i];
+    const float p = re * re + im * im;
+    const float xm = sqrtf(fmaxf(p, eps));
+    const float ym = stft_mag(sy[base + i], sy[base + im_off + i], eps);
+    const float dl = logf(xm) - logf(ym);
+    const float sg = (dl > 0.f) - (dl < 0.f);
+    float dmag = c_sc * (xm - ym) + c_lg * sg / xm;
+    dmag = p >= eps ? dmag / xm : 0.f;   // d sqrt(clamp(p)) / dp * 2  -> (re, im) / mag
+    dsx[base + i] = dmag * re;
+    dsx[base + im_off + i] = dmag * im;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// overlap-add: adjoint of framing a reflect-padded signal (STFT backward).
+// frames_buf (B, win, frames) holds per-frame sample gradients; padded coordinate q receives
+// sum_f buf[q + pad - f*hop, f]; the reflect padding folds q<0 and q>=lx back into [0, lx).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float ola_gather(const float* __restrict__ buf, int q, int win, int frames, int hop, int pad) {
+  const int s = q + pad;  // = f*hop + j
+  if (s < 0) return 0.f;
+  int fmax = s / hop;
+  if (fmax > frames - 1) fmax = frames - 1;
+  int fmin = s - win + 1 <= 0 ? 0 : (s - win + hop) / hop;
+  float acc = 0.f;
+  for (int f = fmin; f <= fmax; ++f) acc += buf[(long long)(s - f * hop) * frames + f];
+  return acc;
+}
+__global__ __launch_bounds__(256) void overlap_add_kernel(const float* __restrict__ buf, float* __restrict__ x, int lx, int win,
+                                                          int frames, int hop, int pad, int reflect, int accumulate) {
+  const int b = blockIdx.y;
+  const float* bb = buf + (long long)b * win * frames;
+  for (int u = blockIdx.x * 256 + threadIdx.x; u < lx; u += gridDim.x * 256) {
+    float v = ola_gather(bb, u, win, frames, hop, pad);
+    if (reflect) {
+      if (u >= 1 && u <= pad) v += ola_gather(bb, -u, win, frames, hop, pad);
+      if (u <= lx - 2 && 2 * (lx - 1) - u <= lx - 1 + pad) v += ola_gather(bb, 2 * (lx - 1) - u, win, frames, hop, pad);
+    }
+    const long long i = (long long)b * lx + u;
+    if (accumulate) v += x[i];
+    x[i] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// multi-tensor Adam (torch.optim.Adam, amsgrad=False, maximize=False; optimizer/adam.yaml:1-9)
+// ---------------------------------------------------------------------------------------------
+constexpr int ADAM_CHUNK = 48;
+struct AdamTable { EbenAdamTensor t[ADAM_CHUNK]; };
+
+__global__ __launch_bounds__(256) void adam_kernel(const AdamTable T, float lr, float beta1, float beta2, float eps, float wd,
+                                                   float bc1, float bc2_sqrt, float grad_scale) {
+  const EbenAdamTensor e = T.t[blockIdx.y];
+  const float step_size = lr / bc1;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < e.numel; i += (long long)gridDim.x * 256) {
+    float g = e.grad[i] * grad_scale;
+    const float p = e.param[i];
+    if (wd != 0.f) g = fmaf(wd, p, g);
+    float m = e.exp_avg[i], v = e.exp_avg_sq[i];
+    m = m + (g - m) * (1.f - beta1);               // exp_avg.lerp_(grad, 1-beta1)
+    v = v * beta2 + (1.f - beta2) * g * g;         // mul_(beta2).addcmul_(g, g, 1-beta2)
+    const float denom = sqrtf(v) / bc2_sqrt + eps;
+    e.param[i] = p - step_size * (m / denom);
+    e.exp_avg[i] = m;
+    e.exp_avg_sq[i] = v;
+  }
+}
+
+static int grid_for(size_t n, int cap = 4096) {
+  size_t b = (n + 255) / 256;
+  if (b > (size_t)cap) b = cap;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+static thread_local char g_err[512] = "";
+char* tls_error_buffer() { return g_err; }
+
+}  // namespace eben
+
+using namespace eben;
+
+extern "C" const char* eben_last_error(void) { return tls_error_buffer(); }
+extern "C" int eben_version(void) { return 1; }
+extern "C" int eben_device_info(char* name, size_t name_bytes) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return -hip_fail(e, "hipGetDevice");
+  hipDeviceProp_t prop;
+  e = hipGetDeviceProperties(&prop, dev);
+  if (e != hipSuccess) return -hip_fail(e, "hipGetDeviceProperties");
+  if (name && name_bytes) { strncpy(name, prop.gcnArchName, name_bytes - 1); name[name_bytes - 1] = 0; }
+  return prop.multiProcessorCount;
+}
+
+extern "C" int eben_fir_decimate(const float* x, const float* w, float* y, int batch, int lx, int ly, int bands, int ntaps,
+                                 int stride, int off0, void* stream) {
+  EBEN_REQUIRE(x && w && y && batch > 0 && lx > 0 && ly > 0 && bands > 0 && ntaps > 0 && stride > 0, "bad fir_decimate arguments");
+  EBEN_REQUIRE(bands * ntaps <= FIR_MAX_W, "fir bank of %d x %d taps exceeds %d", bands, ntaps, FIR_MAX_W);
+  const size_t lds = sizeof(float) * (FIR_MAX_W + (size_t)255 * stride + ntaps);
+  EBEN_REQUIRE(lds <= 64 * 1024, "fir_decimate stride %d too large", stride);
+  hipLaunchKernelGGL(fir_decimate_kernel, dim3(ceil_div(ly, 256), batch), dim3(256), lds, as_stream(stream), x, w, y, lx, ly,
+                     bands, ntaps, stride, off0);
+  EBEN_CHECK_LAUNCH("fir_decimate_kernel");
+  return EBEN_OK;
+}
+
+extern "C" int eben_fir_interp_sum(const float* y, const float* w, float* x, int batch, int lx, int ly, int bands, int ntaps,
+                                   int stride, int off0, void* stream) {
+  EBEN_REQUIRE(x && w && y && batch > 0 && lx > 0 && ly > 0 && bands > 0 && ntaps > 0 && stride > 0, "bad fir_interp_sum arguments");
+  EBEN_REQUIRE(bands * ntaps <= FIR_MAX_W, "fir bank of %d x %d taps exceeds %d", bands, ntaps, FIR_MAX_W);
+  const int tile_t = (255 + ntaps - 1) / stride + 3;
+  const size_t lds = sizeof(float) * (FIR_MAX_W + (size_t)bands * tile_t);
+  EBEN_REQUIRE(lds <= 64 * 1024, "fir_interp_sum tile too large");
+  hipLaunchKernelGGL(fir_interp_sum_kernel, dim3(ceil_div(lx, 256), batch), dim3(256), lds, as_stream(stream), y, w, x, lx, ly,
+                     bands, ntaps, stride, off0, tile_t);
+  EBEN_CHECK_LAUNCH("fir_interp_sum_kernel");
+  return EBEN_OK;
+}
+
+extern "C" int eben_lrelu_fwd(const float* x, float* y, size_t n, float slope, void* stream) {
+  EBEN_REQUIRE(x && y, "null pointer");
+  if (n == 0) return EBEN_OK;
+  hipLaunchKernelGGL(lrelu_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), x, y, n, slope);
+  EBEN_CHECK_LAUNCH("lrelu_fwd_kernel");
+  return EBEN_OK;
+}
+extern "C" int eben_lrelu_bwd(const float* dy, const float* ref, float* dx, size_t n, float slope, void* stream) {
+  EBEN_REQUIRE(dy && ref && dx, "null pointer");
+  if (n == 0) return EBEN_OK;
+  hipLaunchKernelGGL(lrelu_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), dy, ref, dx, n, slope);
+  EBEN_CHECK_LAUNCH("lrelu_bwd_kernel");
+  return EBEN_OK;
+}
+extern "C" int eben_add(const float* a, const float* b, float* out, size_t n, void* stream) {
+  EBEN_REQUIRE(a && b && out, "null pointer");
+  if (n == 0) return EBEN_OK;
+  hipLaunchKernelGGL(add_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), a, b, out, n);
+  EBEN_CHECK_LAUNCH("add_kernel");
+  return EBEN_OK;
+}
+extern "C" int eben_axpby(const float* a, float alpha, const float* b, float beta, float* out, size_t n, void* stream) {
+  EBEN_REQUIRE(a && b && out, "null pointer");
+  if (n == 0) return EBEN_OK;
+  hipLaunchKernelGGL(axpby_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), a, alpha, b, beta, out, n);
+  EBEN_CHECK_LAUNCH("axpby_kernel");
+  return EBEN_OK;
+}
+extern "C" int eben_tanh_lift_fwd(const float* x, const float* lift, float* out, int batch, int channels, int c_lift, int length, void* stream) {
+  EBEN_REQUIRE(x && out && batch > 0 && channels > 0 && length > 0 && c_lift >= 0 && c_lift <= channels, "bad tanh_lift arguments");
+  EBEN_REQUIRE(c_lift == 0 || lift, "null lift");
+  const size_t n = (size_t)batch * channels * length;
+  hipLaunchKernelGGL(tanh_lift_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), x, lift, out, channels, c_lift, length, n);
+  EBEN_CHECK_LAUNCH("tanh_lift_kernel");
+  return EBEN_OK;
+}
+extern "C" int eben_tanh_bwd(const float* dout, const float* out, float* dx, size_t n, void* stream) {
+  EBEN_REQUIRE(dout && out && dx, "null pointer");
+  if (n == 0) return EBEN_OK;
+  hipLaunchKernelGGL(tanh_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), dout, out, dx, n);
+  EBEN_CHECK_LAUNCH("tanh_bwd_kernel");
+  return EBEN_OK;
+}
+extern "C" int eben_reflect_pad_fwd(const float* x, float* y, int rows, int lx, int pad_l, int pad_r, void* stream) {
+  EBEN_REQUIRE(x && y && rows > 0 && lx > 0 && pad_l >= 0 && pad_r >= 0 && pad_l < lx && pad_r < lx, "bad reflect_pad arguments");
+  const size_t n = (size_t)rows * (lx + pad_l + pad_r);
+  hipLaunchKernelGGL(reflect_pad_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), x, y, (size_t)rows, lx, pad_l, pad_r);
+  EBEN_CHECK_LAUNCH("reflect_pad_fwd_kernel");
+  return EBEN_OK;
+}
+extern "C" int eben_reflect_pad_bwd(const float* dy, float* dx, int rows, int lx, int pad_l, int pad_r, void* stream) {
+  EBEN_REQUIRE(dy && dx && rows > 0 && lx > 0 && pad_l >= 0 && pad_r >= 0 && pad_l < lx && pad_r < lx, "bad reflect_pad arguments");
+  const size_t n = (size_t)rows * lx;
+  hipLaunchKernelGGL(reflect_pad_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), dy, dx, (size_t)rows, lx, pad_l, pad_r);
+  EBEN_CHECK_LAUNCH("reflect_pad_bwd_kernel");
+  return EBEN_OK;
+}
+
+extern "C" size_t eben_fm_sums_workspace(int npairs) { return sizeof(float) * 2 * FM_BLOCKS * (size_t)(npairs > 0 ? npairs : 0); }
+
+static int fill_fm_table(FmTable* T, const void* const* ptrs, void* const* da, const int64_t* numel, int p0, int cnt) {
+  for (int i = 0; i < cnt; ++i) {
+    T->a[i] = static_cast<const float*>(ptrs[2 * (p0 + i)]);
+    T->b[i] = static_cast<const float*>(ptrs[2 * (p0 + i) + 1]);
+    T->da[i] = da ? static_cast<float*>(da[p0 + i]) : nullptr;
+    T->n[i] = numel[p0 + i];
+    if (!T->a[i] || !T->b[i] || T->n[i] <= 0) return fail(EBEN_EINVAL, "feature-matching pair %d is null or empty", p0 + i);
+  }
+  return EBEN_OK;
+}
+
+extern "C" int eben_fm_sums(const void* const* ptrs, const int64_t* numel, int npairs, float* partial_ws, size_t ws_bytes,
+                            float* sums, void* stream) {
+  EBEN_REQUIRE(ptrs && numel && npairs > 0 && partial_ws && sums, "bad fm_sums arguments");
+  if (ws_bytes < eben_fm_sums_workspace(npairs)) return fail(EBEN_EWORKSPACE, "fm_sums workspace too small");
+  for (int p0 = 0; p0 < npairs; p0 += FM_MAX_PAIRS) {
+    const int cnt = npairs - p0 < FM_MAX_PAIRS ? npairs - p0 : FM_MAX_PAIRS;
+    FmTable T;
+    int rc = fill_fm_table(&T, ptrs, nullptr, numel, p0, cnt);
+    if (rc) return rc;
+    float* part = partial_ws + (size_t)p0 * FM_BLOCKS * 2;
+    hipLaunchKernelGGL(fm_partial_kernel, dim3(FM_BLOCKS, cnt), dim3(256), 0, as_stream(stream), T, part);
+    EBEN_CHECK_LAUNCH("fm_partial_kernel");
+    hipLaunchKernelGGL(fm_final_kernel, dim3(cnt), dim3(64), 0, as_stream(stream), part, sums + 2 * p0);
+    EBEN_CHECK_LAUNCH("fm_final_kernel");
+  }
+  return EBEN_OK;
+}
+
+extern "C" int eben_fm_bwd(const void* const* ptrs, void* const* da_ptrs, const int64_t* numel, int npairs, const float* sums,
+                           const float* gout, float inv_count, void* stream) {
+  EBEN_REQUIRE(ptrs && da_ptrs && numel && npairs > 0 && sums && gout, "bad fm_bwd arguments");
+  for (int p0 = 0; p0 < npairs; p0 += FM_MAX_PAIRS) {
+    const int cnt = npairs - p0 < FM_MAX_PAIRS ? npairs - p0 : FM_MAX_PAIRS;
+    FmTable T;
+    int rc = fill_fm_table(&T, ptrs, da_ptrs, numel, p0, cnt);
+    if (rc) return rc;
+    long long mx = 0;
+    for (int i = 0; i < cnt; ++i) { if (T.n[i] > mx) mx = T.n[i]; if (!T.da[i]) return fail(EBEN_EINVAL, "null gradient buffer"); }
+    hipLaunchKernelGGL(fm_bwd_kernel, dim3(grid_for((size_t)mx, 1024), cnt), dim3(256), 0, as_stream(stream), T, sums + 2 * p0, gout, inv_count);
+    EBEN_CHECK_LAUNCH("fm_bwd_kernel");
+  }
+  return EBEN_OK;
+}
+
+extern "C" int eben_hinge_fwd(const float* x, size_t n, float target, float* out, void* stream) {
+  EBEN_REQUIRE(x && out && n > 0, "bad hinge arguments");
+  hipLaunchKernelGGL(hinge_fwd_kernel, dim3(1), dim3(256), 0, as_stream(stream), x, n, target, out);
+  EBEN_CHECK_LAUNCH("hinge_fwd_kernel");
+  return EBEN_OK;
+}
+extern "C" int eben_hinge_bwd(const float* x, size_t n, float target, const float* gout, float scale, float* dx, void* stream) {
+  EBEN_REQUIRE(x && gout && dx && n > 0, "bad hinge arguments");
+  hipLaunchKernelGGL(hinge_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), x, n, target, gout, scale, dx);
+  EBEN_CHECK_LAUNCH("hinge_bwd_kernel");
+  return EBEN_OK;
+}
+
+extern "C" int eben_l2norm(const float* x, size_t n, float* out, void* stream) {
+  // out doubles as scratch for up to 256 partials: caller passes >= 257 floats, result in out[0]
+  EBEN_REQUIRE(x && out && n > 0, "bad l2norm arguments");
+  const int nb = grid_for(n, 256);
+  hipLaunchKernelGGL(l2_partial_kernel, dim3(nb), dim3(256), 0, as_stream(stream), x, n, out + 1);
+  EBEN_CHECK_LAUNCH("l2_partial_kernel");
+  hipLaunchKernelGGL(l2_final_kernel, dim3(1), dim3(64), 0, as_stream(stream), out + 1, nb, out);
+  EBEN_CHECK_LAUNCH("l2_final_kernel");
+  return EBEN_OK;
+}
+
+extern "C" int eben_stft_loss_sums(const float* spec_x, const float* spec_y, int rows, int bins, int bins_pad, int frames,
+                                   float eps, float* out, void* stream) {
+  EBEN_REQUIRE(spec_x && spec_y && out && rows > 0 && bins > 0 && bins_pad >= bins && frames > 0, "bad stft_loss arguments");
+  hipLaunchKernelGGL(stft_sums_kernel, dim3(rows), dim3(256), 0, as_stream(stream), spec_x, spec_y, bins, bins_pad, frames, eps, out);
+  EBEN_CHECK_LAUNCH("stft_sums_kernel");
+  return EBEN_OK;
+}
+extern "C" int eben_stft_loss_bwd(const float* spec_x, const float* spec_y, int rows, int bins, int bins_pad, int frames,
+                                  float eps, const float* sums, const float* gout, float scale, float* dspec_x, void* stream) {
+  EBEN_REQUIRE(spec_x && spec_y && sums && gout && dspec_x && rows > 0 && bins > 0 && bins_pad >= bins && frames > 0, "bad stft_loss arguments");
+  const int nb = grid_for((size_t)bins * frames, 64);
+  hipLaunchKernelGGL(stft_bwd_kernel, dim3(nb, rows), dim3(256), 0, as_stream(stream), spec_x, spec_y, rows, bins, bins_pad, frames,
+                     eps, sums, gout, scale, dspec_x);
+  EBEN_CHECK_LAUNCH("stft_bwd_kernel");
+  return EBEN_OK;
+}
+
+extern "C" int eben_overlap_add(const float* frames_buf, float* x, int batch, int lx, int win, int frames, int hop, int pad,
+                                int reflect, int accumulate, void* stream) {
+  EBEN_REQUIRE(frames_buf && x && batch > 0 && lx > 0 && win > 0 && frames > 0 && hop > 0 && pad >= 0, "bad overlap_add arguments");
+  EBEN_REQUIRE(!reflect || pad < lx, "reflect padding must be smaller than the signal");
+  hipLaunchKernelGGL(overlap_add_kernel, dim3(grid_for((size_t)lx, 256), batch), dim3(256), 0, as_stream(stream), frames_buf, x, lx,
+                     win, frames, hop, pad, reflect, accumulate);
+  EBEN_CHECK_LAUNCH("overlap_add_kernel");
+  return EBEN_OK;
+}
+
+extern "C" int eben_adam_step(const EbenAdamTensor* table, int ntensors, int64_t max_numel, float lr, float beta1, float beta2,
+                              float eps, float weight_decay, int step, float grad_scale, void* stream) {
+  EBEN_REQUIRE(table && ntensors > 0 && step > 0, "bad adam arguments");
+  const double bc1 = 1.0 - pow((double)beta1, step);
+  const double bc2 = 1.0 - pow((double)beta2, step);
+  for (int p0 = 0; p0 < ntensors; p0 += ADAM_CHUNK) {
+    const int cnt = ntensors - p0 < ADAM_CHUNK ? ntensors - p0 : ADAM_CHUNK;
+    AdamTable T;
+    int64_t mx = 1;
+    for (int i = 0; i < cnt; ++i) {
+      T.t[i] = table[p0 + i];
+      if (!T.t[i].param || !T.t[i].grad || !T.t[i].exp_avg || !T.t[i].exp_avg_sq || T.t[i].numel <= 0)
+        return fail(EBEN_EINVAL, "adam tensor %d is null or empty", p0 + i);
+      if (T.t[i].numel > mx) mx = T.t[i].numel;
+    }
+    (void)max_numel;
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for((size_t)mx, 2048), cnt), dim3(256), 0, as_stream(stream), T, lr, beta1, beta2, eps,
+                       weight_decay, (float)bc1, (float)sqrt(bc2), grad_scale);
+    EBEN_CHECK_LAUNCH("adam_kernel");
+  }
+  return EBEN_OK;
+}

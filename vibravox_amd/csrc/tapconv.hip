@@ -1,0 +1,550 @@
+// tapconv.hip -- the MFMA implicit-GEMM "tap convolution" of libeben_hip.so (gfx950).
+//
+// One kernel covers the two directions of every Conv1d / ConvTranspose1d of the EBEN generator
+// and discriminators (reference call sites: eben_generator.py:112-166,241-249,272-280,295-312;
+// eben_discriminator.py:66-157; melgan_discriminator.py:89-156) and the STFT of the
+// multi-resolution spectral loss (a strided conv against a windowed DFT basis):
+//
+//   y[b, g*Mg+m, t*OS+oo] = epi( sum_{c<Cg} sum_{j<J} Wp[j,c,m] * xin(b, g*Cg+c, t*S + off0 + j*dstep) )
+//
+//   GS ("gather-strided", S = conv stride, OS = 1): Conv1d forward / ConvTranspose1d input-gradient.
+//   PS ("phase-scatter",  S = 1, OS = conv stride): Conv1d input-gradient / ConvTranspose1d forward,
+//        one stride-1 sub-convolution per output phase r = u mod stride (taps k with
+//        (r + pad - k*dil) % stride == 0), so no zero-stuffed MACs are ever issued.
+//
+// GEMM view per (batch item, group): M = output channels, N = output positions, K = (tap, channel).
+// fp32 in / fp32 accumulate on v_mfma_f32_16x16x4_f32 (exact fp32, 157 TFLOP/s chip peak).
+//   * the input tile (CI_T channels x receptive span) is staged once per channel chunk in LDS,
+//     de-interleaved by stride phase so that the 16 lanes of a B fragment read consecutive
+//     dwords whatever the stride (conflict-free ds_read_b32);
+//   * weights arrive pre-packed [phase][group][chunk][k][Mpad] (weight-norm scale folded in by
+//     the pack kernel), so the A tile is a straight float4 copy, register-prefetched one chunk
+//     ahead of the MFMAs;
+//   * LeakyReLU on load, bias / LeakyReLU / residual / activation-derivative mask in the epilogue;
+//   * blockIdx -> tile mapping is XCD-aware (tiles sharing a weight panel stay on one XCD's L2).
+#include "common.h"
+
+namespace eben {
+
+struct TapArgs {
+  const float* x;
+  const float* xmask;
+  const float* wp;
+  const float* bias;
+  const float* res;
+  const float* emask;
+  float* y;
+  int B, G, Cg, Mg, Mp, Cx, Cy, Lx, Ly;
+  int S, OS, dstep, J, KCpad, CI_T, ncc;
+  int mode;              // 0 GS, 1 PS
+  int off0, nt;          // GS
+  int ps_pad, ps_k, ps_d, ps_kstep;  // PS
+  int reflect, in_mode;  // in_mode 0: lrelu(x, in_slope); 1: x * lrelu'(xmask, in_slope)
+  float in_slope, out_slope, res_slope, emask_slope;
+  int accumulate;
+  int PLEN, CSTRIDE;
+  unsigned s_magic;      // ceil(2^32 / S)
+  int ntt, nmt, nph;
+  long long phase_stride;
+};
+
+template <int WAVES_M, int WAVES_N, int FM, int FN>
+__global__ __launch_bounds__(256) void tapconv_kernel(const TapArgs P) {
+  constexpr int BM = WAVES_M * FM * 16;
+  constexpr int BN = WAVES_N * FN * 16;
+  constexpr int KT = 4096 / BM;         // rows of the staged weight chunk
+  constexpr int WSTR = BM + 16;         // +16: the 2 k-rows of a half-wave hit disjoint banks
+  constexpr int W4_PER_ROW = BM / 4;
+  constexpr int W4_PER_THREAD = KT * BM / 4 / 256;
+  static_assert(WAVES_M * WAVES_N == 4, "4 waves per block");
+  static_assert(W4_PER_THREAD == 4, "weight chunk is 4096 floats");
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  int* koff = reinterpret_cast<int*>(smem);
+  float* Ws = smem + P.KCpad;                 // KCpad is a multiple of 4 -> 16 B aligned
+  float* Xs = Ws + KT * WSTR;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, kk = lane >> 4;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+  // ---- tile decode (XCD-aware) ----
+  unsigned id = xcd_remap(blockIdx.x, gridDim.x);
+  const int tt = id % P.ntt; id /= P.ntt;
+  const int b = id % P.B; id /= P.B;
+  const int ph = id % P.nph; id /= P.nph;
+  const int mt = id % P.nmt;
+  const int g = id / P.nmt;
+  const int t0 = tt * BN, m0 = mt * BM;
+
+  // ---- per-phase tap geometry ----
+  int J = P.J, off0 = P.off0, nt = P.nt, oo = 0;
+  if (P.mode == 1) {
+    const int s = P.OS;
+    int k0 = -1;
+    for (int c = 0; c < P.ps_kstep; ++c) {
+      int v = (ph + P.ps_pad - c * P.ps_d) % s;
+      if (v < 0) v += s;
+      if (v == 0) { k0 = c; break; }
+    }
+    if (k0 >= 0 && k0 < P.ps_k) {
+      J = (P.ps_k - 1 - k0) / P.ps_kstep + 1;
+      off0 = (ph + P.ps_pad - k0 * P.ps_d) / s;
+    } else {
+      J = 0;
+      off0 = 0;
+    }
+    nt = ph < P.Ly ? (P.Ly - ph + s - 1) / s : 0;
+    oo = ph;
+  }
+  if (t0 >= nt) return;  // whole block is outside this phase's range (uniform)
+  const int minoff = (P.dstep >= 0 || J == 0) ? off0 : off0 + (J - 1) * P.dstep;
+  const int adstep = P.dstep >= 0 ? P.dstep : -P.dstep;
+  const int span = J > 0 ? (BN - 1) * P.S + (J - 1) * adstep + 1 : 0;
+  const int KC = ((J * P.CI_T + 3) >> 2) << 2;  // flat K entries actually used by this phase
+
+  for (int f = tid; f < P.KCpad; f += 256) {
+    const int j = f / P.CI_T, cl = f - j * P.CI_T;
+    int o = 0;
+    if (j < J) {
+      const int rel = off0 + j * P.dstep - minoff;
+      int p = 0, dd = rel;
+      if (P.S != 1) { dd = (int)__umulhi((unsigned)rel, P.s_magic); p = rel - dd * P.S; }
+      o = cl * P.CSTRIDE + p * P.PLEN + dd;
+    }
+    koff[f] = o;
+  }
+
+  f32x4 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int n = 0; n < FN; ++n) acc[i][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const float* wbase = P.wp + (long long)ph * P.phase_stride + (long long)g * P.ncc * P.KCpad * P.Mp + m0;
+  const int q0 = t0 * P.S + minoff;
+  const int nkc = (KC + KT - 1) / KT;
+
+  for (int cc = 0; cc < P.ncc && J > 0; ++cc) {
+    __syncthreads();  // previous chunk's MFMAs are done with Xs / Ws (and koff is published)
+    // ---- stage the input tile of CI_T channels, de-interleaved by stride phase ----
+    for (int c = 0; c < P.CI_T; ++c) {
+      const int chan = cc * P.CI_T + c;
+      const bool cv = chan < P.Cg;
+      const long long row = ((long long)b * P.Cx + (long long)g * P.Cg + chan) * P.Lx;
+      const float* xr = P.x + row;
+      float* xs = Xs + c * P.CSTRIDE;
+      for (int r = tid; r < span; r += 256) {
+        int q = q0 + r;
+        if (P.reflect) {
+          q = q < 0 ? -q : q;
+          q = q >= P.Lx ? 2 * (P.Lx - 1) - q : q;
+        }
+        float v = 0.f;
+        if (cv && q >= 0 && q < P.Lx) {
+          v = xr[q];
+          if (P.in_mode == 0) v = lrelu(v, P.in_slope);
+          else v *= dlrelu(P.xmask[row + q], P.in_slope);
+        }
+        int p = 0, i = r;
+        if (P.S != 1) { i = (int)__umulhi((unsigned)r, P.s_magic); p = r - i * P.S; }
+        xs[p * P.PLEN + i] = v;
+      }
+    }
+    // ---- weight chunks: register prefetch one chunk ahead ----
+    const float* wcc = wbase + (long long)cc * P.KCpad * P.Mp;
+    float4 wreg[W4_PER_THREAD];
+    auto prefetch = [&](int kc) {
+      const int rows = min(KT, KC - kc * KT);
+#pragma unroll
+      for (int u = 0; u < W4_PER_THREAD; ++u) {
+        const int i4 = tid + u * 256;
+        const int rrow = i4 / W4_PER_ROW, c4 = i4 - rrow * W4_PER_ROW;
+        wreg[u] = rrow < rows
+                      ? *reinterpret_cast<const float4*>(wcc + (long long)(kc * KT + rrow) * P.Mp + c4 * 4)
+                      : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    };
+    prefetch(0);
+    for (int kc = 0; kc < nkc; ++kc) {
+      if (kc > 0) __syncthreads();  // MFMAs of the previous chunk finished reading Ws
+#pragma unroll
+      for (int u = 0; u < W4_PER_THREAD; ++u) {
+        const int i4 = tid + u * 256;
+        const int rrow = i4 / W4_PER_ROW, c4 = i4 - rrow * W4_PER_ROW;
+        *reinterpret_cast<float4*>(Ws + rrow * WSTR + c4 * 4) = wreg[u];
+      }
+      __syncthreads();
+      if (kc + 1 < nkc) prefetch(kc + 1);
+      const int rows = min(KT, KC - kc * KT);
+      const float* wrow = Ws + kk * WSTR + wm * FM * 16 + l15;
+      const int* ko = koff + kc * KT + kk;
+      const float* xcol = Xs + wn * FN * 16 + l15;
+      for (int ks = 0; ks < rows; ks += 4) {
+        float a[FM], bv[FN];
+        const int xo = ko[ks];
+#pragma unroll
+        for (int i = 0; i < FM; ++i) a[i] = wrow[ks * WSTR + i * 16];
+#pragma unroll
+        for (int n = 0; n < FN; ++n) bv[n] = xcol[xo + n * 16];
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int n = 0; n < FN; ++n)
+            acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], bv[n], acc[i][n], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- epilogue: D fragment = 4 consecutive rows (m) x 1 column (t) per lane ----
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = m0 + wm * FM * 16 + i * 16 + kk * 4 + r;
+      if (m >= P.Mg) continue;
+      const float bias = P.bias ? P.bias[g * P.Mg + m] : 0.f;
+      const long long yrow = ((long long)b * P.Cy + (long long)g * P.Mg + m) * P.Ly;
+#pragma unroll
+      for (int n = 0; n < FN; ++n) {
+        const int t = t0 + wn * FN * 16 + n * 16 + l15;
+        if (t >= nt) continue;
+        const long long idx = yrow + (long long)t * P.OS + oo;
+        float v = acc[i][n][r] + bias;
+        v = lrelu(v, P.out_slope);
+        if (P.res) v += lrelu(P.res[idx], P.res_slope);
+        if (P.emask) v *= dlrelu(P.emask[idx], P.emask_slope);
+        if (P.accumulate) v += P.y[idx];
+        P.y[idx] = v;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// host side: canonical conv, plans, launchers
+// ---------------------------------------------------------------------------------------
+
+int canon_from_desc(const EbenConv1dDesc* d, Canon* c) {
+  EBEN_REQUIRE(d != nullptr, "null conv descriptor");
+  EBEN_REQUIRE(d->batch > 0 && d->c_in > 0 && d->c_out > 0 && d->l_in > 0 && d->l_out > 0, "non-positive conv dims");
+  EBEN_REQUIRE(d->ksize > 0 && d->stride > 0 && d->dilation > 0 && d->groups > 0, "non-positive conv params");
+  EBEN_REQUIRE(d->c_in % d->groups == 0 && d->c_out % d->groups == 0, "channels not divisible by groups");
+  EBEN_REQUIRE(d->stride <= 1024 && d->pad_l >= 0 && d->pad_r >= 0, "bad stride / padding");
+  c->B = d->batch; c->k = d->ksize; c->s = d->stride; c->d = d->dilation; c->g = d->groups;
+  c->pl = d->pad_l; c->pr = d->pad_r;
+  if (!d->transposed) {
+    c->Cin = d->c_in; c->Cout = d->c_out; c->Lin = d->l_in; c->Lout = d->l_out;
+    c->reflect = d->pad_mode == EBEN_PAD_REFLECT;
+    const int expect = (d->l_in + d->pad_l + d->pad_r - d->dilation * (d->ksize - 1) - 1) / d->stride + 1;
+    EBEN_REQUIRE(expect == d->l_out, "Conv1d l_out %d does not match the expected %d", d->l_out, expect);
+    if (c->reflect) EBEN_REQUIRE(d->pad_l < d->l_in && d->pad_r < d->l_in, "reflect padding must be smaller than the input");
+  } else {
+    EBEN_REQUIRE(d->pad_mode == EBEN_PAD_ZERO, "ConvTranspose1d only supports zero padding");
+    c->Cin = d->c_out; c->Cout = d->c_in; c->Lin = d->l_out; c->Lout = d->l_in;
+    c->reflect = 0;
+    c->pr = d->pad_l;
+    // l_out = (l_in-1)*s - 2p + d(k-1) + output_padding + 1 with 0 <= output_padding < s
+    const int base = (d->l_in - 1) * d->stride - 2 * d->pad_l + d->dilation * (d->ksize - 1) + 1;
+    EBEN_REQUIRE(d->l_out >= base && d->l_out < base + d->stride, "ConvTranspose1d l_out %d outside [%d,%d)", d->l_out, base, base + d->stride);
+  }
+  return EBEN_OK;
+}
+
+static int gcd_i(int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a; }
+
+struct TapPlan {
+  int mode;  // 0 GS, 1 PS
+  int Cg, Mg, G, CI_T, ncc, J, KCpad, Mp, cfg, BM, BN;
+  int S, OS, dstep, kstep, nph, PLEN, CSTRIDE;
+  int Lx, Ly, Cx, Cy, off0, nt, ps_pad;
+  int ntt, nmt;
+  size_t lds_bytes;
+  long long phase_stride;
+  size_t packed_floats;
+};
+
+static const int kCfgBM[6] = {128, 64, 32, 16, 32, 16};
+static const int kCfgBN[6] = {128, 128, 256, 256, 128, 128};
+
+static void choose_tile(int Mg, int nt_max, int* cfg) {
+  // largest BM with <= 12.5 % padding waste, else the least wasteful
+  const int cand[4] = {128, 64, 32, 16};
+  int best = -1;
+  double best_waste = 1e9;
+  for (int i = 0; i < 4; ++i) {
+    const double waste = (double)round_up(Mg, cand[i]) / Mg;
+    if (waste <= 1.125) { best = i; break; }
+    if (waste < best_waste - 1e-9) { best_waste = waste; best = i; }
+  }
+  int c = best;  // 0:128x128 1:64x128 2:32x256 3:16x256
+  if (c == 2 && nt_max <= 128) c = 4;
+  if (c == 3 && nt_max <= 128) c = 5;
+  *cfg = c;
+}
+
+// dir 0: canonical forward direction (GS); dir 1: canonical input-gradient direction (PS).
+// For PS with reflect padding the output domain is the padded one (caller folds afterwards).
+static void make_plan(const Canon& c, int dir, TapPlan* p) {
+  p->mode = dir;
+  p->G = c.g;
+  if (dir == 0) {
+    p->Cg = c.Cin / c.g; p->Mg = c.Cout / c.g;
+    p->S = c.s; p->OS = 1; p->dstep = c.d; p->kstep = 1; p->nph = 1; p->J = c.k;
+    p->Lx = c.Lin; p->Ly = c.Lout; p->Cx = c.Cin; p->Cy = c.Cout;
+    p->off0 = -c.pl; p->nt = c.Lout; p->ps_pad = 0;
+  } else {
+    p->Cg = c.Cout / c.g; p->Mg = c.Cin / c.g;
+    p->S = 1; p->OS = c.s;
+    p->kstep = c.s / gcd_i(c.s, c.d);
+    p->dstep = -(c.d * p->kstep) / c.s;
+    p->nph = c.s;
+    p->J = ceil_div(c.k, p->kstep);
+    p->Lx = c.Lout; p->Cx = c.Cout; p->Cy = c.Cin;
+    p->Ly = c.reflect ? c.Lin + c.pl + c.pr : c.Lin;
+    p->ps_pad = c.reflect ? 0 : c.pl;
+    p->off0 = 0; p->nt = ceil_div(p->Ly, c.s);
+  }
+  choose_tile(p->Mg, p->nt, &p->cfg);
+  p->BM = kCfgBM[p->cfg]; p->BN = kCfgBN[p->cfg];
+  p->Mp = round_up(p->Mg, p->BM);
+  p->nmt = p->Mp / p->BM;
+  p->ntt = ceil_div(p->nt, p->BN);
+  // channel chunk: <=16 channels, evenly split; shrink while the tile does not fit 96 KiB of LDS
+  int nch = ceil_div(p->Cg, 16);
+  int ci = p->Cg % nch == 0 ? p->Cg / nch : 16;
+  if (p->Cg <= 16) ci = p->Cg;
+  const int adstep = p->dstep >= 0 ? p->dstep : -p->dstep;
+  const int KT = 4096 / p->BM;
+  for (;;) {
+    const int maxd = ((p->J - 1) * adstep) / p->S + 1;
+    p->PLEN = p->BN + maxd + 1;
+    p->CSTRIDE = round_up(p->S * p->PLEN, 32) + 16;
+    p->CI_T = ci;
+    p->KCpad = round_up(p->J * ci, 4);
+    p->lds_bytes = 4ull * ((size_t)p->KCpad + (size_t)KT * (p->BM + 16) + (size_t)ci * p->CSTRIDE);
+    if (p->lds_bytes <= 96 * 1024 || ci == 1) break;
+    ci = ci > 8 ? 8 : ci / 2;
+    if (ci < 1) ci = 1;
+  }
+  p->ncc = ceil_div(p->Cg, p->CI_T);
+  p->phase_stride = (long long)p->G * p->ncc * p->KCpad * p->Mp;
+  p->packed_floats = (size_t)p->phase_stride * p->nph;
+}
+
+// ---- weight packing -----------------------------------------------------------------------
+struct PackArgs {
+  const float* w;      // canonical (Cout, Cin/g, k)
+  const float* scale;  // per Cout row or null
+  float* wp;
+  int G, Cg, Mg, Mp, CI_T, ncc, KCpad, J, nph;
+  int mode, k, s, d, kstep, ps_pad, Cin_g, Cout_g;
+  long long phase_stride;
+};
+
+__global__ __launch_bounds__(256) void pack_kernel(const PackArgs P) {
+  const long long total = P.phase_stride * P.nph;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    long long r = i;
+    const int m = r % P.Mp; r /= P.Mp;
+    const int f = r % P.KCpad; r /= P.KCpad;
+    const int cc = r % P.ncc; r /= P.ncc;
+    const int g = r % P.G;
+    const int ph = r / P.G;
+    const int j = f / P.CI_T, cl = f - j * P.CI_T;
+    const int chan = cc * P.CI_T + cl;
+    float v = 0.f;
+    if (m < P.Mg && chan < P.Cg && j < P.J) {
+      if (P.mode == 0) {
+        // reduction channel = conv input channel, m = conv output channel, tap j
+        const int co = g * P.Cout_g + m;
+        v = P.w[((long long)co * P.Cin_g + chan) * P.k + j];
+        if (P.scale) v *= P.scale[co];
+      } else {
+        int k0 = -1;
+        for (int c = 0; c < P.kstep; ++c) {
+          int q = (ph + P.ps_pad - c * P.d) % P.s;
+          if (q < 0) q += P.s;
+          if (q == 0) { k0 = c; break; }
+        }
+        const int kk = k0 + j * P.kstep;
+        if (k0 >= 0 && kk < P.k) {
+          const int co = g * P.Cout_g + chan;  // reduction channel = conv output channel
+          v = P.w[((long long)co * P.Cin_g + m) * P.k + kk];
+          if (P.scale) v *= P.scale[co];
+        }
+      }
+    }
+    P.wp[i] = v;
+  }
+}
+
+static int launch_pack(const Canon& c, const TapPlan& p, const float* w, const float* scale, float* wp, hipStream_t st) {
+  PackArgs a;
+  a.w = w; a.scale = scale; a.wp = wp;
+  a.G = p.G; a.Cg = p.Cg; a.Mg = p.Mg; a.Mp = p.Mp; a.CI_T = p.CI_T; a.ncc = p.ncc; a.KCpad = p.KCpad; a.J = p.J; a.nph = p.nph;
+  a.mode = p.mode; a.k = c.k; a.s = c.s; a.d = c.d; a.kstep = p.kstep; a.ps_pad = p.ps_pad;
+  a.Cin_g = c.Cin / c.g; a.Cout_g = c.Cout / c.g;
+  a.phase_stride = p.phase_stride;
+  const long long total = p.phase_stride * p.nph;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(pack_kernel, dim3(blocks), dim3(256), 0, st, a);
+  EBEN_CHECK_LAUNCH("pack_kernel");
+  return EBEN_OK;
+}
+
+// ---- tapconv launcher -----------------------------------------------------------------------
+struct TapIO {
+  const float* x; const float* xmask; int in_mode; float in_slope;
+  const float* wp; const float* bias; const float* res; float res_slope;
+  const float* emask; float emask_slope; float out_slope; float* y; int accumulate;
+};
+
+template <int WM, int WN, int FM, int FN>
+static int launch_cfg(const TapArgs& a, int nblocks, size_t lds, hipStream_t st) {
+  static bool attr_set = false;
+  auto kern = tapconv_kernel<WM, WN, FM, FN>;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(tapconv)");
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), lds, st, a);
+  EBEN_CHECK_LAUNCH("tapconv_kernel");
+  return EBEN_OK;
+}
+
+static int launch_tap(const Canon& c, const TapPlan& p, const TapIO& io, int reflect, hipStream_t st) {
+  if (p.lds_bytes > 160 * 1024) return fail(EBEN_EUNSUPPORTED, "tapconv tile needs %zu B of LDS", p.lds_bytes);
+  TapArgs a;
+  a.x = io.x; a.xmask = io.xmask; a.wp = io.wp; a.bias = io.bias; a.res = io.res; a.emask = io.emask; a.y = io.y;
+  a.B = c.B; a.G = p.G; a.Cg = p.Cg; a.Mg = p.Mg; a.Mp = p.Mp; a.Cx = p.Cx; a.Cy = p.Cy; a.Lx = p.Lx; a.Ly = p.Ly;
+  a.S = p.S; a.OS = p.OS; a.dstep = p.dstep; a.J = p.J; a.KCpad = p.KCpad; a.CI_T = p.CI_T; a.ncc = p.ncc;
+  a.mode = p.mode; a.off0 = p.off0; a.nt = p.nt;
+  a.ps_pad = p.ps_pad; a.ps_k = c.k; a.ps_d = c.d; a.ps_kstep = p.kstep;
+  a.reflect = reflect; a.in_mode = io.in_mode;
+  a.in_slope = io.in_slope; a.out_slope = io.out_slope; a.res_slope = io.res_slope; a.emask_slope = io.emask_slope;
+  a.accumulate = io.accumulate;
+  a.PLEN = p.PLEN; a.CSTRIDE = p.CSTRIDE;
+  a.s_magic = p.S > 1 ? (unsigned)((0x100000000ull + p.S - 1) / p.S) : 0u;
+  a.ntt = p.ntt; a.nmt = p.nmt; a.nph = p.nph;
+  a.phase_stride = p.phase_stride;
+  const long long nb = (long long)p.ntt * c.B * p.nph * p.nmt * p.G;
+  if (nb <= 0 || nb > 0x7fffffffLL) return fail(EBEN_EINVAL, "tapconv grid of %lld blocks", nb);
+  switch (p.cfg) {
+    case 0: return launch_cfg<2, 2, 4, 4>(a, (int)nb, p.lds_bytes, st);
+    case 1: return launch_cfg<1, 4, 4, 2>(a, (int)nb, p.lds_bytes, st);
+    case 2: return launch_cfg<1, 4, 2, 4>(a, (int)nb, p.lds_bytes, st);
+    case 3: return launch_cfg<1, 4, 1, 4>(a, (int)nb, p.lds_bytes, st);
+    case 4: return launch_cfg<1, 4, 2, 2>(a, (int)nb, p.lds_bytes, st);
+    default: return launch_cfg<1, 4, 1, 2>(a, (int)nb, p.lds_bytes, st);
+  }
+}
+
+// reflect-pad fold: dx[u] = D[u+pl] + D[pl-u] (1<=u<=pl) + D[pl+2(L-1)-u] (L-1-pr<=u<=L-2), then mask
+__global__ __launch_bounds__(256) void fold_kernel(const float* __restrict__ D, const float* __restrict__ mask, float* __restrict__ dx,
+                                                   long long rows, int L, int pl, int pr, float slope, int accumulate) {
+  const int Lp = L + pl + pr;
+  const long long total = rows * L;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long row = i / L;
+    const int u = (int)(i - row * L);
+    const float* d = D + row * Lp;
+    float v = d[u + pl];
+    if (u >= 1 && u <= pl) v += d[pl - u];
+    if (u >= L - 1 - pr && u <= L - 2) v += d[pl + 2 * (L - 1) - u];
+    if (mask) v *= dlrelu(mask[i], slope);
+    if (accumulate) v += dx[i];
+    dx[i] = v;
+  }
+}
+
+}  // namespace eben
+
+using namespace eben;
+
+extern "C" size_t eben_conv1d_packed_floats(const EbenConv1dDesc* d, int which) {
+  Canon c;
+  if (canon_from_desc(d, &c) != EBEN_OK) return 0;
+  TapPlan p;
+  // which: 0 = the layer's forward, 1 = the layer's input gradient
+  const int dir = d->transposed ? 1 - which : which;
+  make_plan(c, dir, &p);
+  return p.packed_floats;
+}
+
+extern "C" int eben_conv1d_pack(const EbenConv1dDesc* d, const float* v, const float* scale, float* wp_fwd, float* wp_bwd, void* stream) {
+  Canon c;
+  int rc = canon_from_desc(d, &c);
+  if (rc) return rc;
+  EBEN_REQUIRE(v != nullptr, "null weight");
+  for (int which = 0; which < 2; ++which) {
+    float* dst = which == 0 ? wp_fwd : wp_bwd;
+    if (!dst) continue;
+    TapPlan p;
+    make_plan(c, d->transposed ? 1 - which : which, &p);
+    rc = launch_pack(c, p, v, scale, dst, as_stream(stream));
+    if (rc) return rc;
+  }
+  return EBEN_OK;
+}
+
+extern "C" int eben_conv1d_fwd(const EbenConv1dDesc* d, const float* x, const float* wp_fwd, const float* bias,
+                               const float* residual, float* y, void* stream) {
+  Canon c;
+  int rc = canon_from_desc(d, &c);
+  if (rc) return rc;
+  EBEN_REQUIRE(x && wp_fwd && y, "null pointer in conv1d_fwd");
+  TapPlan p;
+  make_plan(c, d->transposed ? 1 : 0, &p);
+  TapIO io{};
+  io.x = x; io.in_mode = 0; io.in_slope = d->in_slope; io.wp = wp_fwd; io.bias = bias;
+  io.res = residual; io.res_slope = 1.f; io.emask = nullptr; io.emask_slope = 1.f;
+  io.out_slope = d->out_slope; io.y = y; io.accumulate = 0;
+  return launch_tap(c, p, io, c.reflect && !d->transposed, as_stream(stream));
+}
+
+extern "C" size_t eben_conv1d_bwd_dx_workspace(const EbenConv1dDesc* d) {
+  Canon c;
+  if (canon_from_desc(d, &c) != EBEN_OK) return 0;
+  if (!d->transposed && c.reflect) return sizeof(float) * (size_t)c.B * c.Cin * (c.Lin + c.pl + c.pr);
+  return 0;
+}
+
+extern "C" int eben_conv1d_bwd_dx(const EbenConv1dDesc* d, const float* dy, const float* y, const float* wp_bwd,
+                                  const float* x, float* dx, int accumulate, void* workspace, size_t ws_bytes, void* stream) {
+  Canon c;
+  int rc = canon_from_desc(d, &c);
+  if (rc) return rc;
+  EBEN_REQUIRE(dy && wp_bwd && dx, "null pointer in conv1d_bwd_dx");
+  EBEN_REQUIRE(d->out_slope == 1.f || y, "y is required to differentiate the fused output activation");
+  EBEN_REQUIRE(d->in_slope == 1.f || x, "x is required to differentiate the fused input activation");
+  hipStream_t st = as_stream(stream);
+  TapPlan p;
+  make_plan(c, d->transposed ? 0 : 1, &p);
+  TapIO io{};
+  io.x = dy; io.wp = wp_bwd; io.bias = nullptr; io.res = nullptr; io.res_slope = 1.f; io.out_slope = 1.f;
+  if (d->out_slope != 1.f) { io.in_mode = 1; io.xmask = y; io.in_slope = d->out_slope; }
+  else { io.in_mode = 0; io.in_slope = 1.f; }
+  const bool fold = !d->transposed && c.reflect;
+  if (!fold) {
+    io.emask = d->in_slope != 1.f ? x : nullptr; io.emask_slope = d->in_slope;
+    io.y = dx; io.accumulate = accumulate;
+    return launch_tap(c, p, io, 0, st);
+  }
+  const size_t need = eben_conv1d_bwd_dx_workspace(d);
+  if (!workspace || ws_bytes < need) return fail(EBEN_EWORKSPACE, "bwd_dx needs %zu workspace bytes, got %zu", need, ws_bytes);
+  io.emask = nullptr; io.emask_slope = 1.f; io.y = static_cast<float*>(workspace); io.accumulate = 0;
+  rc = launch_tap(c, p, io, 0, st);
+  if (rc) return rc;
+  const long long rows = (long long)c.B * c.Cin;
+  long long blocks = (rows * c.Lin + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(fold_kernel, dim3((unsigned)blocks), dim3(256), 0, st, static_cast<const float*>(workspace),
+                     d->in_slope != 1.f ? x : nullptr, dx, rows, c.Lin, c.pl, c.pr, d->in_slope, accumulate);
+  EBEN_CHECK_LAUNCH("fold_kernel");
+  return EBEN_OK;
+}

@@ -1,0 +1,475 @@
+"""torch.autograd plumbing over the C ABI of libeben_hip.so.
+
+PyTorch is used for device memory (caching allocator), streams and the autograd graph; every
+arithmetic op of the EBEN hot path below is a hand-written HIP kernel (``vibravox_amd/csrc``).
+Nothing here runs on CPU tensors: ``_lib.ptr`` raises for them.
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import EbenConv1dDesc, check, load, ptr, stream
+
+# bumped by optimisers that write parameters behind autograd's back (FusedAdam) so that the
+# packed-weight caches of the conv layers are rebuilt
+_weights_epoch = [0]
+
+
+def bump_weights_epoch() -> None:
+    _weights_epoch[0] += 1
+
+
+def _empty(n_bytes: int, like: torch.Tensor) -> torch.Tensor:
+    return torch.empty(max(1, (n_bytes + 3) // 4), dtype=torch.float32, device=like.device)
+
+
+# --------------------------------------------------------------------------------------------
+# conv layers
+# --------------------------------------------------------------------------------------------
+@dataclass(frozen=True)
+class ConvSpec:
+    """Static description of one Conv1d / ConvTranspose1d layer (+ fused activations)."""
+
+    c_in: int
+    c_out: int
+    ksize: int
+    stride: int = 1
+    dilation: int = 1
+    groups: int = 1
+    pad_l: int = 0
+    pad_r: int = 0
+    reflect: bool = False
+    transposed: bool = False
+    output_padding: int = 0
+    in_slope: float = 1.0
+    out_slope: float = 1.0
+
+    def out_len(self, l_in: int) -> int:
+        if self.transposed:
+            return (l_in - 1) * self.stride - 2 * self.pad_l + self.dilation * (self.ksize - 1) + self.output_padding + 1
+        return (l_in + self.pad_l + self.pad_r - self.dilation * (self.ksize - 1) - 1) // self.stride + 1
+
+    def weight_shape(self) -> Tuple[int, int, int]:
+        if self.transposed:
+            return (self.c_in, self.c_out // self.groups, self.ksize)
+        return (self.c_out, self.c_in // self.groups, self.ksize)
+
+
+_desc_cache: Dict[Tuple[ConvSpec, int, int], EbenConv1dDesc] = {}
+
+
+def conv_desc(spec: ConvSpec, batch: int, l_in: int) -> EbenConv1dDesc:
+    key = (spec, batch, l_in)
+    d = _desc_cache.get(key)
+    if d is None:
+        d = EbenConv1dDesc(
+            batch, spec.c_in, spec.c_out, l_in, spec.out_len(l_in), spec.ksize, spec.stride, spec.dilation, spec.groups,
+            spec.pad_l, spec.pad_r, 1 if spec.reflect else 0, 1 if spec.transposed else 0, spec.in_slope, spec.out_slope,
+        )
+        _desc_cache[key] = d
+    return d
+
+
+class PackedWeights:
+    """Weight-norm scale + MFMA-layout copies of one layer's weights, rebuilt when (v, g) change."""
+
+    __slots__ = ("key", "scale", "norm", "wp_fwd", "wp_bwd")
+
+    def __init__(self):
+        self.key = None
+        self.scale = self.norm = self.wp_fwd = self.wp_bwd = None
+
+
+def pack_weights(spec: ConvSpec, d: EbenConv1dDesc, v: torch.Tensor, g: Optional[torch.Tensor],
+                 cache: Optional[PackedWeights], need_bwd: bool) -> PackedWeights:
+    lib = load()
+    key = (v.data_ptr(), v._version, None if g is None else (g.data_ptr(), g._version), _weights_epoch[0], d.batch, d.l_in)
+    pw = cache if cache is not None else PackedWeights()
+    need_bwd = need_bwd or cache is not None  # a module-level cache serves every later pass
+    if pw.key == key and (pw.wp_bwd is not None or not need_bwd):
+        return pw
+    st = stream()
+    rows = v.shape[0]
+    if g is not None:
+        pw.scale = torch.empty(rows, dtype=torch.float32, device=v.device)
+        pw.norm = torch.empty(rows, dtype=torch.float32, device=v.device)
+        check(lib.eben_wn_scale(ptr(g), ptr(v), rows, v.numel() // rows, ptr(pw.scale), ptr(pw.norm), st), "wn_scale")
+    else:
+        pw.scale = pw.norm = None
+    pw.wp_fwd = torch.empty(lib.eben_conv1d_packed_floats(ctypes.byref(d), 0), dtype=torch.float32, device=v.device)
+    pw.wp_bwd = (
+        torch.empty(lib.eben_conv1d_packed_floats(ctypes.byref(d), 1), dtype=torch.float32, device=v.device) if need_bwd else None
+    )
+    check(lib.eben_conv1d_pack(ctypes.byref(d), ptr(v), ptr(pw.scale), ptr(pw.wp_fwd), ptr(pw.wp_bwd), st), "conv1d_pack")
+    pw.key = key
+    return pw
+
+
+class _ConvLayerFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, v, g, bias, spec: ConvSpec, cache):
+        lib = load()
+        x = x.contiguous()
+        b, c, l_in = x.shape
+        if c != spec.c_in:
+            raise _lib.EbenError(f"conv expects {spec.c_in} input channels, got {c}")
+        d = conv_desc(spec, b, l_in)
+        need_dx = ctx.needs_input_grad[0]
+        pw = pack_weights(spec, d, v.detach(), None if g is None else g.detach(), cache, need_dx)
+        y = torch.empty((b, spec.c_out, d.l_out), dtype=torch.float32, device=x.device)
+        check(lib.eben_conv1d_fwd(ctypes.byref(d), ptr(x), ptr(pw.wp_fwd), ptr(bias), None, ptr(y), stream()), "conv1d_fwd")
+        ctx.spec, ctx.d = spec, d
+        ctx.wp_bwd, ctx.norm = pw.wp_bwd, pw.norm
+        ctx.has_g, ctx.has_bias = g is not None, bias is not None
+        ctx.save_for_backward(x, v, g, y if spec.out_slope != 1.0 else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = load()
+        x, v, g, y = ctx.saved_tensors
+        spec, d = ctx.spec, ctx.d
+        dy = dy.contiguous()
+        st = stream()
+        dx = dv = dg = dbias = None
+        if ctx.needs_input_grad[0]:
+            ws_bytes = lib.eben_conv1d_bwd_dx_workspace(ctypes.byref(d))
+            ws = _empty(ws_bytes, x) if ws_bytes else None
+            dx = torch.empty_like(x)
+            check(lib.eben_conv1d_bwd_dx(ctypes.byref(d), ptr(dy), ptr(y), ptr(ctx.wp_bwd), ptr(x), ptr(dx), 0, ptr(ws), ws_bytes, st),
+                  "conv1d_bwd_dx")
+        if ctx.needs_input_grad[1] or (ctx.has_g and ctx.needs_input_grad[2]) or (ctx.has_bias and ctx.needs_input_grad[3]):
+            nslab, row_stride = ctypes.c_int(0), ctypes.c_int(0)
+            ws_bytes = lib.eben_conv1d_bwd_dw_workspace(ctypes.byref(d), ctypes.byref(nslab), ctypes.byref(row_stride))
+            slabs = _empty(ws_bytes, x)
+            check(lib.eben_conv1d_bwd_dw(ctypes.byref(d), ptr(dy), ptr(y), ptr(x), 1 if ctx.has_bias else 0, ptr(slabs), ws_bytes, st),
+                  "conv1d_bwd_dw")
+            rows = v.shape[0]
+            cols = v.numel() // rows
+            dv = torch.empty_like(v)
+            dg = torch.empty_like(g) if ctx.has_g else None
+            dbias = torch.empty(rows, dtype=torch.float32, device=x.device) if ctx.has_bias else None
+            check(lib.eben_wn_bwd(ptr(slabs), nslab.value, rows * row_stride.value, rows, cols, row_stride.value,
+                                  ptr(g) if ctx.has_g else None, ptr(v), ptr(ctx.norm) if ctx.has_g else None,
+                                  ptr(dg), ptr(dv), ptr(dbias), st), "wn_bwd")
+        return dx, dv, dg, dbias, None, None
+
+
+def conv_layer(x: torch.Tensor, v: torch.Tensor, g: Optional[torch.Tensor], bias: Optional[torch.Tensor], spec: ConvSpec,
+               cache: Optional[PackedWeights] = None) -> torch.Tensor:
+    """lrelu_out(conv(lrelu_in(x); weight_norm(g, v)) + bias) with full autograd support."""
+    return _ConvLayerFn.apply(x, v, g, bias, spec, cache)
+
+
+# --------------------------------------------------------------------------------------------
+# elementwise
+# --------------------------------------------------------------------------------------------
+class _LeakyReluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, slope: float):
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        check(load().eben_lrelu_fwd(ptr(x), ptr(y), x.numel(), slope, stream()), "lrelu_fwd")
+        ctx.slope = slope
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(dy)
+        check(load().eben_lrelu_bwd(ptr(dy), ptr(y), ptr(dx), dy.numel(), ctx.slope, stream()), "lrelu_bwd")
+        return dx, None
+
+
+def leaky_relu(x: torch.Tensor, slope: float) -> torch.Tensor:
+    return _LeakyReluFn.apply(x, slope)
+
+
+class _AddFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = a.contiguous(), b.contiguous()
+        if a.shape != b.shape:
+            raise _lib.EbenError(f"add: shape mismatch {tuple(a.shape)} vs {tuple(b.shape)}")
+        out = torch.empty_like(a)
+        check(load().eben_add(ptr(a), ptr(b), ptr(out), a.numel(), stream()), "add")
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        return dout, dout
+
+
+def add(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    return _AddFn.apply(a, b)
+
+
+class _TanhLiftFn(torch.autograd.Function):
+    """tanh(x + cat(lift, 0)) -- eben_generator.py:203-208; ``lift`` carries no gradient."""
+
+    @staticmethod
+    def forward(ctx, x, lift):
+        x, lift = x.contiguous(), lift.contiguous()
+        b, c, l = x.shape
+        out = torch.empty_like(x)
+        check(load().eben_tanh_lift_fwd(ptr(x), ptr(lift), ptr(out), b, c, lift.shape[1], l, stream()), "tanh_lift_fwd")
+        ctx.save_for_backward(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (out,) = ctx.saved_tensors
+        dout = dout.contiguous()
+        dx = torch.empty_like(out)
+        check(load().eben_tanh_bwd(ptr(dout), ptr(out), ptr(dx), out.numel(), stream()), "tanh_bwd")
+        return dx, None
+
+
+def tanh_lift(x: torch.Tensor, lift: torch.Tensor) -> torch.Tensor:
+    return _TanhLiftFn.apply(x, lift.detach())
+
+
+class _ReflectPadFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, pad_l: int, pad_r: int):
+        x = x.contiguous()
+        b, c, l = x.shape
+        y = torch.empty((b, c, l + pad_l + pad_r), dtype=torch.float32, device=x.device)
+        check(load().eben_reflect_pad_fwd(ptr(x), ptr(y), b * c, l, pad_l, pad_r, stream()), "reflect_pad_fwd")
+        ctx.geom = (b, c, l, pad_l, pad_r)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        b, c, l, pad_l, pad_r = ctx.geom
+        dy = dy.contiguous()
+        dx = torch.empty((b, c, l), dtype=torch.float32, device=dy.device)
+        check(load().eben_reflect_pad_bwd(ptr(dy), ptr(dx), b * c, l, pad_l, pad_r, stream()), "reflect_pad_bwd")
+        return dx, None, None
+
+
+def reflect_pad(x: torch.Tensor, pad_l: int, pad_r: int) -> torch.Tensor:
+    return _ReflectPadFn.apply(x, pad_l, pad_r)
+
+
+# --------------------------------------------------------------------------------------------
+# FIR banks (PQMF, A-weighting)
+# --------------------------------------------------------------------------------------------
+def _fir_decimate(x, w, ly, bands, ntaps, stride, off0):
+    b, _, lx = x.shape
+    y = torch.empty((b, bands, ly), dtype=torch.float32, device=x.device)
+    check(load().eben_fir_decimate(ptr(x), ptr(w), ptr(y), b, lx, ly, bands, ntaps, stride, off0, stream()), "fir_decimate")
+    return y
+
+
+def _fir_interp_sum(y, w, lx, bands, ntaps, stride, off0):
+    b, _, ly = y.shape
+    x = torch.empty((b, 1, lx), dtype=torch.float32, device=y.device)
+    check(load().eben_fir_interp_sum(ptr(y), ptr(w), ptr(x), b, lx, ly, bands, ntaps, stride, off0, stream()), "fir_interp_sum")
+    return x
+
+
+class _FirDecimateFn(torch.autograd.Function):
+    """y[b,k,t] = sum_j w[k,j] x[b,0,t*stride+off0+j]  (pqmf.py:194-202 with off0 = -(N-1))."""
+
+    @staticmethod
+    def forward(ctx, x, w, ly: int, stride: int, off0: int):
+        x, w = x.contiguous(), w.contiguous()
+        bands, ntaps = w.shape[0], w.shape[-1]
+        ctx.geom = (x.shape[2], bands, ntaps, stride, off0)
+        ctx.save_for_backward(w)
+        return _fir_decimate(x, w, ly, bands, ntaps, stride, off0)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (w,) = ctx.saved_tensors
+        lx, bands, ntaps, stride, off0 = ctx.geom
+        dx = _fir_interp_sum(dy.contiguous(), w, lx, bands, ntaps, stride, off0) if ctx.needs_input_grad[0] else None
+        return dx, None, None, None, None
+
+
+class _FirInterpSumFn(torch.autograd.Function):
+    """x[b,0,u] = sum_k sum_{t*stride+off0+j=u} w[k,j] y[b,k,t]  (pqmf.py:204-213 + band sum)."""
+
+    @staticmethod
+    def forward(ctx, y, w, lx: int, stride: int, off0: int):
+        y, w = y.contiguous(), w.contiguous()
+        bands, ntaps = w.shape[0], w.shape[-1]
+        ctx.geom = (y.shape[2], bands, ntaps, stride, off0)
+        ctx.save_for_backward(w)
+        return _fir_interp_sum(y, w, lx, bands, ntaps, stride, off0)
+
+    @staticmethod
+    def backward(ctx, dx):
+        (w,) = ctx.saved_tensors
+        ly, bands, ntaps, stride, off0 = ctx.geom
+        dy = _fir_decimate(dx.contiguous(), w, ly, bands, ntaps, stride, off0) if ctx.needs_input_grad[0] else None
+        return dy, None, None, None, None
+
+
+def fir_decimate(x, w, ly, stride, off0):
+    return _FirDecimateFn.apply(x, w, ly, stride, off0)
+
+
+def fir_interp_sum(y, w, lx, stride, off0):
+    return _FirInterpSumFn.apply(y, w, lx, stride, off0)
+
+
+# --------------------------------------------------------------------------------------------
+# losses
+# --------------------------------------------------------------------------------------------
+def _ptr_array(tensors: Sequence[torch.Tensor]):
+    arr = (ctypes.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = ptr(t)
+    return arr
+
+
+class _FeatureLossFn(torch.autograd.Function):
+    """sum_i mean|a_i-b_i| / mean|a_i| * inv_count  (feature_loss.py:37-50)."""
+
+    @staticmethod
+    def forward(ctx, inv_count: float, n_pairs: int, *tensors):
+        lib = load()
+        a = [t.contiguous() for t in tensors[:n_pairs]]
+        b = [t.contiguous() for t in tensors[n_pairs:]]
+        for ta, tb in zip(a, b):
+            if ta.shape != tb.shape:
+                raise _lib.EbenError(f"feature loss: shape mismatch {tuple(ta.shape)} vs {tuple(tb.shape)}")
+        inter = [None] * (2 * n_pairs)
+        inter[0::2], inter[1::2] = a, b
+        ptrs = _ptr_array(inter)
+        numel = (ctypes.c_int64 * n_pairs)(*[t.numel() for t in a])
+        dev = a[0].device
+        ws_bytes = lib.eben_fm_sums_workspace(n_pairs)
+        ws = _empty(ws_bytes, a[0])
+        sums = torch.empty(2 * n_pairs, dtype=torch.float32, device=dev)
+        check(lib.eben_fm_sums(ptrs, numel, n_pairs, ptr(ws), ws_bytes, ptr(sums), stream()), "fm_sums")
+        ctx.inv_count, ctx.n_pairs = inv_count, n_pairs
+        ctx.save_for_backward(sums, *a, *b)
+        return (sums[0::2] / sums[1::2]).sum() * inv_count
+
+    @staticmethod
+    def backward(ctx, gout):
+        lib = load()
+        n = ctx.n_pairs
+        sums = ctx.saved_tensors[0]
+        a, b = ctx.saved_tensors[1 : 1 + n], ctx.saved_tensors[1 + n :]
+        inter = [None] * (2 * n)
+        inter[0::2], inter[1::2] = a, b
+        da = [torch.empty_like(t) for t in a]
+        gout = gout.contiguous().reshape(1)
+        check(lib.eben_fm_bwd(_ptr_array(inter), _ptr_array(da), (ctypes.c_int64 * n)(*[t.numel() for t in a]), n, ptr(sums),
+                              ptr(gout), ctx.inv_count, stream()), "fm_bwd")
+        return (None, None, *da, *([None] * n))
+
+
+def feature_loss(emb_a: List[List[torch.Tensor]], emb_b: List[List[torch.Tensor]]) -> torch.Tensor:
+    a = [t for scale in emb_a for t in scale[1:-1]]
+    b = [t.detach() for scale in emb_b for t in scale[1:-1]]
+    inv = 1.0 / (len(emb_a) * len(emb_a[-1][1:-1]))
+    return _FeatureLossFn.apply(inv, len(a), *a, *b)
+
+
+class _HingeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, target: float):
+        x = x.contiguous()
+        out = torch.empty(1, dtype=torch.float32, device=x.device)
+        check(load().eben_hinge_fwd(ptr(x), x.numel(), float(target), ptr(out), stream()), "hinge_fwd")
+        ctx.target = float(target)
+        ctx.save_for_backward(x)
+        return out.reshape(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        (x,) = ctx.saved_tensors
+        dx = torch.empty_like(x)
+        gout = gout.contiguous().reshape(1)
+        check(load().eben_hinge_bwd(ptr(x), x.numel(), ctx.target, ptr(gout), 1.0, ptr(dx), stream()), "hinge_bwd")
+        return dx, None
+
+
+def hinge_mean(x: torch.Tensor, target: float) -> torch.Tensor:
+    """mean(relu(1 - target*x)) -- hinge_loss.py:41."""
+    return _HingeFn.apply(x, target)
+
+
+@dataclass
+class StftPlan:
+    n_fft: int
+    hop: int
+    win: int
+    bins: int
+    spec: ConvSpec
+    basis: torch.Tensor  # (2*bins, 1, win) windowed DFT rows: [cos ; -sin]
+    spec_t: ConvSpec  # pointwise conv (2*bins -> win) used by the backward
+    basis_t: torch.Tensor  # (win, 2*bins, 1) = basis transposed
+    cache_fwd: PackedWeights
+    cache_bwd: PackedWeights
+
+
+class _MRSTFTFn(torch.autograd.Function):
+    """auraloss MultiResolutionSTFTLoss(x, y) as configured by multi_stft.yaml (see mrstft_loss.py)."""
+
+    @staticmethod
+    def forward(ctx, x, y, fir, plans: List[StftPlan], eps: float):
+        lib = load()
+        st = stream()
+        x, y = x.contiguous(), y.contiguous()
+        b, c, t = x.shape
+        rows = b * c
+        sig = torch.cat((x.reshape(rows, 1, t), y.reshape(rows, 1, t)), dim=0)
+        if fir is not None:
+            nt = fir.numel()
+            sig = _fir_decimate(sig, fir, t, 1, nt, 1, -(nt // 2))
+        total = None
+        saved = []
+        for p in plans:
+            d2 = conv_desc(p.spec, 2 * rows, t)
+            pw = pack_weights(p.spec, d2, p.basis, None, p.cache_fwd, False)
+            spec = torch.empty((2 * rows, 2 * p.bins, d2.l_out), dtype=torch.float32, device=x.device)
+            check(lib.eben_conv1d_fwd(ctypes.byref(d2), ptr(sig), ptr(pw.wp_fwd), None, None, ptr(spec), st), "stft_fwd")
+            sums = torch.empty((rows, 3), dtype=torch.float32, device=x.device)
+            sx, sy = spec[:rows], spec[rows:]
+            check(lib.eben_stft_loss_sums(ptr(sx), ptr(sy), rows, p.bins, p.bins, d2.l_out, eps, ptr(sums), st), "stft_loss_sums")
+            term = torch.sqrt(sums[:, 0] / sums[:, 1]).mean() + sums[:, 2].sum() / float(rows * p.bins * d2.l_out)
+            total = term if total is None else total + term
+            saved.append((spec, sums, d2.l_out))
+        ctx.plans, ctx.eps, ctx.geom, ctx.saved, ctx.fir = plans, eps, (b, c, t, rows), saved, fir
+        return total / len(plans)
+
+    @staticmethod
+    def backward(ctx, gout):
+        lib = load()
+        st = stream()
+        b, c, t, rows = ctx.geom
+        gout = gout.contiguous().reshape(1)
+        dsig = torch.empty((rows, 1, t), dtype=torch.float32, device=gout.device)
+        for i, (p, (spec, sums, frames)) in enumerate(zip(ctx.plans, ctx.saved)):
+            dspec = torch.empty((rows, 2 * p.bins, frames), dtype=torch.float32, device=gout.device)
+            sx, sy = spec[:rows], spec[rows:]
+            check(lib.eben_stft_loss_bwd(ptr(sx), ptr(sy), rows, p.bins, p.bins, frames, ctx.eps, ptr(sums), ptr(gout),
+                                         1.0 / len(ctx.plans), ptr(dspec), st), "stft_loss_bwd")
+            # d(frames)[b, j, f] = sum_m basis[m, j] dspec[b, m, f]: dense pointwise GEMM, then overlap-add
+            d1 = conv_desc(p.spec_t, rows, frames)
+            pw = pack_weights(p.spec_t, d1, p.basis_t, None, p.cache_bwd, False)
+            dfr = torch.empty((rows, p.win, frames), dtype=torch.float32, device=gout.device)
+            check(lib.eben_conv1d_fwd(ctypes.byref(d1), ptr(dspec), ptr(pw.wp_fwd), None, None, ptr(dfr), st), "stft_bwd_gemm")
+            check(lib.eben_overlap_add(ptr(dfr), ptr(dsig), rows, t, p.win, frames, p.hop, p.spec.pad_l, 1, 1 if i else 0, st),
+                  "overlap_add")
+        if ctx.fir is not None:
+            nt = ctx.fir.numel()
+            dsig = _fir_interp_sum(dsig, ctx.fir, t, 1, nt, 1, -(nt // 2))
+        return dsig.reshape(b, c, t), None, None, None, None
+
+
+def mrstft(x: torch.Tensor, y: torch.Tensor, fir: Optional[torch.Tensor], plans: List[StftPlan], eps: float = 1e-8) -> torch.Tensor:
+    return _MRSTFTFn.apply(x, y.detach(), fir, plans, eps)

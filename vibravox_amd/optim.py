@@ -1,0 +1,56 @@
+"""Multi-tensor Adam on one HIP kernel launch per 48 tensors.
+
+Numerically follows ``torch.optim.Adam`` (amsgrad=False, maximize=False) as configured by
+``configs/lightning_module/optimizer/adam.yaml:1-9`` (lr 3e-4, betas (0.5, 0.9), eps 1e-8, wd 0);
+keeps torch's ``state_dict`` layout (``step`` / ``exp_avg`` / ``exp_avg_sq`` per parameter) so
+optimizer checkpoints interchange with the reference's.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from . import ops
+from ._lib import EbenAdamTensor, check, load, ptr, stream
+
+
+class FusedAdam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, amsgrad=False):
+        if amsgrad:
+            raise NotImplementedError("amsgrad is not used by the EBEN configuration")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=False))
+
+    @torch.no_grad()
+    def step(self, closure=None, grad_scale: float = 1.0):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        lib = load()
+        for group in self.param_groups:
+            live = [p for p in group["params"] if p.grad is not None]
+            if not live:
+                continue
+            by_step = {}
+            for p in live:
+                st = self.state[p]
+                if not st:
+                    st["step"] = torch.tensor(0.0)
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["step"] += 1
+                by_step.setdefault(int(st["step"].item()), []).append(p)
+            beta1, beta2 = group["betas"]
+            for step, plist in by_step.items():
+                table = (EbenAdamTensor * len(plist))()
+                grads = []
+                for i, p in enumerate(plist):
+                    g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                    grads.append(g)
+                    st = self.state[p]
+                    table[i] = EbenAdamTensor(ptr(p.data), ptr(g), ptr(st["exp_avg"]), ptr(st["exp_avg_sq"]), p.numel())
+                check(lib.eben_adam_step(table, len(plist), max(p.numel() for p in plist), group["lr"], beta1, beta2, group["eps"],
+                                         group["weight_decay"], step, grad_scale, stream()), "adam_step")
+        ops.bump_weights_epoch()
+        return loss

@@ -1,0 +1,85 @@
+"""Multi-resolution STFT loss on the HIP tap-conv (windowed-DFT GEMM) and reduction kernels.
+
+Stands in for ``auraloss.freq.MultiResolutionSTFTLoss`` as instantiated by
+``configs/lightning_module/loss_module/multi_stft.yaml:1-18`` and called at
+``vibravox/lightning_modules/eben.py:195-198`` (``loss(enhanced, reference)``).  auraloss is a
+third-party dependency that is not vendored in the reference (pyproject.toml:21, unpinned; 0.4.0
+semantics restated: per-item spectral convergence, log-magnitude L1, A-weighting FIR prefilter,
+mean over resolutions) -- parity for this term is therefore *unpinned* (see DESIGN.md).
+
+Per resolution the STFT is one strided conv: hann(win) centred in n_fft and center=True reflect
+padding reduce to a reflect-padded conv with kernel ``win``, stride ``hop``, padding ``win/2``
+against the 2*(n_fft/2+1) rows [w cos ; -w sin] of the windowed DFT basis.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+
+from ... import ops
+
+
+def a_weighting_taps(fs: float, ntaps: int = 101) -> torch.Tensor:
+    """IEC A-weighting prototype -> bilinear -> freqz(512) -> firls(ntaps) (auraloss FIRFilter 'aw')."""
+    import scipy.signal
+
+    f1, f2, f3, f4, a1000 = 20.598997, 107.65265, 737.86223, 12194.217, 1.9997
+    num = [(2 * np.pi * f4) ** 2 * (10 ** (a1000 / 20)), 0, 0, 0, 0]
+    den = np.polymul([1, 4 * np.pi * f4, (2 * np.pi * f4) ** 2], [1, 4 * np.pi * f1, (2 * np.pi * f1) ** 2])
+    den = np.polymul(np.polymul(den, [1, 2 * np.pi * f3]), [1, 2 * np.pi * f2])
+    b, a = scipy.signal.bilinear(num, den, fs=fs)
+    w, h = scipy.signal.freqz(b, a, worN=512, fs=fs)
+    return torch.tensor(scipy.signal.firls(ntaps, w, abs(h), fs=fs).astype("float32"))
+
+
+def windowed_dft_basis(n_fft: int, win: int) -> torch.Tensor:
+    """(2*bins, 1, win): rows k<bins  w[j] cos(2 pi k (j+lp)/n_fft), rows bins+k  -w[j] sin(...)."""
+    bins = n_fft // 2 + 1
+    window = torch.hann_window(win, dtype=torch.float64)
+    lp = (n_fft - win) // 2
+    n = torch.arange(win, dtype=torch.float64) + lp
+    k = torch.arange(bins, dtype=torch.float64).unsqueeze(1)
+    ang = 2 * math.pi * k * n / n_fft
+    basis = torch.cat((torch.cos(ang) * window, -torch.sin(ang) * window), dim=0)
+    return basis.to(torch.float32).unsqueeze(1).contiguous()
+
+
+class MultiResolutionSTFTLoss(torch.nn.Module):
+    def __init__(self, fft_sizes: Sequence[int] = (1024, 2048, 512), hop_sizes: Sequence[int] = (120, 240, 50),
+                 win_lengths: Sequence[int] = (600, 1200, 240), window: str = "hann_window", w_sc: float = 1.0,
+                 w_log_mag: float = 1.0, w_lin_mag: float = 0.0, w_phs: float = 0.0, sample_rate: Optional[float] = None,
+                 scale: Optional[str] = None, n_bins: Optional[int] = None, perceptual_weighting: bool = False,
+                 scale_invariance: bool = False, eps: float = 1e-8, **kwargs):
+        super().__init__()
+        assert len(fft_sizes) == len(hop_sizes) == len(win_lengths)
+        if window != "hann_window" or w_sc != 1.0 or w_log_mag != 1.0 or w_lin_mag or w_phs or scale or scale_invariance:
+            raise NotImplementedError("only the configuration of configs/lightning_module/loss_module/multi_stft.yaml is built")
+        if perceptual_weighting and sample_rate is None:
+            raise ValueError("`sample_rate` must be supplied when `perceptual_weighting = True`.")
+        self.eps = eps
+        self.fft_sizes, self.hop_sizes, self.win_lengths = tuple(fft_sizes), tuple(hop_sizes), tuple(win_lengths)
+        self.register_buffer("fir", a_weighting_taps(sample_rate) if perceptual_weighting else None, persistent=False)
+        self._plans = None
+        for i, (n_fft, win) in enumerate(zip(self.fft_sizes, self.win_lengths)):
+            basis = windowed_dft_basis(n_fft, win)
+            self.register_buffer(f"basis_{i}", basis, persistent=False)
+            self.register_buffer(f"basis_t_{i}", basis.squeeze(1).t().contiguous().unsqueeze(-1), persistent=False)
+
+    def _build_plans(self):
+        plans = []
+        for i, (n_fft, hop, win) in enumerate(zip(self.fft_sizes, self.hop_sizes, self.win_lengths)):
+            bins = n_fft // 2 + 1
+            spec = ops.ConvSpec(c_in=1, c_out=2 * bins, ksize=win, stride=hop, pad_l=win // 2, pad_r=win // 2, reflect=True)
+            spec_t = ops.ConvSpec(c_in=2 * bins, c_out=win, ksize=1)
+            plans.append(ops.StftPlan(n_fft=n_fft, hop=hop, win=win, bins=bins, spec=spec, basis=getattr(self, f"basis_{i}"),
+                                      spec_t=spec_t, basis_t=getattr(self, f"basis_t_{i}"),
+                                      cache_fwd=ops.PackedWeights(), cache_bwd=ops.PackedWeights()))
+        return plans
+
+    def forward(self, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+        if self._plans is None or self._plans[0].basis.device != x.device or self._plans[0].basis.data_ptr() != self.basis_0.data_ptr():
+            self._plans = self._build_plans()
+        return ops.mrstft(x, y, self.fir, self._plans, self.eps)
