@@ -1,0 +1,179 @@
+#!/usr/bin/env python
+"""EBEN train-step benchmark (BASELINE.json metric: audio-seconds/sec of the full GAN step).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+
+One "step" = EBENLightningModule.training_step on one batch of synthetic (32, 1, 32000) float32
+waveforms already resident in HBM (cut to 31968): generator fwd, MRSTFT + feature-matching + hinge,
+EMA loss balancing, generator backward + Adam, discriminator fwd/backward + Adam, and (N > 1) the
+RCCL gradient all-reduces.  Weak scaling: 32 clips per GPU.  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from functools import partial
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense fp32
+
+
+def build_module(device, batch_seed):
+    from vibravox_amd.lightning_modules.eben import EBENLightningModule
+    from vibravox_amd.optim import FusedAdam
+    from vibravox_amd.torch_modules.dnn.eben_discriminator import DiscriminatorEBENMultiScales
+    from vibravox_amd.torch_modules.dnn.eben_generator import EBENGenerator
+    from vibravox_amd.torch_modules.losses.feature_loss import FeatureLossForDiscriminatorMelganMultiScales
+    from vibravox_amd.torch_modules.losses.hinge_loss import HingeLossForDiscriminatorMelganMultiScales
+    from vibravox_amd.torch_modules.losses.mrstft_loss import MultiResolutionSTFTLoss
+
+    torch.manual_seed(42)  # mirrors run.py:74 seed_everything(42): identical weights on every rank
+    gen, disc = EBENGenerator(m=4, n=32, p=2), DiscriminatorEBENMultiScales(q=4, min_channels=24)
+    opt = partial(FusedAdam, lr=3e-4, betas=(0.5, 0.9))
+    mod = EBENLightningModule(
+        sample_rate=16000, generator=gen.to(device), discriminator=disc.to(device), generator_optimizer=opt,
+        discriminator_optimizer=opt,
+        reconstructive_loss_freq_fn=MultiResolutionSTFTLoss(fft_sizes=(512, 1024, 2048), hop_sizes=(50, 120, 240),
+                                                            win_lengths=(240, 600, 1200), sample_rate=16000,
+                                                            perceptual_weighting=True).to(device),
+        feature_matching_loss_fn=FeatureLossForDiscriminatorMelganMultiScales(),
+        adversarial_loss_fn=HingeLossForDiscriminatorMelganMultiScales(),
+        dynamic_loss_balancing="ema", beta_ema=0.9, update_discriminator_ratio=1)
+    return mod
+
+
+def synthetic_batch(batch, length, seed, device):
+    g = torch.Generator().manual_seed(seed)
+    return {"audio_body_conducted": (0.1 * torch.randn(batch, 1, length, generator=g)).to(device),
+            "audio_airborne": (0.1 * torch.randn(batch, 1, length, generator=g)).to(device)}
+
+
+def cpu_baseline(batch, length, steps):
+    """The CPU oracle (oracle/eben_oracle.py, a restatement pinned to the reference by golden
+    fixtures) running the reference's as-executed step order on the host cores."""
+    from oracle import eben_oracle as O
+    from vibravox_amd.torch_modules.dnn.eben_discriminator import DiscriminatorEBENMultiScales
+    from vibravox_amd.torch_modules.dnn.eben_generator import EBENGenerator
+
+    cores = len(os.sched_getaffinity(0))
+    torch.set_num_threads(cores)
+    torch.manual_seed(42)
+    gen, disc = EBENGenerator(m=4, n=32, p=2), DiscriminatorEBENMultiScales(q=4, min_channels=24)
+    trainer = O.OracleTrainer({k: v.detach() for k, v in gen.state_dict().items()}, {k: v.detach() for k, v in disc.state_dict().items()})
+    data = synthetic_batch(batch, length, 1234, "cpu")
+    trainer.step(data["audio_body_conducted"], data["audio_airborne"])  # warm-up (first call is ~17x slower)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        trainer.step(data["audio_body_conducted"], data["audio_airborne"])
+    dt = (time.perf_counter() - t0) / steps
+    cut = length - (length + 32) % 256
+    return {"value": round(batch * cut / 16000 / dt, 3), "unit": "audio-seconds/sec", "cores": cores, "kind": "port",
+            "sample": f"{steps} timed step(s) after 1 warm-up, batch {batch} x {length} samples, fp32, reference as-executed order, {dt:.2f} s/step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="clips per GPU (BASELINE config 2: 32)")
+    ap.add_argument("--length", type=int, default=32000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=4)
+    ap.add_argument("--cpu-steps", type=int, default=1)
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}"
+    assert torch.cuda.is_available(), "bench.py measures the HIP path: no GPU visible"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=device)
+
+    from vibravox_amd import ops
+    from vibravox_amd.ddp import BucketedZeroGrad, GradSync
+
+    mod = build_module(device, 1234 + rank)
+    if world > 1:
+        g_opt, d_opt = mod.optimizers()
+        gs, ds = GradSync(mod.generator.parameters()), GradSync(mod.discriminator.parameters())
+        g_w, d_w = BucketedZeroGrad(g_opt, gs), BucketedZeroGrad(d_opt, ds)
+        mod._optimizers = [g_w, d_w]
+        mod.grad_sync = {id(g_w): gs, id(d_w): ds}
+    batch = synthetic_batch(args.batch, args.length, 1234 + rank, device)
+    cut = args.length - (args.length + 32) % 256
+
+    # dominant kernel: MelGAN layer 4 (1024->1024, k41, s4, g4) forward, 52 % of conv MACs sit in L3-L5
+    layer = mod.discriminator.melgan_discriminator.discriminator[4][0]
+    timer = ops.KernelTimer(layer.spec)
+    ops.set_kernel_timer(timer)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        mod.training_step(batch)
+    barrier()
+    timer.enabled = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        mod.training_step(batch)
+    barrier()
+    dt = time.perf_counter() - t0
+    timer.enabled = False
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        value = world * args.batch * cut / 16000 / (dt / args.steps)
+        l_in = ((cut // 4 // 4 // 4) if False else None)
+        sp = layer.spec
+        lx = cut
+        for (_, _, k, s, p, _) in [(1, 16, 15, 1, 7, 1), (16, 64, 41, 4, 20, 4), (64, 256, 41, 4, 20, 4), (256, 1024, 41, 4, 20, 4)]:
+            lx = (lx + 2 * p - (k - 1) - 1) // s + 1
+        l_out = sp.out_len(lx)
+        flops = 2.0 * args.batch * sp.c_out * (sp.c_in // sp.groups) * sp.ksize * l_out
+        kms = timer.mean_ms()
+        achieved = flops / (kms * 1e-3) / 1e12 if kms else None
+        line = {
+            "metric": "EBEN train-step audio-seconds/sec (gen+disc)", "value": round(value, 2), "unit": "audio-seconds/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"EBEN full GAN train step (gen+disc+MRSTFT+feature-matching+hinge, EMA balancing, Adam), "
+                                   f"batch {args.batch} x {args.length} samples @16kHz per GPU (cut to {cut})",
+                       "global_batch": world * args.batch, "samples_per_clip": cut, "parallelism": f"dp{world}",
+                       "weights": "random init, torch.manual_seed(42)"},
+            "roofline": {"bound": "mfma", "kernel": "tapconv_kernel<2,2,4,4> MelGAN L4 fwd (1024->1024 k41 s4 g4)",
+                         "achieved": round(achieved, 2) if achieved else None, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4) if achieved else None, "traffic": None,
+                         "launch_ms": round(kms, 4) if kms else None, "flops_per_launch": flops,
+                         "launches_timed": len(timer.events)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.cpu_batch, args.length, args.cpu_steps)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

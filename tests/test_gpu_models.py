@@ -1,0 +1,217 @@
+"""GPU: the drop-in modules and the full GAN train step (all through libeben_hip.so) against the
+CPU oracle and the golden fixtures frozen from the reference.
+
+Gradient comparisons use the relative L2 norm per tensor: the graph is discontinuous (LeakyReLU
+masks, sign(a-b) of the L1 feature loss) and fp32 rounding noise flips isolated elements -- the
+reference's own fp32 and fp64 gradients differ by `check:disc_grad_fp64_floor` (~1e-2) in that
+metric on the discriminator, which is the bar used here.
+"""
+from functools import partial
+
+import numpy as np
+import pytest
+import torch
+
+from formula import formula_audio, formula_state_dict, iter_embeddings, summarize
+from oracle import eben_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda")
+
+
+def rel_l2(got, ref):
+    got, ref = got.detach().double().cpu(), ref.detach().double().cpu()
+    assert got.shape == ref.shape and torch.isfinite(got).all()
+    return float((got - ref).norm() / (ref.norm() + 1e-30))
+
+
+def max_abs(got, ref):
+    return float((got.detach().double().cpu() - ref.detach().double().cpu()).abs().max())
+
+
+def contract(golden, tag):
+    return {k: tuple(int(x) for x in s.split(",")) for k, s in zip(golden[f"contract/{tag}/keys"], golden[f"contract/{tag}/shapes"])}
+
+
+def build_generator(golden, p):
+    from vibravox_amd.torch_modules.dnn.eben_generator import EBENGenerator
+
+    gen = EBENGenerator(m=4, n=32, p=p)
+    shapes = contract(golden, "G")
+    shapes["first_conv.weight"] = (32, p, 3)
+    assert list(gen.state_dict().keys()) == list(contract(golden, "G").keys())
+    sd = formula_state_dict(shapes, f"G{p}")
+    missing, unexpected = gen.load_state_dict(sd, strict=False)
+    assert not unexpected and all(k.startswith("pqmf.") for k in missing)
+    np.testing.assert_array_equal(gen.pqmf.analysis_weights.numpy(), golden["pqmf/analysis_4_32"])
+    osd = {k: v.detach().clone() for k, v in gen.state_dict().items()}
+    return gen.to(DEV), osd
+
+
+def build_discriminator(golden):
+    from vibravox_amd.torch_modules.dnn.eben_discriminator import DiscriminatorEBENMultiScales
+
+    disc = DiscriminatorEBENMultiScales(q=4, min_channels=24)
+    shapes = contract(golden, "D")
+    assert {k: tuple(v.shape) for k, v in disc.state_dict().items()} == shapes
+    sd = formula_state_dict(shapes, "D")
+    disc.load_state_dict(sd, strict=True)
+    return disc.to(DEV), {k: v.clone() for k, v in sd.items()}
+
+
+def check_summary(golden, prefix, t, rtol=5e-5, atol=5e-6):
+    s = summarize(t.detach().cpu())
+    assert tuple(golden[f"{prefix}:shape"]) == tuple(s["shape"])
+    np.testing.assert_allclose(s["probe"], golden[f"{prefix}:probe"], rtol=rtol, atol=atol)
+    np.testing.assert_allclose(s["l2"], golden[f"{prefix}:l2"], rtol=rtol)
+
+
+@pytest.mark.parametrize("p", [2, 1])
+def test_generator_matches_oracle_and_reference_golden(hip, golden, p):
+    gen, osd = build_generator(golden, p)
+    x = O.cut_to_valid_length(formula_audio("g_in", 2, 8192))
+    enh, bands = gen(x.to(DEV))
+    assert enh.shape == x.shape  # the reference's own test (tests/torch_modules/eben_generator_test.py:2-8)
+    check_summary(golden, f"gen{p}/enhanced", enh)
+    check_summary(golden, f"gen{p}/bands", bands)
+    osd = {k: v.requires_grad_(not k.startswith("pqmf.")) for k, v in osd.items()}
+    o_enh, o_bands = O.generator_forward(osd, x, p)
+    assert max_abs(enh, o_enh) < 2e-5 and max_abs(bands, o_bands) < 2e-5
+    mse = float(((enh.detach().cpu().double() - o_enh.detach().double()) ** 2).mean())
+    assert mse < 1e-10  # north_star bar is 1e-5; fp32 floor ~5e-15
+    wgt = formula_audio("g_seed", 2, enh.shape[2], amp=1.0)
+    ((enh * wgt.to(DEV)).sum() + (bands ** 2).sum()).backward()
+    ((o_enh * wgt).sum() + (o_bands ** 2).sum()).backward()
+    worst = 0.0
+    for k, prm in gen.named_parameters():
+        if prm.grad is None:
+            continue
+        worst = max(worst, rel_l2(prm.grad, osd[k].grad))
+        np.testing.assert_allclose(prm.grad.double().norm().item(), golden[f"gen{p}/grad_l2/{k}"], rtol=2e-3)
+    assert worst < 2e-3, worst
+
+
+def test_generator_config1_forward(hip, golden):
+    """BASELINE config 1: generator-only forward, batch 4 x 16000 -> 15840."""
+    gen, _ = build_generator(golden, 2)
+    x = gen.cut_to_valid_length(formula_audio("cfg1", 4, 16000))
+    assert x.shape[2] == 15840
+    with torch.no_grad():
+        enh, bands = gen(x.to(DEV))
+    check_summary(golden, "cfg1/enhanced", enh)
+    check_summary(golden, "cfg1/bands", bands)
+
+
+def test_discriminator_losses_grads(hip, golden):
+    from vibravox_amd.torch_modules.losses.feature_loss import FeatureLossForDiscriminatorMelganMultiScales
+    from vibravox_amd.torch_modules.losses.hinge_loss import HingeLossForDiscriminatorMelganMultiScales
+
+    disc, osd = build_discriminator(golden)
+    bands = formula_audio("d_bands", 8, 2016, amp=0.5).reshape(2, 4, 2016)
+    audio = formula_audio("d_audio", 2, 4 * 2016 - 32)
+    bands_b = formula_audio("d_bands_b", 8, 2016, amp=0.5).reshape(2, 4, 2016)
+    audio_b = formula_audio("d_audio_b", 2, 4 * 2016 - 32)
+    bd, ad = bands.to(DEV).requires_grad_(True), audio.to(DEV).requires_grad_(True)
+    e_a = disc(bands=bd, audio=ad)
+    with torch.no_grad():
+        e_b = disc(bands=bands_b.to(DEV), audio=audio_b.to(DEV))
+    assert [len(s) for s in e_a] == [9, 9, 9, 8]
+    for name, t in iter_embeddings(e_a):
+        check_summary(golden, f"disc/{name}", t)
+    fm, hinge = FeatureLossForDiscriminatorMelganMultiScales(), HingeLossForDiscriminatorMelganMultiScales()
+    l_fm, l_hp, l_hm = fm(e_a, e_b), hinge(embeddings=e_a, target=1), hinge(embeddings=e_a, target=-1)
+    np.testing.assert_allclose(l_fm.item(), golden["loss/fm"], rtol=2e-5)
+    np.testing.assert_allclose(l_hp.item(), golden["loss/hinge_p1"], rtol=1e-5)
+    np.testing.assert_allclose(l_hm.item(), golden["loss/hinge_m1"], rtol=1e-5)
+    (l_fm + 0.5 * l_hp + 0.25 * l_hm).backward()
+    # oracle on the same inputs
+    osd = {k: v.requires_grad_(True) for k, v in osd.items()}
+    ob, oa = bands.clone().requires_grad_(True), audio.clone().requires_grad_(True)
+    o_a = O.discriminator_forward(osd, ob, oa, 4)
+    with torch.no_grad():
+        o_b = O.discriminator_forward(osd, bands_b, audio_b, 4)
+    (O.feature_loss(o_a, o_b) + 0.5 * O.hinge_loss(o_a, 1) + 0.25 * O.hinge_loss(o_a, -1)).backward()
+    floor = float(golden["check:disc_grad_fp64_floor"])
+    worst = max(rel_l2(bd.grad, ob.grad), rel_l2(ad.grad, oa.grad))
+    for k, prm in disc.named_parameters():
+        worst = max(worst, rel_l2(prm.grad, osd[k].grad))
+        np.testing.assert_allclose(prm.grad.double().norm().item(), golden[f"disc/grad_l2/{k}"], rtol=2e-2)
+    assert worst <= 2 * floor + 1e-3, (worst, floor)
+    np.testing.assert_allclose(bd.grad.double().norm().item(), golden["disc/grad_bands:l2"], rtol=2e-3)
+    np.testing.assert_allclose(ad.grad.double().norm().item(), golden["disc/grad_audio:l2"], rtol=2e-3)
+
+
+def make_module(golden, use_mrstft, fused_adam=True):
+    from vibravox_amd.lightning_modules.eben import EBENLightningModule
+    from vibravox_amd.optim import FusedAdam
+    from vibravox_amd.torch_modules.losses.feature_loss import FeatureLossForDiscriminatorMelganMultiScales
+    from vibravox_amd.torch_modules.losses.hinge_loss import HingeLossForDiscriminatorMelganMultiScales
+    from vibravox_amd.torch_modules.losses.mrstft_loss import MultiResolutionSTFTLoss
+
+    gen, g_sd = build_generator(golden, 2)
+    disc, d_sd = build_discriminator(golden)
+    opt = partial(FusedAdam if fused_adam else torch.optim.Adam, lr=3e-4, betas=(0.5, 0.9))
+    mr = MultiResolutionSTFTLoss(fft_sizes=(512, 1024, 2048), hop_sizes=(50, 120, 240), win_lengths=(240, 600, 1200),
+                                 sample_rate=16000, perceptual_weighting=True).to(DEV) if use_mrstft else None
+    mod = EBENLightningModule(sample_rate=16000, generator=gen, discriminator=disc, generator_optimizer=opt,
+                              discriminator_optimizer=opt, reconstructive_loss_freq_fn=mr,
+                              feature_matching_loss_fn=FeatureLossForDiscriminatorMelganMultiScales(),
+                              adversarial_loss_fn=HingeLossForDiscriminatorMelganMultiScales(),
+                              dynamic_loss_balancing="ema", beta_ema=0.9, update_discriminator_ratio=1)
+    return mod, g_sd, d_sd
+
+
+@pytest.mark.parametrize("fused_adam", [True, False])
+def test_two_train_steps_against_reference_replay_golden(hip, golden, fused_adam):
+    """eben.py:82-130 replayed over the REFERENCE modules (golden) vs this build's LightningModule."""
+    mod, g_sd, d_sd = make_module(golden, use_mrstft=False, fused_adam=fused_adam)
+    for i in range(2):
+        batch = {"audio_body_conducted": formula_audio(f"step{i}/bc", 2, 8200).to(DEV),
+                 "audio_airborne": formula_audio(f"step{i}/air", 2, 8200).to(DEV)}
+        out = mod.training_step(batch)
+        assert set(out) == {"corrupted", "enhanced", "reference"}
+        check_summary(golden, f"step{i}/enhanced", out["enhanced"], rtol=2e-4, atol=2e-5)
+        for k in ("train/generator/feature_matching_loss", "train/generator/adv_loss_gen", "train/generator/backprop_loss",
+                  "train/discriminator/real_loss", "train/discriminator/fake_loss", "train/discriminator/backprop_loss"):
+            np.testing.assert_allclose(mod.logged[k].item(), golden[f"step{i}/{k}"], rtol=5e-4)
+        np.testing.assert_allclose(torch.stack(mod.last_norms).cpu().numpy(), golden[f"step{i}/balancing/norms"], rtol=2e-3)
+        np.testing.assert_allclose(torch.stack(mod.last_lambdas).cpu().numpy(), golden[f"step{i}/balancing/lambdas"], rtol=2e-3)
+    for k, v in mod.generator.state_dict().items():
+        if not k.startswith("pqmf."):
+            np.testing.assert_allclose(v.double().norm().item(), golden[f"post/G/{k}"][1], rtol=2e-4)
+    for k, v in mod.discriminator.state_dict().items():
+        np.testing.assert_allclose(v.double().norm().item(), golden[f"post/D/{k}"][1], rtol=2e-4)
+
+
+def test_train_step_with_mrstft_against_oracle(hip, golden):
+    """Full default configuration (MRSTFT + FM + hinge, EMA balancing).  The MRSTFT term is a
+    restatement of third-party auraloss (parity unpinned); everything else is pinned."""
+    mod, g_sd, d_sd = make_module(golden, use_mrstft=True)
+    trainer = O.OracleTrainer(g_sd, d_sd, p=2, q=4, use_mrstft=True)
+    for i in range(2):
+        bc, air = formula_audio(f"mstep{i}/bc", 2, 8200), formula_audio(f"mstep{i}/air", 2, 8200)
+        mod.training_step({"audio_body_conducted": bc.to(DEV), "audio_airborne": air.to(DEV)})
+        logs = trainer.step(bc, air)
+        for k in ("train/generator/reconstructive_loss_freq", "train/generator/feature_matching_loss", "train/generator/adv_loss_gen",
+                  "train/generator/backprop_loss", "train/discriminator/real_loss", "train/discriminator/fake_loss"):
+            np.testing.assert_allclose(mod.logged[k].item(), logs[k].item(), rtol=1e-3, err_msg=k)
+        np.testing.assert_allclose(torch.stack(mod.last_norms).cpu().numpy(), logs["balancing/norms"].numpy(), rtol=5e-3)
+
+
+def test_full_size_step_properties(hip, golden):
+    """BASELINE config 2 shape (batch 32 x 32000 -> 31968): size-independent properties only."""
+    mod, _, _ = make_module(golden, use_mrstft=True)
+    g = torch.Generator().manual_seed(1234)
+    batch = {"audio_body_conducted": (0.1 * torch.randn(32, 1, 32000, generator=g)).to(DEV),
+             "audio_airborne": (0.1 * torch.randn(32, 1, 32000, generator=g)).to(DEV)}
+    before = {k: v.clone() for k, v in mod.discriminator.state_dict().items()}
+    out = mod.training_step(batch)
+    torch.cuda.synchronize()
+    assert out["enhanced"].shape == (32, 1, 31968) and torch.isfinite(out["enhanced"]).all()
+    assert out["enhanced"].abs().max() <= 4.0 * 1.05  # tanh-bounded bands through a gain-4 synthesis bank
+    for k, v in mod.logged.items():
+        assert torch.isfinite(v).all(), k
+    lam = torch.stack(mod.last_lambdas)
+    assert (lam > 0).all() and (lam <= 1e4).all()
+    moved = [float((v - before[k]).abs().max()) for k, v in mod.discriminator.state_dict().items()]
+    assert max(moved) <= 3e-4 * 1.01 and min(moved) > 0  # first Adam step moves every tensor by <= lr

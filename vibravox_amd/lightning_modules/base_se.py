@@ -1,0 +1,66 @@
+"""Constructor / logging contract of ``vibravox/lightning_modules/base_se.py:16-196`` that the EBEN
+train step relies on.  The evaluation hooks of the reference (torchmetrics / torchaudio SQUIM
+pipelines, audio logging) are out of scope: only ``sample_rate``,
+``description`` and the Lightning plumbing used by ``training_step`` are provided.
+
+Lightning is optional: when ``lightning`` is importable the class is a real ``LightningModule``
+(so ``run.py lightning_module=eben`` drives it through ``Trainer.fit``); otherwise a small
+stand-in implements the five methods ``training_step`` calls (``optimizers``, ``toggle_optimizer``,
+``untoggle_optimizer``, ``manual_backward``, ``log``) with Lightning's semantics.
+"""
+from __future__ import annotations
+
+from typing import Dict, List
+
+import torch
+
+try:  # pragma: no cover - not installed in the build image
+    from lightning import LightningModule as _Base
+
+    HAVE_LIGHTNING = True
+except Exception:
+    HAVE_LIGHTNING = False
+
+    class _Base(torch.nn.Module):  # type: ignore
+        """Lightning-free stand-in for the subset of LightningModule used by the EBEN step."""
+
+        def __init__(self):
+            super().__init__()
+            self.automatic_optimization = True
+            self.logged: Dict[str, torch.Tensor] = {}
+            self._optimizers = None
+            self._toggled: Dict[int, List[bool]] = {}
+            self.grad_sync = {}  # optimizer id -> vibravox_amd.ddp.GradSync (data-parallel runs)
+
+        def optimizers(self, use_pl_optimizer: bool = True):
+            if self._optimizers is None:
+                self._optimizers = self.configure_optimizers()
+            return self._optimizers
+
+        def toggle_optimizer(self, optimizer):
+            """requires_grad=False on every parameter not owned by `optimizer` (lightning semantics)."""
+            owned = {id(p) for grp in optimizer.param_groups for p in grp["params"]}
+            state = []
+            for p in self.parameters():
+                state.append((p, p.requires_grad))
+                if id(p) not in owned:
+                    p.requires_grad_(False)
+            self._toggled[id(optimizer)] = state
+
+        def untoggle_optimizer(self, optimizer):
+            for p, req in self._toggled.pop(id(optimizer), []):
+                p.requires_grad_(req)
+
+        def manual_backward(self, loss, *args, **kwargs):
+            loss.backward(*args, **kwargs)
+
+        def log(self, name, value, sync_dist: bool = False, **kwargs):
+            self.logged[name] = value.detach() if torch.is_tensor(value) else torch.as_tensor(value)
+
+
+class BaseSELightningModule(_Base):
+    def __init__(self, sample_rate: int, description: str = None):
+        super().__init__()
+        self.sample_rate = sample_rate
+        self.description = description
+        self.dataloader_names = None

@@ -1,0 +1,160 @@
+"""EBEN GAN training orchestration on the HIP modules.
+
+Drop-in for ``vibravox/lightning_modules/eben.py:9-240`` (``EBENLightningModule``): same constructor
+arguments and asserts (:10-80), the same phase order in ``training_step`` (:82-130) -- generator
+forward, atomic losses logged *before* balancing, dynamic loss balancing on the gradient norms at
+``generator.last_conv.weight`` incl. the first-call EMA quirk (:222-240), manual backward + Adam,
+then the discriminator phase on detached generator outputs with the ``torch.rand(1) < ratio`` draw
+(:118) -- the same logged names and the same returned dict.
+"""
+from __future__ import annotations
+
+from functools import partial
+from typing import Dict
+
+import torch
+
+from .base_se import BaseSELightningModule
+
+
+class EBENLightningModule(BaseSELightningModule):
+    def __init__(
+        self,
+        sample_rate: int,
+        generator: torch.nn.Module,
+        discriminator: torch.nn.Module,
+        generator_optimizer: "partial[torch.optim.Optimizer]",
+        discriminator_optimizer: "partial[torch.optim.Optimizer]",
+        reconstructive_loss_freq_fn: torch.nn.Module = None,
+        reconstructive_loss_time_fn: torch.nn.Module = None,
+        feature_matching_loss_fn: torch.nn.Module = None,
+        adversarial_loss_fn: torch.nn.Module = None,
+        dynamic_loss_balancing: str = None,
+        beta_ema: float = 0.9,
+        update_discriminator_ratio: float = 1.0,
+        description: str = None,
+        push_to_hub_after_testing: bool = False,
+    ):
+        super().__init__(sample_rate=sample_rate, description=description)
+        self.generator = generator
+        self.discriminator = discriminator
+        self.generator_optimizer = generator_optimizer(params=self.generator.parameters())
+        self.discriminator_optimizer = discriminator_optimizer(params=self.discriminator.parameters())
+        self.reconstructive_loss_temp_fn = reconstructive_loss_time_fn
+        self.reconstructive_loss_freq_fn = reconstructive_loss_freq_fn
+        self.feature_matching_loss_fn = feature_matching_loss_fn
+        self.adversarial_loss_fn = adversarial_loss_fn
+        assert dynamic_loss_balancing in {None, "simple", "ema"}, "dynamic_loss_balancing must be in {None, 'simple', 'ema'}"
+        self.dynamic_loss_balancing = dynamic_loss_balancing
+        self.atomic_norms_old = None
+        self.beta_ema = beta_ema
+        assert 0 <= update_discriminator_ratio <= 1, "update_discriminator_ratio must be in [0, 1]"
+        self.update_discriminator_ratio = update_discriminator_ratio
+        self.push_to_hub_after_testing = push_to_hub_after_testing
+        self.automatic_optimization = False
+        self.last_lambdas = None
+        self.last_norms = None
+
+    def configure_optimizers(self):
+        return [self.generator_optimizer, self.discriminator_optimizer]
+
+    # -- data-parallel hook points (no-ops on one GPU) --------------------------------------
+    def _sync_grads(self, optimizer) -> float:
+        sync = getattr(self, "grad_sync", {}).get(id(optimizer)) if hasattr(self, "grad_sync") else None
+        return sync.finish() if sync is not None else 1.0
+
+    def _step(self, optimizer, grad_scale: float):
+        if grad_scale != 1.0:
+            try:
+                optimizer.step(grad_scale=grad_scale)
+                return
+            except TypeError:
+                for grp in optimizer.param_groups:
+                    for p in grp["params"]:
+                        if p.grad is not None:
+                            p.grad.mul_(grad_scale)
+        optimizer.step()
+
+    def training_step(self, batch: Dict[str, torch.Tensor], batch_idx: int = 0):
+        corrupted_speech = self.generator.cut_to_valid_length(batch["audio_body_conducted"])
+        reference_speech = self.generator.cut_to_valid_length(batch["audio_airborne"])
+        generator_optimizer, discriminator_optimizer = self.optimizers(use_pl_optimizer=True)
+
+        # ---- generator phase (eben.py:96-111)
+        self.toggle_optimizer(generator_optimizer)
+        enhanced_speech, decomposed_enhanced_speech = self.generator(corrupted_speech)
+        decomposed_reference_speech = self.generator.pqmf.forward(reference_speech, "analysis")
+        atomic_losses_generator = self.compute_atomic_losses(
+            "generator", enhanced_speech, reference_speech, decomposed_enhanced_speech, decomposed_reference_speech
+        )
+        for key, value in atomic_losses_generator.items():
+            self.log(f"train/generator/{key}", value, sync_dist=True)
+        if self.dynamic_loss_balancing is not None:
+            atomic_losses_generator = self.dynamically_balance_losses(atomic_losses_generator)
+        backprop_loss_generator = sum(atomic_losses_generator.values())
+        self.log("train/generator/backprop_loss", backprop_loss_generator, sync_dist=True)
+        self.manual_backward(backprop_loss_generator)
+        self._step(generator_optimizer, self._sync_grads(generator_optimizer))
+        generator_optimizer.zero_grad()
+        self.untoggle_optimizer(generator_optimizer)
+
+        # ---- discriminator phase (eben.py:114-128)
+        self.toggle_optimizer(discriminator_optimizer)
+        atomic_losses_discriminator = self.compute_atomic_losses(
+            "discriminator", enhanced_speech, reference_speech, decomposed_enhanced_speech, decomposed_reference_speech
+        )
+        if atomic_losses_discriminator and torch.rand(1) < self.update_discriminator_ratio:
+            for key, value in atomic_losses_discriminator.items():
+                self.log(f"train/discriminator/{key}", value, sync_dist=True)
+            backprop_loss_discriminator = atomic_losses_discriminator["real_loss"] + atomic_losses_discriminator["fake_loss"]
+            self.log("train/discriminator/backprop_loss", backprop_loss_discriminator, sync_dist=True)
+            self.manual_backward(backprop_loss_discriminator)
+            self._step(discriminator_optimizer, self._sync_grads(discriminator_optimizer))
+            discriminator_optimizer.zero_grad()
+        self.untoggle_optimizer(discriminator_optimizer)
+
+        return {"corrupted": corrupted_speech, "enhanced": enhanced_speech, "reference": reference_speech}
+
+    def compute_atomic_losses(self, network, enhanced_speech, reference_speech, decomposed_enhanced_speech,
+                              decomposed_reference_speech) -> Dict[str, torch.Tensor]:
+        """eben.py:184-220."""
+        atomic_losses = dict()
+        assert network in {"generator", "discriminator"}
+        if network == "generator":
+            if self.reconstructive_loss_freq_fn:
+                atomic_losses["reconstructive_loss_freq"] = self.reconstructive_loss_freq_fn(enhanced_speech, reference_speech)
+            if self.reconstructive_loss_temp_fn:
+                atomic_losses["reconstructive_loss_temp"] = self.reconstructive_loss_temp_fn(enhanced_speech, reference_speech)
+            if self.feature_matching_loss_fn or self.adversarial_loss_fn:
+                enhanced_embeddings = self.discriminator(bands=decomposed_enhanced_speech, audio=enhanced_speech)
+                if self.feature_matching_loss_fn:
+                    reference_embeddings = self.discriminator(bands=decomposed_reference_speech, audio=reference_speech)
+                    atomic_losses["feature_matching_loss"] = self.feature_matching_loss_fn(enhanced_embeddings, reference_embeddings)
+                if self.adversarial_loss_fn:
+                    atomic_losses["adv_loss_gen"] = self.adversarial_loss_fn(embeddings=enhanced_embeddings, target=1)
+        else:
+            if self.adversarial_loss_fn:
+                enhanced_embeddings = self.discriminator(bands=decomposed_enhanced_speech.detach(), audio=enhanced_speech.detach())
+                reference_embeddings = self.discriminator(bands=decomposed_reference_speech, audio=reference_speech)
+                atomic_losses["real_loss"] = self.adversarial_loss_fn(embeddings=reference_embeddings, target=1)
+                atomic_losses["fake_loss"] = self.adversarial_loss_fn(embeddings=enhanced_embeddings, target=-1)
+        return atomic_losses
+
+    def dynamically_balance_losses(self, atomic_losses: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        """eben.py:222-240 (norms / EMA state / lambdas are rank-local, as under the reference's DDP)."""
+        loss_adjustment_layer = self.generator.last_conv.weight
+        atomic_norms = [
+            torch.norm(torch.autograd.grad(loss, loss_adjustment_layer, retain_graph=True)[0]).detach()
+            for loss in atomic_losses.values()
+        ]
+        if self.atomic_norms_old is None or self.dynamic_loss_balancing == "simple":
+            self.atomic_norms_old = atomic_norms
+        if self.dynamic_loss_balancing == "ema":
+            self.atomic_norms_old = [
+                self.beta_ema * old + (1 - self.beta_ema) * new for old, new in zip(self.atomic_norms_old, atomic_norms)
+            ]
+        lambdas = [torch.clamp(1 / (norm + 1e-4), min=0.0, max=1e4) for norm in self.atomic_norms_old]
+        self.last_norms, self.last_lambdas = atomic_norms, lambdas
+        for key, lambda_ in zip(atomic_losses.keys(), lambdas):
+            atomic_losses[key] = atomic_losses[key] * lambda_
+        return atomic_losses

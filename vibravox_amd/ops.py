@@ -24,6 +24,25 @@ def bump_weights_epoch() -> None:
     _weights_epoch[0] += 1
 
 
+class KernelTimer:
+    """HIP-event timing of one layer's forward kernel on the stream it is launched on (bench.py)."""
+
+    def __init__(self, spec: "ConvSpec"):
+        self.spec, self.enabled, self.events = spec, False, []
+
+    def mean_ms(self) -> Optional[float]:
+        if not self.events:
+            return None
+        return sum(a.elapsed_time(b) for a, b in self.events) / len(self.events)
+
+
+_timer: List[Optional[KernelTimer]] = [None]
+
+
+def set_kernel_timer(t: Optional[KernelTimer]) -> None:
+    _timer[0] = t
+
+
 def _empty(n_bytes: int, like: torch.Tensor) -> torch.Tensor:
     return torch.empty(max(1, (n_bytes + 3) // 4), dtype=torch.float32, device=like.device)
 
@@ -122,7 +141,15 @@ class _ConvLayerFn(torch.autograd.Function):
         need_dx = ctx.needs_input_grad[0]
         pw = pack_weights(spec, d, v.detach(), None if g is None else g.detach(), cache, need_dx)
         y = torch.empty((b, spec.c_out, d.l_out), dtype=torch.float32, device=x.device)
+        tm = _timer[0]
+        timed = tm is not None and tm.enabled and tm.spec == spec
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         check(lib.eben_conv1d_fwd(ctypes.byref(d), ptr(x), ptr(pw.wp_fwd), ptr(bias), None, ptr(y), stream()), "conv1d_fwd")
+        if timed:
+            e1.record()
+            tm.events.append((e0, e1))
         ctx.spec, ctx.d = spec, d
         ctx.wp_bwd, ctx.norm = pw.wp_bwd, pw.norm
         ctx.has_g, ctx.has_bias = g is not None, bias is not None
