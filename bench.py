@@ -127,8 +127,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for i in range(args.warmup):
+        tw = time.perf_counter()
         mod.training_step(batch)
+        torch.cuda.synchronize()
+        if rank == 0:
+            print(f"[bench] warm-up step {i}: {(time.perf_counter() - tw) * 1e3:.1f} ms", file=sys.stderr, flush=True)
     barrier()
     timer.enabled = True
     t0 = time.perf_counter()
@@ -168,6 +172,7 @@ def main():
                          "launch_ms": round(kms, 4) if kms else None, "flops_per_launch": flops,
                          "launches_timed": len(timer.events)},
         }
+        print(f"[bench] GPU: {ms:.1f} ms/step, {value:.1f} audio-s/s", file=sys.stderr, flush=True)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_batch, args.length, args.cpu_steps)
         print(json.dumps(line), flush=True)

@@ -71,7 +71,7 @@ EBEN_API int eben_wn_scale(const float* g, const float* v, int rows, int cols, f
  * the weight gradient, column `cols` -- if has_bias -- the bias gradient).
  *   g != NULL: dg[r] = sum(dw*v)/norm, dv = (g/norm) dw - (g dg/norm^2) v     (weight-norm)
  *   g == NULL: dv = sum of slabs                                                (plain weight)
- * dbias (nullable) = summed bias column. */
+ * dbias (nullable) = summed bias column.  The slabs are scratch: slab 0 is overwritten by the sum. */
 EBEN_API int eben_wn_bwd(const float* dw_slabs, int nslab, size_t slab_stride, int rows, int cols, int row_stride,
                 const float* g, const float* v, const float* norm, float* dg, float* dv, float* dbias, void* stream);
 

@@ -161,10 +161,12 @@ def make_module(golden, use_mrstft, fused_adam=True):
     return mod, g_sd, d_sd
 
 
-@pytest.mark.parametrize("fused_adam", [True, False])
-def test_two_train_steps_against_reference_replay_golden(hip, golden, fused_adam):
-    """eben.py:82-130 replayed over the REFERENCE modules (golden) vs this build's LightningModule."""
+@pytest.mark.parametrize("fused_adam,literal", [(True, False), (False, False), (True, True)])
+def test_two_train_steps_against_reference_replay_golden(hip, golden, fused_adam, literal):
+    """eben.py:82-130 replayed over the REFERENCE modules (golden) vs this build's LightningModule,
+    both in the literal as-executed order and with the redundant discriminator passes removed."""
     mod, g_sd, d_sd = make_module(golden, use_mrstft=False, fused_adam=fused_adam)
+    mod.exploit_step_redundancy = not literal
     for i in range(2):
         batch = {"audio_body_conducted": formula_audio(f"step{i}/bc", 2, 8200).to(DEV),
                  "audio_airborne": formula_audio(f"step{i}/air", 2, 8200).to(DEV)}
@@ -183,10 +185,12 @@ def test_two_train_steps_against_reference_replay_golden(hip, golden, fused_adam
         np.testing.assert_allclose(v.double().norm().item(), golden[f"post/D/{k}"][1], rtol=2e-4)
 
 
-def test_train_step_with_mrstft_against_oracle(hip, golden):
+@pytest.mark.parametrize("literal", [False, True])
+def test_train_step_with_mrstft_against_oracle(hip, golden, literal):
     """Full default configuration (MRSTFT + FM + hinge, EMA balancing).  The MRSTFT term is a
     restatement of third-party auraloss (parity unpinned); everything else is pinned."""
     mod, g_sd, d_sd = make_module(golden, use_mrstft=True)
+    mod.exploit_step_redundancy = not literal
     trainer = O.OracleTrainer(g_sd, d_sd, p=2, q=4, use_mrstft=True)
     for i in range(2):
         bc, air = formula_audio(f"mstep{i}/bc", 2, 8200), formula_audio(f"mstep{i}/air", 2, 8200)
@@ -213,5 +217,9 @@ def test_full_size_step_properties(hip, golden):
         assert torch.isfinite(v).all(), k
     lam = torch.stack(mod.last_lambdas)
     assert (lam > 0).all() and (lam <= 1e4).all()
-    moved = [float((v - before[k]).abs().max()) for k, v in mod.discriminator.state_dict().items()]
-    assert max(moved) <= 3e-4 * 1.01 and min(moved) > 0  # first Adam step moves every tensor by <= lr
+    moved = {k: float((v - before[k]).abs().max()) for k, v in mod.discriminator.state_dict().items()}
+    assert max(moved.values()) <= 3e-4 * 1.01  # first Adam step moves every element by <= lr
+    # the logit biases see d(real)/db = -1/4 and d(fake)/db = +1/4 while every hinge term is active
+    # (near-zero logits at init): exactly zero gradient, so they may stay put; everything else moves
+    still = [k for k, m in moved.items() if m == 0.0]
+    assert all(k.endswith(".bias") for k in still) and len(still) <= 4, still

@@ -201,35 +201,39 @@ __global__ __launch_bounds__(256) void wn_scale_kernel(const float* __restrict__
   }
 }
 
-__global__ __launch_bounds__(256) void wn_bwd_kernel(const float* __restrict__ slabs, int nslab, long long slab_stride, int cols,
-                                                     int row_stride, const float* __restrict__ g, const float* __restrict__ v,
+// slab reduction: out[i] = sum_z slabs[z][i] for i < n (fully parallel, coalesced, fixed order)
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs, int nslab, long long slab_stride,
+                                                          long long n, float* __restrict__ out) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    float s = 0.f;
+    for (int z = 0; z < nslab; ++z) s += slabs[(long long)z * slab_stride + i];
+    out[i] = s;
+  }
+}
+
+// per weight row: dw row (already summed, row stride `row_stride`) -> dg, dv (+ dbias from column `cols`)
+__global__ __launch_bounds__(256) void wn_bwd_kernel(const float* __restrict__ dw, int cols, int row_stride,
+                                                     const float* __restrict__ g, const float* __restrict__ v,
                                                      const float* __restrict__ norm, float* __restrict__ dg, float* __restrict__ dv,
                                                      float* __restrict__ dbias) {
   __shared__ float red[4];
   const int r = blockIdx.x;
-  const float* srow = slabs + (long long)r * row_stride;
-  const float* vrow = v + (long long)r * cols;
+  const float* srow = dw + (long long)r * row_stride;
   float* orow = dv + (long long)r * cols;
-  // pass 1: dw = sum of slabs (kept in dv), dot = <dw, v>
+  if (dbias && threadIdx.x == 0) dbias[r] = srow[cols];
+  if (!g) {
+    for (int i = threadIdx.x; i < cols; i += 256) orow[i] = srow[i];
+    return;
+  }
+  const float* vrow = v + (long long)r * cols;
   float dot = 0.f;
-  for (int i = threadIdx.x; i < cols; i += 256) {
-    float s = 0.f;
-    for (int z = 0; z < nslab; ++z) s += srow[(long long)z * slab_stride + i];
-    orow[i] = s;
-    dot += s * vrow[i];
-  }
-  if (dbias && threadIdx.x == 0) {
-    float s = 0.f;
-    for (int z = 0; z < nslab; ++z) s += srow[(long long)z * slab_stride + cols];
-    dbias[r] = s;
-  }
-  if (!g) return;
+  for (int i = threadIdx.x; i < cols; i += 256) dot += srow[i] * vrow[i];
   dot = block_sum_256(dot, red);
   const float n = norm[r], gr = g[r];
   const float dgr = dot / n;
   if (threadIdx.x == 0) dg[r] = dgr;
   const float c1 = gr / n, c2 = gr * dgr / (n * n);
-  for (int i = threadIdx.x; i < cols; i += 256) orow[i] = c1 * orow[i] - c2 * vrow[i];
+  for (int i = threadIdx.x; i < cols; i += 256) orow[i] = c1 * srow[i] - c2 * vrow[i];
 }
 
 }  // namespace eben
@@ -248,8 +252,18 @@ extern "C" int eben_wn_bwd(const float* dw_slabs, int nslab, size_t slab_stride,
   EBEN_REQUIRE(dw_slabs && dv && nslab > 0 && rows > 0 && cols > 0 && row_stride >= cols, "bad wn_bwd arguments");
   EBEN_REQUIRE(!g || (v && norm && dg), "weight-norm backward needs v, norm and dg");
   EBEN_REQUIRE(!dbias || row_stride > cols, "no bias column in the slabs");
-  hipLaunchKernelGGL(wn_bwd_kernel, dim3(rows), dim3(256), 0, as_stream(stream), dw_slabs, nslab, (long long)slab_stride, cols,
-                     row_stride, g, v ? v : dw_slabs, norm, dg, dv, dbias);
+  EBEN_REQUIRE(nslab == 1 || slab_stride >= (size_t)rows * row_stride, "slab stride smaller than a slab");
+  hipStream_t st = as_stream(stream);
+  if (nslab > 1) {
+    // sum the split-K slabs into slab 0 (in place: slab 0 is read before it is written, element-wise)
+    const long long n = (long long)rows * row_stride;
+    long long blocks = (n + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, dw_slabs, nslab, (long long)slab_stride, n,
+                       const_cast<float*>(dw_slabs));
+    EBEN_CHECK_LAUNCH("slab_reduce_kernel");
+  }
+  hipLaunchKernelGGL(wn_bwd_kernel, dim3(rows), dim3(256), 0, st, dw_slabs, cols, row_stride, g, v, norm, dg, dv, dbias);
   EBEN_CHECK_LAUNCH("wn_bwd_kernel");
   return EBEN_OK;
 }

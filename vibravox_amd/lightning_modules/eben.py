@@ -6,6 +6,20 @@ forward, atomic losses logged *before* balancing, dynamic loss balancing on the 
 ``generator.last_conv.weight`` incl. the first-call EMA quirk (:222-240), manual backward + Adam,
 then the discriminator phase on detached generator outputs with the ``torch.rand(1) < ratio`` draw
 (:118) -- the same logged names and the same returned dict.
+
+``exploit_step_redundancy`` (default on) removes work the reference repeats without changing any
+value:
+  * the two discriminator forwards of the discriminator phase recompute, with unchanged
+    discriminator weights, exactly what the generator phase computed on the same tensors -> the
+    hinge losses are taken from the generator-phase embeddings and back-propagated with
+    ``backward(inputs=discriminator parameters)``;
+  * the generator only reaches the losses through ``bands`` (``enhanced`` = PQMF synthesis of it), so
+    the three balancing gradients are taken at ``bands`` (one discriminator input-gradient pass each
+    for feature-matching and adversarial, none repeated), pushed to ``last_conv.weight`` for the
+    norms, and the final generator backward is seeded with their lambda-weighted sum (linearity)
+    instead of walking the discriminator a third time.
+11 discriminator passes per step become 8 (F_exec -> F_min of SURVEY.md section 8d).  Set the
+attribute to False for the literal as-executed order.
 """
 from __future__ import annotations
 
@@ -18,6 +32,8 @@ from .base_se import BaseSELightningModule
 
 
 class EBENLightningModule(BaseSELightningModule):
+    exploit_step_redundancy: bool = True
+
     def __init__(
         self,
         sample_rate: int,
@@ -76,6 +92,68 @@ class EBENLightningModule(BaseSELightningModule):
         optimizer.step()
 
     def training_step(self, batch: Dict[str, torch.Tensor], batch_idx: int = 0):
+        if (self.exploit_step_redundancy and self.adversarial_loss_fn is not None and self.feature_matching_loss_fn is not None
+                and self.dynamic_loss_balancing is not None):
+            return self._training_step_fused(batch)
+        return self._training_step_literal(batch)
+
+    def _training_step_fused(self, batch: Dict[str, torch.Tensor]):
+        """Same values as ``_training_step_literal`` with 8 instead of 11 discriminator passes."""
+        corrupted_speech = self.generator.cut_to_valid_length(batch["audio_body_conducted"])
+        reference_speech = self.generator.cut_to_valid_length(batch["audio_airborne"])
+        generator_optimizer, discriminator_optimizer = self.optimizers(use_pl_optimizer=True)
+        g_params = [p for p in self.generator.parameters() if p.requires_grad]
+        d_params = [p for p in self.discriminator.parameters() if p.requires_grad]
+
+        # ---- generator phase: every forward of the step happens here
+        enhanced_speech, bands = self.generator(corrupted_speech)
+        bands_ref = self.generator.pqmf.forward(reference_speech, "analysis")
+        losses: Dict[str, torch.Tensor] = {}
+        if self.reconstructive_loss_freq_fn:
+            losses["reconstructive_loss_freq"] = self.reconstructive_loss_freq_fn(enhanced_speech, reference_speech)
+        if self.reconstructive_loss_temp_fn:
+            losses["reconstructive_loss_temp"] = self.reconstructive_loss_temp_fn(enhanced_speech, reference_speech)
+        enhanced_embeddings = self.discriminator(bands=bands, audio=enhanced_speech)
+        reference_embeddings = self.discriminator(bands=bands_ref, audio=reference_speech)
+        losses["feature_matching_loss"] = self.feature_matching_loss_fn(enhanced_embeddings, reference_embeddings)
+        losses["adv_loss_gen"] = self.adversarial_loss_fn(embeddings=enhanced_embeddings, target=1)
+        for key, value in losses.items():
+            self.log(f"train/generator/{key}", value, sync_dist=True)
+
+        # balancing (eben.py:222-240) with the gradients taken at `bands`
+        leaf = self.generator.last_conv.weight
+        seeds = [torch.autograd.grad(loss, bands, retain_graph=True)[0] for loss in losses.values()]
+        atomic_norms = [torch.norm(torch.autograd.grad(bands, leaf, grad_outputs=s, retain_graph=True)[0]).detach() for s in seeds]
+        if self.atomic_norms_old is None or self.dynamic_loss_balancing == "simple":
+            self.atomic_norms_old = atomic_norms
+        if self.dynamic_loss_balancing == "ema":
+            self.atomic_norms_old = [self.beta_ema * old + (1 - self.beta_ema) * new
+                                     for old, new in zip(self.atomic_norms_old, atomic_norms)]
+        lambdas = [torch.clamp(1 / (norm + 1e-4), min=0.0, max=1e4) for norm in self.atomic_norms_old]
+        self.last_norms, self.last_lambdas = atomic_norms, lambdas
+        backprop_loss_generator = sum(loss.detach() * lam for loss, lam in zip(losses.values(), lambdas))
+        self.log("train/generator/backprop_loss", backprop_loss_generator, sync_dist=True)
+        seed = None
+        for s, lam in zip(seeds, lambdas):
+            seed = s * lam if seed is None else seed + s * lam
+        torch.autograd.backward(bands, seed, inputs=g_params, retain_graph=True)
+        self._step(generator_optimizer, self._sync_grads(generator_optimizer))
+        generator_optimizer.zero_grad()
+
+        # ---- discriminator phase on the embeddings already computed (weights untouched since)
+        if torch.rand(1) < self.update_discriminator_ratio:
+            real_loss = self.adversarial_loss_fn(embeddings=reference_embeddings, target=1)
+            fake_loss = self.adversarial_loss_fn(embeddings=enhanced_embeddings, target=-1)
+            self.log("train/discriminator/real_loss", real_loss, sync_dist=True)
+            self.log("train/discriminator/fake_loss", fake_loss, sync_dist=True)
+            backprop_loss_discriminator = real_loss + fake_loss
+            self.log("train/discriminator/backprop_loss", backprop_loss_discriminator, sync_dist=True)
+            backprop_loss_discriminator.backward(inputs=d_params)
+            self._step(discriminator_optimizer, self._sync_grads(discriminator_optimizer))
+            discriminator_optimizer.zero_grad()
+        return {"corrupted": corrupted_speech, "enhanced": enhanced_speech.detach(), "reference": reference_speech}
+
+    def _training_step_literal(self, batch: Dict[str, torch.Tensor]):
         corrupted_speech = self.generator.cut_to_valid_length(batch["audio_body_conducted"])
         reference_speech = self.generator.cut_to_valid_length(batch["audio_airborne"])
         generator_optimizer, discriminator_optimizer = self.optimizers(use_pl_optimizer=True)

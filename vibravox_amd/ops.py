@@ -15,13 +15,20 @@ import torch
 from . import _lib
 from ._lib import EbenConv1dDesc, check, load, ptr, stream
 
-# bumped by optimisers that write parameters behind autograd's back (FusedAdam) so that the
-# packed-weight caches of the conv layers are rebuilt
-_weights_epoch = [0]
+# Optimisers that write parameters behind autograd's back (FusedAdam) bump the epoch of exactly
+# the storages they touched, so that only those layers' packed-weight caches are rebuilt.
+_storage_epoch: Dict[int, int] = {}
 
 
-def bump_weights_epoch() -> None:
-    _weights_epoch[0] += 1
+def bump_weights_epoch(params=None) -> None:
+    if params is None:
+        for k in list(_storage_epoch):
+            _storage_epoch[k] += 1
+        _storage_epoch[-1] = _storage_epoch.get(-1, 0) + 1
+        return
+    for p in params:
+        k = p.data_ptr()
+        _storage_epoch[k] = _storage_epoch.get(k, 0) + 1
 
 
 class KernelTimer:
@@ -107,7 +114,8 @@ class PackedWeights:
 def pack_weights(spec: ConvSpec, d: EbenConv1dDesc, v: torch.Tensor, g: Optional[torch.Tensor],
                  cache: Optional[PackedWeights], need_bwd: bool) -> PackedWeights:
     lib = load()
-    key = (v.data_ptr(), v._version, None if g is None else (g.data_ptr(), g._version), _weights_epoch[0], d.batch, d.l_in)
+    key = (v.data_ptr(), v._version, _storage_epoch.get(v.data_ptr(), 0), _storage_epoch.get(-1, 0),
+           None if g is None else (g.data_ptr(), g._version, _storage_epoch.get(g.data_ptr(), 0)), d.batch, d.l_in)
     pw = cache if cache is not None else PackedWeights()
     need_bwd = need_bwd or cache is not None  # a module-level cache serves every later pass
     if pw.key == key and (pw.wp_bwd is not None or not need_bwd):

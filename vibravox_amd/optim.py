@@ -52,5 +52,5 @@ class FusedAdam(torch.optim.Optimizer):
                     table[i] = EbenAdamTensor(ptr(p.data), ptr(g), ptr(st["exp_avg"]), ptr(st["exp_avg_sq"]), p.numel())
                 check(lib.eben_adam_step(table, len(plist), max(p.numel() for p in plist), group["lr"], beta1, beta2, group["eps"],
                                          group["weight_decay"], step, grad_scale, stream()), "adam_step")
-        ops.bump_weights_epoch()
+        ops.bump_weights_epoch([p for group in self.param_groups for p in group["params"] if p.grad is not None])
         return loss
