@@ -77,12 +77,21 @@ __global__ __launch_bounds__(256) void conv_dw_kernel(const DwArgs P) {
 #pragma unroll
     for (int n = 0; n < FN; ++n) acc[i][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  for (int q = z; q < P.nchunks; q += P.nsplit) {
+  // Software pipeline: the global loads of chunk q+1 (A tile: 16 values per thread; X tile: up to
+  // XR per thread) are issued before the MFMAs of chunk q and land in registers while they run;
+  // they are written to LDS after the barrier that retires chunk q.
+  constexpr int AR = BM * DW_BK / 256;
+  constexpr int XR = 16;
+  const int xtot = nch * span;
+  const bool xfits = xtot <= XR * 256;
+  float areg[AR], xreg[XR];
+
+  auto load_chunk = [&](int q) {
     const int b = q / P.nct;
     const int t0 = (q - b * P.nct) * DW_BK;
-    __syncthreads();
-    // A tile: BM rows x 32 time steps
-    for (int i = tid; i < BM * DW_BK; i += 256) {
+#pragma unroll
+    for (int u = 0; u < AR; ++u) {
+      const int i = tid + u * 256;
       const int r = i / DW_BK, tt = i - r * DW_BK;
       const int m = m0 + r, t = t0 + tt;
       float v = 0.f;
@@ -90,37 +99,92 @@ __global__ __launch_bounds__(256) void conv_dw_kernel(const DwArgs P) {
         const long long idx = ((long long)b * P.Ca + (long long)g * P.Mg + m) * P.La + t;
         v = load_op(P.a, P.amask, idx, P.a_mode, P.a_slope);
       }
-      Ds[r * DW_DSTR + tt] = v;
+      areg[u] = v;
     }
-    // X tile: nch channels x span positions
-    const int qbase = t0 * P.S + P.off0;
-    for (int c = 0; c < nch; ++c) {
-      const long long row = ((long long)b * P.Cx + (long long)g * P.Cg + c_lo + c) * P.Lx;
-      for (int r = tid; r < span; r += 256) {
-        int p = qbase + r;
-        if (P.reflect) {
-          p = p < 0 ? -p : p;
-          p = p >= P.Lx ? 2 * (P.Lx - 1) - p : p;
-        }
+    if (xfits) {
+      const int qbase = t0 * P.S + P.off0;
+#pragma unroll
+      for (int u = 0; u < XR; ++u) {
+        const int i = tid + u * 256;
         float v = 0.f;
-        if (p >= 0 && p < P.Lx) v = load_op(P.x, P.xmask, row + p, P.x_mode, P.x_slope);
-        Xs[c * P.XSTR + r] = v;
+        if (i < xtot) {
+          const int c = i / span, r = i - c * span;
+          int p = qbase + r;
+          if (P.reflect) {
+            p = p < 0 ? -p : p;
+            p = p >= P.Lx ? 2 * (P.Lx - 1) - p : p;
+          }
+          if (p >= 0 && p < P.Lx) {
+            const long long row = ((long long)b * P.Cx + (long long)g * P.Cg + c_lo + c) * P.Lx;
+            v = load_op(P.x, P.xmask, row + p, P.x_mode, P.x_slope);
+          }
+        }
+        xreg[u] = v;
       }
     }
+  };
+  auto store_chunk = [&](int q) {
+#pragma unroll
+    for (int u = 0; u < AR; ++u) {
+      const int i = tid + u * 256;
+      const int r = i / DW_BK, tt = i - r * DW_BK;
+      Ds[r * DW_DSTR + tt] = areg[u];
+    }
+    if (xfits) {
+#pragma unroll
+      for (int u = 0; u < XR; ++u) {
+        const int i = tid + u * 256;
+        if (i < xtot) {
+          const int c = i / span, r = i - c * span;
+          Xs[c * P.XSTR + r] = xreg[u];
+        }
+      }
+    } else {  // oversized X tile (not produced by the EBEN layers): direct staging
+      const int b = q / P.nct;
+      const int t0 = (q - b * P.nct) * DW_BK;
+      const int qbase = t0 * P.S + P.off0;
+      for (int c = 0; c < nch; ++c) {
+        const long long row = ((long long)b * P.Cx + (long long)g * P.Cg + c_lo + c) * P.Lx;
+        for (int r = tid; r < span; r += 256) {
+          int p = qbase + r;
+          if (P.reflect) {
+            p = p < 0 ? -p : p;
+            p = p >= P.Lx ? 2 * (P.Lx - 1) - p : p;
+          }
+          float v = 0.f;
+          if (p >= 0 && p < P.Lx) v = load_op(P.x, P.xmask, row + p, P.x_mode, P.x_slope);
+          Xs[c * P.XSTR + r] = v;
+        }
+      }
+    }
+  };
+
+  if (z < P.nchunks) load_chunk(z);
+  for (int q = z; q < P.nchunks; q += P.nsplit) {
+    __syncthreads();  // MFMAs of the previous chunk are done with Ds / Xs
+    store_chunk(q);
     __syncthreads();
+    if (q + P.nsplit < P.nchunks) load_chunk(q + P.nsplit);
     const float* drow = Ds + (wm * FM * 16 + l15) * DW_DSTR + kk;
+    float a[2][FM], bv[2][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i) a[0][i] = drow[i * 16 * DW_DSTR];
+#pragma unroll
+    for (int n = 0; n < FN; ++n) bv[0][n] = Xs[xoff[n]];
 #pragma unroll
     for (int ks = 0; ks < DW_BK; ks += 4) {
-      float a[FM], bv[FN];
+      const int cur = (ks >> 2) & 1, nxt = cur ^ 1;
+      if (ks + 4 < DW_BK) {
 #pragma unroll
-      for (int i = 0; i < FM; ++i) a[i] = drow[i * 16 * DW_DSTR + ks];
+        for (int i = 0; i < FM; ++i) a[nxt][i] = drow[i * 16 * DW_DSTR + ks + 4];
 #pragma unroll
-      for (int n = 0; n < FN; ++n) bv[n] = Xs[xoff[n] + ks * xstep[n]];
+        for (int n = 0; n < FN; ++n) bv[nxt][n] = Xs[xoff[n] + (ks + 4) * xstep[n]];
+      }
 #pragma unroll
       for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int n = 0; n < FN; ++n)
-          acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], bv[n], acc[i][n], 0, 0, 0);
+          acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cur][i], bv[cur][n], acc[i][n], 0, 0, 0);
     }
   }
 
@@ -158,7 +222,8 @@ static void make_dw_plan(const Canon& c, DwPlan* p) {
   p->nct = ceil_div(c.Lout, DW_BK);
   p->nchunks = c.B * p->nct;
   const int tiles = p->nnt * p->nmt * p->G;
-  int ns = ceil_div(1024, tiles);
+  // enough blocks to fill 256 CUs a few times over; no split at all once the tiles alone do that
+  int ns = tiles >= 384 ? 1 : ceil_div(768, tiles);
   if (ns > 512) ns = 512;
   if (ns > p->nchunks) ns = p->nchunks;
   if (ns < 1) ns = 1;
@@ -201,13 +266,30 @@ __global__ __launch_bounds__(256) void wn_scale_kernel(const float* __restrict__
   }
 }
 
-// slab reduction: out[i] = sum_z slabs[z][i] for i < n (fully parallel, coalesced, fixed order)
+// slab reduction: out[i] = sum_z slabs[z][i] for i < n.  64 elements x 4 z-groups per block: each
+// thread keeps 4 independent partial sums in flight (latency-bound otherwise: tiny layers use up to
+// 512 slabs), the 4 z-groups are combined in a fixed order through LDS (deterministic).
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs, int nslab, long long slab_stride,
                                                           long long n, float* __restrict__ out) {
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-    float s = 0.f;
-    for (int z = 0; z < nslab; ++z) s += slabs[(long long)z * slab_stride + i];
-    out[i] = s;
+  __shared__ float part[4][64];
+  const int lane = threadIdx.x & 63, zg = threadIdx.x >> 6;
+  for (long long base = (long long)blockIdx.x * 64; base < n; base += (long long)gridDim.x * 64) {
+    const long long i = base + lane;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (i < n) {
+      int z = zg;
+      for (; z + 12 < nslab; z += 16) {
+        s0 += slabs[(long long)z * slab_stride + i];
+        s1 += slabs[(long long)(z + 4) * slab_stride + i];
+        s2 += slabs[(long long)(z + 8) * slab_stride + i];
+        s3 += slabs[(long long)(z + 12) * slab_stride + i];
+      }
+      for (; z < nslab; z += 4) s0 += slabs[(long long)z * slab_stride + i];
+    }
+    __syncthreads();
+    part[zg][lane] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (zg == 0 && i < n) out[i] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
   }
 }
 
@@ -257,8 +339,8 @@ extern "C" int eben_wn_bwd(const float* dw_slabs, int nslab, size_t slab_stride,
   if (nslab > 1) {
     // sum the split-K slabs into slab 0 (in place: slab 0 is read before it is written, element-wise)
     const long long n = (long long)rows * row_stride;
-    long long blocks = (n + 255) / 256;
-    if (blocks > 8192) blocks = 8192;
+    long long blocks = (n + 63) / 64;
+    if (blocks > 16384) blocks = 16384;
     hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, dw_slabs, nslab, (long long)slab_stride, n,
                        const_cast<float*>(dw_slabs));
     EBEN_CHECK_LAUNCH("slab_reduce_kernel");

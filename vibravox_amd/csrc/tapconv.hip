@@ -61,7 +61,8 @@ __global__ __launch_bounds__(256) void tapconv_kernel(const TapArgs P) {
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   int* koff = reinterpret_cast<int*>(smem);
-  float* Ws = smem + P.KCpad;                 // KCpad is a multiple of 4 -> 16 B aligned
+  const int koff_len = ((P.KCpad + KT - 1) / KT) * KT;   // padded: the k-loop always runs KT/4 steps
+  float* Ws = smem + koff_len;                           // multiple of 4 -> 16 B aligned
   float* Xs = Ws + KT * WSTR;
 
   const int tid = threadIdx.x;
@@ -104,10 +105,10 @@ __global__ __launch_bounds__(256) void tapconv_kernel(const TapArgs P) {
   const int span = J > 0 ? (BN - 1) * P.S + (J - 1) * adstep + 1 : 0;
   const int KC = ((J * P.CI_T + 3) >> 2) << 2;  // flat K entries actually used by this phase
 
-  for (int f = tid; f < P.KCpad; f += 256) {
+  for (int f = tid; f < koff_len; f += 256) {
     const int j = f / P.CI_T, cl = f - j * P.CI_T;
     int o = 0;
-    if (j < J) {
+    if (f < P.KCpad && j < J) {
       const int rel = off0 + j * P.dstep - minoff;
       int p = 0, dd = rel;
       if (P.S != 1) { dd = (int)__umulhi((unsigned)rel, P.s_magic); p = rel - dd * P.S; }
@@ -177,22 +178,38 @@ __global__ __launch_bounds__(256) void tapconv_kernel(const TapArgs P) {
       }
       __syncthreads();
       if (kc + 1 < nkc) prefetch(kc + 1);
-      const int rows = min(KT, KC - kc * KT);
+      // fixed-trip k-loop (rows past the chunk end are zero weights against a valid offset 0):
+      // tap offsets for the whole chunk are read up front, fragments are loaded one k-step ahead
+      // of the MFMAs that consume them.
       const float* wrow = Ws + kk * WSTR + wm * FM * 16 + l15;
       const int* ko = koff + kc * KT + kk;
       const float* xcol = Xs + wn * FN * 16 + l15;
-      for (int ks = 0; ks < rows; ks += 4) {
-        float a[FM], bv[FN];
-        const int xo = ko[ks];
+      constexpr int NSTEP = KT / 4;
+      constexpr int UNR = NSTEP < 8 ? NSTEP : 8;
+      for (int kb = 0; kb < NSTEP; kb += UNR) {
+        int xo[UNR];
 #pragma unroll
-        for (int i = 0; i < FM; ++i) a[i] = wrow[ks * WSTR + i * 16];
+        for (int u = 0; u < UNR; ++u) xo[u] = ko[(kb + u) * 4];
+        float a[2][FM], bv[2][FN];
 #pragma unroll
-        for (int n = 0; n < FN; ++n) bv[n] = xcol[xo + n * 16];
+        for (int i = 0; i < FM; ++i) a[0][i] = wrow[(kb * 4) * WSTR + i * 16];
 #pragma unroll
-        for (int i = 0; i < FM; ++i)
+        for (int n = 0; n < FN; ++n) bv[0][n] = xcol[xo[0] + n * 16];
 #pragma unroll
-          for (int n = 0; n < FN; ++n)
-            acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], bv[n], acc[i][n], 0, 0, 0);
+        for (int u = 0; u < UNR; ++u) {
+          const int cur = u & 1, nxt = cur ^ 1;
+          if (u + 1 < UNR) {
+#pragma unroll
+            for (int i = 0; i < FM; ++i) a[nxt][i] = wrow[((kb + u + 1) * 4) * WSTR + i * 16];
+#pragma unroll
+            for (int n = 0; n < FN; ++n) bv[nxt][n] = xcol[xo[u + 1] + n * 16];
+          }
+#pragma unroll
+          for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int n = 0; n < FN; ++n)
+              acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cur][i], bv[cur][n], acc[i][n], 0, 0, 0);
+        }
       }
     }
   }
@@ -323,7 +340,7 @@ static void make_plan(const Canon& c, int dir, TapPlan* p) {
     p->CSTRIDE = round_up(p->S * p->PLEN, 32) + 16;
     p->CI_T = ci;
     p->KCpad = round_up(p->J * ci, 4);
-    p->lds_bytes = 4ull * ((size_t)p->KCpad + (size_t)KT * (p->BM + 16) + (size_t)ci * p->CSTRIDE);
+    p->lds_bytes = 4ull * ((size_t)round_up(p->KCpad, KT) + (size_t)KT * (p->BM + 16) + (size_t)ci * p->CSTRIDE);
     if (p->lds_bytes <= 96 * 1024 || ci == 1) break;
     ci = ci > 8 ? 8 : ci / 2;
     if (ci < 1) ci = 1;

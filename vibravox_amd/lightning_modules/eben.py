@@ -28,6 +28,7 @@ from typing import Dict
 
 import torch
 
+from .. import ops
 from .base_se import BaseSELightningModule
 
 
@@ -122,7 +123,8 @@ class EBENLightningModule(BaseSELightningModule):
 
         # balancing (eben.py:222-240) with the gradients taken at `bands`
         leaf = self.generator.last_conv.weight
-        seeds = [torch.autograd.grad(loss, bands, retain_graph=True)[0] for loss in losses.values()]
+        with ops.weight_grads_disabled():  # only d/d(bands) is wanted from these passes
+            seeds = [torch.autograd.grad(loss, bands, retain_graph=True)[0] for loss in losses.values()]
         atomic_norms = [torch.norm(torch.autograd.grad(bands, leaf, grad_outputs=s, retain_graph=True)[0]).detach() for s in seeds]
         if self.atomic_norms_old is None or self.dynamic_loss_balancing == "simple":
             self.atomic_norms_old = atomic_norms

@@ -31,6 +31,21 @@ def bump_weights_epoch(params=None) -> None:
         _storage_epoch[k] = _storage_epoch.get(k, 0) + 1
 
 
+# Set (by the train step) while a backward pass only needs input gradients: a Function's
+# ``needs_input_grad`` is fixed at forward time, so without this the weight-gradient GEMMs would
+# run inside torch.autograd.grad(loss, bands) although their results are discarded.
+_skip_weight_grads = [False]
+
+
+class weight_grads_disabled:
+    def __enter__(self):
+        self.prev = _skip_weight_grads[0]
+        _skip_weight_grads[0] = True
+
+    def __exit__(self, *exc):
+        _skip_weight_grads[0] = self.prev
+
+
 class KernelTimer:
     """HIP-event timing of one layer's forward kernel on the stream it is launched on (bench.py)."""
 
@@ -178,7 +193,8 @@ class _ConvLayerFn(torch.autograd.Function):
             dx = torch.empty_like(x)
             check(lib.eben_conv1d_bwd_dx(ctypes.byref(d), ptr(dy), ptr(y), ptr(ctx.wp_bwd), ptr(x), ptr(dx), 0, ptr(ws), ws_bytes, st),
                   "conv1d_bwd_dx")
-        if ctx.needs_input_grad[1] or (ctx.has_g and ctx.needs_input_grad[2]) or (ctx.has_bias and ctx.needs_input_grad[3]):
+        want_w = ctx.needs_input_grad[1] or (ctx.has_g and ctx.needs_input_grad[2]) or (ctx.has_bias and ctx.needs_input_grad[3])
+        if want_w and not _skip_weight_grads[0]:
             nslab, row_stride = ctypes.c_int(0), ctypes.c_int(0)
             ws_bytes = lib.eben_conv1d_bwd_dw_workspace(ctypes.byref(d), ctypes.byref(nslab), ctypes.byref(row_stride))
             slabs = _empty(ws_bytes, x)
