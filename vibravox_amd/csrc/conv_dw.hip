@@ -10,6 +10,8 @@
 // A = dy * lrelu'(y) (Conv1d) or lrelu(x) (ConvTranspose1d); X = lrelu(x) or dy * lrelu'(y).
 #include "common.h"
 
+#include <cstdlib>
+
 namespace eben {
 
 struct DwArgs {
@@ -86,37 +88,57 @@ __global__ __launch_bounds__(256) void conv_dw_kernel(const DwArgs P) {
   const bool xfits = xtot <= XR * 256;
   float areg[AR], xreg[XR];
 
+  // per-thread coordinates, computed once: A element u sits at row a_r0 + 8u, column a_tt;
+  // X element u at (channel, position) packed as c<<16 | r (or -1 past the tile).
+  const int a_tt = tid & (DW_BK - 1), a_r0 = tid >> 5;
+  int xpk[XR];
+#pragma unroll
+  for (int u = 0; u < XR; ++u) {
+    const int i = tid + u * 256;
+    if (xfits && i < xtot) {
+      const int c = i / span;
+      xpk[u] = (c << 16) | (i - c * span);
+    } else {
+      xpk[u] = -1;
+    }
+  }
+
   auto load_chunk = [&](int q) {
     const int b = q / P.nct;
     const int t0 = (q - b * P.nct) * DW_BK;
+    const long long abase = ((long long)b * P.Ca + (long long)g * P.Mg) * P.La + t0;
+    const float* pa = P.a + abase;
+    const float* pam = P.amask ? P.amask + abase : nullptr;
+    const bool tok = t0 + a_tt < P.La;
 #pragma unroll
     for (int u = 0; u < AR; ++u) {
-      const int i = tid + u * 256;
-      const int r = i / DW_BK, tt = i - r * DW_BK;
-      const int m = m0 + r, t = t0 + tt;
+      const int m = m0 + a_r0 + 8 * u;
       float v = 0.f;
-      if (m < P.Mg && t < P.La) {
-        const long long idx = ((long long)b * P.Ca + (long long)g * P.Mg + m) * P.La + t;
-        v = load_op(P.a, P.amask, idx, P.a_mode, P.a_slope);
+      if (tok && m < P.Mg) {
+        const int off = m * P.La + a_tt;
+        v = pa[off];
+        v = P.a_mode == 0 ? lrelu(v, P.a_slope) : v * dlrelu(pam[off], P.a_slope);
       }
       areg[u] = v;
     }
     if (xfits) {
       const int qbase = t0 * P.S + P.off0;
+      const long long xbase = ((long long)b * P.Cx + (long long)g * P.Cg + c_lo) * P.Lx;
+      const float* px = P.x + xbase;
+      const float* pxm = P.xmask ? P.xmask + xbase : nullptr;
 #pragma unroll
       for (int u = 0; u < XR; ++u) {
-        const int i = tid + u * 256;
         float v = 0.f;
-        if (i < xtot) {
-          const int c = i / span, r = i - c * span;
-          int p = qbase + r;
+        if (xpk[u] >= 0) {
+          int p = qbase + (xpk[u] & 0xffff);
           if (P.reflect) {
             p = p < 0 ? -p : p;
             p = p >= P.Lx ? 2 * (P.Lx - 1) - p : p;
           }
           if (p >= 0 && p < P.Lx) {
-            const long long row = ((long long)b * P.Cx + (long long)g * P.Cg + c_lo + c) * P.Lx;
-            v = load_op(P.x, P.xmask, row + p, P.x_mode, P.x_slope);
+            const int off = (xpk[u] >> 16) * P.Lx + p;
+            v = px[off];
+            v = P.x_mode == 0 ? lrelu(v, P.x_slope) : v * dlrelu(pxm[off], P.x_slope);
           }
         }
         xreg[u] = v;
@@ -125,20 +147,11 @@ __global__ __launch_bounds__(256) void conv_dw_kernel(const DwArgs P) {
   };
   auto store_chunk = [&](int q) {
 #pragma unroll
-    for (int u = 0; u < AR; ++u) {
-      const int i = tid + u * 256;
-      const int r = i / DW_BK, tt = i - r * DW_BK;
-      Ds[r * DW_DSTR + tt] = areg[u];
-    }
+    for (int u = 0; u < AR; ++u) Ds[(a_r0 + 8 * u) * DW_DSTR + a_tt] = areg[u];
     if (xfits) {
 #pragma unroll
-      for (int u = 0; u < XR; ++u) {
-        const int i = tid + u * 256;
-        if (i < xtot) {
-          const int c = i / span, r = i - c * span;
-          Xs[c * P.XSTR + r] = xreg[u];
-        }
-      }
+      for (int u = 0; u < XR; ++u)
+        if (xpk[u] >= 0) Xs[(xpk[u] >> 16) * P.XSTR + (xpk[u] & 0xffff)] = xreg[u];
     } else {  // oversized X tile (not produced by the EBEN layers): direct staging
       const int b = q / P.nct;
       const int t0 = (q - b * P.nct) * DW_BK;
@@ -213,7 +226,11 @@ struct DwPlan {
 static void make_dw_plan(const Canon& c, DwPlan* p) {
   p->G = c.g; p->Cg = c.Cin / c.g; p->Mg = c.Cout / c.g; p->J = c.k;
   p->Ng = p->Cg * c.k; p->row_stride = p->Ng + 1;
-  if (p->Mg > 64) { p->cfg = 0; p->BM = 128; p->BN = 128; }
+  // Measured on MI355X (tools/layer_bench.py): the weight-gradient kernel is latency-bound; 32x256
+  // tiles (3 resident blocks per CU) run 1.8x faster than 128x128 (1 block per CU) on the big layers.
+  static const int env_big = getenv("EBEN_DW_BIG_CFG") ? atoi(getenv("EBEN_DW_BIG_CFG")) : 2;  // tuning aid
+  if (p->Mg > 64 && env_big == 0) { p->cfg = 0; p->BM = 128; p->BN = 128; }
+  else if (p->Mg > 64 && env_big == 2) { p->cfg = 2; p->BM = 32; p->BN = 256; }
   else if (p->Mg > 32) { p->cfg = 1; p->BM = 64; p->BN = 128; }
   else if (p->Mg > 16) { p->cfg = 2; p->BM = 32; p->BN = 256; }
   else { p->cfg = 3; p->BM = 16; p->BN = 256; }

@@ -24,6 +24,8 @@
 //   * blockIdx -> tile mapping is XCD-aware (tiles sharing a weight panel stay on one XCD's L2).
 #include "common.h"
 
+#include <cstdlib>
+
 namespace eben {
 
 struct TapArgs {
@@ -184,9 +186,9 @@ __global__ __launch_bounds__(256) void tapconv_kernel(const TapArgs P) {
       const float* wrow = Ws + kk * WSTR + wm * FM * 16 + l15;
       const int* ko = koff + kc * KT + kk;
       const float* xcol = Xs + wn * FN * 16 + l15;
-      constexpr int NSTEP = KT / 4;
-      constexpr int UNR = NSTEP < 8 ? NSTEP : 8;
-      for (int kb = 0; kb < NSTEP; kb += UNR) {
+      constexpr int UNR = 4;  // k-steps per unrolled block (16 rows of the weight chunk)
+      const int nstep = (min(KT, KC - kc * KT) + 3) >> 2;
+      for (int kb = 0; kb < nstep; kb += UNR) {
         int xo[UNR];
 #pragma unroll
         for (int u = 0; u < UNR; ++u) xo[u] = ko[(kb + u) * 4];
@@ -295,6 +297,8 @@ static void choose_tile(int Mg, int nt_max, int* cfg) {
     if (waste <= 1.125) { best = i; break; }
     if (waste < best_waste - 1e-9) { best_waste = waste; best = i; }
   }
+  static const int env_cfg = getenv("EBEN_TAP_BIG_CFG") ? atoi(getenv("EBEN_TAP_BIG_CFG")) : -1;  // tuning aid
+  if (best == 0 && env_cfg >= 0) best = env_cfg;
   int c = best;  // 0:128x128 1:64x128 2:32x256 3:16x256
   if (c == 2 && nt_max <= 128) c = 4;
   if (c == 3 && nt_max <= 128) c = 5;
@@ -328,22 +332,34 @@ static void make_plan(const Canon& c, int dir, TapPlan* p) {
   p->Mp = round_up(p->Mg, p->BM);
   p->nmt = p->Mp / p->BM;
   p->ntt = ceil_div(p->nt, p->BN);
-  // channel chunk: <=16 channels, evenly split; shrink while the tile does not fit 96 KiB of LDS
-  int nch = ceil_div(p->Cg, 16);
-  int ci = p->Cg % nch == 0 ? p->Cg / nch : 16;
-  if (p->Cg <= 16) ci = p->Cg;
+  // channel chunk: as many input channels per staged tile as 24 KiB of LDS hold (cap 16), evenly
+  // split over the group so that no chunk is mostly padding.  Measured on MI355X (tools/layer_bench.py):
+  // the kernel is latency-bound, so a small tile (3-4 resident blocks per CU) beats a large one
+  // (48 KiB / 64 channels was 10-35 % slower on every heavy layer).
   const int adstep = p->dstep >= 0 ? p->dstep : -p->dstep;
   const int KT = 4096 / p->BM;
-  for (;;) {
+  {
     const int maxd = ((p->J - 1) * adstep) / p->S + 1;
     p->PLEN = p->BN + maxd + 1;
     p->CSTRIDE = round_up(p->S * p->PLEN, 32) + 16;
+  }
+  static const int env_cap = getenv("EBEN_TAP_CI_CAP") ? atoi(getenv("EBEN_TAP_CI_CAP")) : 0;      // tuning aid
+  static const int env_kb = getenv("EBEN_TAP_X_KB") ? atoi(getenv("EBEN_TAP_X_KB")) : 0;          // tuning aid
+  int cap = (int)(((env_kb > 0 ? env_kb : 24) * 1024) / (4 * (size_t)p->CSTRIDE));
+  if (cap > (env_cap > 0 ? env_cap : 16)) cap = env_cap > 0 ? env_cap : 16;
+  if (cap < 1) cap = 1;
+  int ci;
+  if (p->Cg <= cap) ci = p->Cg;
+  else {
+    const int nch = ceil_div(p->Cg, cap);
+    ci = ceil_div(p->Cg, nch);
+  }
+  for (;;) {
     p->CI_T = ci;
     p->KCpad = round_up(p->J * ci, 4);
     p->lds_bytes = 4ull * ((size_t)round_up(p->KCpad, KT) + (size_t)KT * (p->BM + 16) + (size_t)ci * p->CSTRIDE);
-    if (p->lds_bytes <= 96 * 1024 || ci == 1) break;
-    ci = ci > 8 ? 8 : ci / 2;
-    if (ci < 1) ci = 1;
+    if (p->lds_bytes <= 160 * 1024 || ci == 1) break;
+    ci = ci / 2 > 0 ? ci / 2 : 1;
   }
   p->ncc = ceil_div(p->Cg, p->CI_T);
   p->phase_stride = (long long)p->G * p->ncc * p->KCpad * p->Mp;
