@@ -63,7 +63,10 @@ def cpu_baseline(batch, length, steps):
     from vibravox_amd.torch_modules.dnn.eben_discriminator import DiscriminatorEBENMultiScales
     from vibravox_amd.torch_modules.dnn.eben_generator import EBENGenerator
 
-    cores = len(os.sched_getaffinity(0))
+    # torch's intra-op pool: one thread per physical core, capped (256 SMT threads on the 2 x 64-core
+    # GPU host ran >20x slower than 32 on these small convolutions); override with EBEN_CPU_THREADS
+    avail = len(os.sched_getaffinity(0))
+    cores = int(os.environ.get("EBEN_CPU_THREADS", "0")) or max(1, min(32, avail // 2))
     torch.set_num_threads(cores)
     torch.manual_seed(42)
     gen, disc = EBENGenerator(m=4, n=32, p=2), DiscriminatorEBENMultiScales(q=4, min_channels=24)
