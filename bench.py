@@ -63,10 +63,11 @@ def cpu_baseline(batch, length, steps):
     from vibravox_amd.torch_modules.dnn.eben_discriminator import DiscriminatorEBENMultiScales
     from vibravox_amd.torch_modules.dnn.eben_generator import EBENGenerator
 
-    # torch's intra-op pool: one thread per physical core, capped (256 SMT threads on the 2 x 64-core
-    # GPU host ran >20x slower than 32 on these small convolutions); override with EBEN_CPU_THREADS
+    # torch's intra-op pool.  Measured on the GPU host (2 x EPYC 9575F, 256 hardware threads) at the
+    # full batch 32: 8 threads 9.9, 16 threads 14.8, 32 threads 10.6 audio-s/s, 256 threads > 20x slower
+    # -- these convolutions do not scale past ~16 threads, so 16 is the fairest setting.
     avail = len(os.sched_getaffinity(0))
-    cores = int(os.environ.get("EBEN_CPU_THREADS", "0")) or max(1, min(32, avail // 2))
+    cores = int(os.environ.get("EBEN_CPU_THREADS", "0")) or max(1, min(16, avail))
     torch.set_num_threads(cores)
     torch.manual_seed(42)
     gen, disc = EBENGenerator(m=4, n=32, p=2), DiscriminatorEBENMultiScales(q=4, min_channels=24)
@@ -90,7 +91,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="clips per GPU (BASELINE config 2: 32)")
     ap.add_argument("--length", type=int, default=32000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=4)
+    ap.add_argument("--cpu-batch", type=int, default=32)
     ap.add_argument("--cpu-steps", type=int, default=1)
     args = ap.parse_args()
 

@@ -51,15 +51,16 @@ struct TapArgs {
 };
 
 template <int WAVES_M, int WAVES_N, int FM, int FN>
-__global__ __launch_bounds__(256) void tapconv_kernel(const TapArgs P) {
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void tapconv_kernel(const TapArgs P) {
+  constexpr int NT = WAVES_M * WAVES_N * 64;
   constexpr int BM = WAVES_M * FM * 16;
   constexpr int BN = WAVES_N * FN * 16;
   constexpr int KT = 4096 / BM;         // rows of the staged weight chunk
   constexpr int WSTR = BM + 16;         // +16: the 2 k-rows of a half-wave hit disjoint banks
   constexpr int W4_PER_ROW = BM / 4;
-  constexpr int W4_PER_THREAD = KT * BM / 4 / 256;
-  static_assert(WAVES_M * WAVES_N == 4, "4 waves per block");
-  static_assert(W4_PER_THREAD == 4, "weight chunk is 4096 floats");
+  constexpr int W4_PER_THREAD = KT * BM / 4 / NT;
+  static_assert(NT == 256 || NT == 512, "4 or 8 waves per block");
+  static_assert(W4_PER_THREAD * NT * 4 == 4096, "weight chunk is 4096 floats");
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   int* koff = reinterpret_cast<int*>(smem);
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(256) void tapconv_kernel(const TapArgs P) {
   const int span = J > 0 ? (BN - 1) * P.S + (J - 1) * adstep + 1 : 0;
   const int KC = ((J * P.CI_T + 3) >> 2) << 2;  // flat K entries actually used by this phase
 
-  for (int f = tid; f < koff_len; f += 256) {
+  for (int f = tid; f < koff_len; f += NT) {
     const int j = f / P.CI_T, cl = f - j * P.CI_T;
     int o = 0;
     if (f < P.KCpad && j < J) {
@@ -129,57 +130,107 @@ __global__ __launch_bounds__(256) void tapconv_kernel(const TapArgs P) {
   const int q0 = t0 * P.S + minoff;
   const int nkc = (KC + KT - 1) / KT;
 
-  for (int cc = 0; cc < P.ncc && J > 0; ++cc) {
-    __syncthreads();  // previous chunk's MFMAs are done with Xs / Ws (and koff is published)
-    // ---- stage the input tile of CI_T channels, de-interleaved by stride phase ----
+  // ---- main loop.  Both operand streams are software-pipelined through registers:
+  //  * weights: one 4096-float chunk ahead, continuously across channel-chunk boundaries (the packed
+  //    layout is contiguous in consumption order);
+  //  * input tile: when it is small (<= XCAP elements: the k=3..7 layers, which would otherwise
+  //    expose a global-load latency every ~100 K-rows) the next channel chunk's tile is fetched into
+  //    registers under the current chunk's MFMAs; large tiles (k=41 stride-4 layers) are staged
+  //    directly -- there the staging is amortised over ~20 weight chunks.
+  constexpr int XR = 10;
+  constexpr int XCAP = XR * NT;
+  const int xtot = P.CI_T * span;
+  const bool xpre = xtot <= XCAP && span < 65536;
+  int xg[XR];
+  float xreg[XR];
+#pragma unroll
+  for (int u = 0; u < XR; ++u) {
+    const int i = tid + u * NT;
+    if (xpre && i < xtot) {
+      const int c = i / span;
+      xg[u] = (c << 16) | (i - c * span);
+    } else {
+      xg[u] = -1;
+    }
+  }
+  auto fetch_x = [&](int r, long long row, bool cv) -> float {
+    int q = q0 + r;
+    if (P.reflect) {
+      q = q < 0 ? -q : q;
+      q = q >= P.Lx ? 2 * (P.Lx - 1) - q : q;
+    }
+    float v = 0.f;
+    if (cv && q >= 0 && q < P.Lx) {
+      v = P.x[row + q];
+      if (P.in_mode == 0) v = lrelu(v, P.in_slope);
+      else v *= dlrelu(P.xmask[row + q], P.in_slope);
+    }
+    return v;
+  };
+  auto lds_x = [&](int c, int r) -> int {
+    int p = 0, i = r;
+    if (P.S != 1) { i = (int)__umulhi((unsigned)r, P.s_magic); p = r - i * P.S; }
+    return c * P.CSTRIDE + p * P.PLEN + i;
+  };
+  auto load_x = [&](int cc) {
+#pragma unroll
+    for (int u = 0; u < XR; ++u) {
+      float v = 0.f;
+      if (xg[u] >= 0) {
+        const int chan = cc * P.CI_T + (xg[u] >> 16);
+        v = fetch_x(xg[u] & 0xffff, ((long long)b * P.Cx + (long long)g * P.Cg + chan) * P.Lx, chan < P.Cg);
+      }
+      xreg[u] = v;
+    }
+  };
+  auto store_x = [&]() {
+#pragma unroll
+    for (int u = 0; u < XR; ++u)
+      if (xg[u] >= 0) Xs[lds_x(xg[u] >> 16, xg[u] & 0xffff)] = xreg[u];
+  };
+  auto stage_x_direct = [&](int cc) {
     for (int c = 0; c < P.CI_T; ++c) {
       const int chan = cc * P.CI_T + c;
-      const bool cv = chan < P.Cg;
       const long long row = ((long long)b * P.Cx + (long long)g * P.Cg + chan) * P.Lx;
-      const float* xr = P.x + row;
-      float* xs = Xs + c * P.CSTRIDE;
-      for (int r = tid; r < span; r += 256) {
-        int q = q0 + r;
-        if (P.reflect) {
-          q = q < 0 ? -q : q;
-          q = q >= P.Lx ? 2 * (P.Lx - 1) - q : q;
-        }
-        float v = 0.f;
-        if (cv && q >= 0 && q < P.Lx) {
-          v = xr[q];
-          if (P.in_mode == 0) v = lrelu(v, P.in_slope);
-          else v *= dlrelu(P.xmask[row + q], P.in_slope);
-        }
-        int p = 0, i = r;
-        if (P.S != 1) { i = (int)__umulhi((unsigned)r, P.s_magic); p = r - i * P.S; }
-        xs[p * P.PLEN + i] = v;
-      }
+      for (int r = tid; r < span; r += NT) Xs[lds_x(c, r)] = fetch_x(r, row, chan < P.Cg);
     }
-    // ---- weight chunks: register prefetch one chunk ahead ----
+  };
+  float4 wreg[W4_PER_THREAD];
+  auto prefetch_w = [&](int cc, int kc) {
     const float* wcc = wbase + (long long)cc * P.KCpad * P.Mp;
-    float4 wreg[W4_PER_THREAD];
-    auto prefetch = [&](int kc) {
-      const int rows = min(KT, KC - kc * KT);
+    const int rows = min(KT, KC - kc * KT);
 #pragma unroll
-      for (int u = 0; u < W4_PER_THREAD; ++u) {
-        const int i4 = tid + u * 256;
-        const int rrow = i4 / W4_PER_ROW, c4 = i4 - rrow * W4_PER_ROW;
-        wreg[u] = rrow < rows
-                      ? *reinterpret_cast<const float4*>(wcc + (long long)(kc * KT + rrow) * P.Mp + c4 * 4)
-                      : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-    };
-    prefetch(0);
+    for (int u = 0; u < W4_PER_THREAD; ++u) {
+      const int i4 = tid + u * NT;
+      const int rrow = i4 / W4_PER_ROW, c4 = i4 - rrow * W4_PER_ROW;
+      wreg[u] = rrow < rows ? *reinterpret_cast<const float4*>(wcc + (long long)(kc * KT + rrow) * P.Mp + c4 * 4)
+                            : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+
+  if (J > 0) {
+    if (xpre) load_x(0);
+    prefetch_w(0, 0);
+  }
+  for (int cc = 0; cc < P.ncc && J > 0; ++cc) {
+    __syncthreads();  // previous channel chunk's MFMAs are done with Xs / Ws (and koff is published)
+    if (xpre) {
+      store_x();
+      if (cc + 1 < P.ncc) load_x(cc + 1);
+    } else {
+      stage_x_direct(cc);
+    }
     for (int kc = 0; kc < nkc; ++kc) {
       if (kc > 0) __syncthreads();  // MFMAs of the previous chunk finished reading Ws
 #pragma unroll
       for (int u = 0; u < W4_PER_THREAD; ++u) {
-        const int i4 = tid + u * 256;
+        const int i4 = tid + u * NT;
         const int rrow = i4 / W4_PER_ROW, c4 = i4 - rrow * W4_PER_ROW;
         *reinterpret_cast<float4*>(Ws + rrow * WSTR + c4 * 4) = wreg[u];
       }
       __syncthreads();
-      if (kc + 1 < nkc) prefetch(kc + 1);
+      if (kc + 1 < nkc) prefetch_w(cc, kc + 1);
+      else if (cc + 1 < P.ncc) prefetch_w(cc + 1, 0);
       // fixed-trip k-loop (rows past the chunk end are zero weights against a valid offset 0):
       // tap offsets for the whole chunk are read up front, fragments are loaded one k-step ahead
       // of the MFMAs that consume them.
@@ -284,8 +335,8 @@ struct TapPlan {
   size_t packed_floats;
 };
 
-static const int kCfgBM[6] = {128, 64, 32, 16, 32, 16};
-static const int kCfgBN[6] = {128, 128, 256, 256, 128, 128};
+static const int kCfgBM[8] = {128, 64, 32, 16, 32, 16, 128, 64};
+static const int kCfgBN[8] = {128, 128, 256, 256, 128, 128, 128, 128};
 
 static void choose_tile(int Mg, int nt_max, int* cfg) {
   // largest BM with <= 12.5 % padding waste, else the least wasteful
@@ -299,6 +350,11 @@ static void choose_tile(int Mg, int nt_max, int* cfg) {
   }
   static const int env_cfg = getenv("EBEN_TAP_BIG_CFG") ? atoi(getenv("EBEN_TAP_BIG_CFG")) : -1;  // tuning aid
   if (best == 0 && env_cfg >= 0) best = env_cfg;
+  // 8-wave blocks for the two big tiles: same LDS footprint, half the accumulators per wave, up to
+  // 4 waves per SIMD -- measured +5..14 % on the MelGAN / PQMF top layers (profiles/r01_layer_bench_ab*.txt)
+  static const int env_w8 = getenv("EBEN_TAP_WAVES8") ? atoi(getenv("EBEN_TAP_WAVES8")) : 3;  // tuning aid
+  if (best == 0 && (env_w8 & 1)) best = 6;  // 128x128 on 8 waves
+  if (best == 1 && (env_w8 & 2)) best = 7;  // 64x128 on 8 waves
   int c = best;  // 0:128x128 1:64x128 2:32x256 3:16x256
   if (c == 2 && nt_max <= 128) c = 4;
   if (c == 3 && nt_max <= 128) c = 5;
@@ -445,7 +501,7 @@ static int launch_cfg(const TapArgs& a, int nblocks, size_t lds, hipStream_t st)
     if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(tapconv)");
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), lds, st, a);
+  hipLaunchKernelGGL(kern, dim3(nblocks), dim3(WM * WN * 64), lds, st, a);
   EBEN_CHECK_LAUNCH("tapconv_kernel");
   return EBEN_OK;
 }
@@ -473,6 +529,8 @@ static int launch_tap(const Canon& c, const TapPlan& p, const TapIO& io, int ref
     case 2: return launch_cfg<1, 4, 2, 4>(a, (int)nb, p.lds_bytes, st);
     case 3: return launch_cfg<1, 4, 1, 4>(a, (int)nb, p.lds_bytes, st);
     case 4: return launch_cfg<1, 4, 2, 2>(a, (int)nb, p.lds_bytes, st);
+    case 6: return launch_cfg<2, 4, 4, 2>(a, (int)nb, p.lds_bytes, st);
+    case 7: return launch_cfg<2, 4, 2, 2>(a, (int)nb, p.lds_bytes, st);
     default: return launch_cfg<1, 4, 1, 2>(a, (int)nb, p.lds_bytes, st);
   }
 }
