@@ -93,6 +93,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=32)
     ap.add_argument("--cpu-steps", type=int, default=1)
+    ap.add_argument("--force-ddp", action="store_true", help="run the bucketed RCCL gradient path even with one rank")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -104,15 +105,18 @@ def main():
     assert torch.cuda.is_available(), "bench.py measures the HIP path: no GPU visible"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    use_ddp = world > 1 or args.force_ddp
+    if use_ddp:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=device)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     from vibravox_amd import ops
     from vibravox_amd.ddp import BucketedZeroGrad, GradSync
 
     mod = build_module(device, 1234 + rank)
-    if world > 1:
+    if use_ddp:
         g_opt, d_opt = mod.optimizers()
         gs, ds = GradSync(mod.generator.parameters()), GradSync(mod.discriminator.parameters())
         g_w, d_w = BucketedZeroGrad(g_opt, gs), BucketedZeroGrad(d_opt, ds)
@@ -127,7 +131,7 @@ def main():
     ops.set_kernel_timer(timer)
 
     def barrier():
-        if world > 1:
+        if use_ddp:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -180,7 +184,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_batch, args.length, args.cpu_steps)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_ddp:
         dist.destroy_process_group()
 
 

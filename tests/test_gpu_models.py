@@ -223,3 +223,40 @@ def test_full_size_step_properties(hip, golden):
     # (near-zero logits at init): exactly zero gradient, so they may stay put; everything else moves
     still = [k for k, m in moved.items() if m == 0.0]
     assert all(k.endswith(".bias") for k in still) and len(still) <= 4, still
+
+
+def test_bucketed_grad_sync_path_on_gpu_matches_plain_step(hip, golden):
+    """The data-parallel plumbing of bench.py (gradients as views of flat buckets, all-reduce issued
+    from post-accumulate hooks on a side stream, 1/N folded into Adam) on a single-rank RCCL group:
+    must reproduce the plain single-GPU step."""
+    import os
+
+    import torch.distributed as dist
+
+    from vibravox_amd.ddp import BucketedZeroGrad, GradSync
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29541")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=DEV)
+    try:
+        plain, _, _ = make_module(golden, use_mrstft=False)
+        synced, _, _ = make_module(golden, use_mrstft=False)
+        g_opt, d_opt = synced.optimizers()
+        gs = GradSync(synced.generator.parameters(), bucket_bytes=1 << 20)
+        ds = GradSync(synced.discriminator.parameters(), bucket_bytes=8 << 20)
+        g_w, d_w = BucketedZeroGrad(g_opt, gs), BucketedZeroGrad(d_opt, ds)
+        synced._optimizers = [g_w, d_w]
+        synced.grad_sync = {id(g_w): gs, id(d_w): ds}
+        for i in range(2):
+            batch = {"audio_body_conducted": formula_audio(f"step{i}/bc", 2, 8200).to(DEV),
+                     "audio_airborne": formula_audio(f"step{i}/air", 2, 8200).to(DEV)}
+            plain.training_step(batch)
+            synced.training_step(batch)
+        torch.cuda.synchronize()
+        assert gs.launched >= 2 * len(gs.buckets) and ds.launched >= 2 * len(ds.buckets)
+        for (k, a), (_, b) in zip(plain.generator.state_dict().items(), synced.generator.state_dict().items()):
+            assert torch.allclose(a, b, rtol=0, atol=1e-6), k
+        for (k, a), (_, b) in zip(plain.discriminator.state_dict().items(), synced.discriminator.state_dict().items()):
+            assert torch.allclose(a, b, rtol=0, atol=1e-6), k
+    finally:
+        dist.destroy_process_group()

@@ -21,11 +21,12 @@ struct DwArgs {
   int B, G, Cg, Mg, Ca, Cx, La, Lx;
   int S, d, off0, J, Ng, has_bias, row_stride, reflect;
   int nsplit, nct, nchunks, nnt, nmt, XSTR;
+  int bk;  // time steps per K-chunk: 32, 64 or 128 (largest whose X tile fits the register prefetch)
   long long slab_stride;
 };
 
-constexpr int DW_BK = 32;
-constexpr int DW_DSTR = DW_BK + 2;  // 16 rows x 2 k-lanes of a half-wave -> 32 distinct banks
+constexpr int DW_BK_MAX = 128;
+constexpr int DW_XCAP = 5120;  // X-tile elements the register prefetch can hold (per block)
 
 __device__ __forceinline__ float load_op(const float* p, const float* mask, long long idx, int mode, float slope) {
   float v = p[idx];
@@ -33,12 +34,15 @@ __device__ __forceinline__ float load_op(const float* p, const float* mask, long
 }
 
 template <int WAVES_M, int WAVES_N, int FM, int FN>
-__global__ __launch_bounds__(256) void conv_dw_kernel(const DwArgs P) {
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_dw_kernel(const DwArgs P) {
+  constexpr int NT = WAVES_M * WAVES_N * 64;
   constexpr int BM = WAVES_M * FM * 16;
   constexpr int BN = WAVES_N * FN * 16;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* Ds = smem;                  // [BM][DW_DSTR]
-  float* Xs = Ds + BM * DW_DSTR;     // [nch][XSTR] then {0.f, 1.f}
+  const int BK = P.bk;
+  const int DSTR = BK + 2;           // 16 rows x 2 k-lanes of a half-wave -> 32 distinct banks
+  float* Ds = smem;                  // [BM][DSTR]
+  float* Xs = Ds + BM * DSTR;        // [nch][XSTR] then {0.f, 1.f}
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, kk = lane >> 4;
@@ -55,7 +59,7 @@ __global__ __launch_bounds__(256) void conv_dw_kernel(const DwArgs P) {
   int nch = (BN - 1) / P.J + 2;
   if (nch > P.Cg - c_lo) nch = P.Cg - c_lo;
   if (nch < 0) nch = 0;
-  const int span = (DW_BK - 1) * P.S + (P.J - 1) * P.d + 1;
+  const int span = (BK - 1) * P.S + (P.J - 1) * P.d + 1;
   const int cell_zero = nch * P.XSTR, cell_one = cell_zero + 1;
   if (tid == 0) { Xs[cell_zero] = 0.f; Xs[cell_one] = 1.f; }
 
@@ -82,19 +86,21 @@ __global__ __launch_bounds__(256) void conv_dw_kernel(const DwArgs P) {
   // Software pipeline: the global loads of chunk q+1 (A tile: 16 values per thread; X tile: up to
   // XR per thread) are issued before the MFMAs of chunk q and land in registers while they run;
   // they are written to LDS after the barrier that retires chunk q.
-  constexpr int AR = BM * DW_BK / 256;
-  constexpr int XR = 16;
+  constexpr int AR = BM * DW_BK_MAX / NT;    // register slots for the largest chunk
+  constexpr int XR = DW_XCAP / NT;
+  const int a_rows_per_pass = NT / BK;
+  const int a_cnt = BM / a_rows_per_pass;     // slots actually used (<= AR)
   const int xtot = nch * span;
-  const bool xfits = xtot <= XR * 256;
+  const bool xfits = xtot <= XR * NT;
   float areg[AR], xreg[XR];
 
   // per-thread coordinates, computed once: A element u sits at row a_r0 + 8u, column a_tt;
   // X element u at (channel, position) packed as c<<16 | r (or -1 past the tile).
-  const int a_tt = tid & (DW_BK - 1), a_r0 = tid >> 5;
+  const int a_tt = tid & (BK - 1), a_r0 = tid / BK;
   int xpk[XR];
 #pragma unroll
   for (int u = 0; u < XR; ++u) {
-    const int i = tid + u * 256;
+    const int i = tid + u * NT;
     if (xfits && i < xtot) {
       const int c = i / span;
       xpk[u] = (c << 16) | (i - c * span);
@@ -105,16 +111,16 @@ __global__ __launch_bounds__(256) void conv_dw_kernel(const DwArgs P) {
 
   auto load_chunk = [&](int q) {
     const int b = q / P.nct;
-    const int t0 = (q - b * P.nct) * DW_BK;
+    const int t0 = (q - b * P.nct) * BK;
     const long long abase = ((long long)b * P.Ca + (long long)g * P.Mg) * P.La + t0;
     const float* pa = P.a + abase;
     const float* pam = P.amask ? P.amask + abase : nullptr;
     const bool tok = t0 + a_tt < P.La;
 #pragma unroll
     for (int u = 0; u < AR; ++u) {
-      const int m = m0 + a_r0 + 8 * u;
+      const int m = m0 + a_r0 + a_rows_per_pass * u;
       float v = 0.f;
-      if (tok && m < P.Mg) {
+      if (u < a_cnt && tok && m < P.Mg) {
         const int off = m * P.La + a_tt;
         v = pa[off];
         v = P.a_mode == 0 ? lrelu(v, P.a_slope) : v * dlrelu(pam[off], P.a_slope);
@@ -147,18 +153,19 @@ __global__ __launch_bounds__(256) void conv_dw_kernel(const DwArgs P) {
   };
   auto store_chunk = [&](int q) {
 #pragma unroll
-    for (int u = 0; u < AR; ++u) Ds[(a_r0 + 8 * u) * DW_DSTR + a_tt] = areg[u];
+    for (int u = 0; u < AR; ++u)
+      if (u < a_cnt) Ds[(a_r0 + a_rows_per_pass * u) * DSTR + a_tt] = areg[u];
     if (xfits) {
 #pragma unroll
       for (int u = 0; u < XR; ++u)
         if (xpk[u] >= 0) Xs[(xpk[u] >> 16) * P.XSTR + (xpk[u] & 0xffff)] = xreg[u];
     } else {  // oversized X tile (not produced by the EBEN layers): direct staging
       const int b = q / P.nct;
-      const int t0 = (q - b * P.nct) * DW_BK;
+      const int t0 = (q - b * P.nct) * BK;
       const int qbase = t0 * P.S + P.off0;
       for (int c = 0; c < nch; ++c) {
         const long long row = ((long long)b * P.Cx + (long long)g * P.Cg + c_lo + c) * P.Lx;
-        for (int r = tid; r < span; r += 256) {
+        for (int r = tid; r < span; r += NT) {
           int p = qbase + r;
           if (P.reflect) {
             p = p < 0 ? -p : p;
@@ -178,26 +185,28 @@ __global__ __launch_bounds__(256) void conv_dw_kernel(const DwArgs P) {
     store_chunk(q);
     __syncthreads();
     if (q + P.nsplit < P.nchunks) load_chunk(q + P.nsplit);
-    const float* drow = Ds + (wm * FM * 16 + l15) * DW_DSTR + kk;
-    float a[2][FM], bv[2][FN];
+    const float* drow = Ds + (wm * FM * 16 + l15) * DSTR + kk;
+    for (int kb = 0; kb < BK; kb += 32) {   // 8 k-steps per unrolled block, fragments one step ahead
+      float a[2][FM], bv[2][FN];
 #pragma unroll
-    for (int i = 0; i < FM; ++i) a[0][i] = drow[i * 16 * DW_DSTR];
+      for (int i = 0; i < FM; ++i) a[0][i] = drow[i * 16 * DSTR + kb];
 #pragma unroll
-    for (int n = 0; n < FN; ++n) bv[0][n] = Xs[xoff[n]];
+      for (int n = 0; n < FN; ++n) bv[0][n] = Xs[xoff[n] + kb * xstep[n]];
 #pragma unroll
-    for (int ks = 0; ks < DW_BK; ks += 4) {
-      const int cur = (ks >> 2) & 1, nxt = cur ^ 1;
-      if (ks + 4 < DW_BK) {
+      for (int ks = 0; ks < 32; ks += 4) {
+        const int cur = (ks >> 2) & 1, nxt = cur ^ 1;
+        if (ks + 4 < 32) {
 #pragma unroll
-        for (int i = 0; i < FM; ++i) a[nxt][i] = drow[i * 16 * DW_DSTR + ks + 4];
+          for (int i = 0; i < FM; ++i) a[nxt][i] = drow[i * 16 * DSTR + kb + ks + 4];
 #pragma unroll
-        for (int n = 0; n < FN; ++n) bv[nxt][n] = Xs[xoff[n] + (ks + 4) * xstep[n]];
+          for (int n = 0; n < FN; ++n) bv[nxt][n] = Xs[xoff[n] + (kb + ks + 4) * xstep[n]];
+        }
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int n = 0; n < FN; ++n)
+            acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cur][i], bv[cur][n], acc[i][n], 0, 0, 0);
       }
-#pragma unroll
-      for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int n = 0; n < FN; ++n)
-          acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cur][i], bv[cur][n], acc[i][n], 0, 0, 0);
     }
   }
 
@@ -218,7 +227,7 @@ __global__ __launch_bounds__(256) void conv_dw_kernel(const DwArgs P) {
 }
 
 struct DwPlan {
-  int Cg, Mg, G, J, Ng, row_stride, cfg, BM, BN, nnt, nmt, nct, nchunks, nsplit, XSTR, nch_max;
+  int Cg, Mg, G, J, Ng, row_stride, cfg, BM, BN, nnt, nmt, nct, nchunks, nsplit, XSTR, nch_max, bk;
   size_t lds_bytes;
   long long slab_stride;
 };
@@ -226,17 +235,31 @@ struct DwPlan {
 static void make_dw_plan(const Canon& c, DwPlan* p) {
   p->G = c.g; p->Cg = c.Cin / c.g; p->Mg = c.Cout / c.g; p->J = c.k;
   p->Ng = p->Cg * c.k; p->row_stride = p->Ng + 1;
-  // Measured on MI355X (tools/layer_bench.py): the weight-gradient kernel is latency-bound; 32x256
-  // tiles (3 resident blocks per CU) run 1.8x faster than 128x128 (1 block per CU) on the big layers.
-  static const int env_big = getenv("EBEN_DW_BIG_CFG") ? atoi(getenv("EBEN_DW_BIG_CFG")) : 2;  // tuning aid
-  if (p->Mg > 64 && env_big == 0) { p->cfg = 0; p->BM = 128; p->BN = 128; }
-  else if (p->Mg > 64 && env_big == 2) { p->cfg = 2; p->BM = 32; p->BN = 256; }
-  else if (p->Mg > 32) { p->cfg = 1; p->BM = 64; p->BN = 128; }
-  else if (p->Mg > 16) { p->cfg = 2; p->BM = 32; p->BN = 256; }
-  else { p->cfg = 3; p->BM = 16; p->BN = 256; }
+  // Measured on MI355X (tools/layer_bench.py): the weight-gradient kernel is latency-bound, so the
+  // tiles are small and run on 8 waves (half the prefetch registers per thread -> 3-4 waves per SIMD):
+  // 32x256 tiles ran 1.8x faster than 128x128 (1 block per CU) on the big layers.
+  static const int env_big = getenv("EBEN_DW_BIG_CFG") ? atoi(getenv("EBEN_DW_BIG_CFG")) : -1;  // tuning aid
+  if (env_big == 0 && p->Mg > 64) { p->cfg = 0; p->BM = 128; p->BN = 128; }
+  else if (env_big == 2) {  // the 4-wave tiles
+    if (p->Mg > 64 || (p->Mg > 16 && p->Mg <= 32)) { p->cfg = 2; p->BM = 32; p->BN = 256; }
+    else if (p->Mg > 32) { p->cfg = 1; p->BM = 64; p->BN = 128; }
+    else { p->cfg = 3; p->BM = 16; p->BN = 256; }
+  }
+  else if (p->Mg > 32 && p->Mg <= 64) { p->cfg = 5; p->BM = 64; p->BN = 128; }
+  else if (p->Mg > 16) { p->cfg = 4; p->BM = 32; p->BN = 256; }
+  else { p->cfg = 6; p->BM = 16; p->BN = 256; }
   p->nnt = ceil_div(p->row_stride, p->BN);
   p->nmt = ceil_div(p->Mg, p->BM);
-  p->nct = ceil_div(c.Lout, DW_BK);
+  p->nch_max = (p->BN - 1) / c.k + 2;
+  if (p->nch_max > p->Cg) p->nch_max = p->Cg;
+  // K-chunk length: as long as possible (fewer barriers per MFMA) while the X tile still fits the
+  // register prefetch and the chunk is not mostly padding for short rows
+  int bk = DW_BK_MAX;
+  static const int env_bk = getenv("EBEN_DW_BK") ? atoi(getenv("EBEN_DW_BK")) : 0;  // tuning aid
+  if (env_bk == 32 || env_bk == 64 || env_bk == 128) bk = env_bk;
+  while (bk > 32 && ((long long)p->nch_max * ((bk - 1) * c.s + (c.k - 1) * c.d + 1) > DW_XCAP || bk / 2 >= c.Lout)) bk /= 2;
+  p->bk = bk;
+  p->nct = ceil_div(c.Lout, bk);
   p->nchunks = c.B * p->nct;
   const int tiles = p->nnt * p->nmt * p->G;
   // enough blocks to fill 256 CUs a few times over; no split at all once the tiles alone do that
@@ -245,11 +268,9 @@ static void make_dw_plan(const Canon& c, DwPlan* p) {
   if (ns > p->nchunks) ns = p->nchunks;
   if (ns < 1) ns = 1;
   p->nsplit = ns;
-  const int span = (DW_BK - 1) * c.s + (c.k - 1) * c.d + 1;
+  const int span = (bk - 1) * c.s + (c.k - 1) * c.d + 1;
   p->XSTR = span | 1;  // odd row stride
-  p->nch_max = (p->BN - 1) / c.k + 2;
-  if (p->nch_max > p->Cg) p->nch_max = p->Cg;
-  p->lds_bytes = 4ull * ((size_t)p->BM * DW_DSTR + (size_t)p->nch_max * p->XSTR + 2);
+  p->lds_bytes = 4ull * ((size_t)p->BM * (bk + 2) + (size_t)p->nch_max * p->XSTR + 2);
   p->slab_stride = (long long)c.Cout * p->row_stride;
 }
 
@@ -262,7 +283,7 @@ static int launch_dw_cfg(const DwArgs& a, int nblocks, size_t lds, hipStream_t s
     if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(conv_dw)");
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), lds, st, a);
+  hipLaunchKernelGGL(kern, dim3(nblocks), dim3(WM * WN * 64), lds, st, a);
   EBEN_CHECK_LAUNCH("conv_dw_kernel");
   return EBEN_OK;
 }
@@ -404,7 +425,7 @@ extern "C" int eben_conv1d_bwd_dw(const EbenConv1dDesc* d, const float* dy, cons
   a.B = c.B; a.G = c.g; a.Cg = p.Cg; a.Mg = p.Mg; a.Ca = c.Cout; a.Cx = c.Cin; a.La = c.Lout; a.Lx = c.Lin;
   a.S = c.s; a.d = c.d; a.off0 = -c.pl; a.J = c.k; a.Ng = p.Ng; a.has_bias = has_bias ? 1 : 0; a.row_stride = p.row_stride;
   a.reflect = c.reflect;
-  a.nsplit = p.nsplit; a.nct = p.nct; a.nchunks = p.nchunks; a.nnt = p.nnt; a.nmt = p.nmt; a.XSTR = p.XSTR;
+  a.nsplit = p.nsplit; a.nct = p.nct; a.nchunks = p.nchunks; a.nnt = p.nnt; a.nmt = p.nmt; a.XSTR = p.XSTR; a.bk = p.bk;
   a.slab_stride = p.slab_stride;
   const int nb = p.nnt * p.nmt * p.G * p.nsplit;
   hipStream_t st = as_stream(stream);
@@ -412,6 +433,9 @@ extern "C" int eben_conv1d_bwd_dw(const EbenConv1dDesc* d, const float* dy, cons
     case 0: return launch_dw_cfg<2, 2, 4, 4>(a, nb, p.lds_bytes, st);
     case 1: return launch_dw_cfg<1, 4, 4, 2>(a, nb, p.lds_bytes, st);
     case 2: return launch_dw_cfg<1, 4, 2, 4>(a, nb, p.lds_bytes, st);
+    case 4: return launch_dw_cfg<1, 8, 2, 2>(a, nb, p.lds_bytes, st);
+    case 5: return launch_dw_cfg<2, 4, 2, 2>(a, nb, p.lds_bytes, st);
+    case 6: return launch_dw_cfg<1, 8, 1, 2>(a, nb, p.lds_bytes, st);
     default: return launch_dw_cfg<1, 4, 1, 4>(a, nb, p.lds_bytes, st);
   }
 }

@@ -80,7 +80,7 @@ class GradSync:
             self._launch(b)
 
     def _launch(self, b: _Bucket):
-        if self.world == 1:
+        if self.world == 1 and not dist.is_initialized():
             return
         if self.on_gpu:
             self.comm_stream.wait_stream(torch.cuda.current_stream())
