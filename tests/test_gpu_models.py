@@ -237,7 +237,7 @@ def test_bucketed_grad_sync_path_on_gpu_matches_plain_step(hip, golden):
 
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29541")
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=DEV)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
         plain, _, _ = make_module(golden, use_mrstft=False)
         synced, _, _ = make_module(golden, use_mrstft=False)

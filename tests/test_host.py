@@ -174,3 +174,29 @@ def test_oracle_conv_transpose_against_plain_c(cref, k, stride, pad, groups):
     xn, wn = x.numpy().copy(), w.numpy().copy()
     cref.ref_conv_transpose1d(_dp(xn), _dp(wn), _dp(y), b, c_in, c_out, l, ref.shape[2], k, stride, 1, groups, pad)
     np.testing.assert_allclose(ref.numpy(), y, rtol=1e-12, atol=1e-12)
+
+
+def test_run_py_config_composition_and_overrides():
+    """run.py resolves the reference's Hydra surface for the EBEN path: group selection, dotted
+    overrides (a.b=c, +a.b=c, ++a.b=c), ${...} interpolation, _target_/_partial_ instantiation."""
+    import run
+
+    cfg = run.compose(["lightning_module=eben", "lightning_module.generator.p=1", "++trainer.max_steps=3", "+trainer.new_key=7"])
+    assert cfg["lightning_module"]["generator"] == {"_target_": "vibravox_amd.torch_modules.dnn.eben_generator.EBENGenerator", "m": 4, "p": 1, "n": 32}
+    assert cfg["lightning_module"]["discriminator"]["q"] == 4 and cfg["lightning_module"]["discriminator"]["min_channels"] == 24
+    assert cfg["trainer"]["max_steps"] == 3 and cfg["trainer"]["new_key"] == 7
+    assert cfg["lightning_module"]["sample_rate"] == 16000  # ${sample_rate}
+    assert cfg["lightning_module"]["reconstructive_loss_freq_fn"]["fft_sizes"] == [512, 1024, 2048]
+    assert cfg["lightning_module"]["dynamic_loss_balancing"] == "ema" and cfg["lightning_module"]["beta_ema"] == 0.9
+    opt = cfg["lightning_module"]["generator_optimizer"]
+    assert opt["lr"] == 3e-4 and opt["betas"] == [0.5, 0.9] and opt["_partial_"] is True
+    with pytest.raises(KeyError):
+        run.compose(["lightning_module.no_such_key=1"])
+    gen = run.instantiate(cfg["lightning_module"]["generator"])
+    assert type(gen).__name__ == "EBENGenerator" and gen.p == 1
+    part = run.instantiate(opt)
+    o = part(params=gen.parameters())
+    assert type(o).__name__ == "FusedAdam" and o.defaults["lr"] == 3e-4 and o.defaults["betas"] == (0.5, 0.9)
+    module = run.instantiate(cfg["lightning_module"])
+    assert type(module).__name__ == "EBENLightningModule" and module.dynamic_loss_balancing == "ema"
+    assert type(module.reconstructive_loss_freq_fn).__name__ == "MultiResolutionSTFTLoss"
