@@ -50,6 +50,16 @@ def build_module(device, batch_seed):
     return mod
 
 
+def pmc_traffic(batch):
+    """HBM bytes per launch of the roofline kernel from the committed rocprofv3 PMC passes
+    (profiles/r01_pmc_melgan_l4_fwd.json; collected at batch 32 by tools/pmc_traffic.sh)."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_melgan_l4_fwd.json")
+    if batch != 32 or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        return json.load(f).get("traffic_bytes_per_launch")
+
+
 def synthetic_batch(batch, length, seed, device):
     g = torch.Generator().manual_seed(seed)
     return {"audio_body_conducted": (0.1 * torch.randn(batch, 1, length, generator=g)).to(device),
@@ -174,9 +184,9 @@ def main():
                                    f"batch {args.batch} x {args.length} samples @16kHz per GPU (cut to {cut})",
                        "global_batch": world * args.batch, "samples_per_clip": cut, "parallelism": f"dp{world}",
                        "weights": "random init, torch.manual_seed(42)"},
-            "roofline": {"bound": "mfma", "kernel": "tapconv_kernel<2,2,4,4> MelGAN L4 fwd (1024->1024 k41 s4 g4)",
+            "roofline": {"bound": "mfma", "kernel": "eben::tapconv_kernel<2,4,4,2> MelGAN L4 fwd (1024->1024 k41 s4 g4)",
                          "achieved": round(achieved, 2) if achieved else None, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4) if achieved else None, "traffic": None,
+                         "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4) if achieved else None, "traffic": pmc_traffic(args.batch),
                          "launch_ms": round(kms, 4) if kms else None, "flops_per_launch": flops,
                          "launches_timed": len(timer.events)},
         }
