@@ -51,7 +51,9 @@ struct TapArgs {
 };
 
 template <int WAVES_M, int WAVES_N, int FM, int FN>
-__global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void tapconv_kernel(const TapArgs P) {
+// second launch-bound = waves per SIMD: an 8-wave block needs 4 (<= 128 VGPRs) for two blocks to share
+// a CU -- at 133 VGPRs the 128x128 tile silently ran one block per CU
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64, WAVES_M * WAVES_N == 8 ? 4 : 3) void tapconv_kernel(const TapArgs P) {
   constexpr int NT = WAVES_M * WAVES_N * 64;
   constexpr int BM = WAVES_M * FM * 16;
   constexpr int BN = WAVES_N * FN * 16;
@@ -389,6 +391,9 @@ static void make_plan(const Canon& c, int dir, TapPlan* p) {
     p->off0 = 0; p->nt = ceil_div(p->Ly, c.s);
   }
   choose_tile(p->Mg, p->nt, &p->cfg);
+  // a 128-row grid that gives every CU at most one block (the 125-sample layers): halve the tile so
+  // that two blocks overlap per CU (MelGAN L4/L5 fwd +5..8 %; with >= 512 blocks 128 rows stay faster)
+  if (p->cfg == 6 && (long long)ceil_div(p->nt, 128) * c.B * p->nph * ceil_div(p->Mg, 128) * p->G <= 256) p->cfg = 7;
   p->BM = kCfgBM[p->cfg]; p->BN = kCfgBN[p->cfg];
   p->Mp = round_up(p->Mg, p->BM);
   p->nmt = p->Mp / p->BM;
