@@ -8,6 +8,8 @@ element 0 the input and the last element the logits.  Attribute tree / ``state_d
 """
 from __future__ import annotations
 
+import os
+
 import torch
 from torch import nn
 
@@ -62,8 +64,32 @@ class DiscriminatorEBENMultiScales(nn.Module, PyTorchModelHubMixin):
         )
         self.melgan_discriminator = DiscriminatorMelGAN(alpha_leaky_relu=0.2)
 
+    #: run the four independent sub-discriminators on separate HIP streams (forward here, backward by
+    #: autograd on the same streams): their kernels are latency-bound with small grids on the deep
+    #: layers, so overlapping them fills CUs that a single stream leaves idle.
+    concurrent_streams: bool = os.environ.get("EBEN_D_STREAMS", "1") != "0"
+
     def forward(self, bands, audio):
         sub = bands[:, -self.q :, :]
-        embeddings = [dis(sub) for dis in self.pqmf_discriminators]
-        embeddings.append(self.melgan_discriminator(audio))
+        if not (self.concurrent_streams and bands.is_cuda):
+            embeddings = [dis(sub) for dis in self.pqmf_discriminators]
+            embeddings.append(self.melgan_discriminator(audio))
+            return embeddings
+        if sub.data_ptr() != bands.data_ptr() or not sub.is_contiguous():
+            sub = sub.contiguous()
+        main = torch.cuda.current_stream()
+        if getattr(self, "_streams", None) is None or self._streams[0].device != bands.device:
+            self._streams = [torch.cuda.Stream(device=bands.device) for _ in range(4)]
+        nets = list(self.pqmf_discriminators) + [self.melgan_discriminator]
+        inputs = [sub, sub, sub, audio]
+        embeddings = []
+        for net, x, st in zip(nets, inputs, self._streams):
+            st.wait_stream(main)
+            x.record_stream(st)
+            with torch.cuda.stream(st):
+                embeddings.append(net(x))
+        for st, scale in zip(self._streams, embeddings):
+            main.wait_stream(st)
+            for t in scale[1:]:
+                t.record_stream(main)
         return embeddings
