@@ -78,6 +78,10 @@ EBEN_API int eben_wn_bwd(const float* dw_slabs, int nslab, size_t slab_stride, i
 /* ---- conv layers ------------------------------------------------------------------------ */
 /* floats needed for the packed weights of the forward (which=0) / input-gradient (which=1) pass */
 EBEN_API size_t eben_conv1d_packed_floats(const EbenConv1dDesc* d, int which);
+/* which tap-conv kernel generation serves the forward (which=0) / input-gradient (which=1) pass of
+ * this layer: 1 = tapconv.hip (16x16x4 tiles, any shape), 2 = tapconv2.hip (32x32x2 tiles, LDS-DMA
+ * weight stream; deep reductions).  The packed layouts differ; pack / fwd / bwd_dx agree by construction. */
+EBEN_API int eben_conv1d_kernel_generation(const EbenConv1dDesc* d, int which);
 /* pack v (optionally scaled per dim-0 row: weight-norm) into the MFMA-friendly layouts */
 EBEN_API int eben_conv1d_pack(const EbenConv1dDesc* d, const float* v, const float* scale, float* wp_fwd, float* wp_bwd, void* stream);
 /* y = lrelu_out( conv(lrelu_in(x)) + bias ) [+ residual] */

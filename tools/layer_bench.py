@@ -110,7 +110,7 @@ def main():
         tf = [2 * macs / (ms * 1e-3) / 1e12 for ms in t]
         for k, ms in zip(tot, t):
             tot[k] += ms
-        print(f"{name[:58]:58s} {macs/1e9:7.2f} | {t[0]:8.3f} {tf[0]:6.1f} | {t[1]:8.3f} {tf[1]:6.1f} | {t[2]:8.3f} {tf[2]:6.1f}  (nslab {nslab.value})")
+        print(f"{name[:58]:58s} {macs/1e9:7.2f} | {t[0]:8.3f} {tf[0]:6.1f} | {t[1]:8.3f} {tf[1]:6.1f} | {t[2]:8.3f} {tf[2]:6.1f}  (nslab {nslab.value}, gen {lib.eben_conv1d_kernel_generation(ctypes.byref(d), 0)}/{lib.eben_conv1d_kernel_generation(ctypes.byref(d), 1)})")
     print(f"TOTAL ms: fwd {tot['fwd']:.2f}  dx {tot['dx']:.2f}  dw {tot['dw']:.2f}")
 
 

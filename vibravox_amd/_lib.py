@@ -62,6 +62,7 @@ SIGNATURES = {
     "eben_wn_scale": (c_int, [_P, _P, c_int, c_int, _P, _P, _P]),
     "eben_wn_bwd": (c_int, [_P, c_int, c_size_t, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P]),
     "eben_conv1d_packed_floats": (c_size_t, [_D, c_int]),
+    "eben_conv1d_kernel_generation": (c_int, [_D, c_int]),
     "eben_conv1d_pack": (c_int, [_D, _P, _P, _P, _P, _P]),
     "eben_conv1d_fwd": (c_int, [_D, _P, _P, _P, _P, _P, _P]),
     "eben_conv1d_bwd_dx_workspace": (c_size_t, [_D]),

@@ -79,4 +79,47 @@ struct Canon {
 };
 int canon_from_desc(const EbenConv1dDesc* d, Canon* c);
 
+// operands / fused element-wise stages of one tap-conv launch (either kernel generation)
+struct TapIO {
+  const float* x; const float* xmask; int in_mode; float in_slope;
+  const float* wp; const float* bias; const float* res; float res_slope;
+  const float* emask; float emask_slope; float out_slope; float* y; int accumulate;
+};
+
+// Tap geometry of one output phase.  mode 0 (gather-strided): every block uses (J0, off0_gs, nt_gs).
+// mode 1 (phase-scatter): phase ph = output position mod OS keeps the taps k = k0 + j*kstep with
+// (ph + pad - k*dil) % OS == 0; J = 0 when the phase has no tap.
+struct PhaseGeom { int J, off0, minoff, nt, oo, k0; };
+__host__ __device__ inline PhaseGeom phase_geom(int mode, int ph, int J0, int off0_gs, int nt_gs, int dstep, int OS,
+                                                int ps_pad, int ps_k, int ps_d, int ps_kstep, int Ly) {
+  PhaseGeom q;
+  q.J = J0; q.off0 = off0_gs; q.nt = nt_gs; q.oo = 0; q.k0 = 0;
+  if (mode == 1) {
+    int k0 = -1;
+    for (int c = 0; c < ps_kstep; ++c) {
+      int v = (ph + ps_pad - c * ps_d) % OS;
+      if (v < 0) v += OS;
+      if (v == 0) { k0 = c; break; }
+    }
+    if (k0 >= 0 && k0 < ps_k) {
+      q.J = (ps_k - 1 - k0) / ps_kstep + 1;
+      q.off0 = (ph + ps_pad - k0 * ps_d) / OS;
+    } else {
+      q.J = 0;
+      q.off0 = 0;
+    }
+    q.k0 = k0;
+    q.nt = ph < Ly ? (Ly - ph + OS - 1) / OS : 0;
+    q.oo = ph;
+  }
+  q.minoff = (dstep >= 0 || q.J == 0) ? q.off0 : q.off0 + (q.J - 1) * dstep;
+  return q;
+}
+
+// second-generation tap-conv (tapconv2.hip): 32x32x2 MFMA tiles, LDS-DMA weight stream
+int tap2_applicable(const Canon& c, int dir);
+size_t tap2_packed_floats(const Canon& c, int dir);
+int tap2_pack(const Canon& c, int dir, const float* w, const float* scale, float* wp, hipStream_t st);
+int tap2_launch(const Canon& c, int dir, const TapIO& io, int reflect, hipStream_t st);
+
 }  // namespace eben

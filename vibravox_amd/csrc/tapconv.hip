@@ -496,12 +496,6 @@ static int launch_pack(const Canon& c, const TapPlan& p, const float* w, const f
 }
 
 // ---- tapconv launcher -----------------------------------------------------------------------
-struct TapIO {
-  const float* x; const float* xmask; int in_mode; float in_slope;
-  const float* wp; const float* bias; const float* res; float res_slope;
-  const float* emask; float emask_slope; float out_slope; float* y; int accumulate;
-};
-
 template <int WM, int WN, int FM, int FN>
 static int launch_cfg(const TapArgs& a, int nblocks, size_t lds, hipStream_t st) {
   static bool attr_set = false;
@@ -606,8 +600,15 @@ extern "C" size_t eben_conv1d_packed_floats(const EbenConv1dDesc* d, int which) 
   TapPlan p;
   // which: 0 = the layer's forward, 1 = the layer's input gradient
   const int dir = d->transposed ? 1 - which : which;
+  if (tap2_applicable(c, dir)) return tap2_packed_floats(c, dir);
   make_plan(c, dir, &p);
   return p.packed_floats;
+}
+
+extern "C" int eben_conv1d_kernel_generation(const EbenConv1dDesc* d, int which) {
+  Canon c;
+  if (canon_from_desc(d, &c) != EBEN_OK) return 0;
+  return tap2_applicable(c, d->transposed ? 1 - which : which) ? 2 : 1;
 }
 
 extern "C" int eben_conv1d_pack(const EbenConv1dDesc* d, const float* v, const float* scale, float* wp_fwd, float* wp_bwd, void* stream) {
@@ -618,8 +619,14 @@ extern "C" int eben_conv1d_pack(const EbenConv1dDesc* d, const float* v, const f
   for (int which = 0; which < 2; ++which) {
     float* dst = which == 0 ? wp_fwd : wp_bwd;
     if (!dst) continue;
+    const int dir = d->transposed ? 1 - which : which;
+    if (tap2_applicable(c, dir)) {
+      rc = tap2_pack(c, dir, v, scale, dst, as_stream(stream));
+      if (rc) return rc;
+      continue;
+    }
     TapPlan p;
-    make_plan(c, d->transposed ? 1 - which : which, &p);
+    make_plan(c, dir, &p);
     rc = launch_pack(c, p, v, scale, dst, as_stream(stream));
     if (rc) return rc;
   }
@@ -644,6 +651,7 @@ extern "C" int eben_conv1d_fwd(const EbenConv1dDesc* d, const float* x, const fl
   io.x = x; io.in_mode = 0; io.in_slope = d->in_slope; io.wp = wp_fwd; io.bias = bias;
   io.res = residual; io.res_slope = 1.f; io.emask = nullptr; io.emask_slope = 1.f;
   io.out_slope = d->out_slope; io.y = y; io.accumulate = 0;
+  if (tap2_applicable(c, d->transposed ? 1 : 0)) return tap2_launch(c, d->transposed ? 1 : 0, io, c.reflect && !d->transposed, as_stream(stream));
   return launch_tap(c, p, io, c.reflect && !d->transposed, as_stream(stream));
 }
 
@@ -664,7 +672,9 @@ extern "C" int eben_conv1d_bwd_dx(const EbenConv1dDesc* d, const float* dy, cons
   EBEN_REQUIRE(d->in_slope == 1.f || x, "x is required to differentiate the fused input activation");
   hipStream_t st = as_stream(stream);
   TapPlan p;
-  make_plan(c, d->transposed ? 0 : 1, &p);
+  const int dir = d->transposed ? 0 : 1;
+  const bool v2 = tap2_applicable(c, dir);
+  make_plan(c, dir, &p);
   TapIO io{};
   io.x = dy; io.wp = wp_bwd; io.bias = nullptr; io.res = nullptr; io.res_slope = 1.f; io.out_slope = 1.f;
   if (d->out_slope != 1.f) { io.in_mode = 1; io.xmask = y; io.in_slope = d->out_slope; }
@@ -673,12 +683,12 @@ extern "C" int eben_conv1d_bwd_dx(const EbenConv1dDesc* d, const float* dy, cons
   if (!fold) {
     io.emask = d->in_slope != 1.f ? x : nullptr; io.emask_slope = d->in_slope;
     io.y = dx; io.accumulate = accumulate;
-    return launch_tap(c, p, io, 0, st);
+    return v2 ? tap2_launch(c, dir, io, 0, st) : launch_tap(c, p, io, 0, st);
   }
   const size_t need = eben_conv1d_bwd_dx_workspace(d);
   if (!workspace || ws_bytes < need) return fail(EBEN_EWORKSPACE, "bwd_dx needs %zu workspace bytes, got %zu", need, ws_bytes);
   io.emask = nullptr; io.emask_slope = 1.f; io.y = static_cast<float*>(workspace); io.accumulate = 0;
-  rc = launch_tap(c, p, io, 0, st);
+  rc = v2 ? tap2_launch(c, dir, io, 0, st) : launch_tap(c, p, io, 0, st);
   if (rc) return rc;
   const long long rows = (long long)c.B * c.Cin;
   long long blocks = (rows * c.Lin + 255) / 256;
