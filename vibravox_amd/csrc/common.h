@@ -122,4 +122,20 @@ size_t tap2_packed_floats(const Canon& c, int dir);
 int tap2_pack(const Canon& c, int dir, const float* w, const float* scale, float* wp, hipStream_t st);
 int tap2_launch(const Canon& c, int dir, const TapIO& io, int reflect, hipStream_t st);
 
+// second-generation weight-gradient kernel (conv_dw2.hip): pre-transposed A image + LDS-DMA
+struct Dw2Args {
+  const float* a; const float* amask; int a_mode; float a_slope;     // pack pre-pass input
+  const float* x; const float* xmask; int x_mode; float x_slope;
+  float* ap;        // packed A image
+  float* slabs;
+  int B, G, Cg, Mg, Ca, Cx, La, Lx;
+  int S, d, off0, J, Ng, has_bias, row_stride, reflect;
+  int nsplit, nct, nchunks, nnt, nmt, XSTR, nch_max;
+  long long slab_stride;
+};
+
+int dw2_applicable(const Canon& c);
+size_t dw2_workspace(const Canon& c, int* nslab, int* row_stride);
+int dw2_launch(const Canon& c, Dw2Args a, float* workspace, size_t ws_bytes, hipStream_t st);
+
 }  // namespace eben

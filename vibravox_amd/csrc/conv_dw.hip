@@ -391,6 +391,7 @@ extern "C" int eben_wn_bwd(const float* dw_slabs, int nslab, size_t slab_stride,
 extern "C" size_t eben_conv1d_bwd_dw_workspace(const EbenConv1dDesc* d, int* nslab, int* row_stride) {
   Canon c;
   if (canon_from_desc(d, &c) != EBEN_OK) return 0;
+  if (dw2_applicable(c)) return dw2_workspace(c, nslab, row_stride);
   DwPlan p;
   make_dw_plan(c, &p);
   if (nslab) *nslab = p.nsplit;
@@ -406,6 +407,20 @@ extern "C" int eben_conv1d_bwd_dw(const EbenConv1dDesc* d, const float* dy, cons
   EBEN_REQUIRE(dy && x && slabs, "null pointer in conv1d_bwd_dw");
   EBEN_REQUIRE(d->out_slope == 1.f || y, "y is required to differentiate the fused output activation");
   EBEN_REQUIRE(!(d->transposed && has_bias), "ConvTranspose1d bias gradient is not provided by this kernel");
+  if (dw2_applicable(c)) {
+    Dw2Args a2;
+    if (!d->transposed) {
+      a2.a = dy; a2.amask = y; a2.a_mode = d->out_slope != 1.f ? 1 : 0; a2.a_slope = d->out_slope;
+      a2.x = x; a2.xmask = nullptr; a2.x_mode = 0; a2.x_slope = d->in_slope;
+    } else {
+      a2.a = x; a2.amask = nullptr; a2.a_mode = 0; a2.a_slope = d->in_slope;
+      a2.x = dy; a2.xmask = y; a2.x_mode = d->out_slope != 1.f ? 1 : 0; a2.x_slope = d->out_slope;
+    }
+    if (a2.a_mode == 0 && a2.a == dy) a2.a_slope = 1.f;
+    if (a2.x_mode == 0 && a2.x == dy) a2.x_slope = 1.f;
+    a2.has_bias = has_bias ? 1 : 0;
+    return dw2_launch(c, a2, slabs, ws_bytes, as_stream(stream));
+  }
   DwPlan p;
   make_dw_plan(c, &p);
   const size_t need = sizeof(float) * (size_t)p.slab_stride * p.nsplit;
