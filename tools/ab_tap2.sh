@@ -1,4 +1,3 @@
-for cfg in "EBEN_DW2=0" "EBEN_DW2=1" "EBEN_DW2=0" "EBEN_DW2=1"; do
-  echo "== cfg: $cfg"
-  env $cfg python bench.py --steps 10 --warmup 3 --no-cpu-baseline 2>&1 | grep "GPU:"
-done
+python -m pytest tests -m gpu -x -q > gpurun_out/s10_tests.log 2>&1; grep -E "passed|failed" gpurun_out/s10_tests.log
+python tools/layer_bench.py > gpurun_out/s10_layers.log 2>&1; tail -1 gpurun_out/s10_layers.log
+for i in 1 2 3; do python bench.py --steps 20 --warmup 3 --no-cpu-baseline 2>&1 | grep "GPU:"; done

@@ -122,6 +122,14 @@ size_t tap2_packed_floats(const Canon& c, int dir);
 int tap2_pack(const Canon& c, int dir, const float* w, const float* scale, float* wp, hipStream_t st);
 int tap2_launch(const Canon& c, int dir, const TapIO& io, int reflect, hipStream_t st);
 
+// direct (VALU) tap-conv for layers with a handful of output channels per group (thinconv.hip)
+int thin_applicable(const Canon& c, int dir);
+size_t thin_packed_floats(const Canon& c, int dir);
+int thin_pack(const Canon& c, int dir, const float* w, const float* scale, float* wp, hipStream_t st);
+int thin_launch(const Canon& c, int dir, const TapIO& io, int reflect, hipStream_t st);
+// which kernel serves (layer, direction): 1 tapconv.hip, 2 tapconv2.hip, 3 thinconv.hip
+int tap_generation(const Canon& c, int dir);
+
 // second-generation weight-gradient kernel (conv_dw2.hip): pre-transposed A image + LDS-DMA
 struct Dw2Args {
   const float* a; const float* amask; int a_mode; float a_slope;     // pack pre-pass input

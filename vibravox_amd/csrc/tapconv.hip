@@ -594,13 +594,25 @@ __global__ __launch_bounds__(256) void fold_kernel(const float* __restrict__ D, 
 
 using namespace eben;
 
+namespace eben {
+int tap_generation(const Canon& c, int dir) {
+  static const int thin_first = getenv("EBEN_THIN_FIRST") ? atoi(getenv("EBEN_THIN_FIRST")) : 0;
+  const int t2 = tap2_applicable(c, dir), th = thin_applicable(c, dir);
+  if (th && (thin_first || !t2)) return 3;
+  if (t2) return 2;
+  return 1;
+}
+}  // namespace eben
+
 extern "C" size_t eben_conv1d_packed_floats(const EbenConv1dDesc* d, int which) {
   Canon c;
   if (canon_from_desc(d, &c) != EBEN_OK) return 0;
   TapPlan p;
   // which: 0 = the layer's forward, 1 = the layer's input gradient
   const int dir = d->transposed ? 1 - which : which;
-  if (tap2_applicable(c, dir)) return tap2_packed_floats(c, dir);
+  const int gen = tap_generation(c, dir);
+  if (gen == 2) return tap2_packed_floats(c, dir);
+  if (gen == 3) return thin_packed_floats(c, dir);
   make_plan(c, dir, &p);
   return p.packed_floats;
 }
@@ -608,7 +620,7 @@ extern "C" size_t eben_conv1d_packed_floats(const EbenConv1dDesc* d, int which) 
 extern "C" int eben_conv1d_kernel_generation(const EbenConv1dDesc* d, int which) {
   Canon c;
   if (canon_from_desc(d, &c) != EBEN_OK) return 0;
-  return tap2_applicable(c, d->transposed ? 1 - which : which) ? 2 : 1;
+  return tap_generation(c, d->transposed ? 1 - which : which);
 }
 
 extern "C" int eben_conv1d_pack(const EbenConv1dDesc* d, const float* v, const float* scale, float* wp_fwd, float* wp_bwd, void* stream) {
@@ -620,8 +632,9 @@ extern "C" int eben_conv1d_pack(const EbenConv1dDesc* d, const float* v, const f
     float* dst = which == 0 ? wp_fwd : wp_bwd;
     if (!dst) continue;
     const int dir = d->transposed ? 1 - which : which;
-    if (tap2_applicable(c, dir)) {
-      rc = tap2_pack(c, dir, v, scale, dst, as_stream(stream));
+    const int gen = tap_generation(c, dir);
+    if (gen != 1) {
+      rc = gen == 2 ? tap2_pack(c, dir, v, scale, dst, as_stream(stream)) : thin_pack(c, dir, v, scale, dst, as_stream(stream));
       if (rc) return rc;
       continue;
     }
@@ -641,7 +654,7 @@ extern "C" int eben_conv1d_fwd(const EbenConv1dDesc* d, const float* x, const fl
   EBEN_REQUIRE(x && wp_fwd && y, "null pointer in conv1d_fwd");
   TapPlan p;
   make_plan(c, d->transposed ? 1 : 0, &p);
-  if (!d->transposed && c.Cout == 1 && c.g == 1 && c.s == 1 && !c.reflect && d->in_slope == 1.f && !residual) {
+  if (!d->transposed && c.Cout == 1 && c.g == 1 && c.s == 1 && !c.reflect && d->in_slope == 1.f && !residual && tap_generation(c, 0) == 1) {
     hipLaunchKernelGGL(conv_m1_fwd_kernel, dim3(ceil_div(c.Lout, 64), c.B), dim3(1024), 0, as_stream(stream), x, wp_fwd, bias, y,
                        c.Cin, c.Lin, c.Lout, c.k, c.pl, c.d, p.CI_T, p.KCpad, p.Mp, d->out_slope);
     EBEN_CHECK_LAUNCH("conv_m1_fwd_kernel");
@@ -651,7 +664,9 @@ extern "C" int eben_conv1d_fwd(const EbenConv1dDesc* d, const float* x, const fl
   io.x = x; io.in_mode = 0; io.in_slope = d->in_slope; io.wp = wp_fwd; io.bias = bias;
   io.res = residual; io.res_slope = 1.f; io.emask = nullptr; io.emask_slope = 1.f;
   io.out_slope = d->out_slope; io.y = y; io.accumulate = 0;
-  if (tap2_applicable(c, d->transposed ? 1 : 0)) return tap2_launch(c, d->transposed ? 1 : 0, io, c.reflect && !d->transposed, as_stream(stream));
+  const int fgen = tap_generation(c, d->transposed ? 1 : 0);
+  if (fgen == 2) return tap2_launch(c, d->transposed ? 1 : 0, io, c.reflect && !d->transposed, as_stream(stream));
+  if (fgen == 3) return thin_launch(c, d->transposed ? 1 : 0, io, c.reflect && !d->transposed, as_stream(stream));
   return launch_tap(c, p, io, c.reflect && !d->transposed, as_stream(stream));
 }
 
@@ -673,7 +688,7 @@ extern "C" int eben_conv1d_bwd_dx(const EbenConv1dDesc* d, const float* dy, cons
   hipStream_t st = as_stream(stream);
   TapPlan p;
   const int dir = d->transposed ? 0 : 1;
-  const bool v2 = tap2_applicable(c, dir);
+  const int gen = tap_generation(c, dir);
   make_plan(c, dir, &p);
   TapIO io{};
   io.x = dy; io.wp = wp_bwd; io.bias = nullptr; io.res = nullptr; io.res_slope = 1.f; io.out_slope = 1.f;
@@ -683,12 +698,12 @@ extern "C" int eben_conv1d_bwd_dx(const EbenConv1dDesc* d, const float* dy, cons
   if (!fold) {
     io.emask = d->in_slope != 1.f ? x : nullptr; io.emask_slope = d->in_slope;
     io.y = dx; io.accumulate = accumulate;
-    return v2 ? tap2_launch(c, dir, io, 0, st) : launch_tap(c, p, io, 0, st);
+    return gen == 2 ? tap2_launch(c, dir, io, 0, st) : gen == 3 ? thin_launch(c, dir, io, 0, st) : launch_tap(c, p, io, 0, st);
   }
   const size_t need = eben_conv1d_bwd_dx_workspace(d);
   if (!workspace || ws_bytes < need) return fail(EBEN_EWORKSPACE, "bwd_dx needs %zu workspace bytes, got %zu", need, ws_bytes);
   io.emask = nullptr; io.emask_slope = 1.f; io.y = static_cast<float*>(workspace); io.accumulate = 0;
-  rc = v2 ? tap2_launch(c, dir, io, 0, st) : launch_tap(c, p, io, 0, st);
+  rc = gen == 2 ? tap2_launch(c, dir, io, 0, st) : gen == 3 ? thin_launch(c, dir, io, 0, st) : launch_tap(c, p, io, 0, st);
   if (rc) return rc;
   const long long rows = (long long)c.B * c.Cin;
   long long blocks = (rows * c.Lin + 255) / 256;
