@@ -184,7 +184,7 @@ def main():
                                    f"batch {args.batch} x {args.length} samples @16kHz per GPU (cut to {cut})",
                        "global_batch": world * args.batch, "samples_per_clip": cut, "parallelism": f"dp{world}",
                        "weights": "random init, torch.manual_seed(42)"},
-            "roofline": {"bound": "mfma", "kernel": "eben::tapconv_kernel<2,4,4,2> MelGAN L4 fwd (1024->1024 k41 s4 g4)",
+            "roofline": {"bound": "mfma", "kernel": "eben::tap2_kernel<4,4> MelGAN L4 fwd (1024->1024 k41 s4 g4)",
                          "achieved": round(achieved, 2) if achieved else None, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4) if achieved else None, "traffic": pmc_traffic(args.batch),
                          "launch_ms": round(kms, 4) if kms else None, "flops_per_launch": flops,

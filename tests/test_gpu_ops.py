@@ -44,6 +44,16 @@ CONV_CASES = {
     "melgan_l0_k15": (dict(c_in=1, c_out=16, ksize=15, out_slope=0.2), 2, 2014, True, True),
     "stft_like": (dict(c_in=1, c_out=66, ksize=24, stride=5, pad_l=12, pad_r=12, reflect=True), 4, 1003, False, False),
     "tiny_l": (dict(c_in=8, c_out=8, ksize=3, pad_l=1, pad_r=1), 1, 5, True, True),
+    # second-generation kernels: channel-chunked input tiles (tile hand-over mid weight chunk), 96-row tiles,
+    # phase-scatter with several tile refreshes, time chunks that do not divide the length
+    "melgan_l3_like_chunked": (dict(c_in=256, c_out=512, ksize=41, stride=4, pad_l=20, pad_r=20, groups=4, out_slope=0.2), 2, 700, True, True),
+    "melgan_l5_like_dense": (dict(c_in=320, c_out=256, ksize=5, pad_l=2, pad_r=2, out_slope=0.2), 2, 131, True, True),
+    "pqmf_l6_like_96rows": (dict(c_in=384, c_out=384, ksize=5, dilation=3, pad_l=2, pad_r=2, groups=4, out_slope=0.2), 2, 140, True, True),
+    "enc_s8_wide": (dict(c_in=128, c_out=256, ksize=16, stride=8, pad_l=7, pad_r=7, reflect=True, in_slope=0.01), 2, 1500, True, False),
+    # direct (VALU) kernel: 1 / 4 / 6 / 12 / 16 output channels per group, strided, dilated, input gradients
+    "thin_pqmf_l0": (dict(c_in=4, c_out=24, ksize=3, dilation=2, pad_l=1, pad_r=1, groups=4, out_slope=0.2), 3, 1003, True, True),
+    "thin_pqmf_l1": (dict(c_in=24, c_out=48, ksize=7, stride=2, dilation=3, pad_l=3, pad_r=3, groups=4, out_slope=0.2), 3, 999, True, True),
+    "thin_melgan_l1": (dict(c_in=16, c_out=64, ksize=41, stride=4, pad_l=20, pad_r=20, groups=4, out_slope=0.2), 2, 2100, True, True),
 }
 
 
@@ -87,6 +97,28 @@ def test_conv_layer_fwd_bwd(hip, name):
         assert rel_err(dg_.grad, rg.grad) < 2 * tol, f"dg {rel_err(dg_.grad, rg.grad)}"
     if has_bias:
         assert rel_err(db_.grad, rb.grad) < 2 * tol, f"dbias {rel_err(db_.grad, rb.grad)}"
+
+
+def test_kernel_generations_cover_the_eben_layers(hip):
+    """Every kernel family is exercised by the shapes above and serves the layers it was written for."""
+    import ctypes
+
+    from vibravox_amd import ops
+    from vibravox_amd._lib import load
+
+    lib = load()
+
+    def gen(name, which, batch=32):
+        kw, _, length, _, _ = CONV_CASES[name]
+        spec = ops.ConvSpec(**kw)
+        return lib.eben_conv1d_kernel_generation(ctypes.byref(ops.conv_desc(spec, batch, length)), which)
+
+    assert gen("melgan_l3_like_chunked", 0) == 2 and gen("melgan_l3_like_chunked", 1) == 2
+    assert gen("pqmf_l6_like_96rows", 0) == 2
+    assert gen("thin_pqmf_l0", 0) == 3 and gen("thin_pqmf_l1", 1) == 3 and gen("thin_melgan_l1", 1) == 3
+    assert gen("logits_m1", 0) == 1 and gen("stft_like", 0) == 1
+    seen = {gen(n, w) for n in CONV_CASES for w in (0, 1)}
+    assert seen == {1, 2, 3}
 
 
 def test_conv_bad_descriptor_raises(hip):
