@@ -94,6 +94,15 @@ EBEN_API size_t eben_conv1d_bwd_dw_workspace(const EbenConv1dDesc* d, int* nslab
  * accumulate!=0 adds into dx instead of overwriting. */
 EBEN_API int eben_conv1d_bwd_dx(const EbenConv1dDesc* d, const float* dy, const float* y, const float* wp_bwd,
                        const float* x, float* dx, int accumulate, void* workspace, size_t ws_bytes, void* stream);
+/* Batched input gradient for several right-hand sides that share one set of saved activations (rows of
+ * g / dx = d->batch):  dx[b] = ( conv^T(g[b]) + (b < res_rows ? res[b] : 0) ) * lrelu'(mask[map(b)], mask_slope)
+ * with map(b) = seg_map[b / seg] * seg + b % seg (seg = 0: map(b) = b; seg_map = HOST array of 4 ints).
+ * g is used as is (the producer applied its own activation derivative); res / mask may be NULL.
+ * Replaces the four separate backward passes through DiscriminatorEBENMultiScales that
+ * vibravox/lightning_modules/eben.py:99-128,222-240 triggers (three through the enhanced branch, one
+ * through the reference branch) with one pass over stacked gradients. */
+EBEN_API int eben_conv1d_bwd_dx_ex(const EbenConv1dDesc* d, const float* g, const float* wp_bwd, const float* res, int res_rows,
+                          const float* mask, float mask_slope, int seg, const int* seg_map, float* dx, void* stream);
 /* partial weight (+bias) gradients into `slabs` (layout reported by bwd_dw_workspace);
  * finish with eben_wn_bwd. */
 EBEN_API int eben_conv1d_bwd_dw(const EbenConv1dDesc* d, const float* dy, const float* y, const float* x, int has_bias,

@@ -161,12 +161,14 @@ def make_module(golden, use_mrstft, fused_adam=True):
     return mod, g_sd, d_sd
 
 
-@pytest.mark.parametrize("fused_adam,literal", [(True, False), (False, False), (True, True)])
-def test_two_train_steps_against_reference_replay_golden(hip, golden, fused_adam, literal):
-    """eben.py:82-130 replayed over the REFERENCE modules (golden) vs this build's LightningModule,
-    both in the literal as-executed order and with the redundant discriminator passes removed."""
+@pytest.mark.parametrize("fused_adam,literal,engine", [(True, False, True), (False, False, True), (True, False, False), (True, True, False)])
+def test_two_train_steps_against_reference_replay_golden(hip, golden, fused_adam, literal, engine):
+    """eben.py:82-130 replayed over the REFERENCE modules (golden) vs this build's LightningModule:
+    the literal as-executed order, the order with the redundant discriminator passes removed (autograd),
+    and the batched discriminator engine (one forward, one stacked backward)."""
     mod, g_sd, d_sd = make_module(golden, use_mrstft=False, fused_adam=fused_adam)
     mod.exploit_step_redundancy = not literal
+    mod.use_disc_engine = engine
     for i in range(2):
         batch = {"audio_body_conducted": formula_audio(f"step{i}/bc", 2, 8200).to(DEV),
                  "audio_airborne": formula_audio(f"step{i}/air", 2, 8200).to(DEV)}
@@ -185,12 +187,13 @@ def test_two_train_steps_against_reference_replay_golden(hip, golden, fused_adam
         np.testing.assert_allclose(v.double().norm().item(), golden[f"post/D/{k}"][1], rtol=2e-4)
 
 
-@pytest.mark.parametrize("literal", [False, True])
-def test_train_step_with_mrstft_against_oracle(hip, golden, literal):
+@pytest.mark.parametrize("literal,engine", [(False, True), (False, False), (True, False)])
+def test_train_step_with_mrstft_against_oracle(hip, golden, literal, engine):
     """Full default configuration (MRSTFT + FM + hinge, EMA balancing).  The MRSTFT term is a
     restatement of third-party auraloss (parity unpinned); everything else is pinned."""
     mod, g_sd, d_sd = make_module(golden, use_mrstft=True)
     mod.exploit_step_redundancy = not literal
+    mod.use_disc_engine = engine
     trainer = O.OracleTrainer(g_sd, d_sd, p=2, q=4, use_mrstft=True)
     for i in range(2):
         bc, air = formula_audio(f"mstep{i}/bc", 2, 8200), formula_audio(f"mstep{i}/air", 2, 8200)

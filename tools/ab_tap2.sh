@@ -1,3 +1,5 @@
-python -m pytest tests -m gpu -x -q > gpurun_out/s10_tests.log 2>&1; grep -E "passed|failed" gpurun_out/s10_tests.log
-python tools/layer_bench.py > gpurun_out/s10_layers.log 2>&1; tail -1 gpurun_out/s10_layers.log
-for i in 1 2 3; do python bench.py --steps 20 --warmup 3 --no-cpu-baseline 2>&1 | grep "GPU:"; done
+python -m pytest tests -m gpu -x -q > gpurun_out/s11_tests.log 2>&1; grep -E "passed|failed|Error|error" gpurun_out/s11_tests.log | head; tail -30 gpurun_out/s11_tests.log | grep -v "^RCCL\|^HIP\|^ROCm\|^Host\|^Librccl" | tail -25
+for cfg in "EBEN_DISC_ENGINE=0" "EBEN_DISC_ENGINE=1" "EBEN_DISC_ENGINE=0" "EBEN_DISC_ENGINE=1"; do
+  echo "== cfg: $cfg"
+  env $cfg python bench.py --steps 20 --warmup 3 --no-cpu-baseline 2>&1 | grep "GPU:"
+done

@@ -68,6 +68,7 @@ SIGNATURES = {
     "eben_conv1d_bwd_dx_workspace": (c_size_t, [_D]),
     "eben_conv1d_bwd_dw_workspace": (c_size_t, [_D, POINTER(c_int), POINTER(c_int)]),
     "eben_conv1d_bwd_dx": (c_int, [_D, _P, _P, _P, _P, _P, c_int, _P, c_size_t, _P]),
+    "eben_conv1d_bwd_dx_ex": (c_int, [_D, _P, _P, _P, c_int, _P, c_float, c_int, POINTER(c_int), _P, _P]),
     "eben_conv1d_bwd_dw": (c_int, [_D, _P, _P, _P, c_int, _P, c_size_t, _P]),
     "eben_fir_decimate": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "eben_fir_interp_sum": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),

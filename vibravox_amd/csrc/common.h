@@ -84,6 +84,10 @@ struct TapIO {
   const float* x; const float* xmask; int in_mode; float in_slope;
   const float* wp; const float* bias; const float* res; float res_slope;
   const float* emask; float emask_slope; float out_slope; float* y; int accumulate;
+  // batched right-hand sides (eben_conv1d_bwd_dx_ex): the residual is added only for batch rows
+  // b < res_rows (0 = all rows); the epilogue mask is read from batch row
+  // em_map[b / em_seg] * em_seg + b % em_seg (em_seg = 0: row b)
+  int res_rows; int em_seg; int em_map[4];
 };
 
 // Tap geometry of one output phase.  mode 0 (gather-strided): every block uses (J0, off0_gs, nt_gs).

@@ -44,6 +44,7 @@ struct TapArgs {
   int reflect, in_mode;  // in_mode 0: lrelu(x, in_slope); 1: x * lrelu'(xmask, in_slope)
   float in_slope, out_slope, res_slope, emask_slope;
   int accumulate;
+  int res_rows, em_seg, em_map[4];
   int PLEN, CSTRIDE;
   unsigned s_magic;      // ceil(2^32 / S)
   int ntt, nmt, nph;
@@ -269,6 +270,10 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, WAVES_M * WAVES_N == 8 ? 4 
     }
   }
 
+  // batched right-hand sides: residual row limit and remapped mask row (wave-uniform)
+  const bool use_res = P.res != nullptr && (P.res_rows == 0 || b < P.res_rows);
+  const int eb = P.em_seg > 0 ? P.em_map[b / P.em_seg] * P.em_seg + b % P.em_seg : b;
+  const long long eoff = (long long)(eb - b) * P.Cy * P.Ly;
   // ---- epilogue: D fragment = 4 consecutive rows (m) x 1 column (t) per lane ----
 #pragma unroll
   for (int i = 0; i < FM; ++i) {
@@ -285,8 +290,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, WAVES_M * WAVES_N == 8 ? 4 
         const long long idx = yrow + (long long)t * P.OS + oo;
         float v = acc[i][n][r] + bias;
         v = lrelu(v, P.out_slope);
-        if (P.res) v += lrelu(P.res[idx], P.res_slope);
-        if (P.emask) v *= dlrelu(P.emask[idx], P.emask_slope);
+        if (use_res) v += lrelu(P.res[idx], P.res_slope);
+        if (P.emask) v *= dlrelu(P.emask[idx + eoff], P.emask_slope);
         if (P.accumulate) v += P.y[idx];
         P.y[idx] = v;
       }
@@ -521,6 +526,8 @@ static int launch_tap(const Canon& c, const TapPlan& p, const TapIO& io, int ref
   a.reflect = reflect; a.in_mode = io.in_mode;
   a.in_slope = io.in_slope; a.out_slope = io.out_slope; a.res_slope = io.res_slope; a.emask_slope = io.emask_slope;
   a.accumulate = io.accumulate;
+  a.res_rows = io.res_rows; a.em_seg = io.em_seg;
+  for (int i = 0; i < 4; ++i) a.em_map[i] = io.em_map[i];
   a.PLEN = p.PLEN; a.CSTRIDE = p.CSTRIDE;
   a.s_magic = p.S > 1 ? (unsigned)((0x100000000ull + p.S - 1) / p.S) : 0u;
   a.ntt = p.ntt; a.nmt = p.nmt; a.nph = p.nph;
@@ -712,4 +719,34 @@ extern "C" int eben_conv1d_bwd_dx(const EbenConv1dDesc* d, const float* dy, cons
                      d->in_slope != 1.f ? x : nullptr, dx, rows, c.Lin, c.pl, c.pr, d->in_slope, accumulate);
   EBEN_CHECK_LAUNCH("fold_kernel");
   return EBEN_OK;
+}
+
+// Batched input gradient for several right-hand sides that share one set of saved activations
+// (the discriminator backward of the fused train step: feature-matching, adversarial, fake and real
+// seeds stacked along the batch axis):
+//   dx[b] = ( conv^T(g[b]) + (b < res_rows ? res[b] : 0) ) * lrelu'(mask[map(b)], mask_slope)
+// g is consumed as is: the producer already applied its activation derivative in ITS epilogue, so no
+// kernel on this path reads a mask on load.
+extern "C" int eben_conv1d_bwd_dx_ex(const EbenConv1dDesc* d, const float* g, const float* wp_bwd, const float* res, int res_rows,
+                                     const float* mask, float mask_slope, int seg, const int* seg_map, float* dx, void* stream) {
+  Canon c;
+  int rc = canon_from_desc(d, &c);
+  if (rc) return rc;
+  EBEN_REQUIRE(g && wp_bwd && dx, "null pointer in conv1d_bwd_dx_ex");
+  EBEN_REQUIRE(!(c.reflect && !d->transposed), "bwd_dx_ex does not fold reflect padding (pad explicitly)");
+  EBEN_REQUIRE(seg >= 0 && (seg == 0 || (seg_map && c.B <= 4 * seg)), "bad batch segment map");
+  const int dir = d->transposed ? 0 : 1;
+  TapIO io{};
+  io.x = g; io.in_mode = 0; io.in_slope = 1.f; io.wp = wp_bwd; io.out_slope = 1.f;
+  io.res = res; io.res_slope = 1.f; io.res_rows = res_rows;
+  io.emask = mask; io.emask_slope = mask_slope; io.em_seg = mask ? seg : 0;
+  for (int i = 0; i < 4; ++i) io.em_map[i] = (seg > 0 && seg_map) ? seg_map[i] : i;
+  io.y = dx; io.accumulate = 0;
+  const int gen = tap_generation(c, dir);
+  hipStream_t st = as_stream(stream);
+  if (gen == 2) return tap2_launch(c, dir, io, 0, st);
+  if (gen == 3) return thin_launch(c, dir, io, 0, st);
+  TapPlan p;
+  make_plan(c, dir, &p);
+  return launch_tap(c, p, io, 0, st);
 }

@@ -37,6 +37,7 @@ struct Tap2Args {
   int S, OS, dstep, J0, mode, off0, nt, nph;
   int ps_pad, ps_k, ps_d, ps_kstep;
   int reflect, in_mode, accumulate;
+  int res_rows, em_seg, em_map[4];
   float in_slope, out_slope, res_slope, emask_slope;
   int CI_T, CP, ncc, PLEN, CSTRIDE;
   unsigned s_magic;
@@ -252,6 +253,10 @@ __global__ __launch_bounds__(NW * 64, 2) void tap2_kernel(const Tap2Args P) {
     __syncthreads();
   }
 
+  // batched right-hand sides: residual row limit and remapped mask row (wave-uniform)
+  const bool use_res = P.res != nullptr && (P.res_rows == 0 || b < P.res_rows);
+  const int eb = P.em_seg > 0 ? P.em_map[b / P.em_seg] * P.em_seg + b % P.em_seg : b;
+  const long long eoff = (long long)(eb - b) * P.Cy * P.Ly;
   // ---- epilogue: 32x32 D tile: column = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) ----
   const int t = t0 + wn * 32 + (lane & 31);
   if (t >= nt) return;
@@ -265,8 +270,8 @@ __global__ __launch_bounds__(NW * 64, 2) void tap2_kernel(const Tap2Args P) {
       const long long idx = ((long long)b * P.Cy + (long long)g * P.Mg + m) * P.Ly + (long long)t * P.OS + oo;
       float v = acc[i][r] + bias;
       v = lrelu(v, P.out_slope);
-      if (P.res) v += lrelu(P.res[idx], P.res_slope);
-      if (P.emask) v *= dlrelu(P.emask[idx], P.emask_slope);
+      if (use_res) v += lrelu(P.res[idx], P.res_slope);
+      if (P.emask) v *= dlrelu(P.emask[idx + eoff], P.emask_slope);
       if (P.accumulate) v += P.y[idx];
       P.y[idx] = v;
     }
@@ -496,6 +501,8 @@ int tap2_launch(const Canon& c, int dir, const TapIO& io, int reflect, hipStream
   a.S = p.S; a.OS = p.OS; a.dstep = p.dstep; a.J0 = p.J; a.mode = p.mode; a.off0 = p.off0; a.nt = p.nt; a.nph = p.nph;
   a.ps_pad = p.ps_pad; a.ps_k = c.k; a.ps_d = c.d; a.ps_kstep = p.kstep;
   a.reflect = reflect; a.in_mode = io.in_mode; a.accumulate = io.accumulate;
+  a.res_rows = io.res_rows; a.em_seg = io.em_seg;
+  for (int i = 0; i < 4; ++i) a.em_map[i] = io.em_map[i];
   a.in_slope = io.in_slope; a.out_slope = io.out_slope; a.res_slope = io.res_slope; a.emask_slope = io.emask_slope;
   a.CI_T = p.CI_T; a.CP = p.CP; a.ncc = p.ncc; a.PLEN = p.PLEN; a.CSTRIDE = p.CSTRIDE;
   a.s_magic = p.S > 1 ? (unsigned)((0x100000000ull + p.S - 1) / p.S) : 0u;

@@ -1,0 +1,343 @@
+"""Batched forward / backward of ``DiscriminatorEBENMultiScales`` for the fused EBEN train step.
+
+One GAN step (``vibravox/lightning_modules/eben.py:82-130,184-240``) sends FOUR gradient signals
+through the discriminators, all linear in their seed and all sharing the activations of two
+forward passes:
+
+  * feature matching  (``feature_loss.py:37-50``)  -- through the *enhanced* branch, enters at every layer;
+  * adversarial, generator side (``hinge_loss.py:35-43``, target +1) -- enhanced branch, enters at the logits;
+  * ``fake_loss`` (target -1)                       -- enhanced branch, logits, wanted at the weights;
+  * ``real_loss`` (target +1)                       -- *reference* branch, logits, wanted at the weights.
+
+Autograd runs them as four passes of ~80 kernel launches each.  This engine runs the two forwards as
+ONE batch-2B pass ([enhanced; reference]) and the four backwards as ONE pass over gradients stacked
+along the batch axis (rows [fm | adv | fake | real], 4B rows):
+
+  * input gradients: ``eben_conv1d_bwd_dx_ex`` -- the producer's epilogue adds the feature-matching
+    gradient of that layer (first B rows only) and applies the LeakyReLU derivative of the saved
+    activation (row b reads activation row map(b)), so no kernel on the path reads a mask on load
+    and no separate add kernel runs;
+  * weight gradients: rows [fake | real] against activations [enhanced | reference] are exactly a
+    batch-2B ``eben_conv1d_bwd_dw`` (K doubles instead of a second launch + sum).
+
+Same arithmetic per sample as the four separate passes (convolutions are per-sample); only the fp32
+summation order inside the weight gradients changes.  The four sub-discriminators run on their own
+HIP streams.  No autograd graph is built for the discriminator; parameter gradients are handed to
+autograd through ``inject_grads`` so that ``.grad`` accumulation hooks (``ddp.GradSync``) still fire.
+"""
+from __future__ import annotations
+
+import ctypes
+import dataclasses
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import ops
+from ._lib import check, load, ptr
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+class _Layer:
+    """One weight-normalised conv of a sub-discriminator with the packed copies the engine needs."""
+
+    def __init__(self, conv):
+        self.conv = conv
+        self.spec: ops.ConvSpec = conv.spec
+        self.spec_lin = dataclasses.replace(conv.spec, in_slope=1.0, out_slope=1.0)   # gradients arrive pre-masked
+        self.packs: Dict[Tuple[int, int, int], Tuple[tuple, torch.Tensor]] = {}
+        self.scale_key = None
+        self.scale = self.norm = None
+
+    def params(self):
+        prm = self.conv.parametrizations["weight"]
+        return prm.original1, prm.original0, self.conv.bias   # v, g, bias
+
+    def _weights_key(self):
+        v, g, _ = self.params()
+        e = ops._storage_epoch
+        return (v.data_ptr(), v._version, e.get(v.data_ptr(), 0), g.data_ptr(), g._version, e.get(g.data_ptr(), 0), e.get(-1, 0))
+
+    def packed(self, which: int, batch: int, l_in: int) -> torch.Tensor:
+        """MFMA / direct layout of the weights for the forward (0) or input-gradient (1) launch of this
+        exact descriptor (the first-generation layout depends on the batch size)."""
+        lib = load()
+        v, g, _ = self.params()
+        v, g = v.detach(), g.detach()
+        wkey = self._weights_key()
+        if self.scale_key != wkey:
+            rows = v.shape[0]
+            self.scale = torch.empty(rows, dtype=torch.float32, device=v.device)
+            self.norm = torch.empty(rows, dtype=torch.float32, device=v.device)
+            check(lib.eben_wn_scale(ptr(g), ptr(v), rows, v.numel() // rows, ptr(self.scale), ptr(self.norm), _stream()), "wn_scale")
+            self.scale_key = wkey
+        slot = (which, batch, l_in)
+        hit = self.packs.get(slot)
+        if hit is not None and hit[0] == wkey:
+            return hit[1]
+        d = ops.conv_desc(self.spec, batch, l_in)
+        wp = torch.empty(lib.eben_conv1d_packed_floats(ctypes.byref(d), which), dtype=torch.float32, device=v.device)
+        check(lib.eben_conv1d_pack(ctypes.byref(d), ptr(v), ptr(self.scale), ptr(wp) if which == 0 else None,
+                                   ptr(wp) if which == 1 else None, _stream()), "conv1d_pack")
+        self.packs[slot] = (wkey, wp)
+        return wp
+
+
+class _Chain:
+    """A sub-discriminator: ReflectionPad1d(pad) followed by the conv stack (last conv = logits)."""
+
+    def __init__(self, modules):
+        self.layers: List[_Layer] = []
+        self.pad = 0
+        for m in modules:
+            if isinstance(m, torch.nn.Sequential):
+                for sub in m:
+                    if hasattr(sub, "padding") and not hasattr(sub, "spec"):
+                        self.pad = int(sub.padding)
+                    else:
+                        self.layers.append(_Layer(sub))
+            else:
+                self.layers.append(_Layer(m))
+
+    # ---- forward on a (2B, C, L) batch: returns [input, out_0, ..., logits] and the padded input
+    def forward(self, x: torch.Tensor):
+        lib = load()
+        x = x.contiguous()
+        b, c, l = x.shape
+        if self.pad:
+            xp = torch.empty((b, c, l + 2 * self.pad), dtype=torch.float32, device=x.device)
+            check(lib.eben_reflect_pad_fwd(ptr(x), ptr(xp), b * c, l, self.pad, self.pad, _stream()), "reflect_pad_fwd")
+        else:
+            xp = x
+        outs = []
+        cur = xp
+        for lay in self.layers:
+            d = ops.conv_desc(lay.spec, b, cur.shape[2])
+            y = torch.empty((b, lay.spec.c_out, d.l_out), dtype=torch.float32, device=x.device)
+            _, _, bias = lay.params()
+            check(lib.eben_conv1d_fwd(ctypes.byref(d), ptr(cur), ptr(lay.packed(0, b, cur.shape[2])), ptr(bias), None, ptr(y), _stream()),
+                  "conv1d_fwd")
+            outs.append(y)
+            cur = y
+        return [x] + outs, xp
+
+    # ---- backward of the four stacked right-hand sides
+    def backward(self, emb: List[torch.Tensor], xp: torch.Tensor, fm_grads: List[Optional[torch.Tensor]], seeds: torch.Tensor,
+                 half: int, want_param_grads: bool):
+        """emb = [input, out_0..out_{L-1}] with 2*half rows; fm_grads[i] = d(fm)/d(out_i) (half rows) or None;
+        seeds = (4*half, 1, L_logits) rows [fm | adv | fake | real].  Returns (d_input (2*half rows: fm | adv),
+        [(dv, dg, dbias) per layer] or None)."""
+        lib = load()
+        st = _stream()
+        outs = emb[1:]
+        n = len(self.layers)
+        seg_map = (ctypes.c_int * 4)(0, 0, 0, 1)
+        grads = [None] * n
+        g = seeds.contiguous()
+        for i in range(n - 1, -1, -1):
+            lay = self.layers[i]
+            x_in = outs[i - 1] if i > 0 else xp
+            l_in = x_in.shape[2]
+            if want_param_grads:
+                if i == n - 1:
+                    # Logits layer: fake and real branches separately, then added -- the reference's structure
+                    # (two autograd graphs accumulating into one .grad).  While every hinge term is active the
+                    # two bias gradients are -c*N and +c*N summed in the SAME order, i.e. they cancel exactly and
+                    # Adam leaves the bias alone; one sum over both branches leaves a rounding residue that Adam
+                    # (m / sqrt(v)) turns into a full-size step.
+                    gf = self._weight_grads(lay, g[2 * half:3 * half], x_in[:half], st)
+                    gr = self._weight_grads(lay, g[3 * half:], x_in[half:], st)
+                    grads[i] = tuple(None if a is None else a + b for a, b in zip(gf, gr))
+                else:
+                    grads[i] = self._weight_grads(lay, g[2 * half:], x_in, st)
+            if i > 0:
+                rows = 4 * half
+                d = ops.conv_desc(lay.spec_lin, rows, l_in)
+                gp = torch.empty((rows, lay.spec.c_in, l_in), dtype=torch.float32, device=g.device)
+                res = fm_grads[i - 1]
+                prev_slope = self.layers[i - 1].spec.out_slope
+                check(lib.eben_conv1d_bwd_dx_ex(ctypes.byref(d), ptr(g), ptr(lay.packed(1, rows, l_in)), ptr(res), half if res is not None else 0,
+                                                ptr(outs[i - 1]) if prev_slope != 1.0 else None, prev_slope, half, seg_map, ptr(gp), st),
+                      "conv1d_bwd_dx_ex")
+                g = gp
+            else:
+                rows = 2 * half   # only the generator-side signals reach the discriminator input
+                d = ops.conv_desc(lay.spec_lin, rows, l_in)
+                gp = torch.empty((rows, lay.spec.c_in, l_in), dtype=torch.float32, device=g.device)
+                check(lib.eben_conv1d_bwd_dx_ex(ctypes.byref(d), ptr(g), ptr(lay.packed(1, rows, l_in)), None, 0, None, 1.0, 0, None, ptr(gp), st),
+                      "conv1d_bwd_dx_ex")
+                g = gp
+        if self.pad:
+            b2, c, lp = g.shape
+            dx = torch.empty((b2, c, lp - 2 * self.pad), dtype=torch.float32, device=g.device)
+            check(lib.eben_reflect_pad_bwd(ptr(g), ptr(dx), b2 * c, lp - 2 * self.pad, self.pad, self.pad, st), "reflect_pad_bwd")
+            g = dx
+        return g, (grads if want_param_grads else None)
+
+    @staticmethod
+    def _weight_grads(lay: _Layer, g2: torch.Tensor, x_in: torch.Tensor, st: int):
+        lib = load()
+        v, gain, bias = lay.params()
+        rows_b = g2.shape[0]
+        d = ops.conv_desc(lay.spec_lin, rows_b, x_in.shape[2])
+        nslab, row_stride = ctypes.c_int(0), ctypes.c_int(0)
+        ws_bytes = lib.eben_conv1d_bwd_dw_workspace(ctypes.byref(d), ctypes.byref(nslab), ctypes.byref(row_stride))
+        slabs = torch.empty(max(1, (ws_bytes + 3) // 4), dtype=torch.float32, device=g2.device)
+        check(lib.eben_conv1d_bwd_dw(ctypes.byref(d), ptr(g2), None, ptr(x_in), 1 if bias is not None else 0, ptr(slabs), ws_bytes, st),
+              "conv1d_bwd_dw")
+        wrows = v.shape[0]
+        cols = v.numel() // wrows
+        dv = torch.empty_like(v)
+        dg = torch.empty_like(gain)
+        dbias = torch.empty(wrows, dtype=torch.float32, device=g2.device) if bias is not None else None
+        check(lib.eben_wn_bwd(ptr(slabs), nslab.value, wrows * row_stride.value, wrows, cols, row_stride.value, ptr(gain.detach()),
+                              ptr(v.detach()), ptr(lay.norm), ptr(dg), ptr(dv), ptr(dbias), st), "wn_bwd")
+        return dv, dg, dbias
+
+
+class _InjectGrads(torch.autograd.Function):
+    """Hands externally computed parameter gradients to autograd (so accumulation hooks fire)."""
+
+    @staticmethod
+    def forward(ctx, grads, *params):
+        ctx.grads = grads
+        return params[0].new_zeros(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        return (None, *ctx.grads)
+
+
+def inject_grads(params: Sequence[torch.nn.Parameter], grads: Sequence[torch.Tensor]) -> None:
+    live = [(p, g) for p, g in zip(params, grads) if p.requires_grad and g is not None]
+    if not live:
+        return
+    ps, gs = zip(*live)
+    _InjectGrads.apply(list(gs), *ps).backward()
+
+
+class DiscriminatorEngine:
+    def __init__(self, disc):
+        self.disc = disc
+        self.q = disc.q
+        self.chains = [_Chain(d.discriminator) for d in disc.pqmf_discriminators] + [_Chain(disc.melgan_discriminator.discriminator)]
+        self._streams = None
+        self._state = None
+
+    @staticmethod
+    def supports(disc) -> bool:
+        return hasattr(disc, "pqmf_discriminators") and hasattr(disc, "melgan_discriminator") and all(
+            hasattr(m, "discriminator") for m in list(disc.pqmf_discriminators) + [disc.melgan_discriminator])
+
+    def _on_streams(self, fn):
+        """fn(i) for each sub-discriminator on its own HIP stream; results in order."""
+        main = torch.cuda.current_stream()
+        dev = main.device
+        if self._streams is None or self._streams[0].device != dev:
+            self._streams = [torch.cuda.Stream(device=dev) for _ in self.chains]
+        results = [None] * len(self.chains)
+        for i, st in enumerate(self._streams):
+            st.wait_stream(main)
+            with torch.cuda.stream(st):
+                results[i] = fn(i)
+        for st in self._streams:
+            main.wait_stream(st)
+        return results
+
+    # ---- the two forwards as one batch-2B pass -------------------------------------------------
+    @torch.no_grad()
+    def forward(self, bands: torch.Tensor, audio: torch.Tensor, bands_ref: torch.Tensor, audio_ref: torch.Tensor):
+        half = bands.shape[0]
+        sub = torch.cat((bands[:, -self.q:, :], bands_ref[:, -self.q:, :]), dim=0).contiguous()
+        wav = torch.cat((audio, audio_ref), dim=0).contiguous()
+        inputs = [sub] * (len(self.chains) - 1) + [wav]
+        res = self._on_streams(lambda i: self.chains[i].forward(inputs[i]))
+        self._state = dict(half=half, emb=[r[0] for r in res], xp=[r[1] for r in res], bands_shape=tuple(bands.shape))
+        return self._state["emb"]
+
+    # ---- the four scalar losses (device tensors) ------------------------------------------------
+    @torch.no_grad()
+    def losses(self) -> Dict[str, torch.Tensor]:
+        lib = load()
+        s = self._state
+        half, emb = s["half"], s["emb"]
+        dev = emb[0][0].device
+        a = [t[:half] for scale in emb for t in scale[1:-1]]
+        b = [t[half:] for scale in emb for t in scale[1:-1]]
+        n = len(a)
+        inter = [None] * (2 * n)
+        inter[0::2], inter[1::2] = a, b
+        ptrs = (ctypes.c_void_p * (2 * n))(*[ptr(t) for t in inter])
+        numel = (ctypes.c_int64 * n)(*[t.numel() for t in a])
+        ws_bytes = lib.eben_fm_sums_workspace(n)
+        ws = torch.empty(max(1, (ws_bytes + 3) // 4), dtype=torch.float32, device=dev)
+        sums = torch.empty(2 * n, dtype=torch.float32, device=dev)
+        check(lib.eben_fm_sums(ptrs, numel, n, ptr(ws), ws_bytes, ptr(sums), _stream()), "fm_sums")
+        inv = 1.0 / (len(emb) * len(emb[-1][1:-1]))
+        s.update(fm_a=a, fm_b=b, fm_sums=sums, fm_inv=inv, fm_numel=numel, fm_ptrs=ptrs)
+        out = {"feature_matching_loss": (sums[0::2] / sums[1::2]).sum() * inv}
+        hinge = torch.empty(3 * len(emb), dtype=torch.float32, device=dev)
+        for i, scale in enumerate(emb):
+            lg = scale[-1]
+            for k, (rows, target) in enumerate(((lg[:half], 1.0), (lg[:half], -1.0), (lg[half:], 1.0))):
+                check(lib.eben_hinge_fwd(ptr(rows), rows.numel(), target, ptr(hinge[3 * i + k:]), _stream()), "hinge_fwd")
+        hv = hinge.reshape(len(emb), 3).sum(dim=0) / len(emb)
+        out["adv_loss_gen"], out["fake_loss"], out["real_loss"] = hv[0], hv[1], hv[2]
+        return out
+
+    # ---- the four backwards as one stacked pass ------------------------------------------------------
+    @torch.no_grad()
+    def backward(self, want_param_grads: bool = True):
+        """Returns (d fm / d bands, d fm / d audio, d adv / d bands, d adv / d audio, param_grads) with
+        param_grads aligned with ``list(disc.parameters())`` (gradient of real_loss + fake_loss) or None."""
+        lib = load()
+        s = self._state
+        half, emb = s["half"], s["emb"]
+        dev = emb[0][0].device
+        n = len(s["fm_a"])
+        one = torch.ones(1, dtype=torch.float32, device=dev)
+        da = [torch.empty_like(t) for t in s["fm_a"]]
+        da_ptrs = (ctypes.c_void_p * n)(*[ptr(t) for t in da])
+        check(lib.eben_fm_bwd(s["fm_ptrs"], da_ptrs, s["fm_numel"], n, ptr(s["fm_sums"]), ptr(one), s["fm_inv"], _stream()), "fm_bwd")
+        # feature-matching gradients per chain, aligned with out_0 .. out_{L-2}
+        fm_per_chain, k = [], 0
+        for scale in emb:
+            cnt = len(scale) - 2
+            fm_per_chain.append(da[k:k + cnt])
+            k += cnt
+        inv_scales = 1.0 / len(emb)
+
+        def run(i):
+            scale = emb[i]
+            lg = scale[-1]
+            seeds = torch.zeros((4 * half,) + tuple(lg.shape[1:]), dtype=torch.float32, device=dev)
+            per = lg[:half].numel()
+            flat = seeds.reshape(-1)
+            for k2, (rows, target) in enumerate(((lg[:half], 1.0), (lg[:half], -1.0), (lg[half:], 1.0))):
+                check(lib.eben_hinge_bwd(ptr(rows), rows.numel(), target, ptr(one), inv_scales, ptr(flat[(k2 + 1) * per:]), _stream()), "hinge_bwd")
+            return self.chains[i].backward(scale, s["xp"][i], fm_per_chain[i], seeds, half, want_param_grads)
+
+        res = self._on_streams(run)
+        # input gradients: the PQMF-band chains share the `bands[:, -q:]` input, the MelGAN chain reads the waveform
+        bshape = s["bands_shape"]
+        gb = torch.zeros((2 * half,) + bshape[1:], dtype=torch.float32, device=dev)
+        acc = res[0][0]
+        for r in res[1:-1]:
+            acc = acc + r[0]
+        gb[:, -self.q:, :] = acc
+        ga = res[-1][0]
+        param_grads = None
+        if want_param_grads:
+            by_param = {}
+            for ch, r in zip(self.chains, res):
+                for lay, (dv, dg, dbias) in zip(ch.layers, r[1]):
+                    v, gain, bias = lay.params()
+                    by_param[id(v)], by_param[id(gain)] = dv, dg
+                    if bias is not None:
+                        by_param[id(bias)] = dbias
+            param_grads = [by_param.get(id(p)) for p in self.disc.parameters()]
+        self._state = None
+        return gb[:half], ga[:half], gb[half:], ga[half:], param_grads
