@@ -23,7 +23,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int DW2_BK = 64;     // time steps per K chunk
-constexpr int DW2_XR = 12;     // X-tile elements a thread can hold in flight
+constexpr int DW2_XR = 12;     // X-tile elements a thread holds in flight (small tiles)
+constexpr int DW2_XR_BIG = 32; // ... for wide X tiles (pointwise / strongly dilated convs: many channels per 128 columns)
+constexpr int DW2_XR_MID = 20; // ... the same on the 96- / 128-row tiles (register budget)
 
 // ---- pre-pass: transpose / mask / pad A into the LDS image ------------------------------------
 template <int FM, int WAVES_M>
@@ -70,7 +72,7 @@ __device__ __forceinline__ float dwa_elem<1>(const float& a, int) { return a; }
 
 // ---- main kernel ---------------------------------------------------------------------------------
 // block = 4 waves as WAVES_M x WAVES_N; wave tile = FM x FN fragments of 32x32; BN = 128 columns always.
-template <int FM, int FN, int WAVES_M>
+template <int FM, int FN, int WAVES_M, int XR>
 __global__ __launch_bounds__(256, 2) void conv_dw2_kernel(const Dw2Args P) {
   constexpr int WAVES_N = 4 / WAVES_M;
   constexpr int FI = FM == 3 ? 4 : FM;
@@ -80,7 +82,6 @@ __global__ __launch_bounds__(256, 2) void conv_dw2_kernel(const Dw2Args P) {
   constexpr int BK = DW2_BK;
   constexpr int ACH = BK * BMI;                 // floats per A chunk
   constexpr int PIECES = ACH / 4 / 256;
-  constexpr int XR = DW2_XR;
   static_assert(BN == 128, "128 columns per block");
   static_assert(PIECES * 256 * 4 == ACH, "A chunk must split into whole LDS-DMA pieces");
   typedef typename DwAFrag<FI>::type afrag_t;
@@ -237,7 +238,7 @@ __global__ __launch_bounds__(256, 2) void conv_dw2_kernel(const Dw2Args P) {
 // ---------------------------------------------------------------------------------------------------
 struct Dw2Plan {
   int ok;
-  int Cg, Mg, G, J, Ng, row_stride, cfg, BM, BMI, nnt, nmt, nct, nchunks, nsplit, XSTR, nch_max;
+  int Cg, Mg, G, J, Ng, row_stride, cfg, BM, BMI, nnt, nmt, nct, nchunks, nsplit, XSTR, nch_max, big_x;
   size_t lds_bytes, ap_floats;
   long long slab_stride;
 };
@@ -269,7 +270,8 @@ static void make_dw2_plan(const Canon& c, Dw2Plan* p) {
   p->nch_max = 127 / c.k + 2;
   if (p->nch_max > p->Cg) p->nch_max = p->Cg;
   const int span = (DW2_BK - 1) * c.s + (c.k - 1) * c.d + 1;
-  if ((long long)p->nch_max * span > DW2_XR * 256) return;   // X tile must fit the register prefetch
+  if ((long long)p->nch_max * span > (p->cfg <= 1 ? DW2_XR_MID : DW2_XR_BIG) * 256) return;   // X tile must fit the register prefetch
+  p->big_x = (long long)p->nch_max * span > DW2_XR * 256;
   p->XSTR = span | 1;
   p->nct = ceil_div(c.Lout, DW2_BK);
   p->nchunks = c.B * p->nct;
@@ -286,10 +288,10 @@ static void make_dw2_plan(const Canon& c, Dw2Plan* p) {
   p->ok = 1;
 }
 
-template <int FM, int FN, int WAVES_M>
+template <int FM, int FN, int WAVES_M, int XR>
 static int launch_dw2(const Dw2Args& a, const Dw2Plan& p, hipStream_t st) {
   static bool attr_set = false;
-  auto kern = conv_dw2_kernel<FM, FN, WAVES_M>;
+  auto kern = conv_dw2_kernel<FM, FN, WAVES_M, XR>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(conv_dw2)");
@@ -331,11 +333,19 @@ int dw2_launch(const Canon& c, Dw2Args a, float* workspace, size_t ws_bytes, hip
   a.S = c.s; a.d = c.d; a.off0 = -c.pl; a.J = c.k; a.Ng = p.Ng; a.row_stride = p.row_stride; a.reflect = c.reflect;
   a.nsplit = p.nsplit; a.nct = p.nct; a.nchunks = p.nchunks; a.nnt = p.nnt; a.nmt = p.nmt; a.XSTR = p.XSTR; a.nch_max = p.nch_max;
   a.slab_stride = p.slab_stride;
+  if (p.big_x) {
+    switch (p.cfg) {
+      case 0: return launch_dw2<2, 2, 2, DW2_XR_MID>(a, p, st);
+      case 1: return launch_dw2<3, 1, 1, DW2_XR_MID>(a, p, st);
+      case 2: return launch_dw2<2, 1, 1, DW2_XR_BIG>(a, p, st);
+      default: return launch_dw2<1, 1, 1, DW2_XR_BIG>(a, p, st);
+    }
+  }
   switch (p.cfg) {
-    case 0: return launch_dw2<2, 2, 2>(a, p, st);
-    case 1: return launch_dw2<3, 1, 1>(a, p, st);
-    case 2: return launch_dw2<2, 1, 1>(a, p, st);
-    default: return launch_dw2<1, 1, 1>(a, p, st);
+    case 0: return launch_dw2<2, 2, 2, DW2_XR>(a, p, st);
+    case 1: return launch_dw2<3, 1, 1, DW2_XR>(a, p, st);
+    case 2: return launch_dw2<2, 1, 1, DW2_XR>(a, p, st);
+    default: return launch_dw2<1, 1, 1, DW2_XR>(a, p, st);
   }
 }
 

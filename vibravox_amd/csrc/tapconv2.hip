@@ -28,7 +28,8 @@ namespace eben {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int T2_XR = 16;  // input-tile elements a thread can hold in flight
+constexpr int T2_XR = 16;      // input-tile elements a thread holds in flight
+constexpr int T2_XR_BIG = 28;  // ... when 16 would leave fewer than two weight chunks per channel chunk (wide strided / transposed convs)
 
 struct Tap2Args {
   const float* x; const float* xmask; const float* wp; const int* tab;
@@ -55,7 +56,7 @@ __device__ __forceinline__ float a_elem(const typename AFrag<FI>::type& a, int i
 template <>
 __device__ __forceinline__ float a_elem<1>(const float& a, int) { return a; }
 
-template <int FM, int NW>
+template <int FM, int NW, int XR>
 __global__ __launch_bounds__(NW * 64, 2) void tap2_kernel(const Tap2Args P) {
   constexpr int NT = NW * 64;
   constexpr int BN = NW * 32;
@@ -63,7 +64,6 @@ __global__ __launch_bounds__(NW * 64, 2) void tap2_kernel(const Tap2Args P) {
   constexpr int FI = FM == 3 ? 4 : FM;      // floats per lane per k-step in the A image
   constexpr int WCH = 16 * 64 * FI;         // floats per weight chunk (16 k-steps)
   constexpr int PIECES = WCH / 4 / NT;      // 16-byte LDS-DMA pieces per thread per chunk
-  constexpr int XR = T2_XR;
   static_assert(PIECES >= 1 && PIECES * NT * 4 == WCH, "weight chunk must split into whole LDS-DMA pieces");
   typedef typename AFrag<FI>::type afrag_t;
 
@@ -285,7 +285,7 @@ struct Tap2Plan {
   int ok;
   int mode, G, Cg, Mg, S, OS, dstep, kstep, nph, J, Lx, Ly, Cx, Cy, off0, nt, ps_pad;
   int FM, NW, BM, BN, FI, WCH;
-  int CI_T, CP, ncc, PLEN, CSTRIDE, nxbuf;
+  int CI_T, CP, ncc, PLEN, CSTRIDE, nxbuf, XR;
   int nmt, ntt, NCH, tab_phase;
   long long w_tile, w_phase, tab_off;
   size_t packed_floats, lds_bytes;
@@ -333,6 +333,17 @@ static void make_plan2(const Canon& c, int dir, Tap2Plan* p) {
     const int pad = round_up(p->Mg, cand[i]);
     if (pad < best_pad) { best_pad = pad; best = cand[i]; }
   }
+  // a grid that cannot give every CU a block (the 125-sample layers of the generator: 32 items x one
+  // position tile) is cut into shorter tiles while that does not add padded rows
+  {
+    const long long cols = (long long)ceil_div(p->nt, 128) * c.B * p->nph * p->G;
+    static const int fill = env_int("EBEN_TAP2_FILL", 1);
+    while (fill && best > 32 && cols * ceil_div(p->Mg, best) < 256) {
+      const int smaller = best == 128 ? 64 : 32;   // 96 -> 32 keeps the row padding of 96
+      if (round_up(p->Mg, smaller) > round_up(p->Mg, best)) break;
+      best = smaller;
+    }
+  }
   static const int force_bm = env_int("EBEN_TAP2_BM", 0);
   if (force_bm == 32 || force_bm == 64 || force_bm == 96 || force_bm == 128) best = force_bm;
   p->BM = best; p->FM = best / 32; p->FI = p->FM == 3 ? 4 : p->FM;
@@ -351,19 +362,28 @@ static void make_plan2(const Canon& c, int dir, Tap2Plan* p) {
   const int wbytes = 2 * p->WCH * 4;
   const int xbudget = lds_budget - wbytes;
   const int Cg2 = round_up(p->Cg, 2);
+  p->XR = T2_XR;
   if ((long long)Cg2 * p->CSTRIDE * 4 <= xbudget) {
     p->CI_T = Cg2; p->ncc = 1; p->nxbuf = 1;
   } else {
-    int cap = (T2_XR * NT) / span;
-    const int cap_lds = xbudget / 2 / (p->CSTRIDE * 4);
-    if (cap > cap_lds) cap = cap_lds;
-    cap &= ~1;
-    if (cap < 2) return;
-    const int nchk = ceil_div(Cg2, cap);
-    p->CI_T = round_up(ceil_div(p->Cg, nchk), 2);
-    p->ncc = ceil_div(p->Cg, p->CI_T);
-    p->nxbuf = 2;
-    if (p->ncc > 1 && Jmin * (p->CI_T / 2) < 32) return;  // tile hand-over needs >= 2 weight chunks per channel chunk
+    bool found = false;
+    for (int xr : {T2_XR, T2_XR_BIG}) {
+      int cap = (xr * NT) / span;
+      const int cap_lds = xbudget / 2 / (p->CSTRIDE * 4);
+      if (cap > cap_lds) cap = cap_lds;
+      cap &= ~1;
+      if (cap < 2) continue;
+      const int nchk = ceil_div(Cg2, cap);
+      p->CI_T = round_up(ceil_div(p->Cg, nchk), 2);
+      p->ncc = ceil_div(p->Cg, p->CI_T);
+      p->nxbuf = 2;
+      p->XR = xr;
+      // tile hand-over needs >= 2 weight chunks per channel chunk
+      if (p->ncc > 1 && Jmin * (p->CI_T / 2) < 32) continue;
+      found = true;
+      break;
+    }
+    if (!found) return;
   }
   p->CP = p->CI_T / 2;
   const int KSmax = p->ncc * p->J * p->CP;
@@ -444,10 +464,10 @@ __global__ __launch_bounds__(256) void pack2_kernel(const Pack2Args P) {
   }
 }
 
-template <int FM, int NW>
+template <int FM, int NW, int XR>
 static int launch2_cfg(const Tap2Args& a, int nblocks, size_t lds, hipStream_t st) {
   static bool attr_set = false;
-  auto kern = tap2_kernel<FM, NW>;
+  auto kern = tap2_kernel<FM, NW, XR>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(tap2)");
@@ -510,11 +530,19 @@ int tap2_launch(const Canon& c, int dir, const TapIO& io, int reflect, hipStream
   a.w_tile = p.w_tile; a.w_phase = p.w_phase;
   const long long nb = (long long)p.ntt * c.B * p.nph * p.nmt * p.G;
   if (nb <= 0 || nb > 0x7fffffffLL) return fail(EBEN_EINVAL, "tap2 grid of %lld blocks", nb);
+  if (p.XR == T2_XR_BIG) {
+    switch (p.FM) {
+      case 1: return launch2_cfg<1, 4, T2_XR_BIG>(a, (int)nb, p.lds_bytes, st);
+      case 2: return launch2_cfg<2, 4, T2_XR_BIG>(a, (int)nb, p.lds_bytes, st);
+      case 3: return launch2_cfg<3, 4, T2_XR_BIG>(a, (int)nb, p.lds_bytes, st);
+      default: return launch2_cfg<4, 4, T2_XR_BIG>(a, (int)nb, p.lds_bytes, st);
+    }
+  }
   switch (p.FM) {
-    case 1: return launch2_cfg<1, 4>(a, (int)nb, p.lds_bytes, st);
-    case 2: return launch2_cfg<2, 4>(a, (int)nb, p.lds_bytes, st);
-    case 3: return launch2_cfg<3, 4>(a, (int)nb, p.lds_bytes, st);
-    default: return launch2_cfg<4, 4>(a, (int)nb, p.lds_bytes, st);
+    case 1: return launch2_cfg<1, 4, T2_XR>(a, (int)nb, p.lds_bytes, st);
+    case 2: return launch2_cfg<2, 4, T2_XR>(a, (int)nb, p.lds_bytes, st);
+    case 3: return launch2_cfg<3, 4, T2_XR>(a, (int)nb, p.lds_bytes, st);
+    default: return launch2_cfg<4, 4, T2_XR>(a, (int)nb, p.lds_bytes, st);
   }
 }
 
