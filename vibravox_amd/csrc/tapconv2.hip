@@ -321,8 +321,9 @@ static void make_plan2(const Canon& c, int dir, Tap2Plan* p) {
   }
   static const int enabled = env_int("EBEN_TAP2", 1);
   static const int min_m = env_int("EBEN_TAP2_MIN_M", 24);
-  static const int min_c = env_int("EBEN_TAP2_MIN_C", 4);
-  if (!enabled || p->Mg < min_m || p->Cg < min_c || p->nph > 64) return;
+  static const int min_c = env_int("EBEN_TAP2_MIN_C", 2);
+  // at least one full weight chunk (16 k-steps of one tap x two channels) of real reduction
+  if (!enabled || p->Mg < min_m || p->Cg < min_c || p->nph > 64 || (long long)p->Cg * p->J < 32) return;
   // smallest J over the phases that have taps at all (phase-scatter phases differ by at most one tap)
   const int Jmin = dir == 0 ? p->J : (c.k / p->kstep > 0 ? c.k / p->kstep : 1);
 

@@ -465,6 +465,12 @@ class StftPlan:
     basis_t: torch.Tensor  # (win, 2*bins, 1) = basis transposed
     cache_fwd: PackedWeights
     cache_bwd: PackedWeights
+    # polyphase form of the analysis conv (R > 1): the reflect-padded signal de-interleaved into R
+    # channels, kernel win/R, stride hop/R -- the same MACs with a channel pair per MFMA k-step, which
+    # is what the second-generation tap-conv needs (a 1-channel conv stays on the first generation)
+    poly: int = 1
+    spec_r: Optional[ConvSpec] = None
+    basis_r: Optional[torch.Tensor] = None
 
 
 class _MRSTFTFn(torch.autograd.Function):
@@ -484,10 +490,21 @@ class _MRSTFTFn(torch.autograd.Function):
         total = None
         saved = []
         for p in plans:
-            d2 = conv_desc(p.spec, 2 * rows, t)
-            pw = pack_weights(p.spec, d2, p.basis, None, p.cache_fwd, False)
-            spec = torch.empty((2 * rows, 2 * p.bins, d2.l_out), dtype=torch.float32, device=x.device)
-            check(lib.eben_conv1d_fwd(ctypes.byref(d2), ptr(sig), ptr(pw.wp_fwd), None, None, ptr(spec), st), "stft_fwd")
+            pad = p.spec.pad_l
+            if p.poly > 1 and (t + 2 * pad) % p.poly == 0:
+                lp = t + 2 * pad
+                sigp = torch.empty((2 * rows, 1, lp), dtype=torch.float32, device=x.device)
+                check(lib.eben_reflect_pad_fwd(ptr(sig), ptr(sigp), 2 * rows, t, pad, pad, st), "reflect_pad_fwd")
+                sig_r = sigp.view(2 * rows, lp // p.poly, p.poly).transpose(1, 2).contiguous()
+                d2 = conv_desc(p.spec_r, 2 * rows, lp // p.poly)
+                pw = pack_weights(p.spec_r, d2, p.basis_r, None, p.cache_fwd, False)
+                spec = torch.empty((2 * rows, 2 * p.bins, d2.l_out), dtype=torch.float32, device=x.device)
+                check(lib.eben_conv1d_fwd(ctypes.byref(d2), ptr(sig_r), ptr(pw.wp_fwd), None, None, ptr(spec), st), "stft_fwd")
+            else:
+                d2 = conv_desc(p.spec, 2 * rows, t)
+                pw = pack_weights(p.spec, d2, p.basis, None, p.cache_fwd, False)
+                spec = torch.empty((2 * rows, 2 * p.bins, d2.l_out), dtype=torch.float32, device=x.device)
+                check(lib.eben_conv1d_fwd(ctypes.byref(d2), ptr(sig), ptr(pw.wp_fwd), None, None, ptr(spec), st), "stft_fwd")
             sums = torch.empty((rows, 3), dtype=torch.float32, device=x.device)
             sx, sy = spec[:rows], spec[rows:]
             check(lib.eben_stft_loss_sums(ptr(sx), ptr(sy), rows, p.bins, p.bins, d2.l_out, eps, ptr(sums), st), "stft_loss_sums")

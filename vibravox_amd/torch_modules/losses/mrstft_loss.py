@@ -67,6 +67,16 @@ class MultiResolutionSTFTLoss(torch.nn.Module):
             basis = windowed_dft_basis(n_fft, win)
             self.register_buffer(f"basis_{i}", basis, persistent=False)
             self.register_buffer(f"basis_t_{i}", basis.squeeze(1).t().contiguous().unsqueeze(-1), persistent=False)
+            r = self._poly_factor(self.hop_sizes[i], win)
+            # w_r[m, c, i] = w[m, i*r + c]
+            self.register_buffer(f"basis_r_{i}", basis.reshape(basis.shape[0], win // r, r).transpose(1, 2).contiguous(), persistent=False)
+
+    @staticmethod
+    def _poly_factor(hop: int, win: int) -> int:
+        for r in (8, 4, 2):
+            if hop % r == 0 and win % r == 0 and (win // 2) % r == 0:
+                return r
+        return 1
 
     def _build_plans(self):
         plans = []
@@ -74,9 +84,12 @@ class MultiResolutionSTFTLoss(torch.nn.Module):
             bins = n_fft // 2 + 1
             spec = ops.ConvSpec(c_in=1, c_out=2 * bins, ksize=win, stride=hop, pad_l=win // 2, pad_r=win // 2, reflect=True)
             spec_t = ops.ConvSpec(c_in=2 * bins, c_out=win, ksize=1)
+            r = self._poly_factor(hop, win)
+            spec_r = ops.ConvSpec(c_in=r, c_out=2 * bins, ksize=win // r, stride=hop // r) if r > 1 else None
             plans.append(ops.StftPlan(n_fft=n_fft, hop=hop, win=win, bins=bins, spec=spec, basis=getattr(self, f"basis_{i}"),
                                       spec_t=spec_t, basis_t=getattr(self, f"basis_t_{i}"),
-                                      cache_fwd=ops.PackedWeights(), cache_bwd=ops.PackedWeights()))
+                                      cache_fwd=ops.PackedWeights(), cache_bwd=ops.PackedWeights(),
+                                      poly=r, spec_r=spec_r, basis_r=getattr(self, f"basis_r_{i}") if r > 1 else None))
         return plans
 
     def forward(self, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
