@@ -148,7 +148,8 @@ EBEN_API int eben_hinge_bwd(const float* x, size_t n, float target, const float*
  * channels [0,bins) and im in [bins_pad, bins_pad+bins); |.| = sqrt(clamp(re^2+im^2, eps)).
  * per row r: out[3r] = sum (|Y|-|X|)^2, out[3r+1] = sum |Y|^2, out[3r+2] = sum |log|X| - log|Y|| */
 EBEN_API int eben_stft_loss_sums(const float* spec_x, const float* spec_y, int rows, int bins, int bins_pad, int frames,
-                        float eps, float* out, void* stream);
+                        float eps, float* partial_ws, size_t ws_bytes, float* out, void* stream);
+EBEN_API size_t eben_stft_loss_sums_workspace(int rows);
 /* dspec_x from d(loss) with loss = mean_rows(sqrt(s0/s1)) + mean(|log X - log Y|); gout device scalar * scale */
 EBEN_API int eben_stft_loss_bwd(const float* spec_x, const float* spec_y, int rows, int bins, int bins_pad, int frames,
                        float eps, const float* sums, const float* gout, float scale, float* dspec_x, void* stream);

@@ -85,7 +85,8 @@ SIGNATURES = {
     "eben_fm_bwd": (c_int, [POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int64), c_int, _P, _P, c_float, _P]),
     "eben_hinge_fwd": (c_int, [_P, c_size_t, c_float, _P, _P]),
     "eben_hinge_bwd": (c_int, [_P, c_size_t, c_float, _P, c_float, _P, _P]),
-    "eben_stft_loss_sums": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_float, _P, _P]),
+    "eben_stft_loss_sums": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_float, _P, c_size_t, _P, _P]),
+    "eben_stft_loss_sums_workspace": (c_size_t, [c_int]),
     "eben_stft_loss_bwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_float, _P, _P, c_float, _P, _P]),
     "eben_overlap_add": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "eben_adam_step": (c_int, [POINTER(EbenAdamTensor), c_int, c_int64, c_float, c_float, c_float, c_float, c_float, c_int, c_float, _P]),

@@ -224,15 +224,17 @@ __global__ __launch_bounds__(64) void l2_final_kernel(const float* __restrict__ 
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float stft_mag(float re, float im, float eps) { return sqrtf(fmaxf(re * re + im * im, eps)); }
 
+// two-level, order-deterministic: STFT_SPLIT blocks per row write partial sums, one wave per row adds them
+constexpr int STFT_SPLIT = 32;
 __global__ __launch_bounds__(256) void stft_sums_kernel(const float* __restrict__ sx, const float* __restrict__ sy, int bins,
-                                                        int bins_pad, int frames, float eps, float* __restrict__ out) {
+                                                        int bins_pad, int frames, float eps, float* __restrict__ partial) {
   __shared__ float red[4];
-  const int r = blockIdx.x;
+  const int r = blockIdx.y;
   const long long base = (long long)r * 2 * bins_pad * frames;
   const long long im_off = (long long)bins_pad * frames;
   const int n = bins * frames;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-  for (int i = threadIdx.x; i < n; i += 256) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += STFT_SPLIT * 256) {
     const float xm = stft_mag(sx[base + i], sx[base + im_off + i], eps);
     const float ym = stft_mag(sy[base + i], sy[base + im_off + i], eps);
     const float d = ym - xm;
@@ -243,7 +245,18 @@ __global__ __launch_bounds__(256) void stft_sums_kernel(const float* __restrict_
   s0 = block_sum_256(s0, red);
   s1 = block_sum_256(s1, red);
   s2 = block_sum_256(s2, red);
-  if (threadIdx.x == 0) { out[3 * r] = s0; out[3 * r + 1] = s1; out[3 * r + 2] = s2; }
+  if (threadIdx.x == 0) {
+    float* o = partial + ((long long)r * STFT_SPLIT + blockIdx.x) * 3;
+    o[0] = s0; o[1] = s1; o[2] = s2;
+  }
+}
+__global__ __launch_bounds__(64) void stft_sums_final_kernel(const float* __restrict__ partial, float* __restrict__ out) {
+  const int r = blockIdx.x, lane = threadIdx.x;
+  for (int k = 0; k < 3; ++k) {
+    float v = lane < STFT_SPLIT ? partial[((long long)r * STFT_SPLIT + lane) * 3 + k] : 0.f;
+    v = wave_sum(v);
+    if (lane == 0) out[3 * r + k] = v;
+  }
 }
 
 __global__ __launch_bounds__(256) void stft_bwd_kernel(const float* __restrict__ sx, const float* __restrict__ sy, int rows, int bins,
@@ -506,11 +519,16 @@ extern "C" int eben_l2norm(const float* x, size_t n, float* out, void* stream) {
   return EBEN_OK;
 }
 
+extern "C" size_t eben_stft_loss_sums_workspace(int rows) { return sizeof(float) * 3 * (size_t)STFT_SPLIT * (rows > 0 ? rows : 0); }
 extern "C" int eben_stft_loss_sums(const float* spec_x, const float* spec_y, int rows, int bins, int bins_pad, int frames,
-                                   float eps, float* out, void* stream) {
-  EBEN_REQUIRE(spec_x && spec_y && out && rows > 0 && bins > 0 && bins_pad >= bins && frames > 0, "bad stft_loss arguments");
-  hipLaunchKernelGGL(stft_sums_kernel, dim3(rows), dim3(256), 0, as_stream(stream), spec_x, spec_y, bins, bins_pad, frames, eps, out);
+                                   float eps, float* partial_ws, size_t ws_bytes, float* out, void* stream) {
+  EBEN_REQUIRE(spec_x && spec_y && out && partial_ws && rows > 0 && bins > 0 && bins_pad >= bins && frames > 0, "bad stft_loss arguments");
+  if (ws_bytes < eben_stft_loss_sums_workspace(rows)) return fail(EBEN_EWORKSPACE, "stft_loss_sums needs %zu workspace bytes", eben_stft_loss_sums_workspace(rows));
+  hipLaunchKernelGGL(stft_sums_kernel, dim3(STFT_SPLIT, rows), dim3(256), 0, as_stream(stream), spec_x, spec_y, bins, bins_pad, frames, eps,
+                     partial_ws);
   EBEN_CHECK_LAUNCH("stft_sums_kernel");
+  hipLaunchKernelGGL(stft_sums_final_kernel, dim3(rows), dim3(64), 0, as_stream(stream), partial_ws, out);
+  EBEN_CHECK_LAUNCH("stft_sums_final_kernel");
   return EBEN_OK;
 }
 extern "C" int eben_stft_loss_bwd(const float* spec_x, const float* spec_y, int rows, int bins, int bins_pad, int frames,

@@ -69,7 +69,7 @@ __global__ __launch_bounds__(NW * 64, 2) void tap2_kernel(const Tap2Args P) {
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Ws = smem;              // 2 x WCH
-  float* Xs = smem + 2 * WCH;    // 1 or 2 input tiles of CI_T * CSTRIDE floats
+  float* Xa = smem + 2 * WCH;    // 1 or 2 input tiles of CI_T * CSTRIDE floats (16-byte aligned rows when S == 1)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -99,6 +99,11 @@ __global__ __launch_bounds__(NW * 64, 2) void tap2_kernel(const Tap2Args P) {
   const int XBUF = P.CI_T * P.CSTRIDE;
   const unsigned span_magic = span > 0 ? (unsigned)((0x100000000ull + (unsigned)span - 1) / (unsigned)span) : 0u;
 
+  // Stride-1 tiles that lie wholly inside the signal are staged with aligned float4 loads: the tile then
+  // starts at the 16-byte boundary below q0 and every canonical slot moves up by xshift = q0 & 3.
+  const bool fast_x = P.S == 1 && (P.Lx & 3) == 0 && J > 0 && q0 >= 0 && q0 + span <= P.Lx;
+  const int xshift = fast_x ? (q0 & 3) : 0;
+  float* Xs = Xa + xshift;
   const float* wsrc = P.wp + (long long)ph * P.w_phase + ((long long)g * P.nmt + mt) * P.w_tile;
   // constant address space: the table is immutable for the kernel's lifetime, which lets the compiler
   // fetch it with s_load (a plain global pointer next to LDS-DMA writes is loaded per lane instead)
@@ -186,8 +191,39 @@ __global__ __launch_bounds__(NW * 64, 2) void tap2_kernel(const Tap2Args P) {
   int written = 0;
   if (nch > 0) {
     issue_w(0);
-    // tile 0: straight to LDS, 8 loads in flight per thread
-    {
+    if (fast_x) {
+      // tile 0, vector path: 4 x float4 in flight per thread, ds_write_b128
+      const int span4 = (xshift + span + 3) >> 2;
+      const int tot4 = P.CI_T * span4;
+      const unsigned s4_magic = (unsigned)((0x100000000ull + (unsigned)span4 - 1) / (unsigned)span4);
+      const float* xp = P.x + xrow0 + (q0 - xshift);
+      const float* mp = P.in_mode ? P.xmask + xrow0 + (q0 - xshift) : xp;
+      for (int base = 0; base < tot4; base += 4 * NT) {
+        f32x4 v[4], mk[4];
+        int sl[4], ok[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int i = base + tid + u * NT;
+          const int c = (int)__umulhi((unsigned)i, s4_magic);
+          const int k4 = i - c * span4;
+          ok[u] = (int)(i < tot4) & (int)(c < P.Cg);
+          const long long o = ok[u] ? (long long)c * P.Lx + 4 * k4 : 0;
+          v[u] = *reinterpret_cast<const f32x4*>(xp + o);
+          mk[u] = *reinterpret_cast<const f32x4*>(mp + o);
+          sl[u] = i < tot4 ? c * P.CSTRIDE + 4 * k4 : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          f32x4 t;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float w = P.in_mode == 0 ? lrelu(v[u][e], P.in_slope) : v[u][e] * dlrelu(mk[u][e], P.in_slope);
+            t[e] = ok[u] ? w : 0.f;
+          }
+          if (sl[u] >= 0) *reinterpret_cast<f32x4*>(Xa + sl[u]) = t;
+        }
+      }
+    } else {
       const float* xp = P.x + xrow0;
       const float* mp = P.in_mode ? P.xmask + xrow0 : xp;
       for (int base = 0; base < xtot; base += 8 * NT) {
@@ -356,6 +392,8 @@ static void make_plan2(const Canon& c, int dir, Tap2Plan* p) {
   const int adstep = p->dstep >= 0 ? p->dstep : -p->dstep;
   const int maxd = ((p->J - 1) * adstep) / p->S + 1;
   p->PLEN = p->BN + maxd + 1;
+  // stride 1: rows 16-byte aligned with room for the float4 staging (tile start rounded down, end rounded up)
+  if (p->S == 1) p->PLEN = round_up(p->BN + maxd + 5, 4);
   p->CSTRIDE = p->S * p->PLEN;
   const int span = (p->BN - 1) * p->S + (p->J - 1) * adstep + 1;
   const int NT = p->NW * 64;
@@ -394,7 +432,7 @@ static void make_plan2(const Canon& c, int dir, Tap2Plan* p) {
   p->w_phase = p->w_tile * p->nmt * p->G;
   p->tab_off = p->w_phase * p->nph;
   p->packed_floats = (size_t)p->tab_off + (size_t)p->tab_phase * p->nph;
-  p->lds_bytes = (size_t)wbytes + (size_t)p->nxbuf * p->CI_T * p->CSTRIDE * 4 + 16;
+  p->lds_bytes = (size_t)wbytes + (size_t)p->nxbuf * p->CI_T * p->CSTRIDE * 4 + 32;   // + spare slot + tile shift
   if (p->lds_bytes > 160 * 1024) return;
   p->ok = 1;
 }

@@ -507,7 +507,9 @@ class _MRSTFTFn(torch.autograd.Function):
                 check(lib.eben_conv1d_fwd(ctypes.byref(d2), ptr(sig), ptr(pw.wp_fwd), None, None, ptr(spec), st), "stft_fwd")
             sums = torch.empty((rows, 3), dtype=torch.float32, device=x.device)
             sx, sy = spec[:rows], spec[rows:]
-            check(lib.eben_stft_loss_sums(ptr(sx), ptr(sy), rows, p.bins, p.bins, d2.l_out, eps, ptr(sums), st), "stft_loss_sums")
+            ws_bytes = lib.eben_stft_loss_sums_workspace(rows)
+            check(lib.eben_stft_loss_sums(ptr(sx), ptr(sy), rows, p.bins, p.bins, d2.l_out, eps, ptr(_empty(ws_bytes, x)), ws_bytes,
+                                          ptr(sums), st), "stft_loss_sums")
             term = torch.sqrt(sums[:, 0] / sums[:, 1]).mean() + sums[:, 2].sum() / float(rows * p.bins * d2.l_out)
             total = term if total is None else total + term
             saved.append((spec, sums, d2.l_out))
