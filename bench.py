@@ -52,12 +52,13 @@ def build_module(device, batch_seed):
 
 def pmc_traffic(batch):
     """HBM bytes per launch of the roofline kernel from the committed rocprofv3 PMC passes
-    (profiles/r01_pmc_melgan_l4_fwd.json; collected at batch 32 by tools/pmc_traffic.sh)."""
+    (profiles/r01_pmc_melgan_l4_fwd.json; collected by tools/pmc_traffic.sh at the batch the step launches)."""
     path = os.path.join(ROOT, "profiles", "r01_pmc_melgan_l4_fwd.json")
-    if batch != 32 or not os.path.exists(path):
+    if not os.path.exists(path):
         return None
     with open(path) as f:
-        return json.load(f).get("traffic_bytes_per_launch")
+        rec = json.load(f)
+    return rec.get("traffic_bytes_per_launch") if rec.get("launch_batch") == batch else None
 
 
 def synthetic_batch(batch, length, seed, device):
@@ -173,7 +174,8 @@ def main():
         for (_, _, k, s, p, _) in [(1, 16, 15, 1, 7, 1), (16, 64, 41, 4, 20, 4), (64, 256, 41, 4, 20, 4), (256, 1024, 41, 4, 20, 4)]:
             lx = (lx + 2 * p - (k - 1) - 1) // s + 1
         l_out = sp.out_len(lx)
-        flops = 2.0 * args.batch * sp.c_out * (sp.c_in // sp.groups) * sp.ksize * l_out
+        launch_batch = timer.batch or args.batch   # the discriminator engine runs enhanced + reference as one batch-2B launch
+        flops = 2.0 * launch_batch * sp.c_out * (sp.c_in // sp.groups) * sp.ksize * l_out
         kms = timer.mean_ms()
         achieved = flops / (kms * 1e-3) / 1e12 if kms else None
         line = {
@@ -184,9 +186,9 @@ def main():
                                    f"batch {args.batch} x {args.length} samples @16kHz per GPU (cut to {cut})",
                        "global_batch": world * args.batch, "samples_per_clip": cut, "parallelism": f"dp{world}",
                        "weights": "random init, torch.manual_seed(42)"},
-            "roofline": {"bound": "mfma", "kernel": "eben::tap2_kernel<4,4> MelGAN L4 fwd (1024->1024 k41 s4 g4)",
+            "roofline": {"bound": "mfma", "kernel": f"eben::tap2_kernel<4,4,16> MelGAN L4 fwd (1024->1024 k41 s4 g4), {launch_batch} items per launch",
                          "achieved": round(achieved, 2) if achieved else None, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4) if achieved else None, "traffic": pmc_traffic(args.batch),
+                         "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4) if achieved else None, "traffic": pmc_traffic(launch_batch),
                          "launch_ms": round(kms, 4) if kms else None, "flops_per_launch": flops,
                          "launches_timed": len(timer.events)},
         }

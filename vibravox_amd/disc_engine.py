@@ -118,8 +118,17 @@ class _Chain:
             d = ops.conv_desc(lay.spec, b, cur.shape[2])
             y = torch.empty((b, lay.spec.c_out, d.l_out), dtype=torch.float32, device=x.device)
             _, _, bias = lay.params()
-            check(lib.eben_conv1d_fwd(ctypes.byref(d), ptr(cur), ptr(lay.packed(0, b, cur.shape[2])), ptr(bias), None, ptr(y), _stream()),
-                  "conv1d_fwd")
+            wp = lay.packed(0, b, cur.shape[2])
+            tm = ops._timer[0]
+            timed = tm is not None and tm.enabled and tm.spec == lay.spec
+            if timed:   # bench.py: HIP events around the roofline kernel, on the stream it is launched on
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            check(lib.eben_conv1d_fwd(ctypes.byref(d), ptr(cur), ptr(wp), ptr(bias), None, ptr(y), _stream()), "conv1d_fwd")
+            if timed:
+                e1.record()
+                tm.events.append((e0, e1))
+                tm.batch = b
             outs.append(y)
             cur = y
         return [x] + outs, xp

@@ -50,7 +50,7 @@ class KernelTimer:
     """HIP-event timing of one layer's forward kernel on the stream it is launched on (bench.py)."""
 
     def __init__(self, spec: "ConvSpec"):
-        self.spec, self.enabled, self.events = spec, False, []
+        self.spec, self.enabled, self.events, self.batch = spec, False, [], None
 
     def mean_ms(self) -> Optional[float]:
         if not self.events:
@@ -173,6 +173,7 @@ class _ConvLayerFn(torch.autograd.Function):
         if timed:
             e1.record()
             tm.events.append((e0, e1))
+            tm.batch = b
         ctx.spec, ctx.d = spec, d
         ctx.wp_bwd, ctx.norm = pw.wp_bwd, pw.norm
         ctx.has_g, ctx.has_bias = g is not None, bias is not None
