@@ -205,6 +205,22 @@ def test_train_step_with_mrstft_against_oracle(hip, golden, literal, engine):
         np.testing.assert_allclose(torch.stack(mod.last_norms).cpu().numpy(), logs["balancing/norms"].numpy(), rtol=5e-3)
 
 
+@pytest.mark.parametrize("batch,length", [(1, 16000), (1, 4321), (3, 1000)])
+def test_generator_inference_variable_length(hip, golden, batch, length):
+    """the evaluation path (eben.py:132-165: cut_to_valid_length, generator forward under
+    no_grad, any clip length, batch 1) against the oracle on the same weights."""
+    gen, osd = build_generator(golden, 2)
+    x = formula_audio(f"infer/{batch}/{length}", batch, length)
+    with torch.no_grad():
+        cut = gen.cut_to_valid_length(x.to(DEV))
+        enh, bands = gen(cut)
+    o_cut = O.cut_to_valid_length(x)
+    assert cut.shape == o_cut.shape and enh.shape == cut.shape
+    o_enh, o_bands = O.generator_forward(osd, o_cut, 2)
+    assert max_abs(enh, o_enh) < 2e-5 and max_abs(bands, o_bands) < 2e-5
+    assert float(((enh.cpu().double() - o_enh.detach().double()) ** 2).mean()) < 1e-10   # north-star bar: MSE < 1e-5
+
+
 def test_full_size_step_properties(hip, golden):
     """BASELINE config 2 shape (batch 32 x 32000 -> 31968): size-independent properties only."""
     mod, _, _ = make_module(golden, use_mrstft=True)

@@ -121,6 +121,48 @@ def test_kernel_generations_cover_the_eben_layers(hip):
     assert seen == {1, 2, 3}
 
 
+@pytest.mark.parametrize("name", ["pqmf_disc_wide", "melgan_l2_like", "thin_pqmf_l1", "dense_k5_chunks"])
+def test_batched_input_gradient_ex(hip, name):
+    """eben_conv1d_bwd_dx_ex: four stacked right-hand sides [fm | adv | fake | real] against activations
+    [enhanced | reference]: dx[b] = (conv^T(g[b]) + (b < S ? res[b] : 0)) * lrelu'(act[map(b)])."""
+    import ctypes
+    import dataclasses
+
+    from vibravox_amd import ops
+    from vibravox_amd._lib import check, load, ptr, stream
+
+    lib = load()
+    kw, _, length, _, _ = CONV_CASES[name]
+    spec = dataclasses.replace(ops.ConvSpec(**kw), in_slope=1.0, out_slope=1.0)
+    S = 2
+    wshape = spec.weight_shape()
+    w = formula_tensor(f"ex/{name}/w", wshape, 1 / math.sqrt(wshape[1] * wshape[2]))
+    l_out = spec.out_len(length)
+    g = formula_tensor(f"ex/{name}/g", (4 * S, spec.c_out, l_out))
+    act = formula_tensor(f"ex/{name}/act", (2 * S, spec.c_in, length))
+    res = formula_tensor(f"ex/{name}/res", (S, spec.c_in, length))
+    # fp64 reference: the adjoint of the (linear) conv applied to every row
+    xr = torch.zeros(4 * S, spec.c_in, length, dtype=torch.float64, requires_grad=True)
+    okw = {k: v for k, v in kw.items() if k not in ("c_in", "c_out", "ksize", "in_slope", "out_slope")}
+    (O.conv_layer(xr, w.double(), None, None, **okw) * g.double()).sum().backward()
+    ref = xr.grad.clone()
+    ref[:S] += res.double()
+    rows = torch.tensor([0, 1, 0, 1, 0, 1, 2, 3])
+    ref = ref * torch.where(act.double()[rows] > 0, 1.0, 0.2)
+
+    dev = torch.device("cuda")
+    d = ops.conv_desc(spec, 4 * S, length)
+    wd = w.to(dev)
+    wp = torch.empty(lib.eben_conv1d_packed_floats(ctypes.byref(d), 1), dtype=torch.float32, device=dev)
+    check(lib.eben_conv1d_pack(ctypes.byref(d), ptr(wd), None, None, ptr(wp), stream()), "pack")
+    dx = torch.empty(4 * S, spec.c_in, length, dtype=torch.float32, device=dev)
+    seg_map = (ctypes.c_int * 4)(0, 0, 0, 1)
+    check(lib.eben_conv1d_bwd_dx_ex(ctypes.byref(d), ptr(g.to(dev)), ptr(wp), ptr(res.to(dev)), S, ptr(act.to(dev)), 0.2, S, seg_map,
+                                    ptr(dx), stream()), "bwd_dx_ex")
+    torch.cuda.synchronize()
+    assert rel_err(dx, ref) < 3e-5
+
+
 def test_conv_bad_descriptor_raises(hip):
     from vibravox_amd import _lib, ops
 

@@ -59,6 +59,47 @@ def test_descriptor_validation_without_gpu(lib):
     assert lib.eben_conv1d_bwd_dx_workspace(ctypes.byref(refl)) == 4 * 2 * 32 * 118
 
 
+def test_kernel_family_selection_without_gpu(lib):
+    """Host-side planning of the three tap-conv families at the BASELINE config-2 shapes (no launch)."""
+    from vibravox_amd._lib import EbenConv1dDesc
+
+    def gen(desc, which):
+        return lib.eben_conv1d_kernel_generation(ctypes.byref(desc), which)
+
+    melgan_l4 = EbenConv1dDesc(64, 1024, 1024, 500, 125, 41, 4, 1, 4, 20, 20, 0, 0, 1.0, 0.2)
+    assert gen(melgan_l4, 0) == 2 and gen(melgan_l4, 1) == 2            # second-generation MFMA kernel
+    pqmf_l1 = EbenConv1dDesc(64, 24, 48, 8000, 4000, 7, 2, 1, 4, 3, 3, 0, 0, 1.0, 0.2)
+    assert gen(pqmf_l1, 0) == 3 and gen(pqmf_l1, 1) == 3                # direct kernel: 12 / 6 rows per group
+    logits = EbenConv1dDesc(64, 1024, 1, 125, 125, 3, 1, 1, 1, 1, 1, 0, 0, 1.0, 1.0)
+    assert gen(logits, 0) == 1                                           # single-output-channel reduction
+    ru = EbenConv1dDesc(32, 64, 64, 4000, 4000, 3, 1, 9, 1, 9, 9, 1, 0, 0.01, 1.0)
+    assert gen(ru, 0) == 2 and gen(ru, 1) == 2
+    nslab, rs = ctypes.c_int(0), ctypes.c_int(0)
+    assert lib.eben_conv1d_bwd_dw_workspace(ctypes.byref(melgan_l4), ctypes.byref(nslab), ctypes.byref(rs)) > 4 * 1024 * (256 * 41 + 1)
+    assert rs.value == 256 * 41 + 1
+    assert lib.eben_stft_loss_sums_workspace(32) == 4 * 3 * 32 * 32
+
+
+def test_discriminator_engine_layout():
+    """disc_engine.py sees the reference's module tree: 3 x (ReflectionPad1d(1) + 8 convs), 1 x (pad 7 + 7 convs),
+    and parameter order == discriminator.parameters() order (what inject_grads relies on)."""
+    from vibravox_amd.disc_engine import DiscriminatorEngine
+    from vibravox_amd.torch_modules.dnn.eben_discriminator import DiscriminatorEBENMultiScales
+
+    disc = DiscriminatorEBENMultiScales(q=4, min_channels=24)
+    assert DiscriminatorEngine.supports(disc) and not DiscriminatorEngine.supports(torch.nn.Linear(2, 2))
+    eng = DiscriminatorEngine(disc)
+    assert [len(c.layers) for c in eng.chains] == [8, 8, 8, 7] and [c.pad for c in eng.chains] == [1, 1, 1, 7]
+    seen = []
+    for ch in eng.chains:
+        for lay in ch.layers:
+            v, g, bias = lay.params()
+            assert lay.spec_lin.out_slope == 1.0 and lay.spec_lin.in_slope == 1.0 and lay.spec_lin.c_out == lay.spec.c_out
+            seen += [id(bias), id(g), id(v)]
+    assert seen == [id(p) for p in disc.parameters()]
+    assert [lay.spec.out_slope for lay in eng.chains[0].layers] == [0.2] * 7 + [1.0]
+
+
 def test_state_dict_contract_and_same_seed_init(golden):
     from vibravox_amd.torch_modules.dnn.eben_discriminator import DiscriminatorEBENMultiScales
     from vibravox_amd.torch_modules.dnn.eben_generator import EBENGenerator
