@@ -178,7 +178,9 @@ class EBENLightningModule(BaseSELightningModule):
         seed = None
         for s, lam in zip(seeds, lambdas):
             seed = s * lam if seed is None else seed + s * lam
-        torch.autograd.backward(bands, seed, inputs=g_params)
+        with ops.weight_grads_on_side_stream() as side:   # dX chain on this stream, dW work beside it
+            torch.autograd.backward(bands, seed, inputs=g_params)
+        side.join()
         self._step(generator_optimizer, self._sync_grads(generator_optimizer))
         generator_optimizer.zero_grad()
 

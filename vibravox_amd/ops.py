@@ -6,6 +6,7 @@ Nothing here runs on CPU tensors: ``_lib.ptr`` raises for them.
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence, Tuple
@@ -44,6 +45,39 @@ class weight_grads_disabled:
 
     def __exit__(self, *exc):
         _skip_weight_grads[0] = self.prev
+
+
+# Weight-gradient work on a side HIP stream.  A layer's backward is a serial chain of launches: input
+# gradient (needed by the next layer) and, independent of it, the weight-gradient GEMM + slab reduction +
+# weight-norm chain rule.  Inside `weight_grads_on_side_stream()` the second group is issued on a side
+# stream, so the input-gradient chain of the whole network is not held up by it (generator backward:
+# ~2.9 ms of dX launches instead of ~8.6 ms of everything in series).  The caller must `join()` before
+# anything on the main stream reads the parameter gradients (the optimiser step); only valid while
+# `.grad` is None for the parameters involved (AccumulateGrad then just stores the tensor).
+_side = {"enabled": False, "stream": None}
+
+
+class weight_grads_on_side_stream:
+    def __enter__(self):
+        self.prev = _side["enabled"]
+        _side["enabled"] = True
+        return self
+
+    def __exit__(self, *exc):
+        _side["enabled"] = self.prev
+
+    @staticmethod
+    def join():
+        st = _side["stream"]
+        if st is not None:
+            torch.cuda.current_stream(st.device).wait_stream(st)
+
+
+def _side_stream(device) -> "torch.cuda.Stream":
+    st = _side["stream"]
+    if st is None or st.device != device:
+        st = _side["stream"] = torch.cuda.Stream(device=device)
+    return st
 
 
 class KernelTimer:
@@ -196,19 +230,32 @@ class _ConvLayerFn(torch.autograd.Function):
                   "conv1d_bwd_dx")
         want_w = ctx.needs_input_grad[1] or (ctx.has_g and ctx.needs_input_grad[2]) or (ctx.has_bias and ctx.needs_input_grad[3])
         if want_w and not _skip_weight_grads[0]:
-            nslab, row_stride = ctypes.c_int(0), ctypes.c_int(0)
-            ws_bytes = lib.eben_conv1d_bwd_dw_workspace(ctypes.byref(d), ctypes.byref(nslab), ctypes.byref(row_stride))
-            slabs = _empty(ws_bytes, x)
-            check(lib.eben_conv1d_bwd_dw(ctypes.byref(d), ptr(dy), ptr(y), ptr(x), 1 if ctx.has_bias else 0, ptr(slabs), ws_bytes, st),
-                  "conv1d_bwd_dw")
-            rows = v.shape[0]
-            cols = v.numel() // rows
-            dv = torch.empty_like(v)
-            dg = torch.empty_like(g) if ctx.has_g else None
-            dbias = torch.empty(rows, dtype=torch.float32, device=x.device) if ctx.has_bias else None
-            check(lib.eben_wn_bwd(ptr(slabs), nslab.value, rows * row_stride.value, rows, cols, row_stride.value,
-                                  ptr(g) if ctx.has_g else None, ptr(v), ptr(ctx.norm) if ctx.has_g else None,
-                                  ptr(dg), ptr(dv), ptr(dbias), st), "wn_bwd")
+            use_side = _side["enabled"] and v.grad is None and (g is None or g.grad is None)
+            if use_side:
+                main = torch.cuda.current_stream(x.device)
+                side = _side_stream(x.device)
+                side.wait_stream(main)   # dy (and everything saved by the forward) is complete on the main stream
+                for t in (dy, x, y, v, g, ctx.norm):
+                    if t is not None:
+                        t.record_stream(side)
+                stream_ctx = torch.cuda.stream(side)
+            else:
+                stream_ctx = contextlib.nullcontext()
+            with stream_ctx:
+                sw = stream()
+                nslab, row_stride = ctypes.c_int(0), ctypes.c_int(0)
+                ws_bytes = lib.eben_conv1d_bwd_dw_workspace(ctypes.byref(d), ctypes.byref(nslab), ctypes.byref(row_stride))
+                slabs = _empty(ws_bytes, x)
+                check(lib.eben_conv1d_bwd_dw(ctypes.byref(d), ptr(dy), ptr(y), ptr(x), 1 if ctx.has_bias else 0, ptr(slabs), ws_bytes, sw),
+                      "conv1d_bwd_dw")
+                rows = v.shape[0]
+                cols = v.numel() // rows
+                dv = torch.empty_like(v)
+                dg = torch.empty_like(g) if ctx.has_g else None
+                dbias = torch.empty(rows, dtype=torch.float32, device=x.device) if ctx.has_bias else None
+                check(lib.eben_wn_bwd(ptr(slabs), nslab.value, rows * row_stride.value, rows, cols, row_stride.value,
+                                      ptr(g) if ctx.has_g else None, ptr(v), ptr(ctx.norm) if ctx.has_g else None,
+                                      ptr(dg), ptr(dv), ptr(dbias), sw), "wn_bwd")
         return dx, dv, dg, dbias, None, None
 
 
