@@ -157,8 +157,9 @@ def test_batched_input_gradient_ex(hip, name):
     check(lib.eben_conv1d_pack(ctypes.byref(d), ptr(wd), None, None, ptr(wp), stream()), "pack")
     dx = torch.empty(4 * S, spec.c_in, length, dtype=torch.float32, device=dev)
     seg_map = (ctypes.c_int * 4)(0, 0, 0, 1)
-    check(lib.eben_conv1d_bwd_dx_ex(ctypes.byref(d), ptr(g.to(dev)), ptr(wp), ptr(res.to(dev)), S, ptr(act.to(dev)), 0.2, S, seg_map,
-                                    ptr(dx), stream()), "bwd_dx_ex")
+    gd, rd, ad = g.to(dev), res.to(dev), act.to(dev)   # keep them alive: ptr() of a temporary dangles once it is freed
+    check(lib.eben_conv1d_bwd_dx_ex(ctypes.byref(d), ptr(gd), ptr(wp), ptr(rd), S, ptr(ad), 0.2, S, seg_map, ptr(dx), stream()),
+          "bwd_dx_ex")
     torch.cuda.synchronize()
     assert rel_err(dx, ref) < 3e-5
 

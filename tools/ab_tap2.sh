@@ -1,3 +1,2 @@
-python -m pytest tests/test_gpu_ops.py -m gpu -x -q 2>&1 | tail -2
-python tools/layer_bench.py --filter discriminator > gpurun_out/s20_layers.log 2>&1; grep -E "melgan|pqmf_discriminators.0|TOTAL" gpurun_out/s20_layers.log | cut -c1-40,105-160
-for i in 1 2; do python bench.py --steps 20 --warmup 3 --no-cpu-baseline 2>&1 | grep "GPU:"; done
+python -m pytest tests/test_gpu_ops.py -m gpu -q -k "batched_input" 2>&1 | tail -1
+python -m pytest tests -m gpu -x -q > gpurun_out/s25_tests.log 2>&1; grep -E "passed|failed" gpurun_out/s25_tests.log | head -3; grep -E "^E  |^FAILED" gpurun_out/s25_tests.log | head -10

@@ -40,7 +40,7 @@ struct Tap2Args {
   int reflect, in_mode, accumulate;
   int res_rows, em_seg, em_map[4];
   float in_slope, out_slope, res_slope, emask_slope;
-  int CI_T, CP, ncc, PLEN, CSTRIDE;
+  int CI_T, CP, ncc, PLEN, CSTRIDE, nxb;   // nxb: input-tile buffers the channel chunks rotate through (2 or 3)
   unsigned s_magic;
   int ntt, nmt, tab_phase;
   long long w_tile, w_phase;
@@ -160,9 +160,10 @@ __global__ __launch_bounds__(NW * 64, 2) void tap2_kernel(const Tap2Args P) {
       if (P.in_mode != 0) mreg[u] = mp[o];
     }
   };
-  const int dead_slot = 2 * XBUF;   // one spare float behind the tiles: lanes without an element store there
+  const int dead_slot = P.nxb * XBUF;   // one spare float behind the tiles: lanes without an element store there
   auto store_x = [&](int cc) {
-    float* dst = Xs + (cc & 1) * XBUF;
+    const int bsel = cc % P.nxb;
+    float* dst = Xs + bsel * XBUF;
     float t[XR];
     if (P.in_mode == 0) {
 #pragma unroll
@@ -173,7 +174,7 @@ __global__ __launch_bounds__(NW * 64, 2) void tap2_kernel(const Tap2Args P) {
     }
 #pragma unroll
     for (int u = 0; u < XR; ++u) {
-      const int sl = xg[u] >= 0 ? x_slot(xg[u] >> 16, xg[u] & 0xffff) : dead_slot - (cc & 1) * XBUF;
+      const int sl = xg[u] >= 0 ? x_slot(xg[u] >> 16, xg[u] & 0xffff) : dead_slot - bsel * XBUF;
       dst[sl] = ((okmask >> u) & 1u) ? t[u] : 0.f;
     }
   };
@@ -405,22 +406,28 @@ static void make_plan2(const Canon& c, int dir, Tap2Plan* p) {
   if ((long long)Cg2 * p->CSTRIDE * 4 <= xbudget) {
     p->CI_T = Cg2; p->ncc = 1; p->nxbuf = 1;
   } else {
+    // Tile hand-over: the tile first needed by weight chunk ch+1 is written at the end of chunk ch into the
+    // buffer of the tile `nxbuf` channel chunks back, which must be fully consumed before chunk ch starts:
+    // >= 32 k-steps per channel chunk with two buffers, >= 16 with three (pointwise convs over many
+    // channels: the STFT-backward GEMMs, the 128-channel residual units).
     bool found = false;
-    for (int xr : {T2_XR, T2_XR_BIG}) {
-      int cap = (xr * NT) / span;
-      const int cap_lds = xbudget / 2 / (p->CSTRIDE * 4);
-      if (cap > cap_lds) cap = cap_lds;
-      cap &= ~1;
-      if (cap < 2) continue;
-      const int nchk = ceil_div(Cg2, cap);
-      p->CI_T = round_up(ceil_div(p->Cg, nchk), 2);
-      p->ncc = ceil_div(p->Cg, p->CI_T);
-      p->nxbuf = 2;
-      p->XR = xr;
-      // tile hand-over needs >= 2 weight chunks per channel chunk
-      if (p->ncc > 1 && Jmin * (p->CI_T / 2) < 32) continue;
-      found = true;
-      break;
+    for (int nbuf = 2; nbuf <= 3 && !found; ++nbuf) {
+      for (int xr : {T2_XR, T2_XR_BIG}) {
+        int cap = (xr * NT) / span;
+        // three buffers of a useful size do not fit the two-blocks-per-CU budget: that variant runs one block per CU
+        const int cap_lds = (nbuf == 2 ? xbudget : 104 * 1024 - wbytes) / nbuf / (p->CSTRIDE * 4);
+        if (cap > cap_lds) cap = cap_lds;
+        cap &= ~1;
+        if (cap < 2) continue;
+        const int nchk = ceil_div(Cg2, cap);
+        p->CI_T = round_up(ceil_div(p->Cg, nchk), 2);
+        p->ncc = ceil_div(p->Cg, p->CI_T);
+        p->nxbuf = nbuf;
+        p->XR = xr;
+        if (p->ncc > 1 && Jmin * (p->CI_T / 2) < (nbuf == 2 ? 32 : 16)) continue;
+        found = true;
+        break;
+      }
     }
     if (!found) return;
   }
@@ -496,7 +503,7 @@ __global__ __launch_bounds__(256) void pack2_kernel(const Pack2Args P) {
         const int j = rem / P.CP, cp = rem - j * P.CP;
         const int rel = q.off0 + j * P.dstep - q.minoff;
         const int dd = rel / P.S, pp = rel - dd * P.S;
-        o = (P.nxbuf > 1 ? (cc & 1) * P.CI_T * P.CSTRIDE : 0) + 2 * cp * P.CSTRIDE + pp * P.PLEN + dd;
+        o = (P.nxbuf > 1 ? (cc % P.nxbuf) * P.CI_T * P.CSTRIDE : 0) + 2 * cp * P.CSTRIDE + pp * P.PLEN + dd;
       }
       reinterpret_cast<int*>(P.wp)[i] = o;
     }
@@ -563,7 +570,7 @@ int tap2_launch(const Canon& c, int dir, const TapIO& io, int reflect, hipStream
   a.res_rows = io.res_rows; a.em_seg = io.em_seg;
   for (int i = 0; i < 4; ++i) a.em_map[i] = io.em_map[i];
   a.in_slope = io.in_slope; a.out_slope = io.out_slope; a.res_slope = io.res_slope; a.emask_slope = io.emask_slope;
-  a.CI_T = p.CI_T; a.CP = p.CP; a.ncc = p.ncc; a.PLEN = p.PLEN; a.CSTRIDE = p.CSTRIDE;
+  a.CI_T = p.CI_T; a.CP = p.CP; a.ncc = p.ncc; a.PLEN = p.PLEN; a.CSTRIDE = p.CSTRIDE; a.nxb = p.nxbuf < 2 ? 2 : p.nxbuf;
   a.s_magic = p.S > 1 ? (unsigned)((0x100000000ull + p.S - 1) / p.S) : 0u;
   a.ntt = p.ntt; a.nmt = p.nmt; a.tab_phase = p.tab_phase;
   a.w_tile = p.w_tile; a.w_phase = p.w_phase;
