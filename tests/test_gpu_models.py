@@ -221,6 +221,31 @@ def test_generator_inference_variable_length(hip, golden, batch, length):
     assert float(((enh.cpu().double() - o_enh.detach().double()) ** 2).mean()) < 1e-10   # north-star bar: MSE < 1e-5
 
 
+def test_eval_step_logs_reference_losses(hip, golden):
+    """eben.py:132-165: validation / test step -- outputs and the logged atomic losses of both networks
+    equal the oracle's on the same weights; no gradient state is touched."""
+    mod, g_sd, d_sd = make_module(golden, use_mrstft=False)
+    bc, air = formula_audio("eval/bc", 2, 8200), formula_audio("eval/air", 2, 8200)
+    out = mod.validation_step({"audio_body_conducted": bc.to(DEV), "audio_airborne": air.to(DEV)}, 0)
+    assert set(out) == {"corrupted", "enhanced", "reference"} and not out["enhanced"].requires_grad
+    assert all(p.grad is None for p in mod.parameters())
+    x = O.cut_to_valid_length(bc)
+    ref = O.cut_to_valid_length(air)
+    o_enh, o_bands = O.generator_forward(g_sd, x, 2)
+    assert max_abs(out["enhanced"], o_enh) < 2e-5
+    o_ref_bands = O.pqmf_analysis(ref, g_sd["pqmf.analysis_weights"], bands=4)
+    e_emb = O.discriminator_forward(d_sd, o_bands, o_enh, 4)
+    r_emb = O.discriminator_forward(d_sd, o_ref_bands, ref, 4)
+    want = {"validation/generator/feature_matching_loss": O.feature_loss(e_emb, r_emb),
+            "validation/generator/adv_loss_gen": O.hinge_loss(e_emb, 1),
+            "validation/discriminator/real_loss": O.hinge_loss(r_emb, 1),
+            "validation/discriminator/fake_loss": O.hinge_loss(e_emb, -1)}
+    for k, v in want.items():
+        np.testing.assert_allclose(mod.logged[k].item(), float(v), rtol=5e-4, err_msg=k)
+    only_bc = mod.test_step({"audio_body_conducted": bc.to(DEV)}, 0)
+    assert set(only_bc) == {"corrupted", "enhanced"}
+
+
 def test_full_size_step_properties(hip, golden):
     """BASELINE config 2 shape (batch 32 x 32000 -> 31968): size-independent properties only."""
     mod, _, _ = make_module(golden, use_mrstft=True)

@@ -124,6 +124,29 @@ def test_state_dict_contract_and_same_seed_init(golden):
         assert gen.cut_to_valid_length(torch.zeros(1, 1, int(l_in))).shape[2] == int(l_out)
 
 
+def test_generator_checkpoint_round_trip_offline(tmp_path):
+    """the PyTorchModelHubMixin surface of the reference generator
+    (eben_generator.py:72-85, scripts/upload_eben_to_hub.py) -- save_pretrained / from_pretrained on a local
+    directory: config.json carries {m, n, p}, the safetensors file the reference's state_dict keys."""
+    import json
+
+    from vibravox_amd.torch_modules.dnn.eben_generator import EBENGenerator
+
+    torch.manual_seed(7)
+    gen = EBENGenerator(m=4, n=32, p=1)
+    if not hasattr(gen, "save_pretrained"):
+        pytest.skip("huggingface_hub not installed")
+    gen.save_pretrained(str(tmp_path))
+    cfg = json.load(open(tmp_path / "config.json"))
+    assert {k: cfg[k] for k in ("m", "n", "p")} == {"m": 4, "n": 32, "p": 1}
+    assert (tmp_path / "model.safetensors").exists()
+    back = EBENGenerator.from_pretrained(str(tmp_path))
+    a, b = gen.state_dict(), back.state_dict()
+    assert list(a) == list(b) and back.first_conv.weight.shape == (32, 1, 3)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+
+
 def test_reference_constructor_asserts():
     from vibravox_amd.lightning_modules.eben import EBENLightningModule
     from vibravox_amd.torch_modules.dnn.eben_discriminator import DiscriminatorEBEN

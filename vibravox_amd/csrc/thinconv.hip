@@ -173,7 +173,10 @@ static void make_thin_plan(const Canon& c, int dir, ThinPlan* p) {
   // deeper reductions belong on the MFMA kernels (MelGAN layer-2 input gradient, 704 taps x channels
   // for 16 rows: 0.87 ms here against 0.50 ms on 16-row MFMA tiles)
   static const int max_k = thin_env("EBEN_THIN_MAX_K", 256);
-  if (!enabled || p->Mg < 1 || p->Mg > max_m || (long long)p->Cg * p->J > max_k || p->nph > 64) return;
+  // many rows are fine when the reduction is a handful of taps (input gradient of the logits layers:
+  // 768 / 1024 rows from ONE channel x 3 taps -- an outer product, bound by the output write)
+  const bool tiny_k = (long long)p->Cg * p->J <= 16;
+  if (!enabled || p->Mg < 1 || (p->Mg > max_m && !tiny_k) || (long long)p->Cg * p->J > max_k || p->nph > 64) return;
   p->MT = p->Mg == 1 ? 1 : p->Mg <= 4 ? 4 : p->Mg <= 8 ? 8 : 16;
   p->nmt = ceil_div(p->Mg, p->MT);
   const int adstep = p->dstep >= 0 ? p->dstep : -p->dstep;

@@ -291,6 +291,34 @@ class EBENLightningModule(BaseSELightningModule):
 
         return {"corrupted": corrupted_speech, "enhanced": enhanced_speech, "reference": reference_speech}
 
+    # -- evaluation -----------------------------------------------------
+    def common_eval_step(self, batch: Dict[str, torch.Tensor], batch_idx: int, stage: str, dataloader_idx: int = 0):
+        """eben.py:132-165: generator forward on the cut clip; with a reference in the batch also the atomic
+        losses of both networks, logged as ``{stage}/{network}/{loss}[/{dataloader}]``.  (The reference's
+        metric / audio logging of ``base_se.py:67-130`` is torchmetrics / torchaudio code outside this path.)"""
+        with torch.no_grad():
+            corrupted_speech = self.generator.cut_to_valid_length(batch["audio_body_conducted"])
+            enhanced_speech, decomposed_enhanced_speech = self.generator(corrupted_speech)
+            outputs = {"corrupted": corrupted_speech, "enhanced": enhanced_speech}
+            if "audio_airborne" in batch:
+                reference_speech = self.generator.cut_to_valid_length(batch["audio_airborne"])
+                decomposed_reference_speech = self.generator.pqmf.forward(reference_speech, "analysis")
+                outputs["reference"] = reference_speech
+                names = getattr(self, "dataloader_names", None)
+                dl_name = f"/{names[dataloader_idx]}" if names else ""
+                for net_type in ["generator", "discriminator"]:
+                    atomic_losses = self.compute_atomic_losses(net_type, enhanced_speech, reference_speech,
+                                                               decomposed_enhanced_speech, decomposed_reference_speech)
+                    for key, value in atomic_losses.items():
+                        self.log(f"{stage}/{net_type}/{key}{dl_name}", value, sync_dist=True, add_dataloader_idx=False)
+        return outputs
+
+    def validation_step(self, batch, batch_idx: int = 0, dataloader_idx: int = 0):
+        return self.common_eval_step(batch, batch_idx, "validation", dataloader_idx)
+
+    def test_step(self, batch, batch_idx: int = 0, dataloader_idx: int = 0):
+        return self.common_eval_step(batch, batch_idx, "test", dataloader_idx)
+
     def compute_atomic_losses(self, network, enhanced_speech, reference_speech, decomposed_enhanced_speech,
                               decomposed_reference_speech) -> Dict[str, torch.Tensor]:
         """eben.py:184-220."""
