@@ -173,6 +173,21 @@ typedef struct EbenAdamTensor {
 EBEN_API int eben_adam_step(const EbenAdamTensor* table, int ntensors, int64_t max_numel, float lr, float beta1, float beta2,
                    float eps, float weight_decay, int step, float grad_scale, void* stream);
 
+/* ---- noisy-BWE batch assembly (vibravox/lightning_datamodules/noisybwe.py:219-291; utils.py:7-81,195-254) ----
+ * per item:  body_conducted[i, 0, t] = speech[u] + noise[noise_start + u],  airborne[i, 0, t] = airborne_clip[u],
+ * u = t + shift, zero outside [0, length).  shift >= 0: crop offset (set_audio_duration); shift < 0: left zero run
+ * of pad_audio; noise / airborne_clip may be NULL (real noisy data: padding only).  `items` is a HOST array (device
+ * pointers inside), passed to the kernel by value; outputs are (nitems, 1, samples). */
+typedef struct EbenCollateItem {
+  const float* speech;
+  const float* airborne;
+  const float* noise;
+  int64_t length;       /* samples of speech (== airborne) */
+  int64_t noise_start;  /* first noise sample mixed in */
+  int64_t shift;
+} EbenCollateItem;
+EBEN_API int eben_noisy_collate(const EbenCollateItem* items, int nitems, int samples, float* body_conducted, float* airborne, void* stream);
+
 /* ---- misc ------------------------------------------------------------------------------- */
 /* out[0] = sqrt(sum x^2) (torch.norm at eben.py:226); `out` must hold 257 floats (scratch) */
 EBEN_API int eben_l2norm(const float* x, size_t n, float* out, void* stream);

@@ -51,6 +51,11 @@ class EbenAdamTensor(ctypes.Structure):
     ]
 
 
+class EbenCollateItem(ctypes.Structure):
+    _fields_ = [("speech", c_void_p), ("airborne", c_void_p), ("noise", c_void_p), ("length", c_int64), ("noise_start", c_int64),
+                ("shift", c_int64)]
+
+
 _P = c_void_p
 _D = POINTER(EbenConv1dDesc)
 
@@ -90,6 +95,7 @@ SIGNATURES = {
     "eben_stft_loss_bwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_float, _P, _P, c_float, _P, _P]),
     "eben_overlap_add": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "eben_adam_step": (c_int, [POINTER(EbenAdamTensor), c_int, c_int64, c_float, c_float, c_float, c_float, c_float, c_int, c_float, _P]),
+    "eben_noisy_collate": (c_int, [POINTER(EbenCollateItem), c_int, c_int, _P, _P, _P]),
     "eben_l2norm": (c_int, [_P, c_size_t, _P, _P]),
 }
 

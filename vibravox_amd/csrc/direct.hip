@@ -551,6 +551,53 @@ extern "C" int eben_overlap_add(const float* frames_buf, float* x, int batch, in
   return EBEN_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Noisy-BWE batch assembly on the device (vibravox/lightning_datamodules/noisybwe.py:219-291 with
+// vibravox/utils.py:7-81,195-254): per item  bc[t] = speech[u] + noise[noise_start + u],  air[t] = airborne[u]
+// with u = t + shift, zero outside [0, length) -- `shift` >= 0 is the crop offset of set_audio_duration,
+// `shift` < 0 the (quirky) left zero run of pad_audio, 0 with `length` < T plain right padding.
+// One gather pass, the ragged clips never leave HBM.  Items travel by value (48 per launch).
+// ---------------------------------------------------------------------------------------------
+constexpr int COLLATE_CHUNK = 48;
+struct CollateTable { EbenCollateItem t[COLLATE_CHUNK]; };
+
+__global__ __launch_bounds__(256) void noisy_collate_kernel(const CollateTable T, int samples, float* __restrict__ bc, float* __restrict__ air) {
+  const EbenCollateItem it = T.t[blockIdx.y];
+  float* obc = bc + (long long)blockIdx.y * samples;
+  float* oair = air ? air + (long long)blockIdx.y * samples : nullptr;
+  for (int t = blockIdx.x * 256 + threadIdx.x; t < samples; t += gridDim.x * 256) {
+    const long long u = (long long)t + it.shift;
+    const bool in = u >= 0 && u < it.length;
+    float v = 0.f, a = 0.f;
+    if (in) {
+      v = it.speech[u];
+      if (it.noise) v += it.noise[it.noise_start + u];
+      if (it.airborne) a = it.airborne[u];
+    }
+    obc[t] = v;
+    if (oair) oair[t] = a;
+  }
+}
+
+extern "C" int eben_noisy_collate(const EbenCollateItem* items, int nitems, int samples, float* body_conducted, float* airborne, void* stream) {
+  EBEN_REQUIRE(items && nitems > 0 && samples > 0 && body_conducted, "bad collate arguments");
+  for (int p0 = 0; p0 < nitems; p0 += COLLATE_CHUNK) {
+    const int cnt = nitems - p0 < COLLATE_CHUNK ? nitems - p0 : COLLATE_CHUNK;
+    CollateTable T;
+    for (int i = 0; i < cnt; ++i) {
+      T.t[i] = items[p0 + i];
+      if (!T.t[i].speech || T.t[i].length < 0 || T.t[i].noise_start < 0) return fail(EBEN_EINVAL, "collate item %d is malformed", p0 + i);
+      if (airborne && !T.t[i].airborne) return fail(EBEN_EINVAL, "collate item %d has no airborne clip", p0 + i);
+    }
+    int gx = (samples + 255) / 256;
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(noisy_collate_kernel, dim3(gx, cnt), dim3(256), 0, as_stream(stream), T, samples,
+                       body_conducted + (long long)p0 * samples, airborne ? airborne + (long long)p0 * samples : nullptr);
+    EBEN_CHECK_LAUNCH("noisy_collate_kernel");
+  }
+  return EBEN_OK;
+}
+
 extern "C" int eben_adam_step(const EbenAdamTensor* table, int ntensors, int64_t max_numel, float lr, float beta1, float beta2,
                               float eps, float weight_decay, int step, float grad_scale, void* stream) {
   EBEN_REQUIRE(table && ntensors > 0 && step > 0, "bad adam arguments");
