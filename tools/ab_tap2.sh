@@ -1,2 +1,3 @@
-python -m pytest tests -m gpu -x -q > gpurun_out/s27_tests.log 2>&1; grep -E "passed|failed" gpurun_out/s27_tests.log | head -3; grep -E "^E  |^FAILED" gpurun_out/s27_tests.log | head -10
+python -m pytest tests/test_gpu_ops.py -m gpu -x -q 2>&1 | tail -2
+python tools/layer_bench.py --filter melgan_discriminator.discriminator.2 2>&1 | grep melgan | cut -c1-160
 for i in 1 2; do python bench.py --steps 20 --warmup 3 --no-cpu-baseline 2>&1 | grep "GPU:"; done

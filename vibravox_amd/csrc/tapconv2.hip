@@ -56,12 +56,17 @@ __device__ __forceinline__ float a_elem(const typename AFrag<FI>::type& a, int i
 template <>
 __device__ __forceinline__ float a_elem<1>(const float& a, int) { return a; }
 
-template <int FM, int NW, int XR>
+// H16: 16-row variant on v_mfma_f32_16x16x4_f32 for layers with <= 16 rows per group and a deep reduction
+// (MelGAN layer-2 input gradient: 16 rows x 704 taps*channels): a k-step is one tap x FOUR channels, a wave
+// owns FNH = 4 fragments of 16 positions (block = 16 rows x 256 positions), everything else -- LDS-DMA weight
+// image, scalar k-step table, double-buffered input tiles -- is shared with the 32x32x2 form.
+template <int FM, int NW, int XR, bool H16 = false>
 __global__ __launch_bounds__(NW * 64, 2) void tap2_kernel(const Tap2Args P) {
   constexpr int NT = NW * 64;
-  constexpr int BN = NW * 32;
-  constexpr int BM = FM * 32;
-  constexpr int FI = FM == 3 ? 4 : FM;      // floats per lane per k-step in the A image
+  constexpr int FNH = 4;
+  constexpr int BN = H16 ? NW * 16 * FNH : NW * 32;
+  constexpr int BM = H16 ? 16 : FM * 32;
+  constexpr int FI = H16 ? 1 : (FM == 3 ? 4 : FM);      // floats per lane per k-step in the A image
   constexpr int WCH = 16 * 64 * FI;         // floats per weight chunk (16 k-steps)
   constexpr int PIECES = WCH / 4 / NT;      // 16-byte LDS-DMA pieces per thread per chunk
   static_assert(PIECES >= 1 && PIECES * NT * 4 == WCH, "weight chunk must split into whole LDS-DMA pieces");
@@ -115,6 +120,9 @@ __global__ __launch_bounds__(NW * 64, 2) void tap2_kernel(const Tap2Args P) {
   for (int i = 0; i < FM; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  f32x4 acch[FNH];
+#pragma unroll
+  for (int f = 0; f < FNH; ++f) acch[f] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // Input-tile fetch, branch-free: every element's address is clamped to a valid one, all loads of a
   // batch are issued back to back (uniform base + 32-bit lane offset), the fused input stage and the
@@ -251,7 +259,7 @@ __global__ __launch_bounds__(NW * 64, 2) void tap2_kernel(const Tap2Args P) {
   }
   __syncthreads();
 
-  const int lanebase = (lane >> 5) * P.CSTRIDE + wn * 32 + (lane & 31);
+  const int lanebase = H16 ? (lane >> 4) * P.CSTRIDE + wn * 16 * FNH + (lane & 15) : (lane >> 5) * P.CSTRIDE + wn * 32 + (lane & 31);
   int te[16];   // this chunk's k-step offsets (wave-uniform: scalar registers, fetched one chunk ahead)
 #pragma unroll
   for (int ks = 0; ks < 16; ++ks) te[ks] = nch > 0 ? tab[ks] : 0;
@@ -261,20 +269,39 @@ __global__ __launch_bounds__(NW * 64, 2) void tap2_kernel(const Tap2Args P) {
     const float* xb = Xs + lanebase;
     // fragments of k-step s+2 are issued before the MFMAs of step s (sched_barrier pins the order:
     // left alone the scheduler sinks every ds_read next to its first use and exposes the LDS latency)
-    float bv[16];
-    afrag_t a[16];
-    bv[0] = xb[te[0]]; a[0] = *reinterpret_cast<const afrag_t*>(wb);
-    bv[1] = xb[te[1]]; a[1] = *reinterpret_cast<const afrag_t*>(wb + 64 * FI);
+    if constexpr (H16) {
+      float ah[16], bh[16][FNH];
+      auto rdh = [&](int ks) {
+        ah[ks] = wb[ks * 64];
 #pragma unroll
-    for (int ks = 0; ks < 16; ++ks) {
-      if (ks + 2 < 16) {
-        bv[ks + 2] = xb[te[ks + 2]];
-        a[ks + 2] = *reinterpret_cast<const afrag_t*>(wb + (ks + 2) * 64 * FI);
+        for (int f = 0; f < FNH; ++f) bh[ks][f] = xb[te[ks] + f * 16];
+      };
+      rdh(0);
+      rdh(1);
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) {
+        if (ks + 2 < 16) rdh(ks + 2);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int f = 0; f < FNH; ++f) acch[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[ks], bh[ks][f], acch[f], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
-      __builtin_amdgcn_sched_barrier(0);
+    } else {
+      float bv[16];
+      afrag_t a[16];
+      bv[0] = xb[te[0]]; a[0] = *reinterpret_cast<const afrag_t*>(wb);
+      bv[1] = xb[te[1]]; a[1] = *reinterpret_cast<const afrag_t*>(wb + 64 * FI);
 #pragma unroll
-      for (int i = 0; i < FM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_elem<FI>(a[ks], i), bv[ks], acc[i], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
+      for (int ks = 0; ks < 16; ++ks) {
+        if (ks + 2 < 16) {
+          bv[ks + 2] = xb[te[ks + 2]];
+          a[ks + 2] = *reinterpret_cast<const afrag_t*>(wb + (ks + 2) * 64 * FI);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < FM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_elem<FI>(a[ks], i), bv[ks], acc[i], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
     if (ch + 1 < nch) {
 #pragma unroll
@@ -294,6 +321,28 @@ __global__ __launch_bounds__(NW * 64, 2) void tap2_kernel(const Tap2Args P) {
   const bool use_res = P.res != nullptr && (P.res_rows == 0 || b < P.res_rows);
   const int eb = P.em_seg > 0 ? P.em_map[b / P.em_seg] * P.em_seg + b % P.em_seg : b;
   const long long eoff = (long long)(eb - b) * P.Cy * P.Ly;
+  if constexpr (H16) {
+    // ---- epilogue, 16x16 D tile: column = lane & 15, row = (lane >> 4) * 4 + r ----
+#pragma unroll
+    for (int f = 0; f < FNH; ++f) {
+      const int t = t0 + wn * 16 * FNH + f * 16 + (lane & 15);
+      if (t >= nt) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + (lane >> 4) * 4 + r;
+        if (m >= P.Mg) continue;
+        const float bias = P.bias ? P.bias[g * P.Mg + m] : 0.f;
+        const long long idx = ((long long)b * P.Cy + (long long)g * P.Mg + m) * P.Ly + (long long)t * P.OS + oo;
+        float v = acch[f][r] + bias;
+        v = lrelu(v, P.out_slope);
+        if (use_res) v += lrelu(P.res[idx], P.res_slope);
+        if (P.emask) v *= dlrelu(P.emask[idx + eoff], P.emask_slope);
+        if (P.accumulate) v += P.y[idx];
+        P.y[idx] = v;
+      }
+    }
+    return;
+  }
   // ---- epilogue: 32x32 D tile: column = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) ----
   const int t = t0 + wn * 32 + (lane & 31);
   if (t >= nt) return;
@@ -321,7 +370,7 @@ __global__ __launch_bounds__(NW * 64, 2) void tap2_kernel(const Tap2Args P) {
 struct Tap2Plan {
   int ok;
   int mode, G, Cg, Mg, S, OS, dstep, kstep, nph, J, Lx, Ly, Cx, Cy, off0, nt, ps_pad;
-  int FM, NW, BM, BN, FI, WCH;
+  int FM, NW, BM, BN, FI, WCH, H16, KCH;
   int CI_T, CP, ncc, PLEN, CSTRIDE, nxbuf, XR;
   int nmt, ntt, NCH, tab_phase;
   long long w_tile, w_phase, tab_off;
@@ -360,7 +409,12 @@ static void make_plan2(const Canon& c, int dir, Tap2Plan* p) {
   static const int min_m = env_int("EBEN_TAP2_MIN_M", 24);
   static const int min_c = env_int("EBEN_TAP2_MIN_C", 2);
   // at least one full weight chunk (16 k-steps of one tap x two channels) of real reduction
-  if (!enabled || p->Mg < min_m || p->Cg < min_c || p->nph > 64 || (long long)p->Cg * p->J < 32) return;
+  if (!enabled || p->Cg < min_c || p->nph > 64 || (long long)p->Cg * p->J < 32) return;
+  // 16-row variant (16x16x4 MFMA): few rows per group but a reduction too deep for the direct kernel
+  static const int h16_enabled = env_int("EBEN_TAP2_H16", 1);
+  p->H16 = h16_enabled && p->Mg <= 16 && p->Mg >= 8 && (long long)p->Cg * p->J > 256;
+  p->KCH = p->H16 ? 4 : 2;
+  if (!p->H16 && p->Mg < min_m) return;
   // smallest J over the phases that have taps at all (phase-scatter phases differ by at most one tap)
   const int Jmin = dir == 0 ? p->J : (c.k / p->kstep > 0 ? c.k / p->kstep : 1);
 
@@ -386,6 +440,7 @@ static void make_plan2(const Canon& c, int dir, Tap2Plan* p) {
   if (force_bm == 32 || force_bm == 64 || force_bm == 96 || force_bm == 128) best = force_bm;
   p->BM = best; p->FM = best / 32; p->FI = p->FM == 3 ? 4 : p->FM;
   p->NW = 4; p->BN = 128;
+  if (p->H16) { p->BM = 16; p->FM = 1; p->FI = 1; p->BN = 256; }
   p->WCH = 16 * 64 * p->FI;
   p->nmt = ceil_div(p->Mg, p->BM);
   p->ntt = ceil_div(p->nt, p->BN);
@@ -395,13 +450,21 @@ static void make_plan2(const Canon& c, int dir, Tap2Plan* p) {
   p->PLEN = p->BN + maxd + 1;
   // stride 1: rows 16-byte aligned with room for the float4 staging (tile start rounded down, end rounded up)
   if (p->S == 1) p->PLEN = round_up(p->BN + maxd + 5, 4);
+  if (p->H16) {
+    // the four channel rows of a 16x16x4 B fragment are read 2 x 16 lanes at a time: rows must sit 16 banks apart
+    int pl = p->PLEN, tries = 0;
+    while (((long long)p->S * pl) % 32 != 16 && tries < 64) { pl += p->S == 1 ? 4 : 1; ++tries; }
+    if (((long long)p->S * pl) % 32 != 16) return;
+    p->PLEN = pl;
+  }
   p->CSTRIDE = p->S * p->PLEN;
   const int span = (p->BN - 1) * p->S + (p->J - 1) * adstep + 1;
   const int NT = p->NW * 64;
   static const int lds_budget = env_int("EBEN_TAP2_LDS_KB", 72) * 1024;   // two blocks per CU
   const int wbytes = 2 * p->WCH * 4;
   const int xbudget = lds_budget - wbytes;
-  const int Cg2 = round_up(p->Cg, 2);
+  const int KCH = p->KCH;
+  const int Cg2 = round_up(p->Cg, KCH);
   p->XR = T2_XR;
   if ((long long)Cg2 * p->CSTRIDE * 4 <= xbudget) {
     p->CI_T = Cg2; p->ncc = 1; p->nxbuf = 1;
@@ -417,21 +480,21 @@ static void make_plan2(const Canon& c, int dir, Tap2Plan* p) {
         // three buffers of a useful size do not fit the two-blocks-per-CU budget: that variant runs one block per CU
         const int cap_lds = (nbuf == 2 ? xbudget : 104 * 1024 - wbytes) / nbuf / (p->CSTRIDE * 4);
         if (cap > cap_lds) cap = cap_lds;
-        cap &= ~1;
-        if (cap < 2) continue;
+        cap -= cap % KCH;
+        if (cap < KCH) continue;
         const int nchk = ceil_div(Cg2, cap);
-        p->CI_T = round_up(ceil_div(p->Cg, nchk), 2);
+        p->CI_T = round_up(ceil_div(p->Cg, nchk), KCH);
         p->ncc = ceil_div(p->Cg, p->CI_T);
         p->nxbuf = nbuf;
         p->XR = xr;
-        if (p->ncc > 1 && Jmin * (p->CI_T / 2) < (nbuf == 2 ? 32 : 16)) continue;
+        if (p->ncc > 1 && Jmin * (p->CI_T / KCH) < (nbuf == 2 ? 32 : 16)) continue;
         found = true;
         break;
       }
     }
     if (!found) return;
   }
-  p->CP = p->CI_T / 2;
+  p->CP = p->CI_T / KCH;
   const int KSmax = p->ncc * p->J * p->CP;
   p->NCH = ceil_div(KSmax, 16);
   p->tab_phase = p->NCH * 16;
@@ -448,7 +511,7 @@ struct Pack2Args {
   const float* w; const float* scale; float* wp;
   int G, Cg, Mg, nmt, BM, FM, FI, WCH, CI_T, CP, ncc, NCH, nph, tab_phase;
   int mode, J0, off0, nt, dstep, OS, S, ps_pad, k, d, kstep, Ly;
-  int Cin_g, Cout_g, PLEN, CSTRIDE, nxbuf;
+  int Cin_g, Cout_g, PLEN, CSTRIDE, nxbuf, H16, KCH;
   long long w_tile, w_phase, tab_off;
 };
 
@@ -473,8 +536,8 @@ __global__ __launch_bounds__(256) void pack2_kernel(const Pack2Args P) {
       if (q.J > 0 && s < P.ncc * KS_CC && fi < P.FM) {
         const int cc = s / KS_CC, rem = s - cc * KS_CC;
         const int j = rem / P.CP, cp = rem - j * P.CP;
-        const int chan = cc * P.CI_T + 2 * cp + (lane >> 5);
-        const int m = mt * P.BM + fi * 32 + (lane & 31);
+        const int chan = P.H16 ? cc * P.CI_T + 4 * cp + (lane >> 4) : cc * P.CI_T + 2 * cp + (lane >> 5);
+        const int m = P.H16 ? mt * 16 + (lane & 15) : mt * P.BM + fi * 32 + (lane & 31);
         if (chan < P.Cg && m < P.Mg) {
           if (P.mode == 0) {
             const int co = g * P.Cout_g + m;
@@ -503,17 +566,17 @@ __global__ __launch_bounds__(256) void pack2_kernel(const Pack2Args P) {
         const int j = rem / P.CP, cp = rem - j * P.CP;
         const int rel = q.off0 + j * P.dstep - q.minoff;
         const int dd = rel / P.S, pp = rel - dd * P.S;
-        o = (P.nxbuf > 1 ? (cc % P.nxbuf) * P.CI_T * P.CSTRIDE : 0) + 2 * cp * P.CSTRIDE + pp * P.PLEN + dd;
+        o = (P.nxbuf > 1 ? (cc % P.nxbuf) * P.CI_T * P.CSTRIDE : 0) + P.KCH * cp * P.CSTRIDE + pp * P.PLEN + dd;
       }
       reinterpret_cast<int*>(P.wp)[i] = o;
     }
   }
 }
 
-template <int FM, int NW, int XR>
+template <int FM, int NW, int XR, bool H16 = false>
 static int launch2_cfg(const Tap2Args& a, int nblocks, size_t lds, hipStream_t st) {
   static bool attr_set = false;
-  auto kern = tap2_kernel<FM, NW, XR>;
+  auto kern = tap2_kernel<FM, NW, XR, H16>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(tap2)");
@@ -546,7 +609,7 @@ int tap2_pack(const Canon& c, int dir, const float* w, const float* scale, float
   a.CI_T = p.CI_T; a.CP = p.CP; a.ncc = p.ncc; a.NCH = p.NCH; a.nph = p.nph; a.tab_phase = p.tab_phase;
   a.mode = p.mode; a.J0 = p.J; a.off0 = p.off0; a.nt = p.nt; a.dstep = p.dstep; a.OS = p.OS; a.S = p.S; a.ps_pad = p.ps_pad;
   a.k = c.k; a.d = c.d; a.kstep = p.kstep; a.Ly = p.Ly;
-  a.Cin_g = c.Cin / c.g; a.Cout_g = c.Cout / c.g; a.PLEN = p.PLEN; a.CSTRIDE = p.CSTRIDE; a.nxbuf = p.nxbuf;
+  a.Cin_g = c.Cin / c.g; a.Cout_g = c.Cout / c.g; a.PLEN = p.PLEN; a.CSTRIDE = p.CSTRIDE; a.nxbuf = p.nxbuf; a.H16 = p.H16; a.KCH = p.KCH;
   a.w_tile = p.w_tile; a.w_phase = p.w_phase; a.tab_off = p.tab_off;
   long long blocks = ((long long)p.packed_floats + 255) / 256;
   if (blocks > 8192) blocks = 8192;
@@ -576,6 +639,8 @@ int tap2_launch(const Canon& c, int dir, const TapIO& io, int reflect, hipStream
   a.w_tile = p.w_tile; a.w_phase = p.w_phase;
   const long long nb = (long long)p.ntt * c.B * p.nph * p.nmt * p.G;
   if (nb <= 0 || nb > 0x7fffffffLL) return fail(EBEN_EINVAL, "tap2 grid of %lld blocks", nb);
+  if (p.H16) return p.XR == T2_XR_BIG ? launch2_cfg<1, 4, T2_XR_BIG, true>(a, (int)nb, p.lds_bytes, st)
+                                       : launch2_cfg<1, 4, T2_XR, true>(a, (int)nb, p.lds_bytes, st);
   if (p.XR == T2_XR_BIG) {
     switch (p.FM) {
       case 1: return launch2_cfg<1, 4, T2_XR_BIG>(a, (int)nb, p.lds_bytes, st);
