@@ -418,12 +418,16 @@ static void make_plan2(const Canon& c, int dir, Tap2Plan* p) {
   // smallest J over the phases that have taps at all (phase-scatter phases differ by at most one tap)
   const int Jmin = dir == 0 ? p->J : (c.k / p->kstep > 0 ? c.k / p->kstep : 1);
 
-  // rows per block: the tile height with the least padded rows, larger on ties
+  // rows per block: best (measured tile efficiency) x (useful rows / padded rows).  The efficiencies are the
+  // ratios seen on MI355X between the four tile heights on MFMA-bound layers (FM = 4: ~110, 3: ~95-100,
+  // 2: ~90, 1: ~50 TFLOP/s); pure least-padding picked 32-row tiles for the 514-row STFT analysis conv.
   const int cand[4] = {128, 96, 64, 32};
-  int best = 0, best_pad = 1 << 30;
+  const double eff[4] = {1.0, 0.9, 0.8, 0.45};
+  int best = 0;
+  double best_score = -1.0;
   for (int i = 0; i < 4; ++i) {
-    const int pad = round_up(p->Mg, cand[i]);
-    if (pad < best_pad) { best_pad = pad; best = cand[i]; }
+    const double score = eff[i] * p->Mg / round_up(p->Mg, cand[i]);
+    if (score > best_score + 1e-9) { best_score = score; best = cand[i]; }
   }
   // a grid that cannot give every CU a block (the 125-sample layers of the generator: 32 items x one
   // position tile) is cut into shorter tiles while that does not add padded rows
