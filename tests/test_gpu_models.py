@@ -269,6 +269,29 @@ def test_full_size_step_properties(hip, golden):
     assert all(k.endswith(".bias") for k in still) and len(still) <= 4, still
 
 
+def test_train_step_is_bitwise_reproducible(hip, golden):
+    """Every kernel on the path reduces in a fixed order (no float atomics), so two runs from the same
+    state must agree bit for bit -- parameters and Adam moments; a difference is a race between the
+    streams the step runs on (main, weight-gradient side stream, the discriminator chains)."""
+    def run():
+        mod, _, _ = make_module(golden, use_mrstft=True)
+        g = torch.Generator().manual_seed(99)
+        batch = {"audio_body_conducted": (0.1 * torch.randn(8, 1, 16000, generator=g)).to(DEV),
+                 "audio_airborne": (0.1 * torch.randn(8, 1, 16000, generator=g)).to(DEV)}
+        for _ in range(2):
+            mod.training_step(batch)
+        torch.cuda.synchronize()
+        out = {f"G.{k}": v.clone() for k, v in mod.generator.state_dict().items()}
+        out.update({f"D.{k}": v.clone() for k, v in mod.discriminator.state_dict().items()})
+        for oi, opt in enumerate(mod.optimizers()):
+            for pi, prm in enumerate(p for grp in opt.param_groups for p in grp["params"]):
+                out[f"adam{oi}.m.{pi}"] = opt.state[prm]["exp_avg"].clone()
+        return out
+
+    a, b = run(), run()
+    assert [k for k in a if not torch.equal(a[k], b[k])] == []
+
+
 def test_bucketed_grad_sync_path_on_gpu_matches_plain_step(hip, golden):
     """The data-parallel plumbing of bench.py (gradients as views of flat buckets, all-reduce issued
     from post-accumulate hooks on a side stream, 1/N folded into Adam) on a single-rank RCCL group:

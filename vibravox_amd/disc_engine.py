@@ -144,24 +144,14 @@ class _Chain:
         outs = emb[1:]
         n = len(self.layers)
         seg_map = (ctypes.c_int * 4)(0, 0, 0, 1)
-        grads = [None] * n
+        jobs = []   # (layer index, stacked gradient at the layer output, layer input): weight gradients, run later
         g = seeds.contiguous()
         for i in range(n - 1, -1, -1):
             lay = self.layers[i]
             x_in = outs[i - 1] if i > 0 else xp
             l_in = x_in.shape[2]
             if want_param_grads:
-                if i == n - 1:
-                    # Logits layer: fake and real branches separately, then added -- the reference's structure
-                    # (two autograd graphs accumulating into one .grad).  While every hinge term is active the
-                    # two bias gradients are -c*N and +c*N summed in the SAME order, i.e. they cancel exactly and
-                    # Adam leaves the bias alone; one sum over both branches leaves a rounding residue that Adam
-                    # (m / sqrt(v)) turns into a full-size step.
-                    gf = self._weight_grads(lay, g[2 * half:3 * half], x_in[:half], st)
-                    gr = self._weight_grads(lay, g[3 * half:], x_in[half:], st)
-                    grads[i] = tuple(None if a is None else a + b for a, b in zip(gf, gr))
-                else:
-                    grads[i] = self._weight_grads(lay, g[2 * half:], x_in, st)
+                jobs.append((i, g, x_in))
             if i > 0:
                 rows = 4 * half
                 d = ops.conv_desc(lay.spec_lin, rows, l_in)
@@ -184,7 +174,30 @@ class _Chain:
             dx = torch.empty((b2, c, lp - 2 * self.pad), dtype=torch.float32, device=g.device)
             check(lib.eben_reflect_pad_bwd(ptr(g), ptr(dx), b2 * c, lp - 2 * self.pad, self.pad, self.pad, st), "reflect_pad_bwd")
             g = dx
-        return g, (grads if want_param_grads else None)
+        return g, (jobs if want_param_grads else None)
+
+    def weight_grads(self, jobs, half: int):
+        """Second half of the backward: the weight gradients of every layer from the stacked gradients kept by
+        ``backward`` (rows [fake | real] against the layer inputs [enhanced | reference]).  Nothing on the
+        generator side depends on them, so the engine launches them after the input-gradient chain and lets
+        them run underneath the generator backward."""
+        st = _stream()
+        n = len(self.layers)
+        grads = [None] * n
+        for i, g, x_in in jobs:
+            lay = self.layers[i]
+            if i == n - 1:
+                # Logits layer: fake and real branches separately, then added -- the reference's structure
+                # (two autograd graphs accumulating into one .grad).  While every hinge term is active the
+                # two bias gradients are -c*N and +c*N summed in the SAME order, i.e. they cancel exactly and
+                # Adam leaves the bias alone; one sum over both branches leaves a rounding residue that Adam
+                # (m / sqrt(v)) turns into a full-size step.
+                gf = self._weight_grads(lay, g[2 * half:3 * half], x_in[:half], st)
+                gr = self._weight_grads(lay, g[3 * half:], x_in[half:], st)
+                grads[i] = tuple(None if a is None else a + b for a, b in zip(gf, gr))
+            else:
+                grads[i] = self._weight_grads(lay, g[2 * half:], x_in, st)
+        return grads
 
     @staticmethod
     def _weight_grads(lay: _Layer, g2: torch.Tensor, x_in: torch.Tensor, st: int):
@@ -300,8 +313,9 @@ class DiscriminatorEngine:
     # ---- the four backwards as one stacked pass ------------------------------------------------------
     @torch.no_grad()
     def backward(self, want_param_grads: bool = True):
-        """Returns (d fm / d bands, d fm / d audio, d adv / d bands, d adv / d audio, param_grads) with
-        param_grads aligned with ``list(disc.parameters())`` (gradient of real_loss + fake_loss) or None."""
+        """Returns (d fm / d bands, d fm / d audio, d adv / d bands, d adv / d audio).  With ``want_param_grads`` the
+        weight gradients of real_loss + fake_loss are launched behind the input-gradient chains and left running
+        (``collect_param_grads`` joins them)."""
         lib = load()
         s = self._state
         half, emb = s["half"], s["emb"]
@@ -330,6 +344,11 @@ class DiscriminatorEngine:
             return self.chains[i].backward(scale, s["xp"][i], fm_per_chain[i], seeds, half, want_param_grads)
 
         res = self._on_streams(run)
+        main = torch.cuda.current_stream()
+        for r in res:
+            # allocated on a chain stream, read on the main stream from here on: without this the allocator may hand
+            # the block to the chain's next allocation (the weight-gradient workspaces below) while it is still read
+            r[0].record_stream(main)
         # input gradients: the PQMF-band chains share the `bands[:, -q:]` input, the MelGAN chain reads the waveform
         bshape = s["bands_shape"]
         gb = torch.zeros((2 * half,) + bshape[1:], dtype=torch.float32, device=dev)
@@ -338,15 +357,35 @@ class DiscriminatorEngine:
             acc = acc + r[0]
         gb[:, -self.q:, :] = acc
         ga = res[-1][0]
-        param_grads = None
+        self._pending = None
         if want_param_grads:
-            by_param = {}
-            for ch, r in zip(self.chains, res):
-                for lay, (dv, dg, dbias) in zip(ch.layers, r[1]):
-                    v, gain, bias = lay.params()
-                    by_param[id(v)], by_param[id(gain)] = dv, dg
-                    if bias is not None:
-                        by_param[id(bias)] = dbias
-            param_grads = [by_param.get(id(p)) for p in self.disc.parameters()]
+            # phase B: weight gradients on the chains' streams, NOT joined here -- see collect_param_grads()
+            pend = []
+            for i, st in enumerate(self._streams):
+                with torch.cuda.stream(st):
+                    pend.append(self.chains[i].weight_grads(res[i][1], half))
+            self._pending = (pend, s)   # keeps the saved activations alive until the kernels have run
         self._state = None
-        return gb[:half], ga[:half], gb[half:], ga[half:], param_grads
+        return gb[:half], ga[:half], gb[half:], ga[half:]
+
+    def collect_param_grads(self):
+        """Joins the weight-gradient work launched by ``backward`` and returns the gradients of
+        real_loss + fake_loss aligned with ``list(disc.parameters())`` (None if none were requested)."""
+        if getattr(self, "_pending", None) is None:
+            return None
+        pend, _keep = self._pending
+        main = torch.cuda.current_stream()
+        for st in self._streams:
+            main.wait_stream(st)
+        by_param = {}
+        for ch, grads in zip(self.chains, pend):
+            for lay, (dv, dg, dbias) in zip(ch.layers, grads):
+                v, gain, bias = lay.params()
+                by_param[id(v)], by_param[id(gain)] = dv, dg
+                if bias is not None:
+                    by_param[id(bias)] = dbias
+                for t in (dv, dg, dbias):
+                    if t is not None:
+                        t.record_stream(main)
+        self._pending = None
+        return [by_param.get(id(p)) for p in self.disc.parameters()]

@@ -147,13 +147,9 @@ class EBENLightningModule(BaseSELightningModule):
         # the discriminator-phase draw (eben.py:118) is the only CPU RNG use of the step: taking it here
         # leaves the sequence of draws unchanged and lets the stacked backward skip the weight gradients
         update_discriminator = bool(torch.rand(1) < self.update_discriminator_ratio)
-        fm_b, fm_a, adv_b, adv_a, d_grads = engine.backward(want_param_grads=update_discriminator)
-        if update_discriminator:
-            # hand the discriminator gradients over NOW: under data parallelism their all-reduce (92.6 MB,
-            # issued from the accumulation hooks on the communication stream) then runs underneath the whole
-            # generator backward instead of after it
-            inject_grads(list(self.discriminator.parameters()), d_grads)
-            d_grads = None
+        # input gradients now; the discriminator's weight gradients keep running on the engine's streams
+        # underneath the balancing passes and the (launch-bound, GPU-underfilling) generator backward
+        fm_b, fm_a, adv_b, adv_a = engine.backward(want_param_grads=update_discriminator)
 
         # balancing (eben.py:222-240) with every gradient taken at `bands`
         leaf = self.generator.last_conv.weight
@@ -190,6 +186,7 @@ class EBENLightningModule(BaseSELightningModule):
             self.log("train/discriminator/real_loss", real_loss, sync_dist=True)
             self.log("train/discriminator/fake_loss", fake_loss, sync_dist=True)
             self.log("train/discriminator/backprop_loss", real_loss + fake_loss, sync_dist=True)
+            inject_grads(list(self.discriminator.parameters()), engine.collect_param_grads())
             self._step(discriminator_optimizer, self._sync_grads(discriminator_optimizer))
             discriminator_optimizer.zero_grad()
         return {"corrupted": corrupted_speech, "enhanced": enhanced_speech.detach(), "reference": reference_speech}

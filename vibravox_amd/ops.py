@@ -54,7 +54,10 @@ class weight_grads_disabled:
 # ~2.9 ms of dX launches instead of ~8.6 ms of everything in series).  The caller must `join()` before
 # anything on the main stream reads the parameter gradients (the optimiser step); only valid while
 # `.grad` is None for the parameters involved (AccumulateGrad then just stores the tensor).
-_side = {"enabled": False, "stream": None}
+# `keep` holds a reference to every upstream gradient a side-stream kernel reads until `join()`: autograd
+# sums gradients IN PLACE into a buffer it holds the only reference to (a residual add hands the same
+# tensor to both branches), which would rewrite the gradient on the main stream under the kernel reading it.
+_side = {"enabled": False, "stream": None, "keep": []}
 
 
 class weight_grads_on_side_stream:
@@ -71,6 +74,7 @@ class weight_grads_on_side_stream:
         st = _side["stream"]
         if st is not None:
             torch.cuda.current_stream(st.device).wait_stream(st)
+        _side["keep"].clear()
 
 
 def _side_stream(device) -> "torch.cuda.Stream":
@@ -238,6 +242,7 @@ class _ConvLayerFn(torch.autograd.Function):
                 for t in (dy, x, y, v, g, ctx.norm):
                     if t is not None:
                         t.record_stream(side)
+                _side["keep"].append(dy)
                 stream_ctx = torch.cuda.stream(side)
             else:
                 stream_ctx = contextlib.nullcontext()
