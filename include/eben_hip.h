@@ -41,6 +41,12 @@ extern "C" {
 #define EBEN_PAD_ZERO 0
 #define EBEN_PAD_REFLECT 1
 
+/* arithmetic of the contraction (storage, accumulation and the fused element-wise stages are fp32 either way) */
+#define EBEN_MATH_F32 0   /* v_mfma_f32_*_f32 / fp32 FMA: bit-exact fp32 products */
+#define EBEN_MATH_BF16 1  /* both MFMA operands rounded (RNE) to bf16, fp32 accumulate; layers the bf16 kernel does not
+                           * cover run their fp32 kernel.  The mask-on-load input stage (eben_conv1d_bwd_dx with
+                           * out_slope != 1) is not available in this mode: use eben_conv1d_bwd_dx_ex. */
+
 /* One Conv1d / ConvTranspose1d layer (nn.Conv1d / nn.ConvTranspose1d semantics).
  * Replaces the F.conv1d / F.conv_transpose1d call sites behind
  *   vibravox/torch_modules/dnn/eben_generator.py:112-166,241-249,272-280,295-312
@@ -57,6 +63,7 @@ typedef struct EbenConv1dDesc {
   int32_t transposed;       /* 0 Conv1d, 1 ConvTranspose1d */
   float in_slope;           /* LeakyReLU slope fused on the input load (1.0f = none) */
   float out_slope;          /* LeakyReLU slope fused on the output (1.0f = none) */
+  int32_t math;             /* EBEN_MATH_F32 | EBEN_MATH_BF16 */
 } EbenConv1dDesc;
 
 EBEN_API const char* eben_last_error(void);

@@ -121,6 +121,111 @@ def test_kernel_generations_cover_the_eben_layers(hip):
     assert seen == {1, 2, 3}
 
 
+BF16_CASES = {
+    # name: (ConvSpec kwargs, length, (generation of the forward, of the input gradient) at math = bf16)
+    "melgan_l3_like_chunked": (CONV_CASES["melgan_l3_like_chunked"][0], 700, (4, 4)),
+    "pqmf_disc_wide": (CONV_CASES["pqmf_disc_wide"][0], 260, (4, 4)),
+    "dense_k5_chunks": (CONV_CASES["dense_k5_chunks"][0], 300, (4, 4)),
+    "pqmf_l6_like_96rows": (CONV_CASES["pqmf_l6_like_96rows"][0], 140, (4, 4)),
+    "melgan_l2_like": (CONV_CASES["melgan_l2_like"][0], 1100, (4, 2)),   # 16 rows per group on the gradient side: fp32 kernel
+    "pqmf_mid_24ch": (dict(c_in=96, c_out=192, ksize=7, stride=2, dilation=3, pad_l=3, pad_r=3, groups=4, out_slope=0.2), 1001, (4, 4)),
+    "pqmf_low_12ch": (dict(c_in=48, c_out=96, ksize=7, stride=2, dilation=1, pad_l=3, pad_r=3, groups=4, out_slope=0.2), 2003, (None, None)),
+    "melgan_l4_like": (dict(c_in=512, c_out=512, ksize=41, stride=4, pad_l=20, pad_r=20, groups=4, out_slope=0.2), 500, (4, 4)),
+}
+
+
+def _bf16(t):
+    return t.to(torch.bfloat16).to(torch.float64)
+
+
+@pytest.mark.parametrize("name", list(BF16_CASES))
+def test_bf16_math_forward_and_batched_input_gradient(hip, name):
+    """EBEN_MATH_BF16 (tapconv3.hip): both MFMA operands are rounded to bf16 (RNE), everything else is fp32 --
+    so against an fp64 conv of the bf16-ROUNDED operands the kernel must be as tight as the fp32 kernels
+    (this pins the kernel itself; what the rounding costs the train step is measured in test_gpu_models)."""
+    import ctypes
+    import dataclasses
+
+    from vibravox_amd import ops
+    from vibravox_amd._lib import check, load, ptr, stream
+
+    lib = load()
+    kw, length, gens = BF16_CASES[name]
+    spec = ops.ConvSpec(**kw)
+    S = 2
+    wshape = spec.weight_shape()
+    w = formula_tensor(f"bf/{name}/w", wshape, 1 / math.sqrt(wshape[1] * wshape[2]))
+    bias = formula_tensor(f"bf/{name}/b", (spec.c_out,), 0.1)
+    x = formula_tensor(f"bf/{name}/x", (2 * S, spec.c_in, length))
+    l_out = spec.out_len(length)
+    okw = {k: v for k, v in kw.items() if k not in ("c_in", "c_out", "ksize", "in_slope", "out_slope")}
+    dev = torch.device("cuda")
+    wd, bd, xd = w.to(dev), bias.to(dev), x.to(dev)
+
+    # forward: lrelu(conv(bf16(x), bf16(w)) + bias)
+    d = ops.conv_desc(spec, 2 * S, length, ops.MATH_BF16)
+    fgen = lib.eben_conv1d_kernel_generation(ctypes.byref(d), 0)
+    assert gens[0] is None or fgen == gens[0]
+    rnd = _bf16 if fgen == 4 else (lambda t: t.double())
+    ref = torch.nn.functional.leaky_relu(O.conv_layer(rnd(x), rnd(w), None, bias.double(), **okw), spec.out_slope)
+    wp = torch.empty(lib.eben_conv1d_packed_floats(ctypes.byref(d), 0), dtype=torch.float32, device=dev)
+    check(lib.eben_conv1d_pack(ctypes.byref(d), ptr(wd), None, ptr(wp), None, stream()), "pack")
+    y = torch.empty(2 * S, spec.c_out, l_out, dtype=torch.float32, device=dev)
+    check(lib.eben_conv1d_fwd(ctypes.byref(d), ptr(xd), ptr(wp), ptr(bd), None, ptr(y), stream()), "fwd")
+    torch.cuda.synchronize()
+    assert rel_err(y, ref) < 3e-5
+    # ... and the rounding itself costs what bf16 should cost (2^-9 per operand, averaged over the reduction)
+    exact = torch.nn.functional.leaky_relu(O.conv_layer(x.double(), w.double(), None, bias.double(), **okw), spec.out_slope)
+    assert (1e-4 if fgen == 4 else 0.0) < rel_err(y, exact) < 1e-2
+
+    # batched input gradient of the linear conv: dx[b] = (conv^T(bf16(g[b]); bf16(w)) + res[b < S]) * lrelu'(act[map(b)])
+    lin = dataclasses.replace(spec, in_slope=1.0, out_slope=1.0)
+    d = ops.conv_desc(lin, 4 * S, length, ops.MATH_BF16)
+    got_gen = lib.eben_conv1d_kernel_generation(ctypes.byref(d), 1)
+    if gens[1] is not None:
+        assert got_gen == gens[1]
+    g = formula_tensor(f"bf/{name}/g", (4 * S, spec.c_out, l_out))
+    act = formula_tensor(f"bf/{name}/act", (2 * S, spec.c_in, length))
+    res = formula_tensor(f"bf/{name}/res", (S, spec.c_in, length))
+    rounded = got_gen == 4
+    xr = torch.zeros(4 * S, spec.c_in, length, dtype=torch.float64, requires_grad=True)
+    (O.conv_layer(xr, _bf16(w) if rounded else w.double(), None, None, **okw) * (_bf16(g) if rounded else g.double())).sum().backward()
+    ref = xr.grad.clone()
+    ref[:S] += res.double()
+    rows = torch.tensor([0, 1, 0, 1, 0, 1, 2, 3])
+    ref = ref * torch.where(act.double()[rows] > 0, 1.0, 0.2)
+    wp = torch.empty(lib.eben_conv1d_packed_floats(ctypes.byref(d), 1), dtype=torch.float32, device=dev)
+    check(lib.eben_conv1d_pack(ctypes.byref(d), ptr(wd), None, None, ptr(wp), stream()), "pack")
+    dx = torch.empty(4 * S, spec.c_in, length, dtype=torch.float32, device=dev)
+    seg_map = (ctypes.c_int * 4)(0, 0, 0, 1)
+    gd, rd, ad = g.to(dev), res.to(dev), act.to(dev)
+    check(lib.eben_conv1d_bwd_dx_ex(ctypes.byref(d), ptr(gd), ptr(wp), ptr(rd), S, ptr(ad), 0.2, S, seg_map, ptr(dx), stream()),
+          "bwd_dx_ex")
+    torch.cuda.synchronize()
+    assert rel_err(dx, ref) < 3e-5
+
+    # weight / bias gradient over 24 batch rows (one full group of 16 + a half-empty one): k-steps of 16 batch items
+    nb = 24
+    d = ops.conv_desc(lin, nb, length, ops.MATH_BF16)
+    xb = formula_tensor(f"bf/{name}/xb", (nb, spec.c_in, length))
+    gb = formula_tensor(f"bf/{name}/gb", (nb, spec.c_out, l_out))
+    wr = torch.zeros(wshape, dtype=torch.float64, requires_grad=True)
+    (O.conv_layer(_bf16(xb), wr, None, None, **okw) * _bf16(gb)).sum().backward()
+    nslab, row_stride = ctypes.c_int(0), ctypes.c_int(0)
+    ws_bytes = lib.eben_conv1d_bwd_dw_workspace(ctypes.byref(d), ctypes.byref(nslab), ctypes.byref(row_stride))
+    slabs = torch.empty((ws_bytes + 3) // 4, dtype=torch.float32, device=dev)
+    xbd, gbd = xb.to(dev), gb.to(dev)
+    check(lib.eben_conv1d_bwd_dw(ctypes.byref(d), ptr(gbd), None, ptr(xbd), 1, ptr(slabs), ws_bytes, stream()), "bwd_dw")
+    rows, cols = wshape[0], wshape[1] * wshape[2]
+    dv = torch.empty(wshape, dtype=torch.float32, device=dev)
+    dbias = torch.empty(rows, dtype=torch.float32, device=dev)
+    check(lib.eben_wn_bwd(ptr(slabs), nslab.value, rows * row_stride.value, rows, cols, row_stride.value, None, None, None, None,
+                          ptr(dv), ptr(dbias), stream()), "wn_bwd")
+    torch.cuda.synchronize()
+    assert rel_err(dv, wr.grad) < 1e-4
+    assert rel_err(dbias, _bf16(gb).sum(dim=(0, 2))) < 1e-4
+
+
 @pytest.mark.parametrize("name", ["pqmf_disc_wide", "melgan_l2_like", "thin_pqmf_l1", "dense_k5_chunks"])
 def test_batched_input_gradient_ex(hip, name):
     """eben_conv1d_bwd_dx_ex: four stacked right-hand sides [fm | adv | fake | real] against activations

@@ -61,6 +61,7 @@ def main():
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--filter", default="")
     ap.add_argument("--min-gmacs", type=float, default=0.0)
+    ap.add_argument("--math", default="f32", choices=["f32", "bf16"], help="bf16: EBEN_MATH_BF16 descriptors; dx through eben_conv1d_bwd_dx_ex")
     a = ap.parse_args()
     lib = load()
     dev = torch.device("cuda")
@@ -70,7 +71,8 @@ def main():
     for name, spec, l_in, has_bias in rows:
         if a.filter and a.filter not in name:
             continue
-        d = ops.conv_desc(spec, a.batch, l_in)
+        math = ops.MATH_BF16 if a.math == "bf16" else ops.MATH_F32
+        d = ops.conv_desc(spec, a.batch, l_in, math)
         l_out = d.l_out
         wshape = spec.weight_shape()
         macs = a.batch * wshape[0] * wshape[1] * wshape[2] * (l_in if spec.transposed else l_out)
@@ -99,6 +101,8 @@ def main():
             check(lib.eben_conv1d_fwd(ctypes.byref(d), ptr(x), ptr(pw.wp_fwd), ptr(bias), None, ptr(y), st))
 
         def bdx():
+            if math == ops.MATH_BF16:   # the engine's form: linear conv, masks in the producer's epilogue
+                return check(lib.eben_conv1d_bwd_dx_ex(ctypes.byref(d), ptr(dy), ptr(pw.wp_bwd), None, 0, None, 1.0, 0, None, ptr(dx), st))
             check(lib.eben_conv1d_bwd_dx(ctypes.byref(d), ptr(dy), ptr(ymask), ptr(pw.wp_bwd), ptr(xmask), ptr(dx), 0, ptr(ws), wsb, st))
 
         def bdw():

@@ -38,6 +38,7 @@ class EbenConv1dDesc(ctypes.Structure):
         ("transposed", c_int32),
         ("in_slope", c_float),
         ("out_slope", c_float),
+        ("math", c_int32),
     ]
 
 

@@ -10,6 +10,6 @@ HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
   -Wall -Wno-unused-function \
   -I"$root/include" -I"$here" \
   -DEBEN_BUILDING=1 \
-  "$here/tapconv.hip" "$here/tapconv2.hip" "$here/thinconv.hip" "$here/conv_dw.hip" "$here/conv_dw2.hip" "$here/direct.hip" \
+  "$here/tapconv.hip" "$here/tapconv2.hip" "$here/tapconv3.hip" "$here/thinconv.hip" "$here/conv_dw.hip" "$here/conv_dw2.hip" "$here/conv_dw3.hip" "$here/direct.hip" \
   -o "$out/libeben_hip.so" "${@:2}"
 echo "built $out/libeben_hip.so"

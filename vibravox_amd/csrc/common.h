@@ -76,6 +76,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // big side X (B,Cin,Lin), small side Y (B,Cout,Lout), weight (Cout, Cin/g, k).
 struct Canon {
   int B, Cin, Cout, Lin, Lout, k, s, d, g, pl, pr, reflect;
+  int bf16;   // EbenConv1dDesc.math == EBEN_MATH_BF16: bf16 MFMA operands where tapconv3.hip covers the layer
 };
 int canon_from_desc(const EbenConv1dDesc* d, Canon* c);
 
@@ -126,12 +127,18 @@ size_t tap2_packed_floats(const Canon& c, int dir);
 int tap2_pack(const Canon& c, int dir, const float* w, const float* scale, float* wp, hipStream_t st);
 int tap2_launch(const Canon& c, int dir, const TapIO& io, int reflect, hipStream_t st);
 
+// bf16-operand form of the second generation (tapconv3.hip): 32x32x16 bf16 MFMA, fp32 accumulate / storage
+int tap3_applicable(const Canon& c, int dir);
+size_t tap3_packed_floats(const Canon& c, int dir);
+int tap3_pack(const Canon& c, int dir, const float* w, const float* scale, float* wp, hipStream_t st);
+int tap3_launch(const Canon& c, int dir, const TapIO& io, int reflect, hipStream_t st);
+
 // direct (VALU) tap-conv for layers with a handful of output channels per group (thinconv.hip)
 int thin_applicable(const Canon& c, int dir);
 size_t thin_packed_floats(const Canon& c, int dir);
 int thin_pack(const Canon& c, int dir, const float* w, const float* scale, float* wp, hipStream_t st);
 int thin_launch(const Canon& c, int dir, const TapIO& io, int reflect, hipStream_t st);
-// which kernel serves (layer, direction): 1 tapconv.hip, 2 tapconv2.hip, 3 thinconv.hip
+// which kernel serves (layer, direction): 1 tapconv.hip, 2 tapconv2.hip, 3 thinconv.hip, 4 tapconv3.hip (bf16)
 int tap_generation(const Canon& c, int dir);
 
 // second-generation weight-gradient kernel (conv_dw2.hip): pre-transposed A image + LDS-DMA
@@ -149,5 +156,12 @@ struct Dw2Args {
 int dw2_applicable(const Canon& c);
 size_t dw2_workspace(const Canon& c, int* nslab, int* row_stride);
 int dw2_launch(const Canon& c, Dw2Args a, float* workspace, size_t ws_bytes, hipStream_t st);
+
+
+// bf16-operand weight-gradient kernel (conv_dw3.hip): k-step = one time step x 16 batch items
+int dw3_applicable(const Canon& c);
+size_t dw3_workspace(const Canon& c, int* nslab, int* row_stride);
+int dw3_launch(const Canon& c, const float* a, float a_slope, const float* x, float x_slope, int has_bias, float* workspace, size_t ws_bytes,
+               hipStream_t st);
 
 }  // namespace eben

@@ -311,6 +311,8 @@ int canon_from_desc(const EbenConv1dDesc* d, Canon* c) {
   EBEN_REQUIRE(d->stride <= 1024 && d->pad_l >= 0 && d->pad_r >= 0, "bad stride / padding");
   c->B = d->batch; c->k = d->ksize; c->s = d->stride; c->d = d->dilation; c->g = d->groups;
   c->pl = d->pad_l; c->pr = d->pad_r;
+  EBEN_REQUIRE(d->math == EBEN_MATH_F32 || d->math == EBEN_MATH_BF16, "unknown math mode %d", d->math);
+  c->bf16 = d->math == EBEN_MATH_BF16;
   if (!d->transposed) {
     c->Cin = d->c_in; c->Cout = d->c_out; c->Lin = d->l_in; c->Lout = d->l_out;
     c->reflect = d->pad_mode == EBEN_PAD_REFLECT;
@@ -604,6 +606,7 @@ using namespace eben;
 namespace eben {
 int tap_generation(const Canon& c, int dir) {
   static const int thin_first = getenv("EBEN_THIN_FIRST") ? atoi(getenv("EBEN_THIN_FIRST")) : 0;
+  if (c.bf16 && tap3_applicable(c, dir)) return 4;   // layers the bf16 kernel does not cover keep their fp32 kernel
   const int t2 = tap2_applicable(c, dir), th = thin_applicable(c, dir);
   if (th && (thin_first || !t2)) return 3;
   if (t2) return 2;
@@ -620,6 +623,7 @@ extern "C" size_t eben_conv1d_packed_floats(const EbenConv1dDesc* d, int which) 
   const int gen = tap_generation(c, dir);
   if (gen == 2) return tap2_packed_floats(c, dir);
   if (gen == 3) return thin_packed_floats(c, dir);
+  if (gen == 4) return tap3_packed_floats(c, dir);
   make_plan(c, dir, &p);
   return p.packed_floats;
 }
@@ -641,7 +645,8 @@ extern "C" int eben_conv1d_pack(const EbenConv1dDesc* d, const float* v, const f
     const int dir = d->transposed ? 1 - which : which;
     const int gen = tap_generation(c, dir);
     if (gen != 1) {
-      rc = gen == 2 ? tap2_pack(c, dir, v, scale, dst, as_stream(stream)) : thin_pack(c, dir, v, scale, dst, as_stream(stream));
+      rc = gen == 2 ? tap2_pack(c, dir, v, scale, dst, as_stream(stream))
+         : gen == 4 ? tap3_pack(c, dir, v, scale, dst, as_stream(stream)) : thin_pack(c, dir, v, scale, dst, as_stream(stream));
       if (rc) return rc;
       continue;
     }
@@ -674,6 +679,7 @@ extern "C" int eben_conv1d_fwd(const EbenConv1dDesc* d, const float* x, const fl
   const int fgen = tap_generation(c, d->transposed ? 1 : 0);
   if (fgen == 2) return tap2_launch(c, d->transposed ? 1 : 0, io, c.reflect && !d->transposed, as_stream(stream));
   if (fgen == 3) return thin_launch(c, d->transposed ? 1 : 0, io, c.reflect && !d->transposed, as_stream(stream));
+  if (fgen == 4) return tap3_launch(c, d->transposed ? 1 : 0, io, c.reflect && !d->transposed, as_stream(stream));
   return launch_tap(c, p, io, c.reflect && !d->transposed, as_stream(stream));
 }
 
@@ -705,12 +711,14 @@ extern "C" int eben_conv1d_bwd_dx(const EbenConv1dDesc* d, const float* dy, cons
   if (!fold) {
     io.emask = d->in_slope != 1.f ? x : nullptr; io.emask_slope = d->in_slope;
     io.y = dx; io.accumulate = accumulate;
-    return gen == 2 ? tap2_launch(c, dir, io, 0, st) : gen == 3 ? thin_launch(c, dir, io, 0, st) : launch_tap(c, p, io, 0, st);
+    return gen == 2 ? tap2_launch(c, dir, io, 0, st) : gen == 3 ? thin_launch(c, dir, io, 0, st)
+         : gen == 4 ? tap3_launch(c, dir, io, 0, st) : launch_tap(c, p, io, 0, st);
   }
   const size_t need = eben_conv1d_bwd_dx_workspace(d);
   if (!workspace || ws_bytes < need) return fail(EBEN_EWORKSPACE, "bwd_dx needs %zu workspace bytes, got %zu", need, ws_bytes);
   io.emask = nullptr; io.emask_slope = 1.f; io.y = static_cast<float*>(workspace); io.accumulate = 0;
-  rc = gen == 2 ? tap2_launch(c, dir, io, 0, st) : gen == 3 ? thin_launch(c, dir, io, 0, st) : launch_tap(c, p, io, 0, st);
+  rc = gen == 2 ? tap2_launch(c, dir, io, 0, st) : gen == 3 ? thin_launch(c, dir, io, 0, st)
+     : gen == 4 ? tap3_launch(c, dir, io, 0, st) : launch_tap(c, p, io, 0, st);
   if (rc) return rc;
   const long long rows = (long long)c.B * c.Cin;
   long long blocks = (rows * c.Lin + 255) / 256;
@@ -746,6 +754,7 @@ extern "C" int eben_conv1d_bwd_dx_ex(const EbenConv1dDesc* d, const float* g, co
   hipStream_t st = as_stream(stream);
   if (gen == 2) return tap2_launch(c, dir, io, 0, st);
   if (gen == 3) return thin_launch(c, dir, io, 0, st);
+  if (gen == 4) return tap3_launch(c, dir, io, 0, st);
   TapPlan p;
   make_plan(c, dir, &p);
   return launch_tap(c, p, io, 0, st);

@@ -1,0 +1,537 @@
+// tapconv3.hip -- bf16-operand form of the second-generation tap convolution (gfx950), selected per
+// launch by EbenConv1dDesc.math == EBEN_MATH_BF16 (BASELINE config 2 names bf16 for the train step; the
+// discriminator passes -- 91 % of the step's FLOPs -- run here, the generator stays on the exact-fp32 kernels).
+//
+//   y[b, g*Mg+m, t*OS+oo] = epi( sum_{c<Cg} sum_{j<J} W[j,c,m] * xin(b, g*Cg+c, t*S + off0 + j*dstep) )
+//
+// Activations, gradients, bias, the fused element-wise stages and the accumulators stay fp32 in HBM and in
+// registers; only the two MFMA operands are rounded (RNE) to bf16 -- the weights by the pack kernel, the input
+// tile as it is staged into LDS.  Same machine mapping as tapconv2.hip with every "channel" replaced by a
+// BUNDLE of 8 channels (one 16-byte LDS unit):
+//   * v_mfma_f32_32x32x16_bf16 (32 cycles, 16x the fp32 MFMA rate): one k-step = one tap x 16 channels; lane l
+//     feeds column l&31 with channels 8*(l>>5) .. +7, i.e. ONE ds_read_b128 of a staged bundle row -- conflict
+//     free for any stride / dilation because consecutive positions of a tile phase are consecutive units;
+//   * weights: bf16 LDS image [k-step][row tile][lane] of 16-byte units, streamed with global_load_lds_dwordx4
+//     in chunks of KSC k-steps, double-buffered, one barrier per chunk;
+//   * the per-layer k-step table (scalar cache), phase geometry, double / triple-buffered input tiles and the
+//     epilogue are the second generation's.
+#include "common.h"
+
+#include <cstdlib>
+
+namespace eben {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+  const f32x2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));   // v_cvt_pk_bf16_f32 (RNE)
+}
+
+constexpr int T3_KSC = 4;   // k-steps (of 16 reduction elements) per weight chunk
+
+struct Tap3Args {
+  const float* x; const u32x4* wp; const int* tab;
+  const float* bias; const float* res; const float* emask; float* y;
+  int B, G, Cg, Mg, Cx, Cy, Lx, Ly;
+  int S, OS, dstep, J0, mode, off0, nt, nph;
+  int ps_pad, ps_k, ps_d, ps_kstep;
+  int reflect, accumulate;
+  int res_rows, em_seg, em_map[4];
+  float in_slope, out_slope, res_slope, emask_slope;
+  int CI_T, CI_B, CP, ncc, PLEN, CSTRIDE, nxb;   // CI_T channels = CI_B bundles per input tile; CP = CI_B / 2 k-steps per tap
+  unsigned s_magic;
+  int ntt, nmt, tab_phase;
+  long long w_tile, w_phase;                     // in 16-byte units
+};
+
+template <int FM, int XRB>
+__global__ __launch_bounds__(256, 2) void tap3_kernel(const Tap3Args P) {
+  constexpr int NT = 256, BN = 128, BM = FM * 32, KSC = T3_KSC;
+  constexpr int WCHU = KSC * FM * 64;       // 16-byte units per weight chunk
+  constexpr int PIECES = WCHU / NT;
+  static_assert(PIECES >= 1 && PIECES * NT == WCHU, "weight chunk must split into whole LDS-DMA pieces");
+
+  extern __shared__ __attribute__((aligned(16))) u32x4 smem3[];
+  u32x4* Ws = smem3;              // 2 x WCHU
+  u32x4* Xs = smem3 + 2 * WCHU;   // nxb input tiles of CI_B * CSTRIDE units + one spare unit
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  unsigned id = xcd_remap(blockIdx.x, gridDim.x);
+  const int tt = __builtin_amdgcn_readfirstlane(id % P.ntt); id /= P.ntt;
+  const int b = __builtin_amdgcn_readfirstlane(id % P.B); id /= P.B;
+  const int ph = __builtin_amdgcn_readfirstlane(id % P.nph); id /= P.nph;
+  const int mt = __builtin_amdgcn_readfirstlane(id % P.nmt);
+  const int g = __builtin_amdgcn_readfirstlane(id / P.nmt);
+  const int t0 = tt * BN, m0 = mt * BM;
+
+  const PhaseGeom q = phase_geom(P.mode, ph, P.J0, P.off0, P.nt, P.dstep, P.OS, P.ps_pad, P.ps_k, P.ps_d, P.ps_kstep, P.Ly);
+  const int J = q.J, nt = q.nt, oo = q.oo;
+  if (t0 >= nt) return;
+  const int adstep = P.dstep >= 0 ? P.dstep : -P.dstep;
+  const int span = J > 0 ? (BN - 1) * P.S + (J - 1) * adstep + 1 : 0;
+  const int KS_CC = J * P.CP;
+  const int KS = P.ncc * KS_CC;
+  const int nch = (KS + KSC - 1) / KSC;
+  const int q0 = t0 * P.S + q.minoff;
+  const int xtot = P.CI_B * span;          // bundle-positions per input tile
+  const int XBUF = P.CI_B * P.CSTRIDE;
+  const unsigned span_magic = span > 0 ? (unsigned)((0x100000000ull + (unsigned)span - 1) / (unsigned)span) : 0u;
+
+  const u32x4* wsrc = P.wp + (long long)ph * P.w_phase + ((long long)g * P.nmt + mt) * P.w_tile;
+  typedef const __attribute__((address_space(4))) int* ctab_t;
+  ctab_t tab = (ctab_t)(P.tab + (long long)ph * P.tab_phase);
+
+  f32x16 acc[FM];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  // ---- input tile staging: one element = one bundle (8 channels) at one position -------------------
+  const long long xrow0 = ((long long)b * P.Cx + (long long)g * P.Cg) * P.Lx;
+  const int refl = P.reflect;
+  auto x_pos = [&](int r, int& ok) -> int {
+    int qq = q0 + r;
+    const int m1 = qq < 0 ? -qq : qq;
+    const int m2 = m1 >= P.Lx ? 2 * (P.Lx - 1) - m1 : m1;
+    qq = refl ? m2 : qq;
+    ok = (int)(qq >= 0) & (int)(qq < P.Lx);
+    return ok ? qq : 0;
+  };
+  auto x_slot = [&](int bb, int r) -> int {
+    int p = 0, d = r;
+    if (P.S != 1) { d = (int)__umulhi((unsigned)r, P.s_magic); p = r - d * P.S; }
+    return bb * P.CSTRIDE + p * P.PLEN + d;
+  };
+  auto load8 = [&](const float* base, int c0, int qq, float (&v)[8]) {
+    // channels c0 .. c0+7 of this group at position qq; rows past the group's last channel re-read row c0 (zeroed later)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = c0 + e < P.Cg ? c0 + e : (c0 < P.Cg ? c0 : 0);
+      v[e] = base[(long long)c * P.Lx + qq];
+    }
+  };
+  auto cvt8 = [&](const float (&v)[8], int c0, int ok) -> u32x4 {
+    float t[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) t[e] = (ok && c0 + e < P.Cg) ? lrelu(v[e], P.in_slope) : 0.f;
+    u32x4 o;
+    o[0] = pack_bf16(t[0], t[1]); o[1] = pack_bf16(t[2], t[3]); o[2] = pack_bf16(t[4], t[5]); o[3] = pack_bf16(t[6], t[7]);
+    return o;
+  };
+
+  int xg[XRB];
+#pragma unroll
+  for (int u = 0; u < XRB; ++u) {
+    const int i = tid + u * NT;
+    const int bb = (int)__umulhi((unsigned)i, span_magic);
+    xg[u] = (P.ncc > 1 && i < xtot) ? ((bb << 16) | (i - bb * span)) : -1;
+  }
+  float xreg[XRB][8];
+  unsigned okmask = 0;
+  auto fetch_x = [&](int cc) {
+    const float* xp = P.x + xrow0;
+    okmask = 0;
+#pragma unroll
+    for (int u = 0; u < XRB; ++u) {
+      int ok;
+      const int qq = x_pos(xg[u] & 0xffff, ok);
+      ok &= (int)(xg[u] >= 0);
+      okmask |= (unsigned)ok << u;
+      load8(xp, cc * P.CI_T + (xg[u] >= 0 ? (xg[u] >> 16) * 8 : 0), qq, xreg[u]);
+    }
+  };
+  const int dead_slot = P.nxb * XBUF;
+  auto store_x = [&](int cc) {
+    const int bsel = cc % P.nxb;
+    u32x4* dst = Xs + bsel * XBUF;
+#pragma unroll
+    for (int u = 0; u < XRB; ++u) {
+      const int bb = xg[u] >> 16;
+      const int sl = xg[u] >= 0 ? x_slot(bb, xg[u] & 0xffff) : dead_slot - bsel * XBUF;
+      dst[sl] = cvt8(xreg[u], cc * P.CI_T + (xg[u] >= 0 ? bb * 8 : 0), (int)((okmask >> u) & 1u));
+    }
+  };
+
+  auto issue_w = [&](int ch) {
+    const u32x4* src = wsrc + (long long)ch * WCHU;
+    u32x4* dst = Ws + (ch & 1) * WCHU;
+#pragma unroll
+    for (int u = 0; u < PIECES; ++u) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (u * NT + tid)),
+                                       (__attribute__((address_space(3))) void*)(dst + (u * NT + (tid & ~63))), 16, 0, 0);
+    }
+  };
+
+  int written = 0;
+  if (nch > 0) {
+    issue_w(0);
+    const float* xp = P.x + xrow0;
+    for (int base = 0; base < xtot; base += 2 * NT) {
+      float v[2][8];
+      int sl[2], ok[2], c0[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int i = base + tid + u * NT;
+        const int bb = (int)__umulhi((unsigned)i, span_magic);
+        const int r = i - bb * span;
+        const int qq = x_pos(i < xtot ? r : 0, ok[u]);
+        ok[u] &= (int)(i < xtot);
+        c0[u] = i < xtot ? bb * 8 : 0;
+        load8(xp, c0[u], qq, v[u]);
+        sl[u] = i < xtot ? x_slot(bb, r) : -1;
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+        if (sl[u] >= 0) Xs[sl[u]] = cvt8(v[u], c0[u], ok[u]);
+    }
+    if (P.ncc > 1) fetch_x(1);
+  }
+  __syncthreads();
+
+  const int lanebase = (lane >> 5) * P.CSTRIDE + wn * 32 + (lane & 31);
+  int te[KSC];
+#pragma unroll
+  for (int ks = 0; ks < KSC; ++ks) te[ks] = nch > 0 ? tab[ks] : 0;
+  for (int ch = 0; ch < nch; ++ch) {
+    if (ch + 1 < nch) issue_w(ch + 1);
+    const u32x4* wb = Ws + (ch & 1) * WCHU + lane;
+    const u32x4* xb = Xs + lanebase;
+    u32x4 bv[KSC], a[KSC][FM];
+    auto rd = [&](int ks) {
+      bv[ks] = xb[te[ks]];
+#pragma unroll
+      for (int i = 0; i < FM; ++i) a[ks][i] = wb[(ks * FM + i) * 64];
+    };
+    rd(0);
+    rd(1);
+#pragma unroll
+    for (int ks = 0; ks < KSC; ++ks) {
+      if (ks + 2 < KSC) rd(ks + 2);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[ks][i]), __builtin_bit_cast(bf16x8, bv[ks]), acc[i], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (ch + 1 < nch) {
+#pragma unroll
+      for (int ks = 0; ks < KSC; ++ks) te[ks] = tab[(ch + 1) * KSC + ks];
+    }
+    if (P.ncc > 1 && written + 1 < P.ncc && (written + 1) * KS_CC < (ch + 2) * KSC) {
+      ++written;
+      store_x(written);
+      if (written + 1 < P.ncc) fetch_x(written + 1);
+    }
+    __syncthreads();
+  }
+
+  const bool use_res = P.res != nullptr && (P.res_rows == 0 || b < P.res_rows);
+  const int eb = P.em_seg > 0 ? P.em_map[b / P.em_seg] * P.em_seg + b % P.em_seg : b;
+  const long long eoff = (long long)(eb - b) * P.Cy * P.Ly;
+  // ---- epilogue: 32x32 D tile: column = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) ----
+  const int t = t0 + wn * 32 + (lane & 31);
+  if (t >= nt) return;
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      if (m >= P.Mg) continue;
+      const float bias = P.bias ? P.bias[g * P.Mg + m] : 0.f;
+      const long long idx = ((long long)b * P.Cy + (long long)g * P.Mg + m) * P.Ly + (long long)t * P.OS + oo;
+      float v = acc[i][r] + bias;
+      v = lrelu(v, P.out_slope);
+      if (use_res) v += lrelu(P.res[idx], P.res_slope);
+      if (P.emask) v *= dlrelu(P.emask[idx + eoff], P.emask_slope);
+      if (P.accumulate) v += P.y[idx];
+      P.y[idx] = v;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------
+struct Tap3Plan {
+  int ok;
+  int mode, G, Cg, Mg, S, OS, dstep, kstep, nph, J, Lx, Ly, Cx, Cy, off0, nt, ps_pad;
+  int FM, BM, BN, WCHU;
+  int CI_T, CI_B, CP, ncc, PLEN, CSTRIDE, nxbuf, XRB;
+  int nmt, ntt, NCH, tab_phase;
+  long long w_tile, w_phase, tab_off_floats;
+  size_t packed_floats, lds_bytes;
+};
+
+static int gcd3(int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a; }
+
+static int env_int3(const char* name, int dflt) {
+  const char* s = getenv(name);
+  return s ? atoi(s) : dflt;
+}
+
+static void make_plan3(const Canon& c, int dir, Tap3Plan* p) {
+  p->ok = 0;
+  p->mode = dir;
+  p->G = c.g;
+  if (dir == 0) {
+    p->Cg = c.Cin / c.g; p->Mg = c.Cout / c.g;
+    p->S = c.s; p->OS = 1; p->dstep = c.d; p->kstep = 1; p->nph = 1; p->J = c.k;
+    p->Lx = c.Lin; p->Ly = c.Lout; p->Cx = c.Cin; p->Cy = c.Cout;
+    p->off0 = -c.pl; p->nt = c.Lout; p->ps_pad = 0;
+  } else {
+    p->Cg = c.Cout / c.g; p->Mg = c.Cin / c.g;
+    p->S = 1; p->OS = c.s;
+    p->kstep = c.s / gcd3(c.s, c.d);
+    p->dstep = -(c.d * p->kstep) / c.s;
+    p->nph = c.s;
+    p->J = ceil_div(c.k, p->kstep);
+    p->Lx = c.Lout; p->Cx = c.Cout; p->Cy = c.Cin;
+    p->Ly = c.reflect ? c.Lin + c.pl + c.pr : c.Lin;
+    p->ps_pad = c.reflect ? 0 : c.pl;
+    p->off0 = 0; p->nt = ceil_div(p->Ly, c.s);
+  }
+  static const int enabled = env_int3("EBEN_TAP3", 1);
+  static const int min_m = env_int3("EBEN_TAP3_MIN_M", 24);
+  static const int min_c = env_int3("EBEN_TAP3_MIN_C", 12);
+  // worth a 16-channel k-step: at least 3/4 of it real, and a reduction of at least two weight chunks
+  if (!enabled || p->Cg < min_c || p->Mg < min_m || p->nph > 64 || (long long)round_up(p->Cg, 16) * p->J < 2 * 16 * T3_KSC) return;
+  const int Jmin = dir == 0 ? p->J : (c.k / p->kstep > 0 ? c.k / p->kstep : 1);
+
+  const int cand[4] = {128, 96, 64, 32};
+  const double eff[4] = {1.0, 0.9, 0.8, 0.5};
+  int best = 0;
+  double best_score = -1.0;
+  for (int i = 0; i < 4; ++i) {
+    const double score = eff[i] * p->Mg / round_up(p->Mg, cand[i]);
+    if (score > best_score + 1e-9) { best_score = score; best = cand[i]; }
+  }
+  {
+    const long long cols = (long long)ceil_div(p->nt, 128) * c.B * p->nph * p->G;
+    while (best > 32 && cols * ceil_div(p->Mg, best) < 256) {
+      const int smaller = best == 128 ? 64 : 32;
+      if (round_up(p->Mg, smaller) > round_up(p->Mg, best)) break;
+      best = smaller;
+    }
+  }
+  static const int force_bm = env_int3("EBEN_TAP3_BM", 0);
+  if (force_bm == 32 || force_bm == 64 || force_bm == 96 || force_bm == 128) best = force_bm;
+  p->BM = best; p->FM = best / 32; p->BN = 128;
+  p->WCHU = T3_KSC * p->FM * 64;
+  p->nmt = ceil_div(p->Mg, p->BM);
+  p->ntt = ceil_div(p->nt, p->BN);
+
+  const int adstep = p->dstep >= 0 ? p->dstep : -p->dstep;
+  const int maxd = ((p->J - 1) * adstep) / p->S + 1;
+  p->PLEN = p->BN + maxd + 1;
+  p->CSTRIDE = p->S * p->PLEN;
+  const int span = (p->BN - 1) * p->S + (p->J - 1) * adstep + 1;
+  if (span > 0xffff) return;
+  const int NT = 256;
+  static const int lds_budget = env_int3("EBEN_TAP3_LDS_KB", 78) * 1024;   // two blocks per CU
+  const int wbytes = 2 * p->WCHU * 16;
+  const int xbudget = lds_budget - wbytes - 16;
+  const int Cg2 = round_up(p->Cg, 16);
+  p->XRB = 2;
+  if ((long long)(Cg2 / 8) * p->CSTRIDE * 16 <= xbudget) {
+    p->CI_T = Cg2; p->ncc = 1; p->nxbuf = 1;
+  } else {
+    // hand-over rule of tapconv2.hip in weight chunks of T3_KSC k-steps: the tile of the next channel chunk is
+    // written one weight chunk before its first use into the buffer of the tile `nxbuf` chunks back
+    bool found = false;
+    for (int nbuf = 2; nbuf <= 3 && !found; ++nbuf) {
+      for (int xrb : {2, 3, 5}) {
+        int cap = (xrb * NT) / span * 8;          // channels
+        const int cap_lds = (nbuf == 2 ? xbudget : 110 * 1024 - wbytes) / nbuf / (p->CSTRIDE * 16) * 8;
+        if (cap > cap_lds) cap = cap_lds;
+        cap -= cap % 16;
+        if (cap < 16) continue;
+        const int nchk = ceil_div(Cg2, cap);
+        p->CI_T = round_up(ceil_div(p->Cg, nchk), 16);
+        p->ncc = ceil_div(p->Cg, p->CI_T);
+        p->nxbuf = nbuf;
+        p->XRB = xrb;
+        if (p->ncc > 1 && Jmin * (p->CI_T / 16) < (nbuf == 2 ? 2 * T3_KSC : T3_KSC)) continue;
+        found = true;
+        break;
+      }
+    }
+    if (!found) return;
+  }
+  p->CI_B = p->CI_T / 8;
+  p->CP = p->CI_T / 16;
+  const int KSmax = p->ncc * p->J * p->CP;
+  p->NCH = ceil_div(KSmax, T3_KSC);
+  p->tab_phase = p->NCH * T3_KSC;
+  p->w_tile = (long long)p->NCH * p->WCHU;
+  p->w_phase = p->w_tile * p->nmt * p->G;
+  p->tab_off_floats = p->w_phase * p->nph * 4;
+  p->packed_floats = (size_t)p->tab_off_floats + (size_t)p->tab_phase * p->nph;
+  p->lds_bytes = (size_t)wbytes + ((size_t)(p->nxbuf < 2 ? 2 : p->nxbuf) * 0 + (size_t)p->nxbuf * p->CI_B * p->CSTRIDE) * 16 + 16;
+  if (p->lds_bytes > 160 * 1024) return;
+  p->ok = 1;
+}
+
+struct Pack3Args {
+  const float* w; const float* scale; float* wp;
+  int G, Cg, Mg, nmt, BM, FM, WCHU, CI_T, CI_B, CP, ncc, NCH, nph, tab_phase;
+  int mode, J0, off0, nt, dstep, OS, S, ps_pad, k, d, kstep, Ly;
+  int Cin_g, Cout_g, PLEN, CSTRIDE, nxbuf;
+  long long w_tile, w_phase, wunits;
+};
+
+__global__ __launch_bounds__(256) void pack3_kernel(const Pack3Args P) {
+  const long long total = P.wunits + (long long)P.tab_phase * P.nph;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    if (i < P.wunits) {
+      long long r = i;
+      const int ph = (int)(r / P.w_phase); r -= (long long)ph * P.w_phase;
+      const int tile = (int)(r / P.w_tile); r -= (long long)tile * P.w_tile;
+      const int g = tile / P.nmt, mt = tile - g * P.nmt;
+      const int ch = (int)(r / P.WCHU);
+      const int e = (int)(r - (long long)ch * P.WCHU);
+      const int ks = e / (64 * P.FM);
+      const int fm = (e / 64) % P.FM;
+      const int lane = e & 63;
+      const PhaseGeom q = phase_geom(P.mode, ph, P.J0, P.off0, P.nt, P.dstep, P.OS, P.ps_pad, P.k, P.d, P.kstep, P.Ly);
+      const int s = ch * T3_KSC + ks;
+      const int KS_CC = q.J * P.CP;
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = 0.f;
+      if (q.J > 0 && s < P.ncc * KS_CC) {
+        const int cc = s / KS_CC, rem = s - cc * KS_CC;
+        const int j = rem / P.CP, cp = rem - j * P.CP;
+        const int m = mt * P.BM + fm * 32 + (lane & 31);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int chan = cc * P.CI_T + 16 * cp + 8 * (lane >> 5) + u;
+          if (chan < P.Cg && m < P.Mg) {
+            if (P.mode == 0) {
+              const int co = g * P.Cout_g + m;
+              v[u] = P.w[((long long)co * P.Cin_g + chan) * P.k + j];
+              if (P.scale) v[u] *= P.scale[co];
+            } else {
+              const int kk = q.k0 + j * P.kstep;
+              if (kk < P.k) {
+                const int co = g * P.Cout_g + chan;  // reduction channel = conv output channel
+                v[u] = P.w[((long long)co * P.Cin_g + m) * P.k + kk];
+                if (P.scale) v[u] *= P.scale[co];
+              }
+            }
+          }
+        }
+      }
+      u32x4 o;
+      o[0] = pack_bf16(v[0], v[1]); o[1] = pack_bf16(v[2], v[3]); o[2] = pack_bf16(v[4], v[5]); o[3] = pack_bf16(v[6], v[7]);
+      reinterpret_cast<u32x4*>(P.wp)[i] = o;
+    } else {
+      const long long r = i - P.wunits;
+      const int ph = (int)(r / P.tab_phase);
+      const int s = (int)(r - (long long)ph * P.tab_phase);
+      const PhaseGeom q = phase_geom(P.mode, ph, P.J0, P.off0, P.nt, P.dstep, P.OS, P.ps_pad, P.k, P.d, P.kstep, P.Ly);
+      const int KS_CC = q.J * P.CP;
+      int o = 0;
+      if (q.J > 0 && s < P.ncc * KS_CC) {
+        const int cc = s / KS_CC, rem = s - cc * KS_CC;
+        const int j = rem / P.CP, cp = rem - j * P.CP;
+        const int rel = q.off0 + j * P.dstep - q.minoff;
+        const int dd = rel / P.S, pp = rel - dd * P.S;
+        o = (P.nxbuf > 1 ? (cc % P.nxbuf) * P.CI_B * P.CSTRIDE : 0) + 2 * cp * P.CSTRIDE + pp * P.PLEN + dd;
+      }
+      reinterpret_cast<int*>(P.wp)[P.wunits * 4 + r] = o;
+    }
+  }
+}
+
+template <int FM, int XRB>
+static int launch3_cfg(const Tap3Args& a, int nblocks, size_t lds, hipStream_t st) {
+  static bool attr_set = false;
+  auto kern = tap3_kernel<FM, XRB>;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(tap3)");
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), lds, st, a);
+  EBEN_CHECK_LAUNCH("tap3_kernel");
+  return EBEN_OK;
+}
+
+int tap3_applicable(const Canon& c, int dir) {
+  Tap3Plan p;
+  make_plan3(c, dir, &p);
+  return p.ok;
+}
+
+size_t tap3_packed_floats(const Canon& c, int dir) {
+  Tap3Plan p;
+  make_plan3(c, dir, &p);
+  return p.ok ? p.packed_floats : 0;
+}
+
+int tap3_pack(const Canon& c, int dir, const float* w, const float* scale, float* wp, hipStream_t st) {
+  Tap3Plan p;
+  make_plan3(c, dir, &p);
+  if (!p.ok) return fail(EBEN_EUNSUPPORTED, "tap3_pack on a layer the bf16 kernel does not cover");
+  Pack3Args a;
+  a.w = w; a.scale = scale; a.wp = wp;
+  a.G = p.G; a.Cg = p.Cg; a.Mg = p.Mg; a.nmt = p.nmt; a.BM = p.BM; a.FM = p.FM; a.WCHU = p.WCHU;
+  a.CI_T = p.CI_T; a.CI_B = p.CI_B; a.CP = p.CP; a.ncc = p.ncc; a.NCH = p.NCH; a.nph = p.nph; a.tab_phase = p.tab_phase;
+  a.mode = p.mode; a.J0 = p.J; a.off0 = p.off0; a.nt = p.nt; a.dstep = p.dstep; a.OS = p.OS; a.S = p.S; a.ps_pad = p.ps_pad;
+  a.k = c.k; a.d = c.d; a.kstep = p.kstep; a.Ly = p.Ly;
+  a.Cin_g = c.Cin / c.g; a.Cout_g = c.Cout / c.g; a.PLEN = p.PLEN; a.CSTRIDE = p.CSTRIDE; a.nxbuf = p.nxbuf;
+  a.w_tile = p.w_tile; a.w_phase = p.w_phase; a.wunits = p.w_phase * p.nph;
+  long long blocks = (a.wunits + (long long)p.tab_phase * p.nph + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(pack3_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
+  EBEN_CHECK_LAUNCH("pack3_kernel");
+  return EBEN_OK;
+}
+
+int tap3_launch(const Canon& c, int dir, const TapIO& io, int reflect, hipStream_t st) {
+  Tap3Plan p;
+  make_plan3(c, dir, &p);
+  if (!p.ok) return fail(EBEN_EUNSUPPORTED, "tap3_launch on a layer the bf16 kernel does not cover");
+  if (io.in_mode != 0) return fail(EBEN_EUNSUPPORTED, "the bf16 kernel has no mask-on-load input stage (use the epilogue mask of the producer)");
+  Tap3Args a;
+  a.x = io.x; a.wp = reinterpret_cast<const u32x4*>(io.wp); a.tab = reinterpret_cast<const int*>(io.wp + p.tab_off_floats);
+  a.bias = io.bias; a.res = io.res; a.emask = io.emask; a.y = io.y;
+  a.B = c.B; a.G = p.G; a.Cg = p.Cg; a.Mg = p.Mg; a.Cx = p.Cx; a.Cy = p.Cy; a.Lx = p.Lx; a.Ly = p.Ly;
+  a.S = p.S; a.OS = p.OS; a.dstep = p.dstep; a.J0 = p.J; a.mode = p.mode; a.off0 = p.off0; a.nt = p.nt; a.nph = p.nph;
+  a.ps_pad = p.ps_pad; a.ps_k = c.k; a.ps_d = c.d; a.ps_kstep = p.kstep;
+  a.reflect = reflect; a.accumulate = io.accumulate;
+  a.res_rows = io.res_rows; a.em_seg = io.em_seg;
+  for (int i = 0; i < 4; ++i) a.em_map[i] = io.em_map[i];
+  a.in_slope = io.in_slope; a.out_slope = io.out_slope; a.res_slope = io.res_slope; a.emask_slope = io.emask_slope;
+  a.CI_T = p.CI_T; a.CI_B = p.CI_B; a.CP = p.CP; a.ncc = p.ncc; a.PLEN = p.PLEN; a.CSTRIDE = p.CSTRIDE; a.nxb = p.nxbuf;
+  a.s_magic = p.S > 1 ? (unsigned)((0x100000000ull + p.S - 1) / p.S) : 0u;
+  a.ntt = p.ntt; a.nmt = p.nmt; a.tab_phase = p.tab_phase;
+  a.w_tile = p.w_tile; a.w_phase = p.w_phase;
+  const long long nb = (long long)p.ntt * c.B * p.nph * p.nmt * p.G;
+  if (nb <= 0 || nb > 0x7fffffffLL) return fail(EBEN_EINVAL, "tap3 grid of %lld blocks", nb);
+#define EBEN_T3_CASE(FMV)                                                          \
+  switch (p.XRB) {                                                                 \
+    case 2: return launch3_cfg<FMV, 2>(a, (int)nb, p.lds_bytes, st);               \
+    case 3: return launch3_cfg<FMV, 3>(a, (int)nb, p.lds_bytes, st);               \
+    default: return launch3_cfg<FMV, 5>(a, (int)nb, p.lds_bytes, st);              \
+  }
+  switch (p.FM) {
+    case 1: EBEN_T3_CASE(1)
+    case 2: EBEN_T3_CASE(2)
+    case 3: EBEN_T3_CASE(3)
+    default: EBEN_T3_CASE(4)
+  }
+#undef EBEN_T3_CASE
+}
+
+}  // namespace eben

@@ -44,8 +44,9 @@ def _stream() -> int:
 class _Layer:
     """One weight-normalised conv of a sub-discriminator with the packed copies the engine needs."""
 
-    def __init__(self, conv):
+    def __init__(self, conv, math: int = ops.MATH_F32):
         self.conv = conv
+        self.math = math
         self.spec: ops.ConvSpec = conv.spec
         self.spec_lin = dataclasses.replace(conv.spec, in_slope=1.0, out_slope=1.0)   # gradients arrive pre-masked
         self.packs: Dict[Tuple[int, int, int], Tuple[tuple, torch.Tensor]] = {}
@@ -78,7 +79,7 @@ class _Layer:
         hit = self.packs.get(slot)
         if hit is not None and hit[0] == wkey:
             return hit[1]
-        d = ops.conv_desc(self.spec, batch, l_in)
+        d = ops.conv_desc(self.spec, batch, l_in, self.math)
         wp = torch.empty(lib.eben_conv1d_packed_floats(ctypes.byref(d), which), dtype=torch.float32, device=v.device)
         check(lib.eben_conv1d_pack(ctypes.byref(d), ptr(v), ptr(self.scale), ptr(wp) if which == 0 else None,
                                    ptr(wp) if which == 1 else None, _stream()), "conv1d_pack")
@@ -89,18 +90,19 @@ class _Layer:
 class _Chain:
     """A sub-discriminator: ReflectionPad1d(pad) followed by the conv stack (last conv = logits)."""
 
-    def __init__(self, modules):
+    def __init__(self, modules, math: int = ops.MATH_F32):
         self.layers: List[_Layer] = []
         self.pad = 0
+        self.math = math
         for m in modules:
             if isinstance(m, torch.nn.Sequential):
                 for sub in m:
                     if hasattr(sub, "padding") and not hasattr(sub, "spec"):
                         self.pad = int(sub.padding)
                     else:
-                        self.layers.append(_Layer(sub))
+                        self.layers.append(_Layer(sub, math))
             else:
-                self.layers.append(_Layer(m))
+                self.layers.append(_Layer(m, math))
 
     # ---- forward on a (2B, C, L) batch: returns [input, out_0, ..., logits] and the padded input
     def forward(self, x: torch.Tensor):
@@ -115,7 +117,7 @@ class _Chain:
         outs = []
         cur = xp
         for lay in self.layers:
-            d = ops.conv_desc(lay.spec, b, cur.shape[2])
+            d = ops.conv_desc(lay.spec, b, cur.shape[2], self.math)
             y = torch.empty((b, lay.spec.c_out, d.l_out), dtype=torch.float32, device=x.device)
             _, _, bias = lay.params()
             wp = lay.packed(0, b, cur.shape[2])
@@ -154,7 +156,7 @@ class _Chain:
                 jobs.append((i, g, x_in))
             if i > 0:
                 rows = 4 * half
-                d = ops.conv_desc(lay.spec_lin, rows, l_in)
+                d = ops.conv_desc(lay.spec_lin, rows, l_in, self.math)
                 gp = torch.empty((rows, lay.spec.c_in, l_in), dtype=torch.float32, device=g.device)
                 res = fm_grads[i - 1]
                 prev_slope = self.layers[i - 1].spec.out_slope
@@ -164,7 +166,7 @@ class _Chain:
                 g = gp
             else:
                 rows = 2 * half   # only the generator-side signals reach the discriminator input
-                d = ops.conv_desc(lay.spec_lin, rows, l_in)
+                d = ops.conv_desc(lay.spec_lin, rows, l_in, self.math)
                 gp = torch.empty((rows, lay.spec.c_in, l_in), dtype=torch.float32, device=g.device)
                 check(lib.eben_conv1d_bwd_dx_ex(ctypes.byref(d), ptr(g), ptr(lay.packed(1, rows, l_in)), None, 0, None, 1.0, 0, None, ptr(gp), st),
                       "conv1d_bwd_dx_ex")
@@ -204,7 +206,7 @@ class _Chain:
         lib = load()
         v, gain, bias = lay.params()
         rows_b = g2.shape[0]
-        d = ops.conv_desc(lay.spec_lin, rows_b, x_in.shape[2])
+        d = ops.conv_desc(lay.spec_lin, rows_b, x_in.shape[2], lay.math)
         nslab, row_stride = ctypes.c_int(0), ctypes.c_int(0)
         ws_bytes = lib.eben_conv1d_bwd_dw_workspace(ctypes.byref(d), ctypes.byref(nslab), ctypes.byref(row_stride))
         slabs = torch.empty(max(1, (ws_bytes + 3) // 4), dtype=torch.float32, device=g2.device)
@@ -242,10 +244,13 @@ def inject_grads(params: Sequence[torch.nn.Parameter], grads: Sequence[torch.Ten
 
 
 class DiscriminatorEngine:
-    def __init__(self, disc):
+    def __init__(self, disc, math: int = ops.MATH_F32):
+        """math = ops.MATH_BF16: the contractions of the layers tapconv3.hip covers take bf16 operands (fp32
+        accumulation, storage and element-wise stages); everything else is unchanged."""
         self.disc = disc
         self.q = disc.q
-        self.chains = [_Chain(d.discriminator) for d in disc.pqmf_discriminators] + [_Chain(disc.melgan_discriminator.discriminator)]
+        self.math = math
+        self.chains = [_Chain(d.discriminator, math) for d in disc.pqmf_discriminators] + [_Chain(disc.melgan_discriminator.discriminator, math)]
         self._streams = None
         self._state = None
 

@@ -103,6 +103,9 @@ class EBENLightningModule(BaseSELightningModule):
 
     #: run the discriminator passes batched and outside autograd (vibravox_amd/disc_engine.py)
     use_disc_engine: bool = os.environ.get("EBEN_DISC_ENGINE", "1") != "0"
+    #: arithmetic of the discriminator contractions inside the engine: "f32" (bit-exact fp32 products) or "bf16"
+    #: (bf16 MFMA operands, fp32 accumulate -- BASELINE config 2).  The generator always computes in fp32.
+    disc_math: str = os.environ.get("EBEN_DISC_MATH", "f32")
 
     def _engine_usable(self, batch) -> bool:
         from ..disc_engine import DiscriminatorEngine
@@ -124,8 +127,9 @@ class EBENLightningModule(BaseSELightningModule):
         reference_speech = self.generator.cut_to_valid_length(batch["audio_airborne"])
         generator_optimizer, discriminator_optimizer = self.optimizers(use_pl_optimizer=True)
         g_params = [p for p in self.generator.parameters() if p.requires_grad]
-        if getattr(self, "_disc_engine", None) is None or self._disc_engine.disc is not self.discriminator:
-            self._disc_engine = DiscriminatorEngine(self.discriminator)
+        math = {"f32": ops.MATH_F32, "bf16": ops.MATH_BF16}[self.disc_math]
+        if getattr(self, "_disc_engine", None) is None or self._disc_engine.disc is not self.discriminator or self._disc_engine.math != math:
+            self._disc_engine = DiscriminatorEngine(self.discriminator, math)
         engine = self._disc_engine
 
         # ---- generator phase

@@ -142,13 +142,16 @@ class ConvSpec:
 _desc_cache: Dict[Tuple[ConvSpec, int, int], EbenConv1dDesc] = {}
 
 
-def conv_desc(spec: ConvSpec, batch: int, l_in: int) -> EbenConv1dDesc:
-    key = (spec, batch, l_in)
+MATH_F32, MATH_BF16 = 0, 1   # EBEN_MATH_* of include/eben_hip.h
+
+
+def conv_desc(spec: ConvSpec, batch: int, l_in: int, math: int = MATH_F32) -> EbenConv1dDesc:
+    key = (spec, batch, l_in, math)
     d = _desc_cache.get(key)
     if d is None:
         d = EbenConv1dDesc(
             batch, spec.c_in, spec.c_out, l_in, spec.out_len(l_in), spec.ksize, spec.stride, spec.dilation, spec.groups,
-            spec.pad_l, spec.pad_r, 1 if spec.reflect else 0, 1 if spec.transposed else 0, spec.in_slope, spec.out_slope,
+            spec.pad_l, spec.pad_r, 1 if spec.reflect else 0, 1 if spec.transposed else 0, spec.in_slope, spec.out_slope, math,
         )
         _desc_cache[key] = d
     return d
