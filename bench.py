@@ -23,7 +23,8 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense fp32
+MFMA_F32_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2_f32, dense fp32
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense (no sparsity)
 
 
 def build_module(device, batch_seed):
@@ -50,10 +51,10 @@ def build_module(device, batch_seed):
     return mod
 
 
-def pmc_traffic(batch):
+def pmc_traffic(batch, math):
     """HBM bytes per launch of the roofline kernel from the committed rocprofv3 PMC passes
-    (profiles/r01_pmc_melgan_l4_fwd.json; collected by tools/pmc_traffic.sh at the batch the step launches)."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_melgan_l4_fwd.json")
+    (profiles/r01_pmc_melgan_l4_fwd[_bf16].json; collected by tools/pmc_traffic.sh at the batch the step launches)."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_melgan_l4_fwd_bf16.json" if math == "bf16" else "r01_pmc_melgan_l4_fwd.json")
     if not os.path.exists(path):
         return None
     with open(path) as f:
@@ -105,6 +106,10 @@ def main():
     ap.add_argument("--cpu-batch", type=int, default=32)
     ap.add_argument("--cpu-steps", type=int, default=1)
     ap.add_argument("--force-ddp", action="store_true", help="run the bucketed RCCL gradient path even with one rank")
+    ap.add_argument("--disc-math", default=os.environ.get("EBEN_DISC_MATH", "bf16"), choices=["bf16", "f32"],
+                    help="discriminator contractions: bf16 MFMA operands with fp32 accumulate (BASELINE config 2 names bf16) or exact "
+                         "fp32 products; the generator computes in fp32 either way")
+    ap.add_argument("--no-f32-leg", action="store_true", help="skip the extra fp32-discriminator timing reported beside a bf16 run")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -127,6 +132,7 @@ def main():
     from vibravox_amd.ddp import BucketedZeroGrad, GradSync
 
     mod = build_module(device, 1234 + rank)
+    mod.disc_math = args.disc_math
     if use_ddp:
         g_opt, d_opt = mod.optimizers()
         gs, ds = GradSync(mod.generator.parameters()), GradSync(mod.discriminator.parameters())
@@ -165,10 +171,26 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # beside a bf16 run: the same K steps with exact-fp32 discriminator products (the parity mode of tests/), reported
+    # as `f32_discriminator` -- never as `value`
+    dt32 = None
+    if args.disc_math == "bf16" and not args.no_f32_leg:
+        mod.disc_math = "f32"
+        mod.training_step(batch)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            mod.training_step(batch)
+        barrier()
+        dt32 = time.perf_counter() - t1
+        if world > 1:
+            t = torch.tensor([dt32], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt32 = float(t.item())
+
     if rank == 0:
         ms = dt / args.steps * 1e3
         value = world * args.batch * cut / 16000 / (dt / args.steps)
-        l_in = ((cut // 4 // 4 // 4) if False else None)
         sp = layer.spec
         lx = cut
         for (_, _, k, s, p, _) in [(1, 16, 15, 1, 7, 1), (16, 64, 41, 4, 20, 4), (64, 256, 41, 4, 20, 4), (256, 1024, 41, 4, 20, 4)]:
@@ -178,20 +200,27 @@ def main():
         flops = 2.0 * launch_batch * sp.c_out * (sp.c_in // sp.groups) * sp.ksize * l_out
         kms = timer.mean_ms()
         achieved = flops / (kms * 1e-3) / 1e12 if kms else None
+        peak = MFMA_BF16_PEAK_TFLOPS if args.disc_math == "bf16" else MFMA_F32_PEAK_TFLOPS
+        kname = "tap3_kernel<4,*> (v_mfma_f32_32x32x16_bf16)" if args.disc_math == "bf16" else "tap2_kernel<4,4,16> (v_mfma_f32_32x32x2_f32)"
         line = {
             "metric": "EBEN train-step audio-seconds/sec (gen+disc)", "value": round(value, 2), "unit": "audio-seconds/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": args.disc_math, "data": "synthetic",
             "config": {"workload": f"EBEN full GAN train step (gen+disc+MRSTFT+feature-matching+hinge, EMA balancing, Adam), "
                                    f"batch {args.batch} x {args.length} samples @16kHz per GPU (cut to {cut})",
                        "global_batch": world * args.batch, "samples_per_clip": cut, "parallelism": f"dp{world}",
-                       "weights": "random init, torch.manual_seed(42)"},
-            "roofline": {"bound": "mfma", "kernel": f"eben::tap2_kernel<4,4,16> MelGAN L4 fwd (1024->1024 k41 s4 g4), {launch_batch} items per launch",
-                         "achieved": round(achieved, 2) if achieved else None, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4) if achieved else None, "traffic": pmc_traffic(launch_batch),
+                       "weights": "random init, torch.manual_seed(42)",
+                       "precision": ("discriminator contractions (91 % of the step's FLOPs): bf16 MFMA operands, fp32 accumulate; generator, "
+                                     "losses, Adam, storage: fp32" if args.disc_math == "bf16" else "fp32 throughout (exact fp32 MFMA products)")},
+            "roofline": {"bound": "mfma", "kernel": f"eben::{kname} MelGAN L4 fwd (1024->1024 k41 s4 g4), {launch_batch} items per launch",
+                         "achieved": round(achieved, 2) if achieved else None, "peak": peak, "unit": "TFLOP/s",
+                         "frac": round(achieved / peak, 4) if achieved else None, "traffic": pmc_traffic(launch_batch, args.disc_math),
                          "launch_ms": round(kms, 4) if kms else None, "flops_per_launch": flops,
                          "launches_timed": len(timer.events)},
         }
+        if dt32 is not None:
+            line["f32_discriminator"] = {"ms_per_step": round(dt32 / args.steps * 1e3, 3), "steps": args.steps,
+                                         "value": round(world * args.batch * cut / 16000 / (dt32 / args.steps), 2), "unit": "audio-seconds/sec"}
         print(f"[bench] GPU: {ms:.1f} ms/step, {value:.1f} audio-s/s", file=sys.stderr, flush=True)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_batch, args.length, args.cpu_steps)

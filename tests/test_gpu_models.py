@@ -269,6 +269,39 @@ def test_full_size_step_properties(hip, golden):
     assert all(k.endswith(".bias") for k in still) and len(still) <= 4, still
 
 
+def test_bf16_discriminator_math_against_fp32_step(hip, golden):
+    """disc_math = "bf16" (BASELINE config 2): the discriminator contractions take bf16 MFMA operands, everything
+    else -- the generator, accumulation, losses, Adam -- is unchanged fp32.  One step from the same state in both
+    modes: the generator output is IDENTICAL (it never sees the discriminator), the logged losses and balancing
+    norms move by ~1e-3, the generator gradient by < 2 % (whole-vector relative L2; Adam's first moment after one
+    step is (1 - beta1) * grad).  The discriminator gradient is the difference of two coherent sums (fake and real
+    hinge branches, opposite signs) and inherits the bf16 noise of each un-cancelled: tens of percent at
+    initialisation -- the stated cost of this mode, measured here and bounded loosely."""
+    res = {}
+    for math in ("f32", "bf16"):
+        mod, _, _ = make_module(golden, use_mrstft=True)
+        mod.disc_math = math
+        batch = {"audio_body_conducted": formula_audio("bf/bc", 4, 8200).to(DEV), "audio_airborne": formula_audio("bf/air", 4, 8200).to(DEV)}
+        out = mod.training_step(batch)
+        torch.cuda.synchronize()
+        moments = []
+        for opt in mod.optimizers():
+            moments.append(torch.cat([opt.state[p]["exp_avg"].double().flatten().cpu() for grp in opt.param_groups for p in grp["params"]
+                                      if "exp_avg" in opt.state.get(p, {})]))
+        res[math] = (out["enhanced"].clone(), {k: float(v) for k, v in mod.logged.items()}, torch.stack(mod.last_norms).cpu(), moments)
+    a, b = res["f32"], res["bf16"]
+    assert torch.equal(a[0], b[0])
+    rel = {k: abs(b[1][k] - v) / abs(v) for k, v in a[1].items()}
+    n_rel = float(((a[2] - b[2]).abs() / a[2].abs()).max())
+    g_rel = float((a[3][0] - b[3][0]).norm() / a[3][0].norm())
+    d_rel = float((a[3][1] - b[3][1]).norm() / a[3][1].norm())
+    print(f"bf16 discriminator math: losses {rel}, norms {n_rel:.3e}, generator grad rel-L2 {g_rel:.3e}, discriminator grad rel-L2 {d_rel:.3e}")
+    # the feature-matching loss is a sum of L1 distances between nearly equal embeddings (formula weights): percent level
+    for k, r in rel.items():
+        assert r < (5e-2 if "feature_matching" in k or "backprop" in k else 5e-3), (k, r)
+    assert n_rel < 5e-2 and g_rel < 5e-2 and d_rel < 1.0
+
+
 def test_train_step_is_bitwise_reproducible(hip, golden):
     """Every kernel on the path reduces in a fixed order (no float atomics), so two runs from the same
     state must agree bit for bit -- parameters and Adam moments; a difference is a race between the
@@ -285,7 +318,8 @@ def test_train_step_is_bitwise_reproducible(hip, golden):
         out.update({f"D.{k}": v.clone() for k, v in mod.discriminator.state_dict().items()})
         for oi, opt in enumerate(mod.optimizers()):
             for pi, prm in enumerate(p for grp in opt.param_groups for p in grp["params"]):
-                out[f"adam{oi}.m.{pi}"] = opt.state[prm]["exp_avg"].clone()
+                if "exp_avg" in opt.state.get(prm, {}):   # the frozen PQMF banks never get a moment
+                    out[f"adam{oi}.m.{pi}"] = opt.state[prm]["exp_avg"].clone()
         return out
 
     a, b = run(), run()

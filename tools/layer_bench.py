@@ -105,8 +105,17 @@ def main():
                 return check(lib.eben_conv1d_bwd_dx_ex(ctypes.byref(d), ptr(dy), ptr(pw.wp_bwd), None, 0, None, 1.0, 0, None, ptr(dx), st))
             check(lib.eben_conv1d_bwd_dx(ctypes.byref(d), ptr(dy), ptr(ymask), ptr(pw.wp_bwd), ptr(xmask), ptr(dx), 0, ptr(ws), wsb, st))
 
+        if math == ops.MATH_BF16:   # the engine's form: pre-masked gradient, linear conv
+            import dataclasses
+            d_lin = ops.conv_desc(dataclasses.replace(spec, in_slope=1.0, out_slope=1.0), a.batch, l_in, math)
+            dwb = lib.eben_conv1d_bwd_dw_workspace(ctypes.byref(d_lin), ctypes.byref(nslab), ctypes.byref(rs))
+            slabs = torch.empty(max(1, dwb // 4), device=dev)
+
         def bdw():
-            check(lib.eben_conv1d_bwd_dw(ctypes.byref(d), ptr(dy), ptr(ymask), ptr(x), 1 if has_bias else 0, ptr(slabs), dwb, st))
+            if math == ops.MATH_BF16:
+                check(lib.eben_conv1d_bwd_dw(ctypes.byref(d_lin), ptr(dy), None, ptr(x), 1 if has_bias else 0, ptr(slabs), dwb, st))
+            else:
+                check(lib.eben_conv1d_bwd_dw(ctypes.byref(d), ptr(dy), ptr(ymask), ptr(x), 1 if has_bias else 0, ptr(slabs), dwb, st))
             check(lib.eben_wn_bwd(ptr(slabs), nslab.value, wshape[0] * rs.value, wshape[0], wshape[1] * wshape[2], rs.value,
                                   ptr(g), ptr(v), ptr(pw.norm), ptr(dg), ptr(dv), ptr(db), st))
 

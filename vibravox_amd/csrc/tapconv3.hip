@@ -300,7 +300,7 @@ static void make_plan3(const Canon& c, int dir, Tap3Plan* p) {
     p->off0 = 0; p->nt = ceil_div(p->Ly, c.s);
   }
   static const int enabled = env_int3("EBEN_TAP3", 1);
-  static const int min_m = env_int3("EBEN_TAP3_MIN_M", 24);
+  static const int min_m = env_int3("EBEN_TAP3_MIN_M", 16);
   static const int min_c = env_int3("EBEN_TAP3_MIN_C", 12);
   // worth a 16-channel k-step: at least 3/4 of it real, and a reduction of at least two weight chunks
   if (!enabled || p->Cg < min_c || p->Mg < min_m || p->nph > 64 || (long long)round_up(p->Cg, 16) * p->J < 2 * 16 * T3_KSC) return;
@@ -375,7 +375,7 @@ static void make_plan3(const Canon& c, int dir, Tap3Plan* p) {
   p->w_phase = p->w_tile * p->nmt * p->G;
   p->tab_off_floats = p->w_phase * p->nph * 4;
   p->packed_floats = (size_t)p->tab_off_floats + (size_t)p->tab_phase * p->nph;
-  p->lds_bytes = (size_t)wbytes + ((size_t)(p->nxbuf < 2 ? 2 : p->nxbuf) * 0 + (size_t)p->nxbuf * p->CI_B * p->CSTRIDE) * 16 + 16;
+  p->lds_bytes = (size_t)wbytes + (size_t)p->nxbuf * p->CI_B * p->CSTRIDE * 16 + 16;   // + the spare unit
   if (p->lds_bytes > 160 * 1024) return;
   p->ok = 1;
 }
