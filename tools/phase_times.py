@@ -1,0 +1,29 @@
+"""Where the main stream spends the step: HIP events between the phases of the engine train step (mean over steps)."""
+import os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+dev = torch.device("cuda", 0)
+mod = bench.build_module(dev, 1234)
+mod.disc_math = os.environ.get("EBEN_DISC_MATH", "bf16")
+batch = bench.synthetic_batch(32, 32000, 1234, dev)
+for _ in range(3):
+    mod.training_step(batch)
+torch.cuda.synchronize()
+N = 10
+acc = {}
+order = []
+for _ in range(N):
+    mod.phase_events = []
+    mod.training_step(batch)
+    torch.cuda.synchronize()
+    ev = mod.phase_events
+    for (l0, e0), (l1, e1) in zip(ev[:-1], ev[1:]):
+        if l1 not in acc:
+            order.append(l1)
+        acc[l1] = acc.get(l1, 0.0) + e0.elapsed_time(e1)
+tot = 0.0
+for k in order:
+    print(f"{acc[k] / N:7.2f} ms  {k}")
+    tot += acc[k] / N
+print(f"{tot:7.2f} ms  total between first and last marker ({mod.disc_math})")

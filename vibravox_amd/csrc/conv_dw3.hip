@@ -283,8 +283,8 @@ static void make_dw3_plan(const Canon& c, Dw3Plan* p) {
   p->G = c.g; p->Cg = c.Cin / c.g; p->Mg = c.Cout / c.g; p->J = c.k;
   p->Ng = p->Cg * c.k; p->row_stride = p->Ng + 1;
   static const int enabled = dw3_env("EBEN_DW3", 1);
-  static const int min_m = dw3_env("EBEN_DW3_MIN_M", 12);
-  static const int min_n = dw3_env("EBEN_DW3_MIN_N", 64);
+  static const int min_m = dw3_env("EBEN_DW3_MIN_M", 4);
+  static const int min_n = dw3_env("EBEN_DW3_MIN_N", 12);
   if (!enabled || !c.bf16 || p->Mg < min_m || p->Ng < min_n || c.B < 8) return;
   const int cand[4] = {128, 96, 64, 32};
   int best = 0, best_pad = 1 << 30;

@@ -259,31 +259,49 @@ class DiscriminatorEngine:
         return hasattr(disc, "pqmf_discriminators") and hasattr(disc, "melgan_discriminator") and all(
             hasattr(m, "discriminator") for m in list(disc.pqmf_discriminators) + [disc.melgan_discriminator])
 
-    def _on_streams(self, fn):
-        """fn(i) for each sub-discriminator on its own HIP stream; results in order."""
+    def _launch_on_streams(self, fn):
+        """fn(i) for each sub-discriminator on its own HIP stream, the longest chain (MelGAN, last) first so that it
+        is never queued behind a short one; results in chain order.  The caller joins with ``_join_streams``."""
         main = torch.cuda.current_stream()
         dev = main.device
         if self._streams is None or self._streams[0].device != dev:
             self._streams = [torch.cuda.Stream(device=dev) for _ in self.chains]
         results = [None] * len(self.chains)
-        for i, st in enumerate(self._streams):
+        n = len(self.chains)
+        for i in [n - 1] + list(range(n - 1)):
+            st = self._streams[i]
             st.wait_stream(main)
             with torch.cuda.stream(st):
                 results[i] = fn(i)
+        return results
+
+    def _join_streams(self):
+        main = torch.cuda.current_stream()
         for st in self._streams:
             main.wait_stream(st)
+
+    def _on_streams(self, fn):
+        results = self._launch_on_streams(fn)
+        self._join_streams()
         return results
 
     # ---- the two forwards as one batch-2B pass -------------------------------------------------
     @torch.no_grad()
-    def forward(self, bands: torch.Tensor, audio: torch.Tensor, bands_ref: torch.Tensor, audio_ref: torch.Tensor):
+    def forward(self, bands: torch.Tensor, audio: torch.Tensor, bands_ref: torch.Tensor, audio_ref: torch.Tensor, join: bool = True):
+        """join=False leaves the four chains running (the caller overlaps independent work on the main stream and
+        calls ``join()`` before anything reads the embeddings)."""
         half = bands.shape[0]
         sub = torch.cat((bands[:, -self.q:, :], bands_ref[:, -self.q:, :]), dim=0).contiguous()
         wav = torch.cat((audio, audio_ref), dim=0).contiguous()
         inputs = [sub] * (len(self.chains) - 1) + [wav]
-        res = self._on_streams(lambda i: self.chains[i].forward(inputs[i]))
+        res = self._launch_on_streams(lambda i: self.chains[i].forward(inputs[i]))
+        if join:
+            self._join_streams()
         self._state = dict(half=half, emb=[r[0] for r in res], xp=[r[1] for r in res], bands_shape=tuple(bands.shape))
         return self._state["emb"]
+
+    def join(self):
+        self._join_streams()
 
     # ---- the four scalar losses (device tensors) ------------------------------------------------
     @torch.no_grad()
@@ -316,11 +334,14 @@ class DiscriminatorEngine:
         return out
 
     # ---- the four backwards as one stacked pass ------------------------------------------------------
-    @torch.no_grad()
     def backward(self, want_param_grads: bool = True):
-        """Returns (d fm / d bands, d fm / d audio, d adv / d bands, d adv / d audio).  With ``want_param_grads`` the
-        weight gradients of real_loss + fake_loss are launched behind the input-gradient chains and left running
-        (``collect_param_grads`` joins them)."""
+        self.backward_launch(want_param_grads)
+        return self.backward_finish()
+
+    @torch.no_grad()
+    def backward_launch(self, want_param_grads: bool = True):
+        """Launches the stacked input-gradient chains on the four streams and returns; ``backward_finish`` joins them
+        (the caller may run independent main-stream work in between)."""
         lib = load()
         s = self._state
         half, emb = s["half"], s["emb"]
@@ -348,7 +369,20 @@ class DiscriminatorEngine:
                 check(lib.eben_hinge_bwd(ptr(rows), rows.numel(), target, ptr(one), inv_scales, ptr(flat[(k2 + 1) * per:]), _stream()), "hinge_bwd")
             return self.chains[i].backward(scale, s["xp"][i], fm_per_chain[i], seeds, half, want_param_grads)
 
-        res = self._on_streams(run)
+        # `da` / `one` live on the main stream's pool and are read by the chains: keep them referenced until the join
+        self._bwd = (self._launch_on_streams(run), want_param_grads, (da, one, fm_per_chain))
+
+    @torch.no_grad()
+    def backward_finish(self):
+        """Returns (d fm / d bands, d fm / d audio, d adv / d bands, d adv / d audio).  With ``want_param_grads`` the
+        weight gradients of real_loss + fake_loss are launched behind the input-gradient chains and left running
+        (``collect_param_grads`` joins them)."""
+        res, want_param_grads, _keep = self._bwd
+        self._join_streams()
+        self._bwd = _keep = None
+        s = self._state
+        half = s["half"]
+        dev = s["emb"][0][0].device
         main = torch.cuda.current_stream()
         for r in res:
             # allocated on a chain stream, read on the main stream from here on: without this the allocator may hand
@@ -365,10 +399,11 @@ class DiscriminatorEngine:
         self._pending = None
         if want_param_grads:
             # phase B: weight gradients on the chains' streams, NOT joined here -- see collect_param_grads()
-            pend = []
-            for i, st in enumerate(self._streams):
-                with torch.cuda.stream(st):
-                    pend.append(self.chains[i].weight_grads(res[i][1], half))
+            pend = [None] * len(self.chains)
+            n = len(self.chains)
+            for i in [n - 1] + list(range(n - 1)):   # the longest chain first
+                with torch.cuda.stream(self._streams[i]):
+                    pend[i] = self.chains[i].weight_grads(res[i][1], half)
             self._pending = (pend, s)   # keeps the saved activations alive until the kernels have run
         self._state = None
         return gb[:half], ga[:half], gb[half:], ga[half:]

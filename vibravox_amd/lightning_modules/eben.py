@@ -116,6 +116,15 @@ class EBENLightningModule(BaseSELightningModule):
                 and type(self.feature_matching_loss_fn) is FeatureLossForDiscriminatorMelganMultiScales
                 and type(self.adversarial_loss_fn) is HingeLossForDiscriminatorMelganMultiScales)
 
+    #: tools/phase_times.py: list that receives (label, event) pairs recorded on the main stream between the phases
+    phase_events = None
+
+    def _mark(self, label: str) -> None:
+        if self.phase_events is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self.phase_events.append((label, ev))
+
     def _training_step_engine(self, batch: Dict[str, torch.Tensor]):
         """``_training_step_fused`` with the discriminator side run by ``DiscriminatorEngine``: one
         batch-2B forward for the enhanced and reference branches and one stacked backward for the four
@@ -133,16 +142,24 @@ class EBENLightningModule(BaseSELightningModule):
         engine = self._disc_engine
 
         # ---- generator phase
+        self._mark("start")
         enhanced_speech, bands = self.generator(corrupted_speech)
         with torch.no_grad():
             bands_ref = self.generator.pqmf.forward(reference_speech, "analysis")
-        engine.forward(bands.detach(), enhanced_speech.detach(), bands_ref, reference_speech)
-        d_losses = engine.losses()
+        self._mark("generator forward")
+        # the four discriminator chains start on their streams; the reconstructive losses (which do not involve the
+        # discriminators) run on this stream underneath them
+        engine.forward(bands.detach(), enhanced_speech.detach(), bands_ref, reference_speech, join=False)
         losses: Dict[str, torch.Tensor] = {}
         if self.reconstructive_loss_freq_fn:
             losses["reconstructive_loss_freq"] = self.reconstructive_loss_freq_fn(enhanced_speech, reference_speech)
         if self.reconstructive_loss_temp_fn:
             losses["reconstructive_loss_temp"] = self.reconstructive_loss_temp_fn(enhanced_speech, reference_speech)
+        self._mark("reconstructive losses (discriminator forward beside them)")
+        engine.join()
+        self._mark("discriminator forward joined")
+        d_losses = engine.losses()
+        self._mark("fm + hinge losses")
         losses["feature_matching_loss"] = d_losses["feature_matching_loss"]
         losses["adv_loss_gen"] = d_losses["adv_loss_gen"]
         for key, value in losses.items():
@@ -153,10 +170,15 @@ class EBENLightningModule(BaseSELightningModule):
         update_discriminator = bool(torch.rand(1) < self.update_discriminator_ratio)
         # input gradients now; the discriminator's weight gradients keep running on the engine's streams
         # underneath the balancing passes and the (launch-bound, GPU-underfilling) generator backward
-        fm_b, fm_a, adv_b, adv_a = engine.backward(want_param_grads=update_discriminator)
-
-        # balancing (eben.py:222-240) with every gradient taken at `bands`
+        engine.backward_launch(want_param_grads=update_discriminator)
+        # balancing (eben.py:222-240) with every gradient taken at `bands`; the seeds of the losses that do not pass
+        # through the discriminators are taken while its input-gradient chains run
         leaf = self.generator.last_conv.weight
+        own = {key: torch.autograd.grad(loss, bands, retain_graph=True)[0] for key, loss in losses.items()
+               if key not in ("feature_matching_loss", "adv_loss_gen")}
+        self._mark("reconstructive seeds (discriminator input gradients beside them)")
+        fm_b, fm_a, adv_b, adv_a = engine.backward_finish()
+        self._mark("discriminator input gradients joined")
         seeds = []
         for key, loss in losses.items():
             if key == "feature_matching_loss":
@@ -164,7 +186,7 @@ class EBENLightningModule(BaseSELightningModule):
             elif key == "adv_loss_gen":
                 seeds.append(adv_b + torch.autograd.grad(enhanced_speech, bands, grad_outputs=adv_a, retain_graph=True)[0])
             else:
-                seeds.append(torch.autograd.grad(loss, bands, retain_graph=True)[0])
+                seeds.append(own[key])
         atomic_norms = [torch.norm(torch.autograd.grad(bands, leaf, grad_outputs=s, retain_graph=True)[0]).detach() for s in seeds]
         if self.atomic_norms_old is None or self.dynamic_loss_balancing == "simple":
             self.atomic_norms_old = atomic_norms
@@ -178,11 +200,15 @@ class EBENLightningModule(BaseSELightningModule):
         seed = None
         for s, lam in zip(seeds, lambdas):
             seed = s * lam if seed is None else seed + s * lam
+        self._mark("balancing (3 seeds + norms)")
         with ops.weight_grads_on_side_stream() as side:   # dX chain on this stream, dW work beside it
             torch.autograd.backward(bands, seed, inputs=g_params)
+        self._mark("generator backward (dX chain)")
         side.join()
+        self._mark("generator weight gradients joined")
         self._step(generator_optimizer, self._sync_grads(generator_optimizer))
         generator_optimizer.zero_grad()
+        self._mark("generator Adam")
 
         # ---- discriminator phase: the gradients of real_loss + fake_loss are already there
         if update_discriminator:
@@ -191,8 +217,10 @@ class EBENLightningModule(BaseSELightningModule):
             self.log("train/discriminator/fake_loss", fake_loss, sync_dist=True)
             self.log("train/discriminator/backprop_loss", real_loss + fake_loss, sync_dist=True)
             inject_grads(list(self.discriminator.parameters()), engine.collect_param_grads())
+            self._mark("discriminator weight gradients joined")
             self._step(discriminator_optimizer, self._sync_grads(discriminator_optimizer))
             discriminator_optimizer.zero_grad()
+            self._mark("discriminator Adam")
         return {"corrupted": corrupted_speech, "enhanced": enhanced_speech.detach(), "reference": reference_speech}
 
     def _training_step_fused(self, batch: Dict[str, torch.Tensor]):
