@@ -43,21 +43,23 @@ struct Dw3Args {
   long long slab_stride;
 };
 
-// ---- pre-pass: 16 batch items x 32 rows x 16 time steps per block ---------------------------------
+// ---- pre-pass: 8 batch items (one operand half) x 32 rows x 32 time steps per block ------------------
+// reads: 128-byte row segments; writes: 512 contiguous bytes (32 lanes of one half) per (time step, row tile)
 template <int MT>
 __global__ __launch_bounds__(256) void dw3_pack_a_kernel(const Dw3Args P) {
-  __shared__ float tile[16][32][17];
+  __shared__ float tile[8][32][33];
   unsigned id = blockIdx.x;
-  const int nt16 = P.nct * P.BKT / 16;
-  const int tg = id % nt16; id /= nt16;
+  const int nt32 = (P.nct * P.BKT + 31) / 32;   // a 32-step tile may span two 16-step chunks: the image is linear in time per batch group
+  const int tg = id % nt32; id /= nt32;
+  const int half = id & 1; id >>= 1;
   const int bg = id % P.nbg; id /= P.nbg;
   const int m32 = id % (P.nmt * MT);
   const int g = id / (P.nmt * MT);
-  const int t0 = tg * 16;
-  for (int i = threadIdx.x; i < 16 * 32 * 16; i += 256) {
-    const int t = i & 15, m = (i >> 4) & 31, b = i >> 9;
+  const int t0 = tg * 32;
+  for (int i = threadIdx.x; i < 8 * 32 * 32; i += 256) {
+    const int t = i & 31, m = (i >> 5) & 31, b = i >> 10;
     float v = 0.f;
-    const int bb = bg * 16 + b, mm = m32 * 32 + m;
+    const int bb = bg * 16 + half * 8 + b, mm = m32 * 32 + m;
     if (bb < P.B && mm < P.Mg && t0 + t < P.La) v = lrelu(P.a[((long long)bb * P.Ca + (long long)g * P.Mg + mm) * P.La + t0 + t], P.a_slope);
     tile[b][m][t] = v;
   }
@@ -65,13 +67,13 @@ __global__ __launch_bounds__(256) void dw3_pack_a_kernel(const Dw3Args P) {
   const int mt = m32 / MT, fm = m32 - mt * MT;
   const int tc = t0 / P.BKT, tin0 = t0 - tc * P.BKT;
   u32x4* dst = P.ap + ((((long long)g * P.nmt + mt) * P.nchunks + (long long)bg * P.nct + tc) * P.BKT + tin0) * (MT * 64);
-  for (int u = threadIdx.x; u < 16 * 64; u += 256) {
-    const int t = u >> 6, lane = u & 63;
-    const int b0 = 8 * (lane >> 5), m = lane & 31;
+  for (int u = threadIdx.x; u < 32 * 32; u += 256) {
+    const int t = u >> 5, m = u & 31;
+    if (t0 + t >= P.nct * P.BKT) continue;
     u32x4 o;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = dw3_pack_bf16(tile[b0 + 2 * e][m][t], tile[b0 + 2 * e + 1][m][t]);
-    dst[((long long)t * MT + fm) * 64 + lane] = o;
+    for (int e = 0; e < 4; ++e) o[e] = dw3_pack_bf16(tile[2 * e][m][t], tile[2 * e + 1][m][t]);
+    dst[((long long)t * MT + fm) * 64 + half * 32 + m] = o;
   }
 }
 
@@ -341,7 +343,7 @@ static int launch_dw3(const Dw3Args& a, const Dw3Plan& p, hipStream_t st) {
     attr_set = true;
   }
   constexpr int MT = WAVES_M * FM;
-  const int npack = p.G * p.nmt * MT * p.nbg * (p.nct * p.BKT / 16);
+  const int npack = p.G * p.nmt * MT * p.nbg * 2 * ((p.nct * p.BKT + 31) / 32);
   hipLaunchKernelGGL((dw3_pack_a_kernel<MT>), dim3(npack), dim3(256), 0, st, a);
   EBEN_CHECK_LAUNCH("dw3_pack_a_kernel");
   const int nb = p.nnt * p.nmt * p.G * p.nsplit;

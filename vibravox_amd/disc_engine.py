@@ -268,9 +268,12 @@ class DiscriminatorEngine:
             self._streams = [torch.cuda.Stream(device=dev) for _ in self.chains]
         results = [None] * len(self.chains)
         n = len(self.chains)
+        ev = getattr(self, "_prepack_ev", None)
         for i in [n - 1] + list(range(n - 1)):
             st = self._streams[i]
             st.wait_stream(main)
+            if ev is not None:
+                st.wait_event(ev)   # weight images rebuilt ahead of time on the side stream (prepack)
             with torch.cuda.stream(st):
                 results[i] = fn(i)
         return results
@@ -302,6 +305,24 @@ class DiscriminatorEngine:
 
     def join(self):
         self._join_streams()
+
+    def prepack(self):
+        """Rebuilds every packed weight image the last step used (forward at 2B rows, input gradients at 4B / 2B rows)
+        on the side stream, right after the discriminator's optimiser step: the ~100 small launches then run under the
+        next step's generator forward instead of at the head of the four chains."""
+        if not self.chains or not any(lay.packs for ch in self.chains for lay in ch.layers):
+            return
+        dev = next(lay for ch in self.chains for lay in ch.layers if lay.packs).params()[0].device
+        main = torch.cuda.current_stream(dev)
+        side = ops._side_stream(dev)
+        side.wait_stream(main)
+        with torch.cuda.stream(side), torch.no_grad():
+            for ch in self.chains:
+                for lay in ch.layers:
+                    for (which, batch, l_in) in list(lay.packs):
+                        lay.packed(which, batch, l_in)
+            self._prepack_ev = torch.cuda.Event()
+            self._prepack_ev.record()
 
     # ---- the four scalar losses (device tensors) ------------------------------------------------
     @torch.no_grad()

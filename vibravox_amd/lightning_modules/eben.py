@@ -142,6 +142,7 @@ class EBENLightningModule(BaseSELightningModule):
         engine = self._disc_engine
 
         # ---- generator phase
+        ops.join_prepack()
         self._mark("start")
         enhanced_speech, bands = self.generator(corrupted_speech)
         with torch.no_grad():
@@ -209,6 +210,8 @@ class EBENLightningModule(BaseSELightningModule):
         self._step(generator_optimizer, self._sync_grads(generator_optimizer))
         generator_optimizer.zero_grad()
         self._mark("generator Adam")
+        if self.prepack_weights:
+            ops.prepack(self._hip_convs(self.generator))   # next step's generator images, under the discriminator phase
 
         # ---- discriminator phase: the gradients of real_loss + fake_loss are already there
         if update_discriminator:
@@ -221,7 +224,19 @@ class EBENLightningModule(BaseSELightningModule):
             self._step(discriminator_optimizer, self._sync_grads(discriminator_optimizer))
             discriminator_optimizer.zero_grad()
             self._mark("discriminator Adam")
+            if self.prepack_weights:
+                engine.prepack()   # next step's discriminator images, under the next generator forward
         return {"corrupted": corrupted_speech, "enhanced": enhanced_speech.detach(), "reference": reference_speech}
+
+    #: rebuild the packed weight images right after each optimiser step, on the side stream (off the critical path)
+    prepack_weights: bool = os.environ.get("EBEN_PREPACK", "1") != "0"
+
+    def _hip_convs(self, net):
+        cached = getattr(self, "_hip_conv_cache", None)
+        if cached is None or cached[0] is not net:
+            from ..torch_modules.utils import HipConv1d
+            cached = self._hip_conv_cache = (net, [m for m in net.modules() if isinstance(m, HipConv1d)])
+        return cached[1]
 
     def _training_step_fused(self, batch: Dict[str, torch.Tensor]):
         """Same values as ``_training_step_literal`` with 8 instead of 11 discriminator passes."""

@@ -57,7 +57,7 @@ class weight_grads_disabled:
 # `keep` holds a reference to every upstream gradient a side-stream kernel reads until `join()`: autograd
 # sums gradients IN PLACE into a buffer it holds the only reference to (a residual add hands the same
 # tensor to both branches), which would rewrite the gradient on the main stream under the kernel reading it.
-_side = {"enabled": False, "stream": None, "keep": []}
+_side = {"enabled": False, "stream": None, "keep": [], "prepacked": None}
 
 
 class weight_grads_on_side_stream:
@@ -160,11 +160,12 @@ def conv_desc(spec: ConvSpec, batch: int, l_in: int, math: int = MATH_F32) -> Eb
 class PackedWeights:
     """Weight-norm scale + MFMA-layout copies of one layer's weights, rebuilt when (v, g) change."""
 
-    __slots__ = ("key", "scale", "norm", "wp_fwd", "wp_bwd")
+    __slots__ = ("key", "scale", "norm", "wp_fwd", "wp_bwd", "last")
 
     def __init__(self):
         self.key = None
         self.scale = self.norm = self.wp_fwd = self.wp_bwd = None
+        self.last = None   # (spec, descriptor) of the latest pack: what `prepack` rebuilds ahead of the next step
 
 
 def pack_weights(spec: ConvSpec, d: EbenConv1dDesc, v: torch.Tensor, g: Optional[torch.Tensor],
@@ -173,6 +174,8 @@ def pack_weights(spec: ConvSpec, d: EbenConv1dDesc, v: torch.Tensor, g: Optional
     key = (v.data_ptr(), v._version, _storage_epoch.get(v.data_ptr(), 0), _storage_epoch.get(-1, 0),
            None if g is None else (g.data_ptr(), g._version, _storage_epoch.get(g.data_ptr(), 0)), d.batch, d.l_in)
     pw = cache if cache is not None else PackedWeights()
+    if _side["prepacked"] is not None and torch.cuda.current_stream() != _side["stream"]:
+        join_prepack()   # images built ahead of time on the side stream: first consumer waits for them
     need_bwd = need_bwd or cache is not None  # a module-level cache serves every later pass
     if pw.key == key and (pw.wp_bwd is not None or not need_bwd):
         return pw
@@ -190,7 +193,41 @@ def pack_weights(spec: ConvSpec, d: EbenConv1dDesc, v: torch.Tensor, g: Optional
     )
     check(lib.eben_conv1d_pack(ctypes.byref(d), ptr(v), ptr(pw.scale), ptr(pw.wp_fwd), ptr(pw.wp_bwd), st), "conv1d_pack")
     pw.key = key
+    pw.last = (spec, d)
     return pw
+
+
+def prepack(layers) -> None:
+    """Rebuilds the packed weights of ``layers`` (modules with ``_packed`` / ``spec`` / weight-norm parameters, i.e.
+    ``torch_modules.utils.HipConv1d``) for the descriptors of their latest forward, on the side stream: called right
+    after an optimiser step, the ~2 tiny launches per layer (weight-norm scale, pack) leave the next forward's critical
+    path and run underneath whatever the main stream does next.  ``join_prepack`` must precede the next use."""
+    todo = [m for m in layers if getattr(m, "_packed", None) is not None and m._packed.last is not None]
+    if not todo:
+        return
+    dev = todo[0]._packed.wp_fwd.device
+    main = torch.cuda.current_stream(dev)
+    side = _side_stream(dev)
+    side.wait_stream(main)   # the step that used the old images (and the optimiser that changed the weights) is complete
+    with torch.cuda.stream(side), torch.no_grad():
+        for m in todo:
+            spec, d = m._packed.last
+            if m.weight_norm:
+                prm = m.parametrizations["weight"]
+                pack_weights(spec, d, prm.original1.detach(), prm.original0.detach(), m._packed, True)
+            else:
+                pack_weights(spec, d, m.weight.detach(), None, m._packed, True)
+        ev = torch.cuda.Event()
+        ev.record()
+    _side["prepacked"] = ev
+
+
+def join_prepack() -> None:
+    """The current stream waits for the images `prepack` built (an event: later side-stream work is not waited for)."""
+    ev = _side.get("prepacked")
+    if ev is not None:
+        _side["prepacked"] = None
+        torch.cuda.current_stream().wait_event(ev)
 
 
 class _ConvLayerFn(torch.autograd.Function):
