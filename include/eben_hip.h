@@ -167,6 +167,21 @@ EBEN_API int eben_stft_loss_bwd(const float* spec_x, const float* spec_y, int ro
 EBEN_API int eben_overlap_add(const float* frames_buf, float* x, int batch, int lx, int win, int frames, int hop, int pad,
                      int reflect, int accumulate, void* stream);
 
+/* The same three with explicit strides -- element (row r, bin k, frame f) of a spectrum at r*row_stride + k*bin_stride + f
+ * (imaginary part at + im_off), frame-buffer element (item b, window sample j, frame f) at b*row_stride + j*j_stride + f --
+ * so that the windowed DFT of ALL items runs as one dense GEMM over a flat (channels, rows*frames) matrix:
+ *   eben_stft_frames: out[j, r*frames + f] = sig[r, reflect(f*hop + j - pad)]   (torch.stft(center=True, pad_mode="reflect") framing)
+ *   spec (2*bins, R*frames) = basis (2*bins, win) . frames (win, R*frames)        (eben_conv1d_fwd, ksize 1, batch 1) */
+EBEN_API int eben_stft_frames(const float* sig, float* out, int rows, int t, int win, int hop, int pad, int frames, void* stream);
+EBEN_API int eben_stft_loss_sums_ex(const float* spec_x, const float* spec_y, int rows, int bins, int frames, long long row_stride,
+                           long long bin_stride, long long im_off, float eps, float* partial_ws, size_t ws_bytes, float* out,
+                           void* stream);
+EBEN_API int eben_stft_loss_bwd_ex(const float* spec_x, const float* spec_y, int rows, int bins, int frames, long long row_stride,
+                          long long bin_stride, long long im_off, float eps, const float* sums, const float* gout, float scale,
+                          float* dspec_x, long long out_row_stride, long long out_bin_stride, long long out_im_off, void* stream);
+EBEN_API int eben_overlap_add_ex(const float* frames_buf, float* x, int batch, int lx, int win, int frames, int hop, int pad,
+                        int reflect, int accumulate, long long row_stride, long long j_stride, void* stream);
+
 /* ---- optimiser (torch.optim.Adam as configured by configs/lightning_module/optimizer/adam.yaml) --- */
 typedef struct EbenAdamTensor {
   float* param;

@@ -226,15 +226,21 @@ __device__ __forceinline__ float stft_mag(float re, float im, float eps) { retur
 
 // two-level, order-deterministic: STFT_SPLIT blocks per row write partial sums, one wave per row adds them
 constexpr int STFT_SPLIT = 32;
+// element (row r, bin k, frame f) of a spectrum sits at r*row_stride + k*bin_stride + f (real part; imaginary at + im_off):
+// (rows, 2*bins_pad, frames) tensors and the flat (2*bins, rows*frames) GEMM output are both of that form
+struct StftLayout { long long row_stride, bin_stride, im_off; };
+
 __global__ __launch_bounds__(256) void stft_sums_kernel(const float* __restrict__ sx, const float* __restrict__ sy, int bins,
-                                                        int bins_pad, int frames, float eps, float* __restrict__ partial) {
+                                                        StftLayout L, int frames, float eps, float* __restrict__ partial) {
   __shared__ float red[4];
   const int r = blockIdx.y;
-  const long long base = (long long)r * 2 * bins_pad * frames;
-  const long long im_off = (long long)bins_pad * frames;
+  const long long base0 = (long long)r * L.row_stride;
+  const long long im_off = L.im_off;
   const int n = bins * frames;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += STFT_SPLIT * 256) {
+    const int k = i / frames;
+    const long long base = base0 + (long long)k * (L.bin_stride - frames);   // + i = k*bin_stride + f
     const float xm = stft_mag(sx[base + i], sx[base + im_off + i], eps);
     const float ym = stft_mag(sy[base + i], sy[base + im_off + i], eps);
     const float d = ym - xm;
@@ -260,16 +266,18 @@ __global__ __launch_bounds__(64) void stft_sums_final_kernel(const float* __rest
 }
 
 __global__ __launch_bounds__(256) void stft_bwd_kernel(const float* __restrict__ sx, const float* __restrict__ sy, int rows, int bins,
-                                                       int bins_pad, int frames, float eps, const float* __restrict__ sums,
+                                                       StftLayout L, StftLayout LO, int frames, float eps, const float* __restrict__ sums,
                                                        const float* __restrict__ gout, float scale, float* __restrict__ dsx) {
   const int r = blockIdx.y;
-  const long long base = (long long)r * 2 * bins_pad * frames;
-  const long long im_off = (long long)bins_pad * frames;
+  const long long im_off = L.im_off;
   const int n = bins * frames;
   const float g = gout[0] * scale;
   const float c_sc = g / ((float)rows * sqrtf(sums[3 * r]) * sqrtf(sums[3 * r + 1]));
   const float c_lg = g / ((float)rows * (float)bins * (float)frames);
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const int k = i / frames;
+    const long long base = (long long)r * L.row_stride + (long long)k * (L.bin_stride - frames);
+    const long long obase = (long long)r * LO.row_stride + (long long)k * (LO.bin_stride - frames);
     const float re = sx[base + i], im = sx[base + im_off + i];
     const float p = re * re + im * im;
     const float xm = sqrtf(fmaxf(p, eps));
@@ -278,8 +286,8 @@ __global__ __launch_bounds__(256) void stft_bwd_kernel(const float* __restrict__
     const float sg = (dl > 0.f) - (dl < 0.f);
     float dmag = c_sc * (xm - ym) + c_lg * sg / xm;
     dmag = p >= eps ? dmag / xm : 0.f;   // d sqrt(clamp(p)) / dp * 2  -> (re, im) / mag
-    dsx[base + i] = dmag * re;
-    dsx[base + im_off + i] = dmag * im;
+    dsx[obase + i] = dmag * re;
+    dsx[obase + LO.im_off + i] = dmag * im;
   }
 }
 
@@ -288,25 +296,27 @@ __global__ __launch_bounds__(256) void stft_bwd_kernel(const float* __restrict__
 // frames_buf (B, win, frames) holds per-frame sample gradients; padded coordinate q receives
 // sum_f buf[q + pad - f*hop, f]; the reflect padding folds q<0 and q>=lx back into [0, lx).
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float ola_gather(const float* __restrict__ buf, int q, int win, int frames, int hop, int pad) {
+__device__ __forceinline__ float ola_gather(const float* __restrict__ buf, int q, int win, int frames, int hop, int pad, long long j_stride) {
   const int s = q + pad;  // = f*hop + j
   if (s < 0) return 0.f;
   int fmax = s / hop;
   if (fmax > frames - 1) fmax = frames - 1;
   int fmin = s - win + 1 <= 0 ? 0 : (s - win + hop) / hop;
   float acc = 0.f;
-  for (int f = fmin; f <= fmax; ++f) acc += buf[(long long)(s - f * hop) * frames + f];
+  for (int f = fmin; f <= fmax; ++f) acc += buf[(long long)(s - f * hop) * j_stride + f];
   return acc;
 }
+// buf element (item b, sample j of the window, frame f) sits at b*row_stride + j*j_stride + f
 __global__ __launch_bounds__(256) void overlap_add_kernel(const float* __restrict__ buf, float* __restrict__ x, int lx, int win,
-                                                          int frames, int hop, int pad, int reflect, int accumulate) {
+                                                          int frames, int hop, int pad, int reflect, int accumulate,
+                                                          long long row_stride, long long j_stride) {
   const int b = blockIdx.y;
-  const float* bb = buf + (long long)b * win * frames;
+  const float* bb = buf + (long long)b * row_stride;
   for (int u = blockIdx.x * 256 + threadIdx.x; u < lx; u += gridDim.x * 256) {
-    float v = ola_gather(bb, u, win, frames, hop, pad);
+    float v = ola_gather(bb, u, win, frames, hop, pad, j_stride);
     if (reflect) {
-      if (u >= 1 && u <= pad) v += ola_gather(bb, -u, win, frames, hop, pad);
-      if (u <= lx - 2 && 2 * (lx - 1) - u <= lx - 1 + pad) v += ola_gather(bb, 2 * (lx - 1) - u, win, frames, hop, pad);
+      if (u >= 1 && u <= pad) v += ola_gather(bb, -u, win, frames, hop, pad, j_stride);
+      if (u <= lx - 2 && 2 * (lx - 1) - u <= lx - 1 + pad) v += ola_gather(bb, 2 * (lx - 1) - u, win, frames, hop, pad, j_stride);
     }
     const long long i = (long long)b * lx + u;
     if (accumulate) v += x[i];
@@ -520,34 +530,82 @@ extern "C" int eben_l2norm(const float* x, size_t n, float* out, void* stream) {
 }
 
 extern "C" size_t eben_stft_loss_sums_workspace(int rows) { return sizeof(float) * 3 * (size_t)STFT_SPLIT * (rows > 0 ? rows : 0); }
-extern "C" int eben_stft_loss_sums(const float* spec_x, const float* spec_y, int rows, int bins, int bins_pad, int frames,
-                                   float eps, float* partial_ws, size_t ws_bytes, float* out, void* stream) {
-  EBEN_REQUIRE(spec_x && spec_y && out && partial_ws && rows > 0 && bins > 0 && bins_pad >= bins && frames > 0, "bad stft_loss arguments");
+extern "C" int eben_stft_loss_sums_ex(const float* spec_x, const float* spec_y, int rows, int bins, int frames, long long row_stride,
+                                      long long bin_stride, long long im_off, float eps, float* partial_ws, size_t ws_bytes, float* out,
+                                      void* stream) {
+  EBEN_REQUIRE(spec_x && spec_y && out && partial_ws && rows > 0 && bins > 0 && frames > 0 && bin_stride >= frames, "bad stft_loss arguments");
   if (ws_bytes < eben_stft_loss_sums_workspace(rows)) return fail(EBEN_EWORKSPACE, "stft_loss_sums needs %zu workspace bytes", eben_stft_loss_sums_workspace(rows));
-  hipLaunchKernelGGL(stft_sums_kernel, dim3(STFT_SPLIT, rows), dim3(256), 0, as_stream(stream), spec_x, spec_y, bins, bins_pad, frames, eps,
+  const StftLayout L{row_stride, bin_stride, im_off};
+  hipLaunchKernelGGL(stft_sums_kernel, dim3(STFT_SPLIT, rows), dim3(256), 0, as_stream(stream), spec_x, spec_y, bins, L, frames, eps,
                      partial_ws);
   EBEN_CHECK_LAUNCH("stft_sums_kernel");
   hipLaunchKernelGGL(stft_sums_final_kernel, dim3(rows), dim3(64), 0, as_stream(stream), partial_ws, out);
   EBEN_CHECK_LAUNCH("stft_sums_final_kernel");
   return EBEN_OK;
 }
-extern "C" int eben_stft_loss_bwd(const float* spec_x, const float* spec_y, int rows, int bins, int bins_pad, int frames,
-                                  float eps, const float* sums, const float* gout, float scale, float* dspec_x, void* stream) {
-  EBEN_REQUIRE(spec_x && spec_y && sums && gout && dspec_x && rows > 0 && bins > 0 && bins_pad >= bins && frames > 0, "bad stft_loss arguments");
+extern "C" int eben_stft_loss_sums(const float* spec_x, const float* spec_y, int rows, int bins, int bins_pad, int frames,
+                                   float eps, float* partial_ws, size_t ws_bytes, float* out, void* stream) {
+  EBEN_REQUIRE(bins_pad >= bins, "bad stft_loss arguments");
+  return eben_stft_loss_sums_ex(spec_x, spec_y, rows, bins, frames, 2LL * bins_pad * frames, frames, (long long)bins_pad * frames, eps,
+                                partial_ws, ws_bytes, out, stream);
+}
+extern "C" int eben_stft_loss_bwd_ex(const float* spec_x, const float* spec_y, int rows, int bins, int frames, long long row_stride,
+                                     long long bin_stride, long long im_off, float eps, const float* sums, const float* gout, float scale,
+                                     float* dspec_x, long long out_row_stride, long long out_bin_stride, long long out_im_off, void* stream) {
+  EBEN_REQUIRE(spec_x && spec_y && sums && gout && dspec_x && rows > 0 && bins > 0 && frames > 0, "bad stft_loss arguments");
+  EBEN_REQUIRE(bin_stride >= frames && out_bin_stride >= frames, "bad stft_loss strides");
   const int nb = grid_for((size_t)bins * frames, 64);
-  hipLaunchKernelGGL(stft_bwd_kernel, dim3(nb, rows), dim3(256), 0, as_stream(stream), spec_x, spec_y, rows, bins, bins_pad, frames,
+  const StftLayout L{row_stride, bin_stride, im_off}, LO{out_row_stride, out_bin_stride, out_im_off};
+  hipLaunchKernelGGL(stft_bwd_kernel, dim3(nb, rows), dim3(256), 0, as_stream(stream), spec_x, spec_y, rows, bins, L, LO, frames,
                      eps, sums, gout, scale, dspec_x);
   EBEN_CHECK_LAUNCH("stft_bwd_kernel");
   return EBEN_OK;
 }
+extern "C" int eben_stft_loss_bwd(const float* spec_x, const float* spec_y, int rows, int bins, int bins_pad, int frames,
+                                  float eps, const float* sums, const float* gout, float scale, float* dspec_x, void* stream) {
+  EBEN_REQUIRE(bins_pad >= bins, "bad stft_loss arguments");
+  const long long rs = 2LL * bins_pad * frames, io = (long long)bins_pad * frames;
+  return eben_stft_loss_bwd_ex(spec_x, spec_y, rows, bins, frames, rs, frames, io, eps, sums, gout, scale, dspec_x, rs, frames, io, stream);
+}
 
-extern "C" int eben_overlap_add(const float* frames_buf, float* x, int batch, int lx, int win, int frames, int hop, int pad,
-                                int reflect, int accumulate, void* stream) {
+extern "C" int eben_overlap_add_ex(const float* frames_buf, float* x, int batch, int lx, int win, int frames, int hop, int pad,
+                                   int reflect, int accumulate, long long row_stride, long long j_stride, void* stream) {
   EBEN_REQUIRE(frames_buf && x && batch > 0 && lx > 0 && win > 0 && frames > 0 && hop > 0 && pad >= 0, "bad overlap_add arguments");
   EBEN_REQUIRE(!reflect || pad < lx, "reflect padding must be smaller than the signal");
   hipLaunchKernelGGL(overlap_add_kernel, dim3(grid_for((size_t)lx, 256), batch), dim3(256), 0, as_stream(stream), frames_buf, x, lx,
-                     win, frames, hop, pad, reflect, accumulate);
+                     win, frames, hop, pad, reflect, accumulate, row_stride, j_stride);
   EBEN_CHECK_LAUNCH("overlap_add_kernel");
+  return EBEN_OK;
+}
+extern "C" int eben_overlap_add(const float* frames_buf, float* x, int batch, int lx, int win, int frames, int hop, int pad,
+                                int reflect, int accumulate, void* stream) {
+  return eben_overlap_add_ex(frames_buf, x, batch, lx, win, frames, hop, pad, reflect, accumulate, (long long)win * frames, frames, stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// STFT framing (im2col of torch.stft(center=True, pad_mode="reflect")): out[j, r*frames + f] = sig[r, reflect(f*hop + j - pad)].
+// The (win, rows*frames) matrix makes the windowed DFT ONE dense GEMM over all items' frames (a pointwise tap-conv
+// with batch 1): no N-tile padding per item (134 frames per item fill 52 % of two 128-column tiles).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void stft_frames_kernel(const float* __restrict__ sig, float* __restrict__ out, int rows, int t,
+                                                          int win, int hop, int pad, int frames) {
+  const int j = blockIdx.y;
+  const long long cols = (long long)rows * frames;
+  float* o = out + (long long)j * cols;
+  for (long long c = (long long)blockIdx.x * 256 + threadIdx.x; c < cols; c += (long long)gridDim.x * 256) {
+    const int r = (int)(c / frames), f = (int)(c - (long long)r * frames);
+    int q = f * hop + j - pad;
+    q = q < 0 ? -q : q;
+    q = q >= t ? 2 * (t - 1) - q : q;
+    o[c] = sig[(long long)r * t + q];
+  }
+}
+extern "C" int eben_stft_frames(const float* sig, float* out, int rows, int t, int win, int hop, int pad, int frames, void* stream) {
+  EBEN_REQUIRE(sig && out && rows > 0 && t > 1 && win > 0 && hop > 0 && pad >= 0 && pad < t && frames > 0, "bad stft_frames arguments");
+  EBEN_REQUIRE((frames - 1) * hop + win - 1 - pad <= 2 * (t - 1), "stft_frames: frames reach past the reflected signal");
+  hipLaunchKernelGGL(stft_frames_kernel, dim3(grid_for((size_t)rows * frames, 64), win), dim3(256), 0, as_stream(stream), sig, out, rows,
+                     t, win, hop, pad, frames);
+  EBEN_CHECK_LAUNCH("stft_frames_kernel");
   return EBEN_OK;
 }
 

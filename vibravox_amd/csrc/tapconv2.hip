@@ -263,8 +263,13 @@ __global__ __launch_bounds__(NW * 64, 2) void tap2_kernel(const Tap2Args P) {
   int te[16];   // this chunk's k-step offsets (wave-uniform: scalar registers, fetched one chunk ahead)
 #pragma unroll
   for (int ks = 0; ks < 16; ++ks) te[ks] = nch > 0 ? tab[ks] : 0;
+  int pending = -1;   // tile whose global loads are issued at the top of the next chunk
   for (int ch = 0; ch < nch; ++ch) {
     if (ch + 1 < nch) issue_w(ch + 1);
+    // the loads of the tile after the one just written are issued HERE, under this chunk's MFMAs: issued right before
+    // the barrier they would be drained by its vmcnt(0) with their whole latency exposed -- once per weight chunk for a
+    // pointwise conv (one tile hand-over per chunk), which is what held those layers at a third of the MFMA rate
+    if (pending >= 0) { fetch_x(pending); pending = -1; }
     const float* wb = Ws + (ch & 1) * WCH + lane * FI;
     const float* xb = Xs + lanebase;
     // fragments of k-step s+2 are issued before the MFMAs of step s (sched_barrier pins the order:
@@ -312,7 +317,7 @@ __global__ __launch_bounds__(NW * 64, 2) void tap2_kernel(const Tap2Args P) {
     if (P.ncc > 1 && written + 1 < P.ncc && (written + 1) * KS_CC < (ch + 2) * 16) {
       ++written;
       store_x(written);
-      if (written + 1 < P.ncc) fetch_x(written + 1);
+      if (written + 1 < P.ncc) pending = written + 1;
     }
     __syncthreads();
   }

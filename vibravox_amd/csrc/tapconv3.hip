@@ -201,8 +201,10 @@ __global__ __launch_bounds__(256, 2) void tap3_kernel(const Tap3Args P) {
   int te[KSC];
 #pragma unroll
   for (int ks = 0; ks < KSC; ++ks) te[ks] = nch > 0 ? tab[ks] : 0;
+  int pending = -1;   // tile whose global loads are issued at the top of the next chunk (not in front of the barrier)
   for (int ch = 0; ch < nch; ++ch) {
     if (ch + 1 < nch) issue_w(ch + 1);
+    if (pending >= 0) { fetch_x(pending); pending = -1; }
     const u32x4* wb = Ws + (ch & 1) * WCHU + lane;
     const u32x4* xb = Xs + lanebase;
     u32x4 bv[KSC], a[KSC][FM];
@@ -229,7 +231,7 @@ __global__ __launch_bounds__(256, 2) void tap3_kernel(const Tap3Args P) {
     if (P.ncc > 1 && written + 1 < P.ncc && (written + 1) * KS_CC < (ch + 2) * KSC) {
       ++written;
       store_x(written);
-      if (written + 1 < P.ncc) fetch_x(written + 1);
+      if (written + 1 < P.ncc) pending = written + 1;
     }
     __syncthreads();
   }

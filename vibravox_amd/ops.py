@@ -552,22 +552,23 @@ class StftPlan:
     hop: int
     win: int
     bins: int
-    spec: ConvSpec
-    basis: torch.Tensor  # (2*bins, 1, win) windowed DFT rows: [cos ; -sin]
+    pad: int
+    spec_f: ConvSpec  # pointwise conv (win -> 2*bins): the windowed DFT of a frame matrix
+    basis_f: torch.Tensor  # (2*bins, win, 1) windowed DFT rows: [cos ; -sin]
     spec_t: ConvSpec  # pointwise conv (2*bins -> win) used by the backward
     basis_t: torch.Tensor  # (win, 2*bins, 1) = basis transposed
     cache_fwd: PackedWeights
     cache_bwd: PackedWeights
-    # polyphase form of the analysis conv (R > 1): the reflect-padded signal de-interleaved into R
-    # channels, kernel win/R, stride hop/R -- the same MACs with a channel pair per MFMA k-step, which
-    # is what the second-generation tap-conv needs (a 1-channel conv stays on the first generation)
-    poly: int = 1
-    spec_r: Optional[ConvSpec] = None
-    basis_r: Optional[torch.Tensor] = None
 
 
 class _MRSTFTFn(torch.autograd.Function):
-    """auraloss MultiResolutionSTFTLoss(x, y) as configured by multi_stft.yaml (see mrstft_loss.py)."""
+    """auraloss MultiResolutionSTFTLoss(x, y) as configured by multi_stft.yaml (see mrstft_loss.py).
+
+    Per resolution: ``eben_stft_frames`` writes the reflect-padded frames of ALL signals (x and y rows) as one
+    (win, R*frames) matrix, the windowed DFT is one dense GEMM over it (pointwise tap-conv, batch 1 -- a strided conv
+    per item would pad every item's 134 / 267 frames to whole 128-column tiles), the loss sums read the flat
+    (2*bins, R*frames) spectrum through strides; backward: d(spec) in the same flat form, d(frames) = basis^T . d(spec)
+    as one GEMM, overlap-add back onto the waveform."""
 
     @staticmethod
     def forward(ctx, x, y, fir, plans: List[StftPlan], eps: float):
@@ -583,29 +584,22 @@ class _MRSTFTFn(torch.autograd.Function):
         total = None
         saved = []
         for p in plans:
-            pad = p.spec.pad_l
-            if p.poly > 1 and (t + 2 * pad) % p.poly == 0:
-                lp = t + 2 * pad
-                sigp = torch.empty((2 * rows, 1, lp), dtype=torch.float32, device=x.device)
-                check(lib.eben_reflect_pad_fwd(ptr(sig), ptr(sigp), 2 * rows, t, pad, pad, st), "reflect_pad_fwd")
-                sig_r = sigp.view(2 * rows, lp // p.poly, p.poly).transpose(1, 2).contiguous()
-                d2 = conv_desc(p.spec_r, 2 * rows, lp // p.poly)
-                pw = pack_weights(p.spec_r, d2, p.basis_r, None, p.cache_fwd, False)
-                spec = torch.empty((2 * rows, 2 * p.bins, d2.l_out), dtype=torch.float32, device=x.device)
-                check(lib.eben_conv1d_fwd(ctypes.byref(d2), ptr(sig_r), ptr(pw.wp_fwd), None, None, ptr(spec), st), "stft_fwd")
-            else:
-                d2 = conv_desc(p.spec, 2 * rows, t)
-                pw = pack_weights(p.spec, d2, p.basis, None, p.cache_fwd, False)
-                spec = torch.empty((2 * rows, 2 * p.bins, d2.l_out), dtype=torch.float32, device=x.device)
-                check(lib.eben_conv1d_fwd(ctypes.byref(d2), ptr(sig), ptr(pw.wp_fwd), None, None, ptr(spec), st), "stft_fwd")
+            frames = (t + 2 * p.pad - p.win) // p.hop + 1
+            cols = 2 * rows * frames
+            fr = torch.empty((1, p.win, cols), dtype=torch.float32, device=x.device)
+            check(lib.eben_stft_frames(ptr(sig), ptr(fr), 2 * rows, t, p.win, p.hop, p.pad, frames, st), "stft_frames")
+            d2 = conv_desc(p.spec_f, 1, cols)
+            pw = pack_weights(p.spec_f, d2, p.basis_f, None, p.cache_fwd, False)
+            spec = torch.empty((1, 2 * p.bins, cols), dtype=torch.float32, device=x.device)
+            check(lib.eben_conv1d_fwd(ctypes.byref(d2), ptr(fr), ptr(pw.wp_fwd), None, None, ptr(spec), st), "stft_fwd")
             sums = torch.empty((rows, 3), dtype=torch.float32, device=x.device)
-            sx, sy = spec[:rows], spec[rows:]
+            # y rows: same strides, column offset rows*frames
             ws_bytes = lib.eben_stft_loss_sums_workspace(rows)
-            check(lib.eben_stft_loss_sums(ptr(sx), ptr(sy), rows, p.bins, p.bins, d2.l_out, eps, ptr(_empty(ws_bytes, x)), ws_bytes,
-                                          ptr(sums), st), "stft_loss_sums")
-            term = torch.sqrt(sums[:, 0] / sums[:, 1]).mean() + sums[:, 2].sum() / float(rows * p.bins * d2.l_out)
+            check(lib.eben_stft_loss_sums_ex(ptr(spec), ptr(spec) + 4 * rows * frames, rows, p.bins, frames, frames, cols, p.bins * cols, eps,
+                                             ptr(_empty(ws_bytes, x)), ws_bytes, ptr(sums), st), "stft_loss_sums")
+            term = torch.sqrt(sums[:, 0] / sums[:, 1]).mean() + sums[:, 2].sum() / float(rows * p.bins * frames)
             total = term if total is None else total + term
-            saved.append((spec, sums, d2.l_out))
+            saved.append((spec, sums, frames))
         ctx.plans, ctx.eps, ctx.geom, ctx.saved, ctx.fir = plans, eps, (b, c, t, rows), saved, fir
         return total / len(plans)
 
@@ -617,16 +611,17 @@ class _MRSTFTFn(torch.autograd.Function):
         gout = gout.contiguous().reshape(1)
         dsig = torch.empty((rows, 1, t), dtype=torch.float32, device=gout.device)
         for i, (p, (spec, sums, frames)) in enumerate(zip(ctx.plans, ctx.saved)):
-            dspec = torch.empty((rows, 2 * p.bins, frames), dtype=torch.float32, device=gout.device)
-            sx, sy = spec[:rows], spec[rows:]
-            check(lib.eben_stft_loss_bwd(ptr(sx), ptr(sy), rows, p.bins, p.bins, frames, ctx.eps, ptr(sums), ptr(gout),
-                                         1.0 / len(ctx.plans), ptr(dspec), st), "stft_loss_bwd")
-            # d(frames)[b, j, f] = sum_m basis[m, j] dspec[b, m, f]: dense pointwise GEMM, then overlap-add
-            d1 = conv_desc(p.spec_t, rows, frames)
+            cols, xcols = 2 * rows * frames, rows * frames
+            dspec = torch.empty((1, 2 * p.bins, xcols), dtype=torch.float32, device=gout.device)
+            check(lib.eben_stft_loss_bwd_ex(ptr(spec), ptr(spec) + 4 * xcols, rows, p.bins, frames, frames, cols, p.bins * cols, ctx.eps,
+                                            ptr(sums), ptr(gout), 1.0 / len(ctx.plans), ptr(dspec), frames, xcols, p.bins * xcols, st),
+                  "stft_loss_bwd")
+            # d(frames)[j, (r, f)] = sum_m basis[m, j] dspec[m, (r, f)]: one dense GEMM, then overlap-add
+            d1 = conv_desc(p.spec_t, 1, xcols)
             pw = pack_weights(p.spec_t, d1, p.basis_t, None, p.cache_bwd, False)
-            dfr = torch.empty((rows, p.win, frames), dtype=torch.float32, device=gout.device)
+            dfr = torch.empty((1, p.win, xcols), dtype=torch.float32, device=gout.device)
             check(lib.eben_conv1d_fwd(ctypes.byref(d1), ptr(dspec), ptr(pw.wp_fwd), None, None, ptr(dfr), st), "stft_bwd_gemm")
-            check(lib.eben_overlap_add(ptr(dfr), ptr(dsig), rows, t, p.win, frames, p.hop, p.spec.pad_l, 1, 1 if i else 0, st),
+            check(lib.eben_overlap_add_ex(ptr(dfr), ptr(dsig), rows, t, p.win, frames, p.hop, p.pad, 1, 1 if i else 0, frames, xcols, st),
                   "overlap_add")
         if ctx.fir is not None:
             nt = ctx.fir.numel()

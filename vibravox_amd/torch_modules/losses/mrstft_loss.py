@@ -7,9 +7,9 @@ third-party dependency that is not vendored in the reference (pyproject.toml:21,
 semantics restated: per-item spectral convergence, log-magnitude L1, A-weighting FIR prefilter,
 mean over resolutions) -- parity for this term is therefore *unpinned* (see DESIGN.md).
 
-Per resolution the STFT is one strided conv: hann(win) centred in n_fft and center=True reflect
-padding reduce to a reflect-padded conv with kernel ``win``, stride ``hop``, padding ``win/2``
-against the 2*(n_fft/2+1) rows [w cos ; -w sin] of the windowed DFT basis.
+Per resolution the STFT is a framing pass + one dense GEMM: hann(win) centred in n_fft and center=True
+reflect padding reduce to frames of ``win`` samples at hop ``hop`` over the signal reflect-padded by
+``win/2``, multiplied by the 2*(n_fft/2+1) rows [w cos ; -w sin] of the windowed DFT basis.
 """
 from __future__ import annotations
 
@@ -64,35 +64,23 @@ class MultiResolutionSTFTLoss(torch.nn.Module):
         self.register_buffer("fir", a_weighting_taps(sample_rate) if perceptual_weighting else None, persistent=False)
         self._plans = None
         for i, (n_fft, win) in enumerate(zip(self.fft_sizes, self.win_lengths)):
-            basis = windowed_dft_basis(n_fft, win)
-            self.register_buffer(f"basis_{i}", basis, persistent=False)
-            self.register_buffer(f"basis_t_{i}", basis.squeeze(1).t().contiguous().unsqueeze(-1), persistent=False)
-            r = self._poly_factor(self.hop_sizes[i], win)
-            # w_r[m, c, i] = w[m, i*r + c]
-            self.register_buffer(f"basis_r_{i}", basis.reshape(basis.shape[0], win // r, r).transpose(1, 2).contiguous(), persistent=False)
-
-    @staticmethod
-    def _poly_factor(hop: int, win: int) -> int:
-        for r in (8, 4, 2):
-            if hop % r == 0 and win % r == 0 and (win // 2) % r == 0:
-                return r
-        return 1
+            basis = windowed_dft_basis(n_fft, win).squeeze(1)                       # (2*bins, win)
+            self.register_buffer(f"basis_{i}", basis.unsqueeze(-1).contiguous(), persistent=False)            # (2*bins, win, 1)
+            self.register_buffer(f"basis_t_{i}", basis.t().contiguous().unsqueeze(-1), persistent=False)      # (win, 2*bins, 1)
 
     def _build_plans(self):
         plans = []
         for i, (n_fft, hop, win) in enumerate(zip(self.fft_sizes, self.hop_sizes, self.win_lengths)):
             bins = n_fft // 2 + 1
-            spec = ops.ConvSpec(c_in=1, c_out=2 * bins, ksize=win, stride=hop, pad_l=win // 2, pad_r=win // 2, reflect=True)
-            spec_t = ops.ConvSpec(c_in=2 * bins, c_out=win, ksize=1)
-            r = self._poly_factor(hop, win)
-            spec_r = ops.ConvSpec(c_in=r, c_out=2 * bins, ksize=win // r, stride=hop // r) if r > 1 else None
-            plans.append(ops.StftPlan(n_fft=n_fft, hop=hop, win=win, bins=bins, spec=spec, basis=getattr(self, f"basis_{i}"),
-                                      spec_t=spec_t, basis_t=getattr(self, f"basis_t_{i}"),
-                                      cache_fwd=ops.PackedWeights(), cache_bwd=ops.PackedWeights(),
-                                      poly=r, spec_r=spec_r, basis_r=getattr(self, f"basis_r_{i}") if r > 1 else None))
+            # hann(win) centred in n_fft + center=True reflect padding of n_fft/2 == frames of length `win` taken at
+            # reflect padding win/2 (the window is zero outside its centred `win` samples)
+            plans.append(ops.StftPlan(n_fft=n_fft, hop=hop, win=win, bins=bins, pad=win // 2,
+                                      spec_f=ops.ConvSpec(c_in=win, c_out=2 * bins, ksize=1), basis_f=getattr(self, f"basis_{i}"),
+                                      spec_t=ops.ConvSpec(c_in=2 * bins, c_out=win, ksize=1), basis_t=getattr(self, f"basis_t_{i}"),
+                                      cache_fwd=ops.PackedWeights(), cache_bwd=ops.PackedWeights()))
         return plans
 
     def forward(self, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
-        if self._plans is None or self._plans[0].basis.device != x.device or self._plans[0].basis.data_ptr() != self.basis_0.data_ptr():
+        if self._plans is None or self._plans[0].basis_f.device != x.device or self._plans[0].basis_f.data_ptr() != self.basis_0.data_ptr():
             self._plans = self._build_plans()
         return ops.mrstft(x, y, self.fir, self._plans, self.eps)
