@@ -109,6 +109,8 @@ def main():
     ap.add_argument("--disc-math", default=os.environ.get("EBEN_DISC_MATH", "bf16"), choices=["bf16", "f32"],
                     help="discriminator contractions: bf16 MFMA operands with fp32 accumulate (BASELINE config 2 names bf16) or exact "
                          "fp32 products; the generator computes in fp32 either way")
+    ap.add_argument("--gen-bwd-math", default=None, choices=["bf16", "f32"],
+                    help="generator backward contractions (default: same as --disc-math); the generator forward is always fp32")
     ap.add_argument("--no-f32-leg", action="store_true", help="skip the extra fp32-discriminator timing reported beside a bf16 run")
     args = ap.parse_args()
 
@@ -133,6 +135,7 @@ def main():
 
     mod = build_module(device, 1234 + rank)
     mod.disc_math = args.disc_math
+    mod.gen_backward_math = args.gen_bwd_math or args.disc_math
     if use_ddp:
         g_opt, d_opt = mod.optimizers()
         gs, ds = GradSync(mod.generator.parameters()), GradSync(mod.discriminator.parameters())
@@ -175,7 +178,7 @@ def main():
     # as `f32_discriminator` -- never as `value`
     dt32 = None
     if args.disc_math == "bf16" and not args.no_f32_leg:
-        mod.disc_math = "f32"
+        mod.disc_math = mod.gen_backward_math = "f32"
         mod.training_step(batch)
         barrier()
         t1 = time.perf_counter()
@@ -210,8 +213,9 @@ def main():
                                    f"batch {args.batch} x {args.length} samples @16kHz per GPU (cut to {cut})",
                        "global_batch": world * args.batch, "samples_per_clip": cut, "parallelism": f"dp{world}",
                        "weights": "random init, torch.manual_seed(42)",
-                       "precision": ("discriminator contractions (91 % of the step's FLOPs): bf16 MFMA operands, fp32 accumulate; generator, "
-                                     "losses, Adam, storage: fp32" if args.disc_math == "bf16" else "fp32 throughout (exact fp32 MFMA products)")},
+                       "precision": (f"discriminator contractions (91 % of the step's FLOPs): bf16 MFMA operands, fp32 accumulate; generator "
+                                     f"forward, losses, Adam, storage: fp32; generator backward contractions: {mod.gen_backward_math}"
+                                     if args.disc_math == "bf16" else "fp32 throughout (exact fp32 MFMA products)")},
             "roofline": {"bound": "mfma", "kernel": f"eben::{kname} MelGAN L4 fwd (1024->1024 k41 s4 g4), {launch_batch} items per launch",
                          "achieved": round(achieved, 2) if achieved else None, "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4) if achieved else None, "traffic": pmc_traffic(launch_batch, args.disc_math),

@@ -43,9 +43,8 @@ extern "C" {
 
 /* arithmetic of the contraction (storage, accumulation and the fused element-wise stages are fp32 either way) */
 #define EBEN_MATH_F32 0   /* v_mfma_f32_*_f32 / fp32 FMA: bit-exact fp32 products */
-#define EBEN_MATH_BF16 1  /* both MFMA operands rounded (RNE) to bf16, fp32 accumulate; layers the bf16 kernel does not
-                           * cover run their fp32 kernel.  The mask-on-load input stage (eben_conv1d_bwd_dx with
-                           * out_slope != 1) is not available in this mode: use eben_conv1d_bwd_dx_ex. */
+#define EBEN_MATH_BF16 1  /* both MFMA operands rounded (RNE) to bf16 -- after the fused input stage (LeakyReLU or its
+                           * derivative mask) -- fp32 accumulate; layers the bf16 kernels do not cover run their fp32 kernel */
 
 /* One Conv1d / ConvTranspose1d layer (nn.Conv1d / nn.ConvTranspose1d semantics).
  * Replaces the F.conv1d / F.conv_transpose1d call sites behind

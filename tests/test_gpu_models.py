@@ -278,9 +278,10 @@ def test_bf16_discriminator_math_against_fp32_step(hip, golden):
     hinge branches, opposite signs) and inherits the bf16 noise of each un-cancelled: tens of percent at
     initialisation -- the stated cost of this mode, measured here and bounded loosely."""
     res = {}
-    for math in ("f32", "bf16"):
+    for math in ("f32", "bf16", "bf16+gen"):
         mod, _, _ = make_module(golden, use_mrstft=True)
-        mod.disc_math = math
+        mod.disc_math = math.split("+")[0]
+        mod.gen_backward_math = "bf16" if math.endswith("+gen") else "f32"
         batch = {"audio_body_conducted": formula_audio("bf/bc", 4, 8200).to(DEV), "audio_airborne": formula_audio("bf/air", 4, 8200).to(DEV)}
         out = mod.training_step(batch)
         torch.cuda.synchronize()
@@ -289,6 +290,13 @@ def test_bf16_discriminator_math_against_fp32_step(hip, golden):
             moments.append(torch.cat([opt.state[p]["exp_avg"].double().flatten().cpu() for grp in opt.param_groups for p in grp["params"]
                                       if "exp_avg" in opt.state.get(p, {})]))
         res[math] = (out["enhanced"].clone(), {k: float(v) for k, v in mod.logged.items()}, torch.stack(mod.last_norms).cpu(), moments)
+    # ... and with the generator's BACKWARD contractions in bf16 as well (bench.py's default): its forward is still exact
+    a, c = res["f32"], res["bf16+gen"]
+    assert torch.equal(a[0], c[0])
+    g_rel = float((a[3][0] - c[3][0]).norm() / a[3][0].norm())
+    n_rel = float(((a[2] - c[2]).abs() / a[2].abs()).max())
+    print(f"bf16 discriminator + generator-backward math: norms {n_rel:.3e}, generator grad rel-L2 {g_rel:.3e}")
+    assert n_rel < 5e-2 and g_rel < 5e-2
     a, b = res["f32"], res["bf16"]
     assert torch.equal(a[0], b[0])
     rel = {k: abs(b[1][k] - v) / abs(v) for k, v in a[1].items()}

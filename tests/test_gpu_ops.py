@@ -227,6 +227,32 @@ def test_bf16_math_forward_and_batched_input_gradient(hip, name):
     assert rel_err(dv, wr.grad) < 1e-4
     assert rel_err(dbias, _bf16(gb).sum(dim=(0, 2))) < 1e-4
 
+    # autograd's form of the backward (ops.backward_math): the fused output activation is differentiated ON LOAD --
+    # the gradient operand is dy * lrelu'(y), rounded after the mask
+    if spec.out_slope != 1.0 and not spec.reflect:
+        d = ops.conv_desc(spec, nb, length, ops.MATH_BF16)
+        yb = formula_tensor(f"bf/{name}/yb", (nb, spec.c_out, l_out))
+        masked = gb.double() * torch.where(yb.double() > 0, 1.0, spec.out_slope)
+        gens_m = (lib.eben_conv1d_kernel_generation(ctypes.byref(d), 1), )
+        rnd = _bf16 if gens_m[0] == 4 else (lambda t: t.double())
+        xr = torch.zeros(nb, spec.c_in, length, dtype=torch.float64, requires_grad=True)
+        (O.conv_layer(xr, rnd(w), None, None, **okw) * rnd(masked)).sum().backward()
+        wp = torch.empty(lib.eben_conv1d_packed_floats(ctypes.byref(d), 1), dtype=torch.float32, device=dev)
+        check(lib.eben_conv1d_pack(ctypes.byref(d), ptr(wd), None, None, ptr(wp), stream()), "pack")
+        dxm = torch.empty(nb, spec.c_in, length, dtype=torch.float32, device=dev)
+        ybd = yb.to(dev)
+        check(lib.eben_conv1d_bwd_dx(ctypes.byref(d), ptr(gbd), ptr(ybd), ptr(wp), None, ptr(dxm), 0, None, 0, stream()), "bwd_dx")
+        wr2 = torch.zeros(wshape, dtype=torch.float64, requires_grad=True)
+        (O.conv_layer(_bf16(xb), wr2, None, None, **okw) * _bf16(masked)).sum().backward()
+        ws_bytes = lib.eben_conv1d_bwd_dw_workspace(ctypes.byref(d), ctypes.byref(nslab), ctypes.byref(row_stride))
+        slabs = torch.empty((ws_bytes + 3) // 4, dtype=torch.float32, device=dev)
+        check(lib.eben_conv1d_bwd_dw(ctypes.byref(d), ptr(gbd), ptr(ybd), ptr(xbd), 1, ptr(slabs), ws_bytes, stream()), "bwd_dw")
+        check(lib.eben_wn_bwd(ptr(slabs), nslab.value, rows * row_stride.value, rows, cols, row_stride.value, None, None, None, None,
+                              ptr(dv), ptr(dbias), stream()), "wn_bwd")
+        torch.cuda.synchronize()
+        assert rel_err(dxm, xr.grad) < 3e-5
+        assert rel_err(dv, wr2.grad) < 1e-4
+
 
 @pytest.mark.parametrize("name", ["pqmf_disc_wide", "melgan_l2_like", "thin_pqmf_l1", "dense_k5_chunks"])
 def test_batched_input_gradient_ex(hip, name):

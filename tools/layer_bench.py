@@ -102,7 +102,7 @@ def main():
 
         def bdx():
             if math == ops.MATH_BF16:   # the engine's form: linear conv, masks in the producer's epilogue
-                return check(lib.eben_conv1d_bwd_dx_ex(ctypes.byref(d), ptr(dy), ptr(pw.wp_bwd), None, 0, None, 1.0, 0, None, ptr(dx), st))
+                return check(lib.eben_conv1d_bwd_dx(ctypes.byref(d_lin), ptr(dy), None, ptr(pw.wp_bwd), None, ptr(dx), 0, ptr(ws), wsb, st))
             check(lib.eben_conv1d_bwd_dx(ctypes.byref(d), ptr(dy), ptr(ymask), ptr(pw.wp_bwd), ptr(xmask), ptr(dx), 0, ptr(ws), wsb, st))
 
         if math == ops.MATH_BF16:   # the engine's form: pre-masked gradient, linear conv

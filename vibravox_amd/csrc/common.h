@@ -161,7 +161,7 @@ int dw2_launch(const Canon& c, Dw2Args a, float* workspace, size_t ws_bytes, hip
 // bf16-operand weight-gradient kernel (conv_dw3.hip): k-step = one time step x 16 batch items
 int dw3_applicable(const Canon& c);
 size_t dw3_workspace(const Canon& c, int* nslab, int* row_stride);
-int dw3_launch(const Canon& c, const float* a, float a_slope, const float* x, float x_slope, int has_bias, float* workspace, size_t ws_bytes,
-               hipStream_t st);
+int dw3_launch(const Canon& c, const float* a, const float* amask, float a_slope, const float* x, float x_slope, int has_bias, float* workspace,
+               size_t ws_bytes, hipStream_t st);
 
 }  // namespace eben

@@ -392,7 +392,7 @@ extern "C" int eben_wn_bwd(const float* dw_slabs, int nslab, size_t slab_stride,
 extern "C" size_t eben_conv1d_bwd_dw_workspace(const EbenConv1dDesc* d, int* nslab, int* row_stride) {
   Canon c;
   if (canon_from_desc(d, &c) != EBEN_OK) return 0;
-  if (d->out_slope == 1.f && dw3_applicable(c)) return dw3_workspace(c, nslab, row_stride);   // bf16 math, no mask on load
+  if ((d->out_slope == 1.f || !d->transposed) && dw3_applicable(c)) return dw3_workspace(c, nslab, row_stride);   // bf16 math (no mask on the X operand)
   if (dw2_applicable(c)) return dw2_workspace(c, nslab, row_stride);
   DwPlan p;
   make_dw_plan(c, &p);
@@ -409,9 +409,10 @@ extern "C" int eben_conv1d_bwd_dw(const EbenConv1dDesc* d, const float* dy, cons
   EBEN_REQUIRE(dy && x && slabs, "null pointer in conv1d_bwd_dw");
   EBEN_REQUIRE(d->out_slope == 1.f || y, "y is required to differentiate the fused output activation");
   EBEN_REQUIRE(!(d->transposed && has_bias), "ConvTranspose1d bias gradient is not provided by this kernel");
-  if (d->out_slope == 1.f && dw3_applicable(c)) {
-    if (!d->transposed) return dw3_launch(c, dy, 1.f, x, d->in_slope, has_bias ? 1 : 0, slabs, ws_bytes, as_stream(stream));
-    return dw3_launch(c, x, d->in_slope, dy, 1.f, 0, slabs, ws_bytes, as_stream(stream));
+  if ((d->out_slope == 1.f || !d->transposed) && dw3_applicable(c)) {
+    if (!d->transposed)   // the gradient operand carries the activation derivative of the fused output stage
+      return dw3_launch(c, dy, d->out_slope != 1.f ? y : nullptr, d->out_slope, x, d->in_slope, has_bias ? 1 : 0, slabs, ws_bytes, as_stream(stream));
+    return dw3_launch(c, x, nullptr, d->in_slope, dy, 1.f, 0, slabs, ws_bytes, as_stream(stream));
   }
   if (dw2_applicable(c)) {
     Dw2Args a2;

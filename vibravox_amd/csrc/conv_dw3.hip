@@ -33,7 +33,7 @@ __device__ __forceinline__ unsigned dw3_pack_bf16(float a, float b) {
 constexpr int DW3_KSC = 4;   // time steps (k-steps of 16 batch items) per A sub-chunk
 
 struct Dw3Args {
-  const float* a; float a_slope;
+  const float* a; const float* amask; int a_mode; float a_slope;   // a_mode 1: a * lrelu'(amask)
   const float* x; float x_slope;
   u32x4* ap;
   float* slabs;
@@ -60,7 +60,10 @@ __global__ __launch_bounds__(256) void dw3_pack_a_kernel(const Dw3Args P) {
     const int t = i & 31, m = (i >> 5) & 31, b = i >> 10;
     float v = 0.f;
     const int bb = bg * 16 + half * 8 + b, mm = m32 * 32 + m;
-    if (bb < P.B && mm < P.Mg && t0 + t < P.La) v = lrelu(P.a[((long long)bb * P.Ca + (long long)g * P.Mg + mm) * P.La + t0 + t], P.a_slope);
+    if (bb < P.B && mm < P.Mg && t0 + t < P.La) {
+      const long long idx = ((long long)bb * P.Ca + (long long)g * P.Mg + mm) * P.La + t0 + t;
+      v = P.a_mode == 0 ? lrelu(P.a[idx], P.a_slope) : P.a[idx] * dlrelu(P.amask[idx], P.a_slope);
+    }
     tile[b][m][t] = v;
   }
   __syncthreads();
@@ -367,8 +370,8 @@ size_t dw3_workspace(const Canon& c, int* nslab, int* row_stride) {
   return sizeof(float) * (size_t)p.slab_stride * p.nsplit + 16 * p.ap_units + 16;
 }
 
-int dw3_launch(const Canon& c, const float* a, float a_slope, const float* x, float x_slope, int has_bias, float* workspace, size_t ws_bytes,
-               hipStream_t st) {
+int dw3_launch(const Canon& c, const float* a, const float* amask, float a_slope, const float* x, float x_slope, int has_bias, float* workspace,
+               size_t ws_bytes, hipStream_t st) {
   Dw3Plan p;
   make_dw3_plan(c, &p);
   if (!p.ok) return fail(EBEN_EUNSUPPORTED, "dw3_launch on a layer the bf16 weight-gradient kernel does not cover");
@@ -376,7 +379,7 @@ int dw3_launch(const Canon& c, const float* a, float a_slope, const float* x, fl
   const size_t need = slab_bytes + 16 * p.ap_units + 16;
   if (ws_bytes < need) return fail(EBEN_EWORKSPACE, "bwd_dw needs %zu workspace bytes, got %zu", need, ws_bytes);
   Dw3Args k;
-  k.a = a; k.a_slope = a_slope; k.x = x; k.x_slope = x_slope;
+  k.a = a; k.amask = amask; k.a_mode = amask ? 1 : 0; k.a_slope = a_slope; k.x = x; k.x_slope = x_slope;
   k.slabs = workspace;
   k.ap = reinterpret_cast<u32x4*>((reinterpret_cast<uintptr_t>(workspace) + slab_bytes + 15) & ~(uintptr_t)15);
   k.B = c.B; k.G = c.g; k.Cg = p.Cg; k.Mg = p.Mg; k.Ca = c.Cout; k.Cx = c.Cin; k.La = c.Lout; k.Lx = c.Lin;

@@ -35,12 +35,12 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
 constexpr int T3_KSC = 4;   // k-steps (of 16 reduction elements) per weight chunk
 
 struct Tap3Args {
-  const float* x; const u32x4* wp; const int* tab;
+  const float* x; const float* xmask; const u32x4* wp; const int* tab;
   const float* bias; const float* res; const float* emask; float* y;
   int B, G, Cg, Mg, Cx, Cy, Lx, Ly;
   int S, OS, dstep, J0, mode, off0, nt, nph;
   int ps_pad, ps_k, ps_d, ps_kstep;
-  int reflect, accumulate;
+  int reflect, accumulate, in_mode;   // in_mode 1: the input is multiplied by lrelu'(xmask) as it is staged (autograd's mask-on-load)
   int res_rows, em_seg, em_map[4];
   float in_slope, out_slope, res_slope, emask_slope;
   int CI_T, CI_B, CP, ncc, PLEN, CSTRIDE, nxb;   // CI_T channels = CI_B bundles per input tile; CP = CI_B / 2 k-steps per tap
@@ -49,7 +49,7 @@ struct Tap3Args {
   long long w_tile, w_phase;                     // in 16-byte units
 };
 
-template <int FM, int XRB>
+template <int FM, int XRB, bool IM = false>
 __global__ __launch_bounds__(256, 2) void tap3_kernel(const Tap3Args P) {
   constexpr int NT = 256, BN = 128, BM = FM * 32, KSC = T3_KSC;
   constexpr int WCHU = KSC * FM * 64;       // 16-byte units per weight chunk
@@ -119,10 +119,13 @@ __global__ __launch_bounds__(256, 2) void tap3_kernel(const Tap3Args P) {
       v[e] = base[(long long)c * P.Lx + qq];
     }
   };
-  auto cvt8 = [&](const float (&v)[8], int c0, int ok) -> u32x4 {
+  auto cvt8 = [&](const float (&v)[8], const float (&mk)[8], int c0, int ok) -> u32x4 {
     float t[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) t[e] = (ok && c0 + e < P.Cg) ? lrelu(v[e], P.in_slope) : 0.f;
+    for (int e = 0; e < 8; ++e) {
+      const float w = IM ? v[e] * dlrelu(mk[e], P.in_slope) : lrelu(v[e], P.in_slope);
+      t[e] = (ok && c0 + e < P.Cg) ? w : 0.f;
+    }
     u32x4 o;
     o[0] = pack_bf16(t[0], t[1]); o[1] = pack_bf16(t[2], t[3]); o[2] = pack_bf16(t[4], t[5]); o[3] = pack_bf16(t[6], t[7]);
     return o;
@@ -135,10 +138,11 @@ __global__ __launch_bounds__(256, 2) void tap3_kernel(const Tap3Args P) {
     const int bb = (int)__umulhi((unsigned)i, span_magic);
     xg[u] = (P.ncc > 1 && i < xtot) ? ((bb << 16) | (i - bb * span)) : -1;
   }
-  float xreg[XRB][8];
+  float xreg[XRB][8], mreg[IM ? XRB : 1][8];
   unsigned okmask = 0;
   auto fetch_x = [&](int cc) {
     const float* xp = P.x + xrow0;
+    const float* mp = P.xmask + xrow0;
     okmask = 0;
 #pragma unroll
     for (int u = 0; u < XRB; ++u) {
@@ -147,6 +151,7 @@ __global__ __launch_bounds__(256, 2) void tap3_kernel(const Tap3Args P) {
       ok &= (int)(xg[u] >= 0);
       okmask |= (unsigned)ok << u;
       load8(xp, cc * P.CI_T + (xg[u] >= 0 ? (xg[u] >> 16) * 8 : 0), qq, xreg[u]);
+      if constexpr (IM) load8(mp, cc * P.CI_T + (xg[u] >= 0 ? (xg[u] >> 16) * 8 : 0), qq, mreg[u]);
     }
   };
   const int dead_slot = P.nxb * XBUF;
@@ -157,7 +162,7 @@ __global__ __launch_bounds__(256, 2) void tap3_kernel(const Tap3Args P) {
     for (int u = 0; u < XRB; ++u) {
       const int bb = xg[u] >> 16;
       const int sl = xg[u] >= 0 ? x_slot(bb, xg[u] & 0xffff) : dead_slot - bsel * XBUF;
-      dst[sl] = cvt8(xreg[u], cc * P.CI_T + (xg[u] >= 0 ? bb * 8 : 0), (int)((okmask >> u) & 1u));
+      dst[sl] = cvt8(xreg[u], mreg[IM ? u : 0], cc * P.CI_T + (xg[u] >= 0 ? bb * 8 : 0), (int)((okmask >> u) & 1u));
     }
   };
 
@@ -175,8 +180,9 @@ __global__ __launch_bounds__(256, 2) void tap3_kernel(const Tap3Args P) {
   if (nch > 0) {
     issue_w(0);
     const float* xp = P.x + xrow0;
+    const float* mp = P.xmask + xrow0;
     for (int base = 0; base < xtot; base += 2 * NT) {
-      float v[2][8];
+      float v[2][8], mk[IM ? 2 : 1][8];
       int sl[2], ok[2], c0[2];
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
@@ -187,11 +193,12 @@ __global__ __launch_bounds__(256, 2) void tap3_kernel(const Tap3Args P) {
         ok[u] &= (int)(i < xtot);
         c0[u] = i < xtot ? bb * 8 : 0;
         load8(xp, c0[u], qq, v[u]);
+        if constexpr (IM) load8(mp, c0[u], qq, mk[u]);
         sl[u] = i < xtot ? x_slot(bb, r) : -1;
       }
 #pragma unroll
       for (int u = 0; u < 2; ++u)
-        if (sl[u] >= 0) Xs[sl[u]] = cvt8(v[u], c0[u], ok[u]);
+        if (sl[u] >= 0) Xs[sl[u]] = cvt8(v[u], mk[IM ? u : 0], c0[u], ok[u]);
     }
     if (P.ncc > 1) fetch_x(1);
   }
@@ -304,10 +311,11 @@ static void make_plan3(const Canon& c, int dir, Tap3Plan* p) {
   static const int enabled = env_int3("EBEN_TAP3", 1);
   static const int min_m = env_int3("EBEN_TAP3_MIN_M", 4);
   static const int min_c = env_int3("EBEN_TAP3_MIN_C", 4);
+  static const int min_k = env_int3("EBEN_TAP3_MIN_K", 2 * 16 * T3_KSC);
   // the layers below these sizes are staging-bound either way; measured faster here than on the direct kernel from
   // 4 channels / 4 rows per group up (MelGAN L1 forward 0.23 -> 0.15 ms, its input gradient 0.47 -> 0.34 ms), given a
   // reduction of at least two weight chunks
-  if (!enabled || p->Cg < min_c || p->Mg < min_m || p->nph > 64 || (long long)round_up(p->Cg, 16) * p->J < 2 * 16 * T3_KSC) return;
+  if (!enabled || p->Cg < min_c || p->Mg < min_m || p->nph > 64 || (long long)round_up(p->Cg, 16) * p->J < min_k) return;
   const int Jmin = dir == 0 ? p->J : (c.k / p->kstep > 0 ? c.k / p->kstep : 1);
 
   const int cand[4] = {128, 96, 64, 32};
@@ -456,10 +464,10 @@ __global__ __launch_bounds__(256) void pack3_kernel(const Pack3Args P) {
   }
 }
 
-template <int FM, int XRB>
-static int launch3_cfg(const Tap3Args& a, int nblocks, size_t lds, hipStream_t st) {
+template <int FM, int XRB, bool IM>
+static int launch3_im(const Tap3Args& a, int nblocks, size_t lds, hipStream_t st) {
   static bool attr_set = false;
-  auto kern = tap3_kernel<FM, XRB>;
+  auto kern = tap3_kernel<FM, XRB, IM>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(tap3)");
@@ -468,6 +476,10 @@ static int launch3_cfg(const Tap3Args& a, int nblocks, size_t lds, hipStream_t s
   hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), lds, st, a);
   EBEN_CHECK_LAUNCH("tap3_kernel");
   return EBEN_OK;
+}
+template <int FM, int XRB>
+static int launch3_cfg(const Tap3Args& a, int nblocks, size_t lds, hipStream_t st) {
+  return a.in_mode ? launch3_im<FM, XRB, true>(a, nblocks, lds, st) : launch3_im<FM, XRB, false>(a, nblocks, lds, st);
 }
 
 int tap3_applicable(const Canon& c, int dir) {
@@ -506,9 +518,8 @@ int tap3_launch(const Canon& c, int dir, const TapIO& io, int reflect, hipStream
   Tap3Plan p;
   make_plan3(c, dir, &p);
   if (!p.ok) return fail(EBEN_EUNSUPPORTED, "tap3_launch on a layer the bf16 kernel does not cover");
-  if (io.in_mode != 0) return fail(EBEN_EUNSUPPORTED, "the bf16 kernel has no mask-on-load input stage (use the epilogue mask of the producer)");
   Tap3Args a;
-  a.x = io.x; a.wp = reinterpret_cast<const u32x4*>(io.wp); a.tab = reinterpret_cast<const int*>(io.wp + p.tab_off_floats);
+  a.x = io.x; a.xmask = io.in_mode ? io.xmask : io.x; a.in_mode = io.in_mode; a.wp = reinterpret_cast<const u32x4*>(io.wp); a.tab = reinterpret_cast<const int*>(io.wp + p.tab_off_floats);
   a.bias = io.bias; a.res = io.res; a.emask = io.emask; a.y = io.y;
   a.B = c.B; a.G = p.G; a.Cg = p.Cg; a.Mg = p.Mg; a.Cx = p.Cx; a.Cy = p.Cy; a.Lx = p.Lx; a.Ly = p.Ly;
   a.S = p.S; a.OS = p.OS; a.dstep = p.dstep; a.J0 = p.J; a.mode = p.mode; a.off0 = p.off0; a.nt = p.nt; a.nph = p.nph;

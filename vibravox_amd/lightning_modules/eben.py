@@ -106,6 +106,9 @@ class EBENLightningModule(BaseSELightningModule):
     #: arithmetic of the discriminator contractions inside the engine: "f32" (bit-exact fp32 products) or "bf16"
     #: (bf16 MFMA operands, fp32 accumulate -- BASELINE config 2).  The generator always computes in fp32.
     disc_math: str = os.environ.get("EBEN_DISC_MATH", "f32")
+    #: arithmetic of the generator's BACKWARD contractions (input / weight gradients) in the engine step; its forward --
+    #: the product's output -- is exact fp32 either way
+    gen_backward_math: str = os.environ.get("EBEN_GEN_BWD_MATH", "f32")
 
     def _engine_usable(self, batch) -> bool:
         from ..disc_engine import DiscriminatorEngine
@@ -144,7 +147,8 @@ class EBENLightningModule(BaseSELightningModule):
         # ---- generator phase
         ops.join_prepack()
         self._mark("start")
-        enhanced_speech, bands = self.generator(corrupted_speech)
+        with ops.backward_math({"f32": ops.MATH_F32, "bf16": ops.MATH_BF16}[self.gen_backward_math]):
+            enhanced_speech, bands = self.generator(corrupted_speech)
         with torch.no_grad():
             bands_ref = self.generator.pqmf.forward(reference_speech, "analysis")
         self._mark("generator forward")

@@ -144,6 +144,24 @@ _desc_cache: Dict[Tuple[ConvSpec, int, int], EbenConv1dDesc] = {}
 
 MATH_F32, MATH_BF16 = 0, 1   # EBEN_MATH_* of include/eben_hip.h
 
+# Arithmetic of the BACKWARD contractions (input and weight gradients) of `conv_layer`; the forward is always exact fp32.
+# Read when the forward runs (the backward image of the weights is packed then).
+_backward_math = [MATH_F32]
+
+
+class backward_math:
+    """with ops.backward_math(ops.MATH_BF16): forwards run inside record bf16 backward contractions."""
+
+    def __init__(self, math: int):
+        self.math = math
+
+    def __enter__(self):
+        self.prev = _backward_math[0]
+        _backward_math[0] = self.math
+
+    def __exit__(self, *exc):
+        _backward_math[0] = self.prev
+
 
 def conv_desc(spec: ConvSpec, batch: int, l_in: int, math: int = MATH_F32) -> EbenConv1dDesc:
     key = (spec, batch, l_in, math)
@@ -169,10 +187,12 @@ class PackedWeights:
 
 
 def pack_weights(spec: ConvSpec, d: EbenConv1dDesc, v: torch.Tensor, g: Optional[torch.Tensor],
-                 cache: Optional[PackedWeights], need_bwd: bool) -> PackedWeights:
+                 cache: Optional[PackedWeights], need_bwd: bool, d_bwd: Optional[EbenConv1dDesc] = None) -> PackedWeights:
+    """d_bwd: descriptor of the backward launches when it differs from the forward's (bf16 backward math)."""
     lib = load()
+    d_bwd = d if d_bwd is None else d_bwd
     key = (v.data_ptr(), v._version, _storage_epoch.get(v.data_ptr(), 0), _storage_epoch.get(-1, 0),
-           None if g is None else (g.data_ptr(), g._version, _storage_epoch.get(g.data_ptr(), 0)), d.batch, d.l_in)
+           None if g is None else (g.data_ptr(), g._version, _storage_epoch.get(g.data_ptr(), 0)), d.batch, d.l_in, d_bwd.math)
     pw = cache if cache is not None else PackedWeights()
     if _side["prepacked"] is not None and torch.cuda.current_stream() != _side["stream"]:
         join_prepack()   # images built ahead of time on the side stream: first consumer waits for them
@@ -189,11 +209,15 @@ def pack_weights(spec: ConvSpec, d: EbenConv1dDesc, v: torch.Tensor, g: Optional
         pw.scale = pw.norm = None
     pw.wp_fwd = torch.empty(lib.eben_conv1d_packed_floats(ctypes.byref(d), 0), dtype=torch.float32, device=v.device)
     pw.wp_bwd = (
-        torch.empty(lib.eben_conv1d_packed_floats(ctypes.byref(d), 1), dtype=torch.float32, device=v.device) if need_bwd else None
+        torch.empty(lib.eben_conv1d_packed_floats(ctypes.byref(d_bwd), 1), dtype=torch.float32, device=v.device) if need_bwd else None
     )
-    check(lib.eben_conv1d_pack(ctypes.byref(d), ptr(v), ptr(pw.scale), ptr(pw.wp_fwd), ptr(pw.wp_bwd), st), "conv1d_pack")
+    if d_bwd is d or not need_bwd:
+        check(lib.eben_conv1d_pack(ctypes.byref(d), ptr(v), ptr(pw.scale), ptr(pw.wp_fwd), ptr(pw.wp_bwd), st), "conv1d_pack")
+    else:
+        check(lib.eben_conv1d_pack(ctypes.byref(d), ptr(v), ptr(pw.scale), ptr(pw.wp_fwd), None, st), "conv1d_pack")
+        check(lib.eben_conv1d_pack(ctypes.byref(d_bwd), ptr(v), ptr(pw.scale), None, ptr(pw.wp_bwd), st), "conv1d_pack")
     pw.key = key
-    pw.last = (spec, d)
+    pw.last = (spec, d, d_bwd)
     return pw
 
 
@@ -211,12 +235,12 @@ def prepack(layers) -> None:
     side.wait_stream(main)   # the step that used the old images (and the optimiser that changed the weights) is complete
     with torch.cuda.stream(side), torch.no_grad():
         for m in todo:
-            spec, d = m._packed.last
+            spec, d, d_bwd = m._packed.last
             if m.weight_norm:
                 prm = m.parametrizations["weight"]
-                pack_weights(spec, d, prm.original1.detach(), prm.original0.detach(), m._packed, True)
+                pack_weights(spec, d, prm.original1.detach(), prm.original0.detach(), m._packed, True, d_bwd)
             else:
-                pack_weights(spec, d, m.weight.detach(), None, m._packed, True)
+                pack_weights(spec, d, m.weight.detach(), None, m._packed, True, d_bwd)
         ev = torch.cuda.Event()
         ev.record()
     _side["prepacked"] = ev
@@ -239,8 +263,9 @@ class _ConvLayerFn(torch.autograd.Function):
         if c != spec.c_in:
             raise _lib.EbenError(f"conv expects {spec.c_in} input channels, got {c}")
         d = conv_desc(spec, b, l_in)
+        d_bwd = conv_desc(spec, b, l_in, _backward_math[0]) if _backward_math[0] != MATH_F32 else d
         need_dx = ctx.needs_input_grad[0]
-        pw = pack_weights(spec, d, v.detach(), None if g is None else g.detach(), cache, need_dx)
+        pw = pack_weights(spec, d, v.detach(), None if g is None else g.detach(), cache, need_dx, d_bwd)
         y = torch.empty((b, spec.c_out, d.l_out), dtype=torch.float32, device=x.device)
         tm = _timer[0]
         timed = tm is not None and tm.enabled and tm.spec == spec
@@ -252,7 +277,7 @@ class _ConvLayerFn(torch.autograd.Function):
             e1.record()
             tm.events.append((e0, e1))
             tm.batch = b
-        ctx.spec, ctx.d = spec, d
+        ctx.spec, ctx.d = spec, d_bwd   # the descriptor the backward launches use
         ctx.wp_bwd, ctx.norm = pw.wp_bwd, pw.norm
         ctx.has_g, ctx.has_bias = g is not None, bias is not None
         ctx.save_for_backward(x, v, g, y if spec.out_slope != 1.0 else None)
