@@ -191,6 +191,34 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt32 = float(t.item())
 
+    # the roofline kernel once more, ALONE on the device (inside the step it shares the GPU with the three other
+    # discriminator chains and the MRSTFT GEMMs, which stretches its launch-to-finish time): reported as `isolated`
+    iso_ms = None
+    if rank == 0:
+        import ctypes
+        from vibravox_amd._lib import check, load, ptr, stream
+        lib = load()
+        math = ops.MATH_BF16 if args.disc_math == "bf16" else ops.MATH_F32
+        lb = timer.batch or 2 * args.batch
+        lx = cut
+        for (k, s_, p_) in [(15, 1, 7), (41, 4, 20), (41, 4, 20), (41, 4, 20)]:
+            lx = (lx + 2 * p_ - (k - 1) - 1) // s_ + 1
+        d = ops.conv_desc(layer.spec, lb, lx, math)
+        prm = layer.parametrizations["weight"]
+        pw = ops.pack_weights(layer.spec, d, prm.original1.detach(), prm.original0.detach(), None, False)
+        xin = torch.randn(lb, layer.spec.c_in, lx, device=device)
+        yout = torch.empty(lb, layer.spec.c_out, d.l_out, device=device)
+        torch.cuda.synchronize()
+        for _ in range(3):
+            check(lib.eben_conv1d_fwd(ctypes.byref(d), ptr(xin), ptr(pw.wp_fwd), ptr(layer.bias), None, ptr(yout), stream()))
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            check(lib.eben_conv1d_fwd(ctypes.byref(d), ptr(xin), ptr(pw.wp_fwd), ptr(layer.bias), None, ptr(yout), stream()))
+        e1.record()
+        torch.cuda.synchronize()
+        iso_ms = e0.elapsed_time(e1) / 20
+
     if rank == 0:
         ms = dt / args.steps * 1e3
         value = world * args.batch * cut / 16000 / (dt / args.steps)
@@ -220,7 +248,10 @@ def main():
                          "achieved": round(achieved, 2) if achieved else None, "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4) if achieved else None, "traffic": pmc_traffic(launch_batch, args.disc_math),
                          "launch_ms": round(kms, 4) if kms else None, "flops_per_launch": flops,
-                         "launches_timed": len(timer.events)},
+                         "launches_timed": len(timer.events),
+                         "isolated": {"launch_ms": round(iso_ms, 4), "achieved": round(flops / (iso_ms * 1e-3) / 1e12, 2),
+                                      "frac": round(flops / (iso_ms * 1e-3) / 1e12 / peak, 4),
+                                      "note": "same launch alone on the device, 20 back-to-back launches after the timed region"}},
         }
         if dt32 is not None:
             line["f32_discriminator"] = {"ms_per_step": round(dt32 / args.steps * 1e3, 3), "steps": args.steps,

@@ -81,6 +81,22 @@ EBEN_API int eben_wn_scale(const float* g, const float* v, int rows, int cols, f
 EBEN_API int eben_wn_bwd(const float* dw_slabs, int nslab, size_t slab_stride, int rows, int cols, int row_stride,
                 const float* g, const float* v, const float* norm, float* dg, float* dv, float* dbias, void* stream);
 
+/* Multi-tensor forms of the two calls above: one launch (per 36 items) for every layer of a network.  `items` is a HOST
+ * array (device pointers inside), passed to the kernels by value.  Bit-identical results. */
+typedef struct EbenWnScaleItem {
+  const float* g; const float* v; float* scale; float* norm;
+  int32_t rows, cols;
+} EbenWnScaleItem;
+typedef struct EbenWnBwdItem {
+  const float* slabs;                 /* as dw_slabs of eben_wn_bwd: slab 0 is overwritten by the sum */
+  const float* g; const float* v; const float* norm;   /* g == NULL: plain weight */
+  float* dg; float* dv; float* dbias; /* dbias nullable */
+  int64_t slab_stride;                /* floats between slabs */
+  int32_t nslab, rows, cols, row_stride;
+} EbenWnBwdItem;
+EBEN_API int eben_wn_scale_multi(const EbenWnScaleItem* items, int n, void* stream);
+EBEN_API int eben_wn_bwd_multi(const EbenWnBwdItem* items, int n, void* stream);
+
 /* ---- conv layers ------------------------------------------------------------------------ */
 /* floats needed for the packed weights of the forward (which=0) / input-gradient (which=1) pass */
 EBEN_API size_t eben_conv1d_packed_floats(const EbenConv1dDesc* d, int which);

@@ -42,6 +42,16 @@ class EbenConv1dDesc(ctypes.Structure):
     ]
 
 
+class EbenWnScaleItem(ctypes.Structure):
+    _fields_ = [("g", c_void_p), ("v", c_void_p), ("scale", c_void_p), ("norm", c_void_p), ("rows", c_int32), ("cols", c_int32)]
+
+
+class EbenWnBwdItem(ctypes.Structure):
+    _fields_ = [("slabs", c_void_p), ("g", c_void_p), ("v", c_void_p), ("norm", c_void_p), ("dg", c_void_p), ("dv", c_void_p),
+                ("dbias", c_void_p), ("slab_stride", c_int64), ("nslab", c_int32), ("rows", c_int32), ("cols", c_int32),
+                ("row_stride", c_int32)]
+
+
 class EbenAdamTensor(ctypes.Structure):
     _fields_ = [
         ("param", c_void_p),
@@ -67,6 +77,8 @@ SIGNATURES = {
     "eben_device_info": (c_int, [ctypes.c_char_p, c_size_t]),
     "eben_wn_scale": (c_int, [_P, _P, c_int, c_int, _P, _P, _P]),
     "eben_wn_bwd": (c_int, [_P, c_int, c_size_t, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P]),
+    "eben_wn_scale_multi": (c_int, [POINTER(EbenWnScaleItem), c_int, _P]),
+    "eben_wn_bwd_multi": (c_int, [POINTER(EbenWnBwdItem), c_int, _P]),
     "eben_conv1d_packed_floats": (c_size_t, [_D, c_int]),
     "eben_conv1d_kernel_generation": (c_int, [_D, c_int]),
     "eben_conv1d_pack": (c_int, [_D, _P, _P, _P, _P, _P]),
@@ -139,15 +151,17 @@ def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     """Device pointer of a tensor the kernels may touch (contiguous float32 on a HIP device)."""
     if t is None:
         return None
-    if t.device.type != "cuda":
+    if not t.is_cuda:
         raise EbenError(
             f"vibravox_amd ops run only on an MI355X HIP device (got a tensor on '{t.device}'); "
             "there is no CPU path -- the CPU oracle lives under oracle/ and is test-only."
         )
-    if t.dtype != torch.float32 or not t.is_contiguous():
+    if t.dtype is not torch.float32 or not t.is_contiguous():
         raise EbenError(f"expected a contiguous float32 tensor, got {t.dtype} contiguous={t.is_contiguous()}")
     return t.data_ptr()
 
 
 def stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+    """Raw handle of torch's current HIP stream (two C calls: ~20x cheaper than torch.cuda.current_stream().cuda_stream,
+    which builds a Python Stream object -- it was 2.6 ms of CPU per train step)."""
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())

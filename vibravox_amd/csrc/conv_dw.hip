@@ -357,9 +357,133 @@ __global__ __launch_bounds__(256) void wn_bwd_kernel(const float* __restrict__ d
   for (int i = threadIdx.x; i < cols; i += 256) orow[i] = c1 * srow[i] - c2 * vrow[i];
 }
 
+// ---- multi-tensor forms: one launch for every layer of a network (the per-layer launches are ~5 us kernels whose
+// launch overhead and dependent-launch gaps dominate; 75 + 166 of the ~1070 launches of a train step) -------------
+constexpr int WN_CHUNK = 36;
+struct WnScaleTable { EbenWnScaleItem t[WN_CHUNK]; };
+struct WnBwdTable { EbenWnBwdItem t[WN_CHUNK]; };
+
+__global__ __launch_bounds__(256) void wn_scale_multi_kernel(const WnScaleTable T) {
+  __shared__ float red[4];
+  const EbenWnScaleItem e = T.t[blockIdx.y];
+  const int r = blockIdx.x;
+  if (r >= e.rows) return;
+  const float* row = e.v + (long long)r * e.cols;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < e.cols; i += 256) { const float t = row[i]; s += t * t; }
+  s = block_sum_256(s, red);
+  if (threadIdx.x == 0) {
+    const float n = sqrtf(s);
+    e.norm[r] = n;
+    e.scale[r] = e.g[r] / n;
+  }
+}
+
+// same arithmetic and summation order as slab_reduce_kernel / wn_bwd_kernel (results are bit-identical)
+__global__ __launch_bounds__(256) void slab_reduce_multi_kernel(const WnBwdTable T) {
+  __shared__ float part[4][64];
+  const EbenWnBwdItem e = T.t[blockIdx.y];
+  if (e.nslab <= 1) return;
+  const long long n = (long long)e.rows * e.row_stride;
+  const float* slabs = e.slabs;
+  float* out = const_cast<float*>(e.slabs);
+  const int lane = threadIdx.x & 63, zg = threadIdx.x >> 6;
+  for (long long base = (long long)blockIdx.x * 64; base < n; base += (long long)gridDim.x * 64) {
+    const long long i = base + lane;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (i < n) {
+      int z = zg;
+      for (; z + 12 < e.nslab; z += 16) {
+        s0 += slabs[(long long)z * e.slab_stride + i];
+        s1 += slabs[(long long)(z + 4) * e.slab_stride + i];
+        s2 += slabs[(long long)(z + 8) * e.slab_stride + i];
+        s3 += slabs[(long long)(z + 12) * e.slab_stride + i];
+      }
+      for (; z < e.nslab; z += 4) s0 += slabs[(long long)z * e.slab_stride + i];
+    }
+    __syncthreads();
+    part[zg][lane] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (zg == 0 && i < n) out[i] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+  }
+}
+
+__global__ __launch_bounds__(256) void wn_bwd_multi_kernel(const WnBwdTable T) {
+  __shared__ float red[4];
+  const EbenWnBwdItem e = T.t[blockIdx.y];
+  const int r = blockIdx.x;
+  if (r >= e.rows) return;
+  const int cols = e.cols;
+  const float* srow = e.slabs + (long long)r * e.row_stride;
+  float* orow = e.dv + (long long)r * cols;
+  if (e.dbias && threadIdx.x == 0) e.dbias[r] = srow[cols];
+  if (!e.g) {
+    for (int i = threadIdx.x; i < cols; i += 256) orow[i] = srow[i];
+    return;
+  }
+  const float* vrow = e.v + (long long)r * cols;
+  float dot = 0.f;
+  for (int i = threadIdx.x; i < cols; i += 256) dot += srow[i] * vrow[i];
+  dot = block_sum_256(dot, red);
+  const float n = e.norm[r], gr = e.g[r];
+  const float dgr = dot / n;
+  if (threadIdx.x == 0) e.dg[r] = dgr;
+  const float c1 = gr / n, c2 = gr * dgr / (n * n);
+  for (int i = threadIdx.x; i < cols; i += 256) orow[i] = c1 * srow[i] - c2 * vrow[i];
+}
+
 }  // namespace eben
 
 using namespace eben;
+
+extern "C" int eben_wn_scale_multi(const EbenWnScaleItem* items, int n, void* stream) {
+  EBEN_REQUIRE(items && n > 0, "bad wn_scale_multi arguments");
+  for (int base = 0; base < n; base += WN_CHUNK) {
+    WnScaleTable T;
+    const int cnt = n - base < WN_CHUNK ? n - base : WN_CHUNK;
+    int max_rows = 0;
+    for (int i = 0; i < cnt; ++i) {
+      const EbenWnScaleItem& e = items[base + i];
+      EBEN_REQUIRE(e.g && e.v && e.scale && e.norm && e.rows > 0 && e.cols > 0, "bad wn_scale_multi item %d", base + i);
+      T.t[i] = e;
+      if (e.rows > max_rows) max_rows = e.rows;
+    }
+    hipLaunchKernelGGL(wn_scale_multi_kernel, dim3(max_rows, cnt), dim3(256), 0, as_stream(stream), T);
+    EBEN_CHECK_LAUNCH("wn_scale_multi_kernel");
+  }
+  return EBEN_OK;
+}
+
+extern "C" int eben_wn_bwd_multi(const EbenWnBwdItem* items, int n, void* stream) {
+  EBEN_REQUIRE(items && n > 0, "bad wn_bwd_multi arguments");
+  for (int base = 0; base < n; base += WN_CHUNK) {
+    WnBwdTable T;
+    const int cnt = n - base < WN_CHUNK ? n - base : WN_CHUNK;
+    int max_rows = 0;
+    long long max_blocks = 0;
+    for (int i = 0; i < cnt; ++i) {
+      const EbenWnBwdItem& e = items[base + i];
+      EBEN_REQUIRE(e.slabs && e.dv && e.nslab > 0 && e.rows > 0 && e.cols > 0 && e.row_stride >= e.cols, "bad wn_bwd_multi item %d", base + i);
+      EBEN_REQUIRE(!e.g || (e.v && e.norm && e.dg), "weight-norm backward needs v, norm and dg (item %d)", base + i);
+      EBEN_REQUIRE(!e.dbias || e.row_stride > e.cols, "no bias column in the slabs (item %d)", base + i);
+      EBEN_REQUIRE(e.nslab == 1 || e.slab_stride >= (long long)e.rows * e.row_stride, "slab stride smaller than a slab (item %d)", base + i);
+      T.t[i] = e;
+      if (e.rows > max_rows) max_rows = e.rows;
+      if (e.nslab > 1) {
+        const long long b = ((long long)e.rows * e.row_stride + 63) / 64;
+        if (b > max_blocks) max_blocks = b;
+      }
+    }
+    if (max_blocks > 0) {
+      if (max_blocks > 4096) max_blocks = 4096;
+      hipLaunchKernelGGL(slab_reduce_multi_kernel, dim3((unsigned)max_blocks, cnt), dim3(256), 0, as_stream(stream), T);
+      EBEN_CHECK_LAUNCH("slab_reduce_multi_kernel");
+    }
+    hipLaunchKernelGGL(wn_bwd_multi_kernel, dim3(max_rows, cnt), dim3(256), 0, as_stream(stream), T);
+    EBEN_CHECK_LAUNCH("wn_bwd_multi_kernel");
+  }
+  return EBEN_OK;
+}
 
 extern "C" int eben_wn_scale(const float* g, const float* v, int rows, int cols, float* scale, float* norm, void* stream) {
   EBEN_REQUIRE(g && v && scale && norm && rows > 0 && cols > 0, "bad wn_scale arguments");

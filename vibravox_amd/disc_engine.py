@@ -37,8 +37,7 @@ from . import ops
 from ._lib import check, load, ptr
 
 
-def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+from ._lib import stream as _stream  # noqa: E402  (raw handle of the current HIP stream)
 
 
 class _Layer:
@@ -186,6 +185,8 @@ class _Chain:
         st = _stream()
         n = len(self.layers)
         grads = [None] * n
+        wn_jobs = []   # slab sums + weight-norm chain rule of the whole chain: one multi-tensor launch at the end
+        logits = None
         for i, g, x_in in jobs:
             lay = self.layers[i]
             if i == n - 1:
@@ -194,15 +195,19 @@ class _Chain:
                 # two bias gradients are -c*N and +c*N summed in the SAME order, i.e. they cancel exactly and
                 # Adam leaves the bias alone; one sum over both branches leaves a rounding residue that Adam
                 # (m / sqrt(v)) turns into a full-size step.
-                gf = self._weight_grads(lay, g[2 * half:3 * half], x_in[:half], st)
-                gr = self._weight_grads(lay, g[3 * half:], x_in[half:], st)
-                grads[i] = tuple(None if a is None else a + b for a, b in zip(gf, gr))
+                gf = self._weight_grads(lay, g[2 * half:3 * half], x_in[:half], st, wn_jobs)
+                gr = self._weight_grads(lay, g[3 * half:], x_in[half:], st, wn_jobs)
+                logits = (i, gf, gr)
             else:
-                grads[i] = self._weight_grads(lay, g[2 * half:], x_in, st)
+                grads[i] = self._weight_grads(lay, g[2 * half:], x_in, st, wn_jobs)
+        ops.wn_bwd_multi(wn_jobs)
+        if logits is not None:
+            i, gf, gr = logits
+            grads[i] = tuple(None if a is None else a + b for a, b in zip(gf, gr))
         return grads
 
     @staticmethod
-    def _weight_grads(lay: _Layer, g2: torch.Tensor, x_in: torch.Tensor, st: int):
+    def _weight_grads(lay: _Layer, g2: torch.Tensor, x_in: torch.Tensor, st: int, wn_jobs: list):
         lib = load()
         v, gain, bias = lay.params()
         rows_b = g2.shape[0]
@@ -217,8 +222,8 @@ class _Chain:
         dv = torch.empty_like(v)
         dg = torch.empty_like(gain)
         dbias = torch.empty(wrows, dtype=torch.float32, device=g2.device) if bias is not None else None
-        check(lib.eben_wn_bwd(ptr(slabs), nslab.value, wrows * row_stride.value, wrows, cols, row_stride.value, ptr(gain.detach()),
-                              ptr(v.detach()), ptr(lay.norm), ptr(dg), ptr(dv), ptr(dbias), st), "wn_bwd")
+        wn_jobs.append((slabs, nslab.value, wrows * row_stride.value, wrows, cols, row_stride.value, gain.detach(), v.detach(), lay.norm,
+                        dg, dv, dbias))
         return dv, dg, dbias
 
 
@@ -317,6 +322,18 @@ class DiscriminatorEngine:
         side = ops._side_stream(dev)
         side.wait_stream(main)
         with torch.cuda.stream(side), torch.no_grad():
+            jobs = []
+            for ch in self.chains:   # weight-norm scales of all layers: one multi-tensor launch
+                for lay in ch.layers:
+                    wkey = lay._weights_key()
+                    if lay.packs and lay.scale_key != wkey:
+                        v, g, _ = lay.params()
+                        rows = v.shape[0]
+                        lay.scale = torch.empty(rows, dtype=torch.float32, device=dev)
+                        lay.norm = torch.empty(rows, dtype=torch.float32, device=dev)
+                        lay.scale_key = wkey
+                        jobs.append((g.detach(), v.detach(), rows, v.numel() // rows, lay.scale, lay.norm))
+            ops.wn_scale_multi(jobs)
             for ch in self.chains:
                 for lay in ch.layers:
                     for (which, batch, l_in) in list(lay.packs):

@@ -14,7 +14,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import torch
 
 from . import _lib
-from ._lib import EbenConv1dDesc, check, load, ptr, stream
+from ._lib import EbenConv1dDesc, EbenWnBwdItem, EbenWnScaleItem, check, load, ptr, stream
 
 # Optimisers that write parameters behind autograd's back (FusedAdam) bump the epoch of exactly
 # the storages they touched, so that only those layers' packed-weight caches are rebuilt.
@@ -57,7 +57,7 @@ class weight_grads_disabled:
 # `keep` holds a reference to every upstream gradient a side-stream kernel reads until `join()`: autograd
 # sums gradients IN PLACE into a buffer it holds the only reference to (a residual add hands the same
 # tensor to both branches), which would rewrite the gradient on the main stream under the kernel reading it.
-_side = {"enabled": False, "stream": None, "keep": [], "prepacked": None}
+_side = {"enabled": False, "stream": None, "keep": [], "prepacked": None, "wn_jobs": []}
 
 
 class weight_grads_on_side_stream:
@@ -73,6 +73,10 @@ class weight_grads_on_side_stream:
     def join():
         st = _side["stream"]
         if st is not None:
+            if _side["wn_jobs"]:
+                with torch.cuda.stream(st):
+                    wn_bwd_multi(_side["wn_jobs"])   # slab sums + weight-norm chain rule of every layer: two launches
+                _side["wn_jobs"] = []
             torch.cuda.current_stream(st.device).wait_stream(st)
         _side["keep"].clear()
 
@@ -82,6 +86,30 @@ def _side_stream(device) -> "torch.cuda.Stream":
     if st is None or st.device != device:
         st = _side["stream"] = torch.cuda.Stream(device=device)
     return st
+
+
+def wn_bwd_multi(jobs) -> None:
+    """jobs: (slabs, nslab, slab_stride, rows, cols, row_stride, g, v, norm, dg, dv, dbias) per layer -- the arguments of
+    ``eben_wn_bwd`` -- on the current stream, as one multi-tensor call."""
+    if not jobs:
+        return
+    items = (EbenWnBwdItem * len(jobs))()
+    p = lambda t: t if t is None or isinstance(t, int) else ptr(t)   # outputs may arrive as raw device pointers
+    for it, (slabs, nslab, slab_stride, rows, cols, row_stride, g, v, norm, dg, dv, dbias) in zip(items, jobs):
+        it.slabs, it.g, it.v, it.norm = ptr(slabs), ptr(g), ptr(v), ptr(norm)
+        it.dg, it.dv, it.dbias = p(dg), p(dv), p(dbias)
+        it.slab_stride, it.nslab, it.rows, it.cols, it.row_stride = slab_stride, nslab, rows, cols, row_stride
+    check(load().eben_wn_bwd_multi(items, len(jobs), stream()), "wn_bwd_multi")
+
+
+def wn_scale_multi(jobs) -> None:
+    """jobs: (g, v, rows, cols, scale, norm) per layer, one multi-tensor call on the current stream."""
+    if not jobs:
+        return
+    items = (EbenWnScaleItem * len(jobs))()
+    for it, (g, v, rows, cols, scale, norm) in zip(items, jobs):
+        it.g, it.v, it.scale, it.norm, it.rows, it.cols = ptr(g), ptr(v), ptr(scale), ptr(norm), rows, cols
+    check(load().eben_wn_scale_multi(items, len(jobs), stream()), "wn_scale_multi")
 
 
 class KernelTimer:
@@ -187,8 +215,9 @@ class PackedWeights:
 
 
 def pack_weights(spec: ConvSpec, d: EbenConv1dDesc, v: torch.Tensor, g: Optional[torch.Tensor],
-                 cache: Optional[PackedWeights], need_bwd: bool, d_bwd: Optional[EbenConv1dDesc] = None) -> PackedWeights:
-    """d_bwd: descriptor of the backward launches when it differs from the forward's (bf16 backward math)."""
+                 cache: Optional[PackedWeights], need_bwd: bool, d_bwd: Optional[EbenConv1dDesc] = None, pre_scale=None) -> PackedWeights:
+    """d_bwd: descriptor of the backward launches when it differs from the forward's (bf16 backward math);
+    pre_scale: (scale, norm) already computed for the current weights (multi-tensor launch in `prepack`)."""
     lib = load()
     d_bwd = d if d_bwd is None else d_bwd
     key = (v.data_ptr(), v._version, _storage_epoch.get(v.data_ptr(), 0), _storage_epoch.get(-1, 0),
@@ -201,7 +230,9 @@ def pack_weights(spec: ConvSpec, d: EbenConv1dDesc, v: torch.Tensor, g: Optional
         return pw
     st = stream()
     rows = v.shape[0]
-    if g is not None:
+    if g is not None and pre_scale is not None:
+        pw.scale, pw.norm = pre_scale
+    elif g is not None:
         pw.scale = torch.empty(rows, dtype=torch.float32, device=v.device)
         pw.norm = torch.empty(rows, dtype=torch.float32, device=v.device)
         check(lib.eben_wn_scale(ptr(g), ptr(v), rows, v.numel() // rows, ptr(pw.scale), ptr(pw.norm), st), "wn_scale")
@@ -234,11 +265,22 @@ def prepack(layers) -> None:
     side = _side_stream(dev)
     side.wait_stream(main)   # the step that used the old images (and the optimiser that changed the weights) is complete
     with torch.cuda.stream(side), torch.no_grad():
+        scales, jobs = {}, []
+        for m in todo:   # weight-norm scales of every layer: one multi-tensor launch
+            if m.weight_norm:
+                prm = m.parametrizations["weight"]
+                v, g = prm.original1.detach(), prm.original0.detach()
+                rows = v.shape[0]
+                sc = torch.empty(rows, dtype=torch.float32, device=dev)
+                nm = torch.empty(rows, dtype=torch.float32, device=dev)
+                scales[id(m)] = (sc, nm)
+                jobs.append((g, v, rows, v.numel() // rows, sc, nm))
+        wn_scale_multi(jobs)
         for m in todo:
             spec, d, d_bwd = m._packed.last
             if m.weight_norm:
                 prm = m.parametrizations["weight"]
-                pack_weights(spec, d, prm.original1.detach(), prm.original0.detach(), m._packed, True, d_bwd)
+                pack_weights(spec, d, prm.original1.detach(), prm.original0.detach(), m._packed, True, d_bwd, scales[id(m)])
             else:
                 pack_weights(spec, d, m.weight.detach(), None, m._packed, True, d_bwd)
         ev = torch.cuda.Event()
@@ -323,9 +365,16 @@ class _ConvLayerFn(torch.autograd.Function):
                 dv = torch.empty_like(v)
                 dg = torch.empty_like(g) if ctx.has_g else None
                 dbias = torch.empty(rows, dtype=torch.float32, device=x.device) if ctx.has_bias else None
-                check(lib.eben_wn_bwd(ptr(slabs), nslab.value, rows * row_stride.value, rows, cols, row_stride.value,
-                                      ptr(g) if ctx.has_g else None, ptr(v), ptr(ctx.norm) if ctx.has_g else None,
-                                      ptr(dg), ptr(dv), ptr(dbias), sw), "wn_bwd")
+                job = (slabs, nslab.value, rows * row_stride.value, rows, cols, row_stride.value, g if ctx.has_g else None, v,
+                       ctx.norm if ctx.has_g else None, dg, dv, dbias)
+                if use_side:
+                    # .grad is None for these parameters: AccumulateGrad just stores dv / dg / dbias -- PROVIDED nothing else
+                    # references them (it clones a gradient it does not own exclusively), so the deferred job keeps their
+                    # device pointers, not the tensors.  The slab sums and the weight-norm chain rule of ALL layers are
+                    # then issued as one multi-tensor launch at join().
+                    _side["wn_jobs"].append(job[:9] + (ptr(dg), ptr(dv), ptr(dbias)))
+                else:
+                    wn_bwd_multi([job])
         return dx, dv, dg, dbias, None, None
 
 
