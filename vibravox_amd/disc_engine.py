@@ -270,7 +270,12 @@ class DiscriminatorEngine:
         main = torch.cuda.current_stream()
         dev = main.device
         if self._streams is None or self._streams[0].device != dev:
-            self._streams = [torch.cuda.Stream(device=dev) for _ in self.chains]
+            import os
+            if os.environ.get("EBEN_CHAIN_STREAMS", "4") == "2":   # the three PQMF-band chains share one stream
+                a, b = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+                self._streams = [a] * (len(self.chains) - 1) + [b]
+            else:
+                self._streams = [torch.cuda.Stream(device=dev) for _ in self.chains]
         results = [None] * len(self.chains)
         n = len(self.chains)
         ev = getattr(self, "_prepack_ev", None)
