@@ -35,6 +35,7 @@ class _Bucket:
             off += p.numel()
         self.pending = len(params)
         self.work = None
+        self.index = {id(p): i for i, p in enumerate(params)}
 
 
 class GradSync:
@@ -69,9 +70,27 @@ class GradSync:
         self.launched = 0
 
     # -- hooks -------------------------------------------------------------------------------
+    def grad_buffer(self, p: torch.nn.Parameter) -> Optional[torch.Tensor]:
+        """The bucket view that holds p's gradient (contiguous, p's shape) -- a kernel may write the finished gradient
+        there directly (then report it with ``mark_ready``) instead of handing a tensor to autograd."""
+        b = self._owner.get(id(p))
+        return None if b is None else b.views[b.index[id(p)]]
+
+    def mark_ready(self, params: Iterable[torch.nn.Parameter]) -> None:
+        """Gradients written straight into ``grad_buffer(p)`` (complete on the current stream): the same accounting as
+        the post-accumulate hook -- a bucket's all-reduce is issued when its last gradient is there."""
+        for p in params:
+            b = self._owner.get(id(p))
+            if b is None:
+                continue
+            p.grad = b.views[b.index[id(p)]]
+            b.pending -= 1
+            if b.pending == 0 and self.overlap:
+                self._launch(b)
+
     def _on_grad(self, p: torch.nn.Parameter):
         b = self._owner[id(p)]
-        view = b.views[[id(q) for q in b.params].index(id(p))]
+        view = b.views[b.index[id(p)]]
         if p.grad is not view:  # autograd replaced the tensor (first accumulation after set_to_none)
             view.copy_(p.grad)
             p.grad = view

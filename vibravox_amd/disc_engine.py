@@ -177,7 +177,7 @@ class _Chain:
             g = dx
         return g, (jobs if want_param_grads else None)
 
-    def weight_grads(self, jobs, half: int):
+    def weight_grads(self, jobs, half: int, sink=None):
         """Second half of the backward: the weight gradients of every layer from the stacked gradients kept by
         ``backward`` (rows [fake | real] against the layer inputs [enhanced | reference]).  Nothing on the
         generator side depends on them, so the engine launches them after the input-gradient chain and lets
@@ -199,15 +199,17 @@ class _Chain:
                 gr = self._weight_grads(lay, g[3 * half:], x_in[half:], st, wn_jobs)
                 logits = (i, gf, gr)
             else:
-                grads[i] = self._weight_grads(lay, g[2 * half:], x_in, st, wn_jobs)
+                grads[i] = self._weight_grads(lay, g[2 * half:], x_in, st, wn_jobs, sink)
         ops.wn_bwd_multi(wn_jobs)
         if logits is not None:
             i, gf, gr = logits
-            grads[i] = tuple(None if a is None else a + b for a, b in zip(gf, gr))
+            outs = [None if sink is None or p is None else sink.grad_buffer(p) for p in self.layers[i].params()]
+            grads[i] = tuple(None if a is None else (a + b if o is None else torch.add(a, b, out=o)) for a, b, o in zip(gf, gr, outs))
         return grads
 
     @staticmethod
-    def _weight_grads(lay: _Layer, g2: torch.Tensor, x_in: torch.Tensor, st: int, wn_jobs: list):
+    def _weight_grads(lay: _Layer, g2: torch.Tensor, x_in: torch.Tensor, st: int, wn_jobs: list, sink=None):
+        """sink (ddp.GradSync): the gradients are written straight into its bucket views."""
         lib = load()
         v, gain, bias = lay.params()
         rows_b = g2.shape[0]
@@ -219,9 +221,13 @@ class _Chain:
               "conv1d_bwd_dw")
         wrows = v.shape[0]
         cols = v.numel() // wrows
-        dv = torch.empty_like(v)
-        dg = torch.empty_like(gain)
-        dbias = torch.empty(wrows, dtype=torch.float32, device=g2.device) if bias is not None else None
+        dv = dg = dbias = None
+        if sink is not None:
+            dv, dg, dbias = sink.grad_buffer(v), sink.grad_buffer(gain), (sink.grad_buffer(bias) if bias is not None else None)
+        dv = torch.empty_like(v) if dv is None else dv
+        dg = torch.empty_like(gain) if dg is None else dg
+        if bias is not None and dbias is None:
+            dbias = torch.empty(wrows, dtype=torch.float32, device=g2.device)
         wn_jobs.append((slabs, nslab.value, wrows * row_stride.value, wrows, cols, row_stride.value, gain.detach(), v.detach(), lay.norm,
                         dg, dv, dbias))
         return dv, dg, dbias
@@ -377,14 +383,16 @@ class DiscriminatorEngine:
         return out
 
     # ---- the four backwards as one stacked pass ------------------------------------------------------
-    def backward(self, want_param_grads: bool = True):
-        self.backward_launch(want_param_grads)
+    def backward(self, want_param_grads: bool = True, sink=None):
+        self.backward_launch(want_param_grads, sink)
         return self.backward_finish()
 
     @torch.no_grad()
-    def backward_launch(self, want_param_grads: bool = True):
+    def backward_launch(self, want_param_grads: bool = True, sink=None):
         """Launches the stacked input-gradient chains on the four streams and returns; ``backward_finish`` joins them
-        (the caller may run independent main-stream work in between)."""
+        (the caller may run independent main-stream work in between).  sink (``ddp.GradSync``): the weight gradients are
+        written straight into its bucket views and reported by ``collect_param_grads`` (data-parallel runs)."""
+        self._sink = sink
         lib = load()
         s = self._state
         half, emb = s["half"], s["emb"]
@@ -446,7 +454,7 @@ class DiscriminatorEngine:
             n = len(self.chains)
             for i in [n - 1] + list(range(n - 1)):   # the longest chain first
                 with torch.cuda.stream(self._streams[i]):
-                    pend[i] = self.chains[i].weight_grads(res[i][1], half)
+                    pend[i] = self.chains[i].weight_grads(res[i][1], half, self._sink)
             self._pending = (pend, s)   # keeps the saved activations alive until the kernels have run
         self._state = None
         return gb[:half], ga[:half], gb[half:], ga[half:]
@@ -460,6 +468,11 @@ class DiscriminatorEngine:
         main = torch.cuda.current_stream()
         for st in self._streams:
             main.wait_stream(st)
+        sink = getattr(self, "_sink", None)
+        if sink is not None:   # already in the gradient buckets: report them (the buckets' all-reduces start), nothing to inject
+            self._pending = self._sink = None
+            sink.mark_ready([p for p in self.disc.parameters() if p.requires_grad])
+            return None
         by_param = {}
         for ch, grads in zip(self.chains, pend):
             for lay, (dv, dg, dbias) in zip(ch.layers, grads):

@@ -175,7 +175,9 @@ class EBENLightningModule(BaseSELightningModule):
         update_discriminator = bool(torch.rand(1) < self.update_discriminator_ratio)
         # input gradients now; the discriminator's weight gradients keep running on the engine's streams
         # underneath the balancing passes and the (launch-bound, GPU-underfilling) generator backward
-        engine.backward_launch(want_param_grads=update_discriminator)
+        syncs = getattr(self, "grad_sync", None) or {}
+        g_sink, d_sink = syncs.get(id(generator_optimizer)), syncs.get(id(discriminator_optimizer))
+        engine.backward_launch(want_param_grads=update_discriminator, sink=d_sink)
         # balancing (eben.py:222-240) with every gradient taken at `bands`; the seeds of the losses that do not pass
         # through the discriminators are taken while its input-gradient chains run
         leaf = self.generator.last_conv.weight
@@ -206,7 +208,7 @@ class EBENLightningModule(BaseSELightningModule):
         for s, lam in zip(seeds, lambdas):
             seed = s * lam if seed is None else seed + s * lam
         self._mark("balancing (3 seeds + norms)")
-        with ops.weight_grads_on_side_stream() as side:   # dX chain on this stream, dW work beside it
+        with ops.weight_grads_on_side_stream(sink=g_sink) as side:   # dX chain on this stream, dW work beside it
             torch.autograd.backward(bands, seed, inputs=g_params)
         self._mark("generator backward (dX chain)")
         side.join()
@@ -223,7 +225,9 @@ class EBENLightningModule(BaseSELightningModule):
             self.log("train/discriminator/real_loss", real_loss, sync_dist=True)
             self.log("train/discriminator/fake_loss", fake_loss, sync_dist=True)
             self.log("train/discriminator/backprop_loss", real_loss + fake_loss, sync_dist=True)
-            inject_grads(list(self.discriminator.parameters()), engine.collect_param_grads())
+            d_grads = engine.collect_param_grads()   # None when they went straight into the data-parallel buckets
+            if d_grads is not None:
+                inject_grads(list(self.discriminator.parameters()), d_grads)
             self._mark("discriminator weight gradients joined")
             self._step(discriminator_optimizer, self._sync_grads(discriminator_optimizer))
             discriminator_optimizer.zero_grad()

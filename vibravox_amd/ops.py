@@ -57,20 +57,27 @@ class weight_grads_disabled:
 # `keep` holds a reference to every upstream gradient a side-stream kernel reads until `join()`: autograd
 # sums gradients IN PLACE into a buffer it holds the only reference to (a residual add hands the same
 # tensor to both branches), which would rewrite the gradient on the main stream under the kernel reading it.
-_side = {"enabled": False, "stream": None, "keep": [], "prepacked": None, "wn_jobs": []}
+_side = {"enabled": False, "stream": None, "keep": [], "prepacked": None, "wn_jobs": [], "sink": None, "sunk": []}
 
 
 class weight_grads_on_side_stream:
+    """sink: an object with ``grad_buffer(param) -> tensor | None`` and ``mark_ready(params)`` (``ddp.GradSync``): the
+    weight gradients are then written straight into the sink's buffers (data-parallel gradient buckets) and reported at
+    ``join()``, instead of being handed to autograd -- which would accumulate them into ``p.grad`` on the main stream
+    the moment the layer's backward returns, i.e. force the weight-gradient work back onto the critical path."""
+
+    def __init__(self, sink=None):
+        self.sink = sink
+
     def __enter__(self):
-        self.prev = _side["enabled"]
-        _side["enabled"] = True
+        self.prev = (_side["enabled"], _side["sink"])
+        _side["enabled"], _side["sink"] = True, self.sink
         return self
 
     def __exit__(self, *exc):
-        _side["enabled"] = self.prev
+        _side["enabled"], _side["sink"] = self.prev
 
-    @staticmethod
-    def join():
+    def join(self):
         st = _side["stream"]
         if st is not None:
             if _side["wn_jobs"]:
@@ -79,6 +86,9 @@ class weight_grads_on_side_stream:
                 _side["wn_jobs"] = []
             torch.cuda.current_stream(st.device).wait_stream(st)
         _side["keep"].clear()
+        if _side["sunk"]:
+            sunk, _side["sunk"] = _side["sunk"], []
+            self.sink.mark_ready(sunk)
 
 
 def _side_stream(device) -> "torch.cuda.Stream":
@@ -322,6 +332,7 @@ class _ConvLayerFn(torch.autograd.Function):
         ctx.spec, ctx.d = spec, d_bwd   # the descriptor the backward launches use
         ctx.wp_bwd, ctx.norm = pw.wp_bwd, pw.norm
         ctx.has_g, ctx.has_bias = g is not None, bias is not None
+        ctx.bias_param = bias   # identity only: the gradient sink looks its bucket view up by parameter
         ctx.save_for_backward(x, v, g, y if spec.out_slope != 1.0 else None)
         return y
 
@@ -342,6 +353,14 @@ class _ConvLayerFn(torch.autograd.Function):
         want_w = ctx.needs_input_grad[1] or (ctx.has_g and ctx.needs_input_grad[2]) or (ctx.has_bias and ctx.needs_input_grad[3])
         if want_w and not _skip_weight_grads[0]:
             use_side = _side["enabled"] and v.grad is None and (g is None or g.grad is None)
+            sunk = None
+            if _side["enabled"] and not use_side and _side["sink"] is not None:
+                # data-parallel run: p.grad is a view of a gradient bucket -- write the results there directly
+                sk = _side["sink"]
+                sunk = (sk.grad_buffer(v), sk.grad_buffer(g) if ctx.has_g else None, sk.grad_buffer(ctx.bias_param) if ctx.has_bias else None)
+                if sunk[0] is None or (ctx.has_g and sunk[1] is None) or (ctx.has_bias and sunk[2] is None):
+                    sunk = None
+                use_side = sunk is not None
             if use_side:
                 main = torch.cuda.current_stream(x.device)
                 side = _side_stream(x.device)
@@ -362,9 +381,12 @@ class _ConvLayerFn(torch.autograd.Function):
                       "conv1d_bwd_dw")
                 rows = v.shape[0]
                 cols = v.numel() // rows
-                dv = torch.empty_like(v)
-                dg = torch.empty_like(g) if ctx.has_g else None
-                dbias = torch.empty(rows, dtype=torch.float32, device=x.device) if ctx.has_bias else None
+                if sunk is not None:
+                    dv, dg, dbias = sunk
+                else:
+                    dv = torch.empty_like(v)
+                    dg = torch.empty_like(g) if ctx.has_g else None
+                    dbias = torch.empty(rows, dtype=torch.float32, device=x.device) if ctx.has_bias else None
                 job = (slabs, nslab.value, rows * row_stride.value, rows, cols, row_stride.value, g if ctx.has_g else None, v,
                        ctx.norm if ctx.has_g else None, dg, dv, dbias)
                 if use_side:
@@ -375,6 +397,9 @@ class _ConvLayerFn(torch.autograd.Function):
                     _side["wn_jobs"].append(job[:9] + (ptr(dg), ptr(dv), ptr(dbias)))
                 else:
                     wn_bwd_multi([job])
+            if sunk is not None:   # autograd gets nothing for these parameters; join() reports them to the sink
+                _side["sunk"].extend(p for p in (v, g if ctx.has_g else None, ctx.bias_param if ctx.has_bias else None) if p is not None)
+                dv = dg = dbias = None
         return dx, dv, dg, dbias, None, None
 
 
