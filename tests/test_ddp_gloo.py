@@ -51,6 +51,24 @@ def _worker(rank, world, port, q):
                 assert torch.allclose(p, r, atol=1e-6), (step, (p - r).abs().max())
             assert all(p.grad is v for b in sync.buckets for p, v in zip(b.params, b.views))  # grads stay bucket views
         assert sync.launched >= 3 * len(sync.buckets)  # every bucket went out from its hook, every step
+        # the sink form the engine step uses: gradients computed outside autograd are written straight into the bucket views
+        # (grad_buffer) and reported with mark_ready -- same exchange, same result
+        launched = sync.launched
+        x = data[rank] + 7
+        grads = torch.autograd.grad(net(x).pow(2).sum(), list(net.parameters()))
+        plist = list(net.parameters())
+        for p, gr in zip(plist, grads):
+            buf = sync.grad_buffer(p)
+            assert buf is not None and buf.shape == p.shape and buf.is_contiguous()
+            buf.copy_(gr)
+        sync.mark_ready(reversed(plist))
+        scale = sync.finish()
+        assert sync.launched == launched + len(sync.buckets)
+        want = torch.autograd.grad(sum(ref(data[r] + 7).pow(2).sum() for r in range(world)), list(ref.parameters()))
+        for p, w in zip(plist, want):
+            assert p.grad is sync.grad_buffer(p)
+            assert torch.allclose(p.grad * scale, w / world, atol=1e-6)
+        opt.zero_grad()
         vals = all_reduce_scalars([torch.tensor(float(rank)), torch.tensor(10.0 + rank)])
         assert abs(float(vals[0]) - 0.5) < 1e-6 and abs(float(vals[1]) - 10.5) < 1e-6
         q.put((rank, "ok"))
