@@ -161,6 +161,12 @@ def main():
         torch.cuda.synchronize()
         if rank == 0:
             print(f"[bench] warm-up step {i}: {(time.perf_counter() - tw) * 1e3:.1f} ms", file=sys.stderr, flush=True)
+    # Python's cyclic GC walks every tracked object of the process on a full collection (~100 ms here, a few times per
+    # 40 steps: +2..5 ms/step and most of the run-to-run spread): the objects alive after warm-up are moved to the
+    # permanent generation, as a long-running training process would do once after set-up (run.py does the same)
+    import gc
+    gc.collect()
+    gc.freeze()
     barrier()
     timer.enabled = True
     t0 = time.perf_counter()

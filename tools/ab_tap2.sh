@@ -1,5 +1,2 @@
-timeout 1500 python -m pytest tests/test_gpu_models.py -m gpu -x -q 2>&1 | grep -E "passed|failed|^E  " | head -8
-for rep in 1 2; do
-timeout 600 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-f32-leg --force-ddp 2>&1 | grep -E "GPU:|Error|error" | head -3
-timeout 600 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-f32-leg 2>&1 | grep -E "GPU:|Error|error" | head -3
-done
+for i in 1 2 3 4 5; do python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-f32-leg 2>&1 | grep "GPU:"; done
+python bench.py 2>&1 | tail -1 | cut -c1-250

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 dev = torch.device("cuda", 0)
 mod = bench.build_module(dev, 1234)
-mod.disc_math = os.environ.get("EBEN_DISC_MATH", "bf16")
+mod.disc_math = os.environ.get("EBEN_DISC_MATH", "bf16"); mod.gen_backward_math = os.environ.get("EBEN_GEN_BWD_MATH", mod.disc_math)
 batch = bench.synthetic_batch(32, 32000, 1234, dev)
 for _ in range(3):
     mod.training_step(batch)
@@ -13,11 +13,16 @@ torch.cuda.synchronize()
 N = 10
 acc = {}
 order = []
+SYNC = os.environ.get("SYNC_EACH_STEP", "0") == "1"
+runs = []
 for _ in range(N):
     mod.phase_events = []
     mod.training_step(batch)
-    torch.cuda.synchronize()
-    ev = mod.phase_events
+    if SYNC:
+        torch.cuda.synchronize()
+    runs.append(mod.phase_events)
+torch.cuda.synchronize()
+for ev in runs:
     for (l0, e0), (l1, e1) in zip(ev[:-1], ev[1:]):
         if l1 not in acc:
             order.append(l1)

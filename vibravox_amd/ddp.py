@@ -47,7 +47,13 @@ class GradSync:
         assert self.params, "no trainable parameter to synchronise"
         dev, dtype = self.params[0].device, self.params[0].dtype
         self.on_gpu = dev.type == "cuda"
-        self.comm_stream = torch.cuda.Stream(device=dev) if self.on_gpu else None
+        if self.on_gpu:
+            # no stream of its own: a fifth stream would share a hardware queue with the main stream or a compute chain
+            # (see ops.aux_stream); the exchange is issued after the work of the side stream it rides on
+            from . import ops
+            self.comm_stream = ops.aux_stream(2, dev)
+        else:
+            self.comm_stream = None
         self.overlap = overlap
         # reverse parameter order ~ the order in which backward finishes gradients
         self.buckets: List[_Bucket] = []

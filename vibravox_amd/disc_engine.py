@@ -276,12 +276,10 @@ class DiscriminatorEngine:
         main = torch.cuda.current_stream()
         dev = main.device
         if self._streams is None or self._streams[0].device != dev:
-            import os
-            if os.environ.get("EBEN_CHAIN_STREAMS", "4") == "2":   # the three PQMF-band chains share one stream
-                a, b = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
-                self._streams = [a] * (len(self.chains) - 1) + [b]
-            else:
-                self._streams = [torch.cuda.Stream(device=dev) for _ in self.chains]
+            # MelGAN chain on one stream, the three (shorter, equal) PQMF-band chains in series on another: with the main
+            # and the side stream that is four streams = four hardware queues, none shared (ops.aux_stream)
+            pq, mel = ops.aux_stream(1, dev), ops.aux_stream(0, dev)
+            self._streams = [pq] * (len(self.chains) - 1) + [mel]
         results = [None] * len(self.chains)
         n = len(self.chains)
         ev = getattr(self, "_prepack_ev", None)
@@ -296,7 +294,7 @@ class DiscriminatorEngine:
 
     def _join_streams(self):
         main = torch.cuda.current_stream()
-        for st in self._streams:
+        for st in set(self._streams):
             main.wait_stream(st)
 
     def _on_streams(self, fn):
@@ -466,7 +464,7 @@ class DiscriminatorEngine:
             return None
         pend, _keep = self._pending
         main = torch.cuda.current_stream()
-        for st in self._streams:
+        for st in set(self._streams):
             main.wait_stream(st)
         sink = getattr(self, "_sink", None)
         if sink is not None:   # already in the gradient buckets: report them (the buckets' all-reduces start), nothing to inject

@@ -91,10 +91,25 @@ class weight_grads_on_side_stream:
             self.sink.mark_ready(sunk)
 
 
+# The HIP runtime multiplexes streams onto FOUR hardware queues (GPU_MAX_HW_QUEUES; 8 measured 50 % slower): a fifth
+# stream shares a queue with another one and its launches are executed in submission order with that one's -- a tiny
+# Adam launch on the main stream then sits behind ~17 ms of weight-gradient kernels of a stream it has nothing to do with
+# (seen as 28 / 33 / 36 ms steps from run to run, depending on which streams happened to collide).  So the step uses the
+# main stream plus exactly THREE auxiliary streams, created once, in this order:
+#   0: MelGAN discriminator chain   1: the three PQMF-band discriminator chains (in series)   2: generator weight
+#   gradients, weight pre-packing
+_aux = {"device": None, "streams": None}
+
+
+def aux_stream(i: int, device=None) -> "torch.cuda.Stream":
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+    if _aux["streams"] is None or _aux["device"] != device:
+        _aux["device"], _aux["streams"] = device, [torch.cuda.Stream(device=device) for _ in range(3)]
+    return _aux["streams"][i]
+
+
 def _side_stream(device) -> "torch.cuda.Stream":
-    st = _side["stream"]
-    if st is None or st.device != device:
-        st = _side["stream"] = torch.cuda.Stream(device=device)
+    st = _side["stream"] = aux_stream(2, device)
     return st
 
 
