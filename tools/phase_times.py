@@ -10,6 +10,7 @@ batch = bench.synthetic_batch(32, 32000, 1234, dev)
 for _ in range(3):
     mod.training_step(batch)
 torch.cuda.synchronize()
+import gc; gc.collect(); gc.freeze()
 N = 10
 acc = {}
 order = []

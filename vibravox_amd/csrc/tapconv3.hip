@@ -32,7 +32,10 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
   return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));   // v_cvt_pk_bf16_f32 (RNE)
 }
 
-constexpr int T3_KSC = 4;   // k-steps (of 16 reduction elements) per weight chunk
+#ifndef EBEN_T3_KSC
+#define EBEN_T3_KSC 4
+#endif
+constexpr int T3_KSC = EBEN_T3_KSC;   // k-steps (of 16 reduction elements) per weight chunk
 
 struct Tap3Args {
   const float* x; const float* xmask; const u32x4* wp; const int* tab;

@@ -105,19 +105,28 @@ class _Chain:
 
     # ---- forward on a (2B, C, L) batch: returns [input, out_0, ..., logits] and the padded input
     def forward(self, x: torch.Tensor):
+        bufs = self.forward_rows(x.contiguous(), None, 0, x.shape[0])
+        return bufs["emb"], bufs["xp"]
+
+    def forward_rows(self, x_full: torch.Tensor, bufs: Optional[dict], r0: int, r1: int) -> dict:
+        """Runs the chain on batch rows [r0, r1) of ``x_full`` and writes rows [r0, r1) of full-batch activation tensors
+        (allocated on the first call, passed back as ``bufs`` for the remaining rows): the reference half of the batch
+        does not depend on the generator, so the engine runs it underneath the generator forward."""
         lib = load()
-        x = x.contiguous()
-        b, c, l = x.shape
+        nb, c, l = x_full.shape
+        b = r1 - r0
+        if bufs is None:
+            xp_full = torch.empty((nb, c, l + 2 * self.pad), dtype=torch.float32, device=x_full.device) if self.pad else x_full
+            bufs = {"xp": xp_full, "outs": [None] * len(self.layers)}
+        xp_full = bufs["xp"]
         if self.pad:
-            xp = torch.empty((b, c, l + 2 * self.pad), dtype=torch.float32, device=x.device)
-            check(lib.eben_reflect_pad_fwd(ptr(x), ptr(xp), b * c, l, self.pad, self.pad, _stream()), "reflect_pad_fwd")
-        else:
-            xp = x
-        outs = []
-        cur = xp
-        for lay in self.layers:
+            check(lib.eben_reflect_pad_fwd(ptr(x_full[r0:r1]), ptr(xp_full[r0:r1]), b * c, l, self.pad, self.pad, _stream()), "reflect_pad_fwd")
+        cur = xp_full[r0:r1]
+        for i, lay in enumerate(self.layers):
             d = ops.conv_desc(lay.spec, b, cur.shape[2], self.math)
-            y = torch.empty((b, lay.spec.c_out, d.l_out), dtype=torch.float32, device=x.device)
+            if bufs["outs"][i] is None:
+                bufs["outs"][i] = torch.empty((nb, lay.spec.c_out, d.l_out), dtype=torch.float32, device=x_full.device)
+            y = bufs["outs"][i][r0:r1]
             _, _, bias = lay.params()
             wp = lay.packed(0, b, cur.shape[2])
             tm = ops._timer[0]
@@ -130,9 +139,9 @@ class _Chain:
                 e1.record()
                 tm.events.append((e0, e1))
                 tm.batch = b
-            outs.append(y)
             cur = y
-        return [x] + outs, xp
+        bufs["emb"] = [x_full] + bufs["outs"]
+        return bufs
 
     # ---- backward of the four stacked right-hand sides
     def backward(self, emb: List[torch.Tensor], xp: torch.Tensor, fm_grads: List[Optional[torch.Tensor]], seeds: torch.Tensor,
@@ -302,19 +311,47 @@ class DiscriminatorEngine:
         self._join_streams()
         return results
 
-    # ---- the two forwards as one batch-2B pass -------------------------------------------------
+    # ---- the two forwards: one batch-2B pass, or the reference half ahead of time ----------------------
+    def _inputs(self, half, bands_like, audio_like):
+        dev = audio_like.device
+        sub = torch.empty((2 * half, self.q) + tuple(bands_like.shape[2:]), dtype=torch.float32, device=dev)
+        wav = torch.empty((2 * half,) + tuple(audio_like.shape[1:]), dtype=torch.float32, device=dev)
+        return sub, wav
+
+    @torch.no_grad()
+    def forward_reference(self, bands_ref: torch.Tensor, audio_ref: torch.Tensor):
+        """Launches the discriminators on the REFERENCE half of the batch (rows [B, 2B) of every activation tensor) and
+        returns at once: nothing in it depends on the generator, so the caller runs the generator forward on the main
+        stream meanwhile; ``forward`` then only has the enhanced half left."""
+        half = audio_ref.shape[0]
+        sub, wav = self._inputs(half, bands_ref, audio_ref)
+        sub[half:].copy_(bands_ref[:, -self.q:, :])
+        wav[half:].copy_(audio_ref)
+        inputs = [sub] * (len(self.chains) - 1) + [wav]
+        bufs = self._launch_on_streams(lambda i: self.chains[i].forward_rows(inputs[i], None, half, 2 * half))
+        self._partial = dict(half=half, sub=sub, wav=wav, bufs=bufs)
+
     @torch.no_grad()
     def forward(self, bands: torch.Tensor, audio: torch.Tensor, bands_ref: torch.Tensor, audio_ref: torch.Tensor, join: bool = True):
-        """join=False leaves the four chains running (the caller overlaps independent work on the main stream and
-        calls ``join()`` before anything reads the embeddings)."""
+        """join=False leaves the chains running (the caller overlaps independent work on the main stream and calls
+        ``join()`` before anything reads the embeddings).  After ``forward_reference`` only the enhanced half is run."""
         half = bands.shape[0]
-        sub = torch.cat((bands[:, -self.q:, :], bands_ref[:, -self.q:, :]), dim=0).contiguous()
-        wav = torch.cat((audio, audio_ref), dim=0).contiguous()
-        inputs = [sub] * (len(self.chains) - 1) + [wav]
-        res = self._launch_on_streams(lambda i: self.chains[i].forward(inputs[i]))
+        part = getattr(self, "_partial", None)
+        self._partial = None
+        if part is not None and part["half"] == half:
+            sub, wav = part["sub"], part["wav"]
+            sub[:half].copy_(bands[:, -self.q:, :])
+            wav[:half].copy_(audio)
+            inputs = [sub] * (len(self.chains) - 1) + [wav]
+            res = self._launch_on_streams(lambda i: self.chains[i].forward_rows(inputs[i], part["bufs"][i], 0, half))
+        else:
+            sub = torch.cat((bands[:, -self.q:, :], bands_ref[:, -self.q:, :]), dim=0).contiguous()
+            wav = torch.cat((audio, audio_ref), dim=0).contiguous()
+            inputs = [sub] * (len(self.chains) - 1) + [wav]
+            res = self._launch_on_streams(lambda i: self.chains[i].forward_rows(inputs[i], None, 0, 2 * half))
         if join:
             self._join_streams()
-        self._state = dict(half=half, emb=[r[0] for r in res], xp=[r[1] for r in res], bands_shape=tuple(bands.shape))
+        self._state = dict(half=half, emb=[r["emb"] for r in res], xp=[r["xp"] for r in res], bands_shape=tuple(bands.shape))
         return self._state["emb"]
 
     def join(self):
