@@ -225,6 +225,15 @@ typedef struct EbenCollateItem {
 } EbenCollateItem;
 EBEN_API int eben_noisy_collate(const EbenCollateItem* items, int nitems, int samples, float* body_conducted, float* airborne, void* stream);
 
+/* ---- waveform augmentation (vibravox/torch_modules/dsp/data_augmentation.py:38-71) -------------------------------
+ * time masking (dsp/time_masking_waveform.py:18-36): x[r, first : first+count] = 0 in place for r < rows;
+ * polyphase windowed-sinc resampling (torchaudio.functional.resample as used by T.SpeedPerturbation, restated):
+ *   out[r, q*nw + p] = sum_{j < 2*width+orig} kernels[p, j] * xpad[r, q*orig + j], xpad = x with `width` zeros in front;
+ *   kernels (nw, 2*width+orig) fp32 on the device; t_out <= ceil(nw * t_in / orig). */
+EBEN_API int eben_time_mask(float* x, long long rows, int t, int first, int count, void* stream);
+EBEN_API int eben_resample(const float* x, const float* kernels, float* out, int rows, int t_in, int t_out, int orig, int nw,
+                  int width, void* stream);
+
 /* ---- misc ------------------------------------------------------------------------------- */
 /* out[0] = sqrt(sum x^2) (torch.norm at eben.py:226); `out` must hold 257 floats (scratch) */
 EBEN_API int eben_l2norm(const float* x, size_t n, float* out, void* stream);

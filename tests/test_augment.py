@@ -1,0 +1,124 @@
+"""Waveform augmentation: the CPU oracle against golden vectors produced by the reference's own
+classes (draw order + time masking), the sinc resampling restatement against analytic signals (torchaudio is not
+installed: unpinned), and (GPU) the device module against both."""
+import math
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import augment_oracle as A
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+from formula import formula_tensor  # noqa: E402
+from make_augment_golden import CASES, inputs  # noqa: E402  (only the case table and the inputs; the reference is not imported)
+
+
+@pytest.fixture(scope="module")
+def agold():
+    return np.load(os.path.join(HERE, "golden", "augment_golden.npz"))
+
+
+def expected(x, rec):
+    first, count = int(rec[0]), int(rec[1])
+    y = x.clone()
+    y[..., first:first + count] = 0
+    assert abs(float(y.double().sum()) - rec[2]) <= 1e-9 * max(1.0, abs(rec[2]))
+    return y
+
+
+def run_cases(agold, make, to_dev=lambda t: t):
+    for i, (seed, p_aug, p_mask, shape) in enumerate(CASES):
+        aug = make(16000, p_data_augmentation=p_aug, p_speed_perturbation=0.0, p_pitch_shift=0.0, p_time_masking=p_mask)
+        a, b = inputs(i, shape)
+        torch.manual_seed(seed)
+        oa, ob = aug(to_dev(a.clone()), to_dev(b.clone()))
+        assert torch.equal(oa.cpu(), expected(a, agold[f"aug/{i}/a"])), i
+        assert torch.equal(ob.cpu(), expected(b, agold[f"aug/{i}/b"])), i
+        assert float(torch.rand(1)) == float(agold[f"aug/{i}/next_draw"][0]), i   # same number of draws as the reference
+
+
+def test_oracle_matches_reference_draws_and_time_masking(agold):
+    run_cases(agold, A.WaveformDataAugmentation)
+    for pct in (1, 3, 8, 50):
+        x = formula_tensor(f"tm/{pct}", (2, 2, 1000))
+        torch.manual_seed(10 + pct)
+        assert torch.equal(A.time_masking(x.clone(), pct), expected(x, agold[f"tm/{pct}"]))
+
+
+@pytest.mark.parametrize("factor", [0.85, 0.9, 0.95, 1.05, 1.1, 1.15, 0.7, 1.3])
+def test_oracle_speed_on_a_sine(factor):
+    """speed(x, factor) plays x `factor` times faster: a 200 Hz sine comes out at 200 * factor Hz, ceil(new*T/orig) samples."""
+    sr, t = 16000, 8000
+    src = int(factor * sr)
+    g = math.gcd(src, sr)
+    n = np.arange(t)
+    y = A.speed(np.sin(2 * np.pi * 200.0 * n / sr)[None, :], sr, factor)
+    assert y.shape == (1, math.ceil((sr // g) * t / (src // g)))
+    m = np.arange(y.shape[1])
+    want = np.sin(2 * np.pi * 200.0 * factor * m / sr)
+    assert np.abs(y[0, 200:-200] - want[200:-200]).max() < 2e-3   # rolloff 0.99 * width-6 hann sinc: ~1e-3 passband ripple
+    assert np.array_equal(A.resample(y, 16000, 16000), y)
+
+
+def test_device_module_surface_on_cpu():
+    from vibravox_amd.augment import WaveformDataAugmentation
+
+    with pytest.raises(NotImplementedError):
+        WaveformDataAugmentation(16000, p_data_augmentation=0.3)           # default p_pitch_shift = 0.3
+    with pytest.raises(AssertionError):
+        WaveformDataAugmentation(16000, p_data_augmentation=1.5)
+    ident = WaveformDataAugmentation(16000)                                 # identity.yaml: p_data_augmentation = 0
+    x = torch.randn(2, 1, 100)
+    a, b = ident(x, None)
+    assert a is x and b is None
+
+
+@pytest.mark.gpu
+def test_device_time_masking_matches_reference_golden(agold):
+    from vibravox_amd.augment import WaveformDataAugmentation, time_masking_
+
+    dev = torch.device("cuda")
+    run_cases(agold, WaveformDataAugmentation, lambda t: t.to(dev))
+    for pct in (1, 3, 8, 50):
+        x = formula_tensor(f"tm/{pct}", (2, 2, 1000))
+        torch.manual_seed(10 + pct)
+        assert torch.equal(time_masking_(x.clone().to(dev), pct).cpu(), expected(x, agold[f"tm/{pct}"]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("factor,shape", [(0.85, (3, 1, 4000)), (0.9, (2, 1, 7777)), (1.15, (4, 1, 1234)), (1.3, (1, 2, 3, 501)), (0.7, (2, 16000))])
+def test_device_speed_matches_oracle(factor, shape):
+    from vibravox_amd.augment import speed
+
+    x = formula_tensor(f"sp/{factor}", shape)
+    got = speed(x.to(torch.device("cuda")), 16000, factor).cpu()
+    ref = A.speed(x.numpy(), 16000, factor)
+    assert tuple(got.shape) == ref.shape
+    assert float(np.abs(got.double().numpy() - ref).max()) < 2e-6 * max(1.0, float(np.abs(ref).max()))
+
+
+@pytest.mark.gpu
+def test_device_module_follows_the_oracle_with_speed_and_masking():
+    from vibravox_amd.augment import WaveformDataAugmentation
+
+    dev = torch.device("cuda")
+    kw = dict(p_data_augmentation=0.8, p_speed_perturbation=0.6, p_pitch_shift=0.0, p_time_masking=0.6,
+              speed_perturbation_factors=(0.85, 0.9, 0.95, 1.05, 1.1, 1.15), time_masking_percentage=(1, 2, 3))
+    d, o = WaveformDataAugmentation(16000, **kw), A.WaveformDataAugmentation(16000, **kw)
+    changed = 0
+    for seed in range(12):
+        a, b = formula_tensor(f"augm/{seed}/a", (3, 1, 3000)), formula_tensor(f"augm/{seed}/b", (3, 1, 3000))
+        torch.manual_seed(seed)
+        ra, rb = o(a.clone(), b.clone())
+        state = float(torch.rand(1))
+        torch.manual_seed(seed)
+        ga, gb = d(a.clone().to(dev), b.clone().to(dev))
+        assert float(torch.rand(1)) == state
+        assert ga.shape == ra.shape and gb.shape == rb.shape
+        assert float((ga.cpu() - ra).abs().max()) < 1e-5 and float((gb.cpu() - rb).abs().max()) < 1e-5
+        changed += int(ra.shape != a.shape or not torch.equal(ra, a))
+    assert changed >= 6   # the seeds exercise both transforms

@@ -1,0 +1,110 @@
+"""Waveform augmentation on the device.
+
+Counterpart of ``vibravox/torch_modules/dsp/data_augmentation.py:8-71`` (``WaveformDataAugmentation``, applied by the BWE
+collator to the padded batch, bwe.py:286) for batches that already live in HBM: the same constructor, the same sequence
+of ``torch.rand(1)`` / ``torch.randint`` draws on the CPU generator (so a seed selects the same augmentation), the work
+itself as HIP kernels:
+
+  * time masking (``dsp/time_masking_waveform.py:18-36``): one in-place zero-fill launch per waveform;
+  * speed perturbation (``T.SpeedPerturbation`` = ``torchaudio.functional.speed`` -> ``resample``): windowed-sinc polyphase
+    interpolation, ``eben_resample``; the kernel table follows torchaudio's ``_get_sinc_resample_kernel`` (hann window,
+    lowpass width 6, rolloff 0.99) -- torchaudio is not installed here, so this part is a restatement (parity unpinned);
+  * pitch shift (``T.PitchShift``: phase vocoder + resample) is NOT built: constructing the module with
+    ``p_pitch_shift > 0`` and ``p_data_augmentation > 0`` raises.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Tuple
+
+import torch
+
+from ._lib import check, load, ptr, stream
+
+
+def sinc_resample_kernel(orig_freq: int, new_freq: int, lowpass_filter_width: int = 6, rolloff: float = 0.99, device=None):
+    """(kernels (new, 2*width+orig) float32, width, orig, new) -- torchaudio.functional._get_sinc_resample_kernel, hann."""
+    g = math.gcd(int(orig_freq), int(new_freq))
+    orig, new = int(orig_freq) // g, int(new_freq) // g
+    base = min(orig, new) * rolloff
+    width = math.ceil(lowpass_filter_width * orig / base)
+    idx = torch.arange(-width, width + orig, dtype=torch.float64)[None, :] / orig
+    t = torch.arange(0, -new, -1, dtype=torch.float64)[:, None] / new + idx
+    t = (t * base).clamp_(-lowpass_filter_width, lowpass_filter_width)
+    window = torch.cos(t * math.pi / lowpass_filter_width / 2) ** 2
+    t = t * math.pi
+    k = torch.where(t == 0, torch.ones_like(t), torch.sin(t) / t) * window * (base / orig)
+    return k.to(torch.float32).contiguous().to(device), width, orig, new
+
+
+_kernel_cache = {}
+
+
+def resample(x: torch.Tensor, orig_freq: int, new_freq: int) -> torch.Tensor:
+    """torchaudio.functional.resample(x, orig_freq, new_freq) on the device; x (..., time) float32."""
+    key = (int(orig_freq), int(new_freq), x.device)
+    if key not in _kernel_cache:
+        _kernel_cache[key] = sinc_resample_kernel(orig_freq, new_freq, device=x.device)
+    k, width, orig, new = _kernel_cache[key]
+    if orig == new:
+        return x.clone()
+    lead, t = x.shape[:-1], x.shape[-1]
+    rows = max(1, math.prod(lead))
+    x2 = x.contiguous().reshape(rows, t)
+    t_out = int(math.ceil(new * t / orig))
+    out = torch.empty((rows, t_out), dtype=torch.float32, device=x.device)
+    check(load().eben_resample(ptr(x2), ptr(k), ptr(out), rows, t, t_out, orig, new, width, stream()), "resample")
+    return out.reshape(*lead, t_out)
+
+
+def speed(x: torch.Tensor, sample_rate: int, factor: float) -> torch.Tensor:
+    """torchaudio.functional.speed: play `factor` times faster = resample from int(factor * rate) to rate."""
+    return resample(x, int(factor * sample_rate), int(sample_rate))
+
+
+def time_masking_(x: torch.Tensor, masking_percentage: float) -> torch.Tensor:
+    """TimeMaskingBlockWaveform.forward (time_masking_waveform.py:28-36): in place, one torch.randint draw."""
+    t = x.shape[-1]
+    masked = int(t * masking_percentage / 100)
+    first = torch.randint(0, t - masked, (1,)).item()
+    if not x.is_contiguous():
+        raise ValueError("time masking works in place on a contiguous (..., time) tensor")
+    check(load().eben_time_mask(ptr(x), x.numel() // t, t, first, masked, stream()), "time_mask")
+    return x
+
+
+class WaveformDataAugmentation(torch.nn.Module):
+    def __init__(self, sample_rate, p_data_augmentation=0, p_speed_perturbation=0.3, p_pitch_shift=0.3, p_time_masking=0.3,
+                 speed_perturbation_factors=(0.7, 0.8, 0.85, 0.9, 0.95, 1.05, 1.1, 1.15, 1.2, 1.3),
+                 pitch_shift_steps=(-4, -3, -2, -1, 1, 2, 3, 4, 5, 6), time_masking_percentage=(1, 2, 3, 4, 5, 6, 7, 8)):
+        super().__init__()
+        self.sample_rate = sample_rate
+        assert 0 <= p_data_augmentation <= 1, "p_data_augmentation must be in [0, 1]"
+        assert 0 <= p_speed_perturbation <= 1, "p_speed_perturbation must be in [0, 1]"
+        assert 0 <= p_pitch_shift <= 1, "p_pitch_shift must be in [0, 1]"
+        assert 0 <= p_time_masking <= 1, "p_time_masking must be in [0, 1]"
+        if p_data_augmentation > 0 and p_pitch_shift > 0:
+            raise NotImplementedError("pitch shift (phase vocoder) is not built on the device: set p_pitch_shift=0")
+        self.apply_data_augmentation = p_data_augmentation
+        self.p_speed_perturbation = p_speed_perturbation
+        self.p_pitch_shift = p_pitch_shift
+        self.p_time_masking = p_time_masking
+        self.speed_perturbation_factors = speed_perturbation_factors
+        self.pitch_shift_steps = pitch_shift_steps
+        self.time_masking_percentage = time_masking_percentage
+
+    def forward(self, waveform_1: torch.Tensor, waveform_2: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+        if torch.rand(1) < self.apply_data_augmentation:
+            if torch.rand(1) < self.p_speed_perturbation:
+                f = self.speed_perturbation_factors[torch.randint(len(self.speed_perturbation_factors), size=(1,)).item()]
+                waveform_1 = speed(waveform_1, self.sample_rate, f)
+                if waveform_2 is not None:
+                    waveform_2 = speed(waveform_2, self.sample_rate, f)
+            if torch.rand(1) < self.p_pitch_shift:   # unreachable with p_pitch_shift == 0; the draw itself is the reference's
+                raise NotImplementedError("pitch shift is not built")
+            if torch.rand(1) < self.p_time_masking:
+                pct = self.time_masking_percentage[torch.randint(len(self.time_masking_percentage), size=(1,)).item()]
+                waveform_1 = time_masking_(waveform_1, pct)
+                if waveform_2 is not None:
+                    waveform_2 = time_masking_(waveform_2, pct)
+        return waveform_1, waveform_2

@@ -610,6 +610,57 @@ extern "C" int eben_stft_frames(const float* sig, float* out, int rows, int t, i
 }
 
 // ---------------------------------------------------------------------------------------------
+// Waveform augmentation on the device (vibravox/torch_modules/dsp/data_augmentation.py:38-71):
+//   * time masking (dsp/time_masking_waveform.py:18-36): x[..., first : first + count] = 0, in place;
+//   * speed perturbation = torchaudio.functional.speed -> resample(source = int(factor * rate), target = rate): the
+//     windowed-sinc polyphase interpolation of torchaudio.functional.resample ("sinc_interp_hann", lowpass width 6, rolloff
+//     0.99), restated: with the rates reduced by their gcd to orig / new and `width` zero samples of left padding,
+//         out[r, q*new + p] = sum_j kernel[p, j] * xpad[r, q*orig + j],   j < taps = 2*width + orig
+//     (kernel table built on the host, vibravox_amd/augment.py).  HBM-bound: taps reads per output hit the L1/L2.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void time_mask_kernel(float* __restrict__ x, long long rows, int t, int first, int count) {
+  const long long n = rows * count;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const long long r = i / count;
+    x[r * t + first + (int)(i - r * count)] = 0.f;
+  }
+}
+extern "C" int eben_time_mask(float* x, long long rows, int t, int first, int count, void* stream) {
+  EBEN_REQUIRE(x && rows > 0 && t > 0 && first >= 0 && count >= 0 && first + count <= t, "bad time_mask arguments");
+  if (count == 0) return EBEN_OK;
+  hipLaunchKernelGGL(time_mask_kernel, dim3(grid_for((size_t)rows * count, 1024)), dim3(256), 0, as_stream(stream), x, rows, t, first, count);
+  EBEN_CHECK_LAUNCH("time_mask_kernel");
+  return EBEN_OK;
+}
+
+__global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__ x, const float* __restrict__ kernels, float* __restrict__ out,
+                                                       int t_in, int t_out, int orig, int nw, int width, int taps) {
+  const int r = blockIdx.y;
+  const float* xr = x + (long long)r * t_in;
+  float* o = out + (long long)r * t_out;
+  for (int n = blockIdx.x * 256 + threadIdx.x; n < t_out; n += gridDim.x * 256) {
+    const int q = n / nw, p = n - q * nw;
+    const float* k = kernels + (long long)p * taps;
+    const int base = q * orig - width;
+    float acc = 0.f;
+    for (int j = 0; j < taps; ++j) {
+      const int i = base + j;
+      if (i >= 0 && i < t_in) acc = fmaf(k[j], xr[i], acc);
+    }
+    o[n] = acc;
+  }
+}
+extern "C" int eben_resample(const float* x, const float* kernels, float* out, int rows, int t_in, int t_out, int orig, int nw, int width,
+                             void* stream) {
+  EBEN_REQUIRE(x && kernels && out && rows > 0 && t_in > 0 && t_out > 0 && orig > 0 && nw > 0 && width >= 0, "bad resample arguments");
+  EBEN_REQUIRE((long long)t_out <= ((long long)nw * t_in + orig - 1) / orig, "resample: t_out beyond ceil(new * t_in / orig)");
+  hipLaunchKernelGGL(resample_kernel, dim3(grid_for((size_t)t_out, 256), rows), dim3(256), 0, as_stream(stream), x, kernels, out, t_in, t_out,
+                     orig, nw, width, 2 * width + orig);
+  EBEN_CHECK_LAUNCH("resample_kernel");
+  return EBEN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Noisy-BWE batch assembly on the device (vibravox/lightning_datamodules/noisybwe.py:219-291 with
 // vibravox/utils.py:7-81,195-254): per item  bc[t] = speech[u] + noise[noise_start + u],  air[t] = airborne[u]
 // with u = t + shift, zero outside [0, length) -- `shift` >= 0 is the crop offset of set_audio_duration,
