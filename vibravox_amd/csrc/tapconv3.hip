@@ -212,9 +212,12 @@ __global__ __launch_bounds__(256, 2) void tap3_kernel(const Tap3Args P) {
 #pragma unroll
   for (int ks = 0; ks < KSC; ++ks) te[ks] = nch > 0 ? tab[ks] : 0;
   int pending = -1;   // tile whose global loads are issued at the top of the next chunk (not in front of the barrier)
+#ifndef EBEN_T3_DBG
+#define EBEN_T3_DBG 0   // scratch-build ablations (wrong results): 1 no weight stream, 2 no tile refresh, 4 no barrier, 8 no MFMA
+#endif
   for (int ch = 0; ch < nch; ++ch) {
-    if (ch + 1 < nch) issue_w(ch + 1);
-    if (pending >= 0) { fetch_x(pending); pending = -1; }
+    if ((EBEN_T3_DBG & 1) == 0 && ch + 1 < nch) issue_w(ch + 1);
+    if ((EBEN_T3_DBG & 2) == 0 && pending >= 0) { fetch_x(pending); pending = -1; }
     const u32x4* wb = Ws + (ch & 1) * WCHU + lane;
     const u32x4* xb = Xs + lanebase;
     u32x4 bv[KSC], a[KSC][FM];
@@ -230,20 +233,22 @@ __global__ __launch_bounds__(256, 2) void tap3_kernel(const Tap3Args P) {
       if (ks + 2 < KSC) rd(ks + 2);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int i = 0; i < FM; ++i)
-        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[ks][i]), __builtin_bit_cast(bf16x8, bv[ks]), acc[i], 0, 0, 0);
+      for (int i = 0; i < FM; ++i) {
+        if (EBEN_T3_DBG & 8) acc[i][0] += __builtin_bit_cast(float, a[ks][i][0] ^ bv[ks][i & 3]);
+        else acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[ks][i]), __builtin_bit_cast(bf16x8, bv[ks]), acc[i], 0, 0, 0);
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
     if (ch + 1 < nch) {
 #pragma unroll
       for (int ks = 0; ks < KSC; ++ks) te[ks] = tab[(ch + 1) * KSC + ks];
     }
-    if (P.ncc > 1 && written + 1 < P.ncc && (written + 1) * KS_CC < (ch + 2) * KSC) {
+    if ((EBEN_T3_DBG & 2) == 0 && P.ncc > 1 && written + 1 < P.ncc && (written + 1) * KS_CC < (ch + 2) * KSC) {
       ++written;
       store_x(written);
       if (written + 1 < P.ncc) pending = written + 1;
     }
-    __syncthreads();
+    if ((EBEN_T3_DBG & 4) == 0) __syncthreads();
   }
 
   const bool use_res = P.res != nullptr && (P.res_rows == 0 || b < P.res_rows);
