@@ -231,6 +231,10 @@ EBEN_API int eben_noisy_collate(const EbenCollateItem* items, int nitems, int sa
  *   out[r, q*nw + p] = sum_{j < 2*width+orig} kernels[p, j] * xpad[r, q*orig + j], xpad = x with `width` zeros in front;
  *   kernels (nw, 2*width+orig) fp32 on the device; t_out <= ceil(nw * t_in / orig). */
 EBEN_API int eben_time_mask(float* x, long long rows, int t, int first, int count, void* stream);
+/* phase vocoder of T.PitchShift (torchaudio.functional.phase_vocoder, restated): spec / out are flat (2*bins, rows*frames) /
+ * (2*bins, rows*frames_out) spectra (re rows, then im rows), frames_out = ceil(frames / rate), hop = STFT hop length */
+EBEN_API int eben_phase_vocoder(const float* spec, float* out, int rows, int bins, int frames, int frames_out, double rate, float hop,
+                       void* stream);
 EBEN_API int eben_resample(const float* x, const float* kernels, float* out, int rows, int t_in, int t_out, int orig, int nw,
                   int width, void* stream);
 

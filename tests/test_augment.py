@@ -67,8 +67,6 @@ def test_oracle_speed_on_a_sine(factor):
 def test_device_module_surface_on_cpu():
     from vibravox_amd.augment import WaveformDataAugmentation
 
-    with pytest.raises(NotImplementedError):
-        WaveformDataAugmentation(16000, p_data_augmentation=0.3)           # default p_pitch_shift = 0.3
     with pytest.raises(AssertionError):
         WaveformDataAugmentation(16000, p_data_augmentation=1.5)
     ident = WaveformDataAugmentation(16000)                                 # identity.yaml: p_data_augmentation = 0
@@ -101,13 +99,40 @@ def test_device_speed_matches_oracle(factor, shape):
     assert float(np.abs(got.double().numpy() - ref).max()) < 2e-6 * max(1.0, float(np.abs(ref).max()))
 
 
+@pytest.mark.parametrize("steps", [-2, -1, 1, 2, 5])
+def test_oracle_pitch_shift_on_a_sine(steps):
+    """pitch_shift keeps the duration and moves a 440 Hz sine to 440 * 2^(steps/12) Hz."""
+    sr, t = 16000, 8000
+    y = A.pitch_shift(np.sin(2 * np.pi * 440.0 * np.arange(t) / sr)[None, :], sr, steps)
+    assert y.shape == (1, t)
+    seg = y[0, 1000:7000] * np.hanning(6000)
+    peak = np.argmax(np.abs(np.fft.rfft(seg))) * sr / 6000
+    assert abs(peak - 440.0 * 2 ** (steps / 12)) < 3.0
+    assert 0.9 < np.abs(y[0, 1000:7000]).max() < 1.1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("steps,shape", [(-2, (3, 1, 4000)), (1, (2, 1, 7777)), (4, (2, 2, 3001)), (-4, (1, 16000))])
+def test_device_pitch_shift_matches_oracle(steps, shape):
+    from vibravox_amd.augment import pitch_shift
+
+    x = formula_tensor(f"ps/{steps}", shape)
+    got = pitch_shift(x.to(torch.device("cuda")), 16000, steps).cpu()
+    ref = A.pitch_shift(x.numpy(), 16000, steps)
+    assert tuple(got.shape) == ref.shape == tuple(shape)
+    err = np.abs(got.double().numpy() - ref)
+    scale = float(np.abs(ref).max())
+    # fp32 phase accumulation over a few hundred frames against float64: compare in RMS and bound the peak
+    assert float(np.sqrt((err ** 2).mean())) < 1e-3 * scale and float(err.max()) < 2e-2 * scale
+
+
 @pytest.mark.gpu
 def test_device_module_follows_the_oracle_with_speed_and_masking():
     from vibravox_amd.augment import WaveformDataAugmentation
 
     dev = torch.device("cuda")
-    kw = dict(p_data_augmentation=0.8, p_speed_perturbation=0.6, p_pitch_shift=0.0, p_time_masking=0.6,
-              speed_perturbation_factors=(0.85, 0.9, 0.95, 1.05, 1.1, 1.15), time_masking_percentage=(1, 2, 3))
+    kw = dict(p_data_augmentation=0.8, p_speed_perturbation=0.6, p_pitch_shift=0.5, p_time_masking=0.6,
+              speed_perturbation_factors=(0.85, 0.9, 0.95, 1.05, 1.1, 1.15), pitch_shift_steps=(-2, -1, 1, 2), time_masking_percentage=(1, 2, 3))
     d, o = WaveformDataAugmentation(16000, **kw), A.WaveformDataAugmentation(16000, **kw)
     changed = 0
     for seed in range(12):
@@ -119,6 +144,6 @@ def test_device_module_follows_the_oracle_with_speed_and_masking():
         ga, gb = d(a.clone().to(dev), b.clone().to(dev))
         assert float(torch.rand(1)) == state
         assert ga.shape == ra.shape and gb.shape == rb.shape
-        assert float((ga.cpu() - ra).abs().max()) < 1e-5 and float((gb.cpu() - rb).abs().max()) < 1e-5
+        assert float((ga.cpu() - ra).abs().max()) < 2e-2 and float((gb.cpu() - rb).abs().max()) < 2e-2
         changed += int(ra.shape != a.shape or not torch.equal(ra, a))
     assert changed >= 6   # the seeds exercise both transforms

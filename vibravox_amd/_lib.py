@@ -108,6 +108,7 @@ SIGNATURES = {
     "eben_stft_loss_bwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_float, _P, _P, c_float, _P, _P]),
     "eben_overlap_add": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "eben_time_mask": (c_int, [_P, c_int64, c_int, c_int, c_int, _P]),
+    "eben_phase_vocoder": (c_int, [_P, _P, c_int, c_int, c_int, c_int, ctypes.c_double, c_float, _P]),
     "eben_resample": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "eben_stft_frames": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "eben_stft_loss_sums_ex": (c_int, [_P, _P, c_int, c_int, c_int, c_int64, c_int64, c_int64, c_float, _P, c_size_t, _P, _P]),

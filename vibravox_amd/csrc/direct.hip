@@ -661,6 +661,52 @@ extern "C" int eben_resample(const float* x, const float* kernels, float* out, i
 }
 
 // ---------------------------------------------------------------------------------------------
+// Phase vocoder (torchaudio.functional.phase_vocoder as used by T.PitchShift, restated): time-stretch a complex
+// spectrogram by `rate` without changing pitch.  Input / output spectra are flat (2*bins, rows*frames) matrices (real
+// parts in rows [0, bins), imaginary in [bins, 2*bins)) like the STFT GEMM's.  One thread per (row, bin) walks the output
+// frames in order (the phase is a running sum):
+//   ts = i*rate, i0 = floor(ts), alpha = ts - i0, s0 = spec[i0], s1 = spec[i0+1] (zero past the end)
+//   dphi = wrap(angle(s1) - angle(s0) - adv[k]) + adv[k];  phase_i = angle(spec[0]) + sum_{i' < i} dphi_i'
+//   out_i = (alpha*|s1| + (1-alpha)*|s0|) * exp(j*phase_i),   adv[k] = pi*hop*k/(bins-1)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void phase_vocoder_kernel(const float* __restrict__ spec, float* __restrict__ out, int rows, int bins,
+                                                            int frames, int frames_out, double rate, float hop) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= rows * bins) return;
+  const int r = i / bins, k = i - r * bins;
+  const long long in_cols = (long long)rows * frames, out_cols = (long long)rows * frames_out;
+  const float* re = spec + (long long)k * in_cols + (long long)r * frames;
+  const float* im = re + (long long)bins * in_cols;
+  float* ore = out + (long long)k * out_cols + (long long)r * frames_out;
+  float* oim = ore + (long long)bins * out_cols;
+  const float two_pi = 6.283185307179586f;
+  const float adv = 3.14159265358979323846f * hop * (float)k / (float)(bins - 1);
+  float phase = atan2f(im[0], re[0]);
+  for (int f = 0; f < frames_out; ++f) {
+    const double ts = (double)f * rate;   // as torch.arange(0, frames, rate) in float64: the frame index must not flip
+    const int i0 = (int)ts;
+    const float alpha = (float)(ts - (double)i0);
+    const float r0 = i0 < frames ? re[i0] : 0.f, m0 = i0 < frames ? im[i0] : 0.f;
+    const float r1 = i0 + 1 < frames ? re[i0 + 1] : 0.f, m1 = i0 + 1 < frames ? im[i0 + 1] : 0.f;
+    const float n0 = sqrtf(r0 * r0 + m0 * m0), n1 = sqrtf(r1 * r1 + m1 * m1);
+    const float mag = alpha * n1 + (1.f - alpha) * n0;
+    ore[f] = mag * cosf(phase);
+    oim[f] = mag * sinf(phase);
+    float d = atan2f(m1, r1) - atan2f(m0, r0) - adv;
+    d = d - two_pi * rintf(d / two_pi);
+    phase += d + adv;
+  }
+}
+extern "C" int eben_phase_vocoder(const float* spec, float* out, int rows, int bins, int frames, int frames_out, double rate, float hop,
+                                  void* stream) {
+  EBEN_REQUIRE(spec && out && rows > 0 && bins > 1 && frames > 0 && frames_out > 0 && rate > 0.0, "bad phase_vocoder arguments");
+  hipLaunchKernelGGL(phase_vocoder_kernel, dim3(grid_for((size_t)rows * bins, 1 << 20)), dim3(256), 0, as_stream(stream), spec, out, rows, bins,
+                     frames, frames_out, rate, hop);
+  EBEN_CHECK_LAUNCH("phase_vocoder_kernel");
+  return EBEN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Noisy-BWE batch assembly on the device (vibravox/lightning_datamodules/noisybwe.py:219-291 with
 // vibravox/utils.py:7-81,195-254): per item  bc[t] = speech[u] + noise[noise_start + u],  air[t] = airborne[u]
 // with u = t + shift, zero outside [0, length) -- `shift` >= 0 is the crop offset of set_audio_duration,
