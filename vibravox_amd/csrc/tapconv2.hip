@@ -496,7 +496,13 @@ static void make_plan2(const Canon& c, int dir, Tap2Plan* p) {
         p->ncc = ceil_div(p->Cg, p->CI_T);
         p->nxbuf = nbuf;
         p->XR = xr;
-        if (p->ncc > 1 && Jmin * (p->CI_T / KCH) < (nbuf == 2 ? 32 : 16)) continue;
+        // two buffers are also enough when the tiles change exactly on weight-chunk boundaries (every phase has J taps
+        // and J * CI_T / KCH is a multiple of 16): the tile written at the end of chunk ch replaces the one last read in
+        // chunk ch - 1.  That is the pointwise GEMMs over many channels (the STFT): 67 KB instead of 104 KB of LDS, two
+        // blocks per CU instead of one.
+        const int kscc = Jmin * (p->CI_T / KCH);
+        const bool aligned = Jmin == p->J && kscc >= 16 && kscc % 16 == 0;
+        if (p->ncc > 1 && kscc < (nbuf == 2 ? 32 : 16) && !(nbuf == 2 && aligned)) continue;
         found = true;
         break;
       }
