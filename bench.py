@@ -259,6 +259,11 @@ def main():
                                       "frac": round(flops / (iso_ms * 1e-3) / 1e12 / peak, 4),
                                       "note": "same launch alone on the device, 20 back-to-back launches after the timed region"}},
         }
+        # whole-step arithmetic rate on SURVEY section 8d's minimal algorithmic count F_min = 2*(3G + 8D) (no credit for redundant passes)
+        f_min = 2.0 * (3 * 6.727e8 + 8 * 2.5255e9) * (world * args.batch * cut / 16000.0)
+        line["step_work"] = {"f_min_flop": f_min, "achieved_tflops": round(f_min / (dt / args.steps) / 1e12, 1),
+                             "note": "F_min = 2*(3G+8D), G = 6.727e8 and D = 2.5255e9 MACs per audio-second; 91 % of it (the discriminator passes) "
+                                     "runs on bf16 MFMA operands in this mode" if args.disc_math == "bf16" else "F_min = 2*(3G+8D), all fp32"}
         if dt32 is not None:
             line["f32_discriminator"] = {"ms_per_step": round(dt32 / args.steps * 1e3, 3), "steps": args.steps,
                                          "value": round(world * args.batch * cut / 16000 / (dt32 / args.steps), 2), "unit": "audio-seconds/sec"}
