@@ -42,15 +42,27 @@ __global__ __launch_bounds__(256) void dw_pack_a_kernel(const Dw2Args P) {
   const int g = id / P.nmt;
   const int m0 = mt * BM, t0 = tc * BK;
   const long long abase = ((long long)b * P.Ca + (long long)g * P.Mg) * P.La;
-  for (int i = threadIdx.x; i < BM * BK; i += 256) {
-    const int m = i / BK, t = i - m * BK;
-    float v = 0.f;
-    if (m0 + m < P.Mg && t0 + t < P.La) {
-      const long long idx = abase + (long long)(m0 + m) * P.La + t0 + t;
-      v = P.a[idx];
-      v = P.a_mode == 0 ? lrelu(v, P.a_slope) : v * dlrelu(P.amask[idx], P.a_slope);
+  // eight independent loads in flight per thread (see dw3_pack_a_kernel)
+  static_assert((BM * BK) % (8 * 256) == 0, "tile must split into batches of eight loads per thread");
+  for (int base = 0; base < BM * BK; base += 8 * 256) {
+    float v[8], mk[8];
+    int ok[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = base + u * 256 + threadIdx.x;
+      const int m = i / BK, t = i - m * BK;
+      ok[u] = (int)(m0 + m < P.Mg) & (int)(t0 + t < P.La);
+      const long long idx = ok[u] ? abase + (long long)(m0 + m) * P.La + t0 + t : abase;
+      v[u] = P.a[idx];
+      mk[u] = P.a_mode ? P.amask[idx] : 0.f;
     }
-    tile[m][t] = v;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = base + u * 256 + threadIdx.x;
+      const int m = i / BK, t = i - m * BK;
+      const float w = P.a_mode == 0 ? lrelu(v[u], P.a_slope) : v[u] * dlrelu(mk[u], P.a_slope);
+      tile[m][t] = ok[u] ? w : 0.f;
+    }
   }
   __syncthreads();
   float* dst = P.ap + ((((long long)g * P.nmt + mt) * P.B + b) * P.nct + tc) * (long long)(BK * BMI);
