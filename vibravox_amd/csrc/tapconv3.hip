@@ -425,30 +425,28 @@ __global__ __launch_bounds__(256) void pack3_kernel(const Pack3Args P) {
       const int s = ch * T3_KSC + ks;
       const int KS_CC = q.J * P.CP;
       float v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = 0.f;
-      if (q.J > 0 && s < P.ncc * KS_CC) {
-        const int cc = s / KS_CC, rem = s - cc * KS_CC;
+      {
+        // all eight weight loads are issued unconditionally (clamped index), the padding is a select afterwards
+        const bool live = q.J > 0 && s < P.ncc * KS_CC;
+        const int sc = live ? s : 0;
+        const int KSd = KS_CC > 0 ? KS_CC : 1;
+        const int cc = sc / KSd, rem = sc - cc * KSd;
         const int j = rem / P.CP, cp = rem - j * P.CP;
         const int m = mt * P.BM + fm * 32 + (lane & 31);
+        const int kk = q.k0 + j * P.kstep;
+        float sc8[8];
+        bool ok[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
           const int chan = cc * P.CI_T + 16 * cp + 8 * (lane >> 5) + u;
-          if (chan < P.Cg && m < P.Mg) {
-            if (P.mode == 0) {
-              const int co = g * P.Cout_g + m;
-              v[u] = P.w[((long long)co * P.Cin_g + chan) * P.k + j];
-              if (P.scale) v[u] *= P.scale[co];
-            } else {
-              const int kk = q.k0 + j * P.kstep;
-              if (kk < P.k) {
-                const int co = g * P.Cout_g + chan;  // reduction channel = conv output channel
-                v[u] = P.w[((long long)co * P.Cin_g + m) * P.k + kk];
-                if (P.scale) v[u] *= P.scale[co];
-              }
-            }
-          }
+          ok[u] = live && chan < P.Cg && m < P.Mg && (P.mode == 0 || kk < P.k);
+          const int co = P.mode == 0 ? g * P.Cout_g + m : g * P.Cout_g + chan;   // mode 1: reduction channel = conv output channel
+          const long long idx = P.mode == 0 ? ((long long)co * P.Cin_g + chan) * P.k + j : ((long long)co * P.Cin_g + m) * P.k + kk;
+          v[u] = P.w[ok[u] ? idx : 0];
+          sc8[u] = P.scale ? P.scale[ok[u] ? co : 0] : 1.f;
         }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = ok[u] ? v[u] * sc8[u] : 0.f;
       }
       u32x4 o;
       o[0] = pack_bf16(v[0], v[1]); o[1] = pack_bf16(v[2], v[3]); o[2] = pack_bf16(v[4], v[5]); o[3] = pack_bf16(v[6], v[7]);
