@@ -321,7 +321,7 @@ static void make_dw3_plan(const Canon& c, Dw3Plan* p) {
   int chosen = 0;
   for (int pass = 0; pass < 2 && !chosen; ++pass) {
     const size_t budget = pass == 0 ? 78 * 1024 : 156 * 1024;   // two blocks per CU, else one
-    for (int bkt : {32, 16}) {
+    for (int bkt : {32, 16, 8, 4}) {   // 8, 4: wide X tiles (pointwise convs over 128 channels, dilation 9): fewer time steps per chunk
       if (pass == 1 && bkt == 32) continue;
       const int span = (bkt - 1) * c.s + (c.k - 1) * c.d + 1;
       if (span > 0xffff || 2 * p->nch_max * span > 8 * 256) continue;   // X tile must fit the register prefetch
