@@ -132,6 +132,8 @@ BF16_CASES = {
     "melgan_l0_k15": (CONV_CASES["melgan_l0_k15"][0], 2014, (None, None)),   # one input channel: direct kernel, bf16 weight gradient
     "pqmf_mid_24ch": (dict(c_in=96, c_out=192, ksize=7, stride=2, dilation=3, pad_l=3, pad_r=3, groups=4, out_slope=0.2), 1001, (4, 4)),
     "pqmf_low_12ch": (dict(c_in=48, c_out=96, ksize=7, stride=2, dilation=1, pad_l=3, pad_r=3, groups=4, out_slope=0.2), 2003, (None, None)),
+    "ru32_dilated": (dict(c_in=32, c_out=32, ksize=3, dilation=9, pad_l=9, pad_r=9, out_slope=0.01), 900, (4, 4)),   # reduction of 96: 1.5 weight chunks
+    "ru64_pointwise": (dict(c_in=64, c_out=64, ksize=1, out_slope=0.01), 517, (4, 4)),                                # reduction of 64: one chunk
     "melgan_l4_like": (dict(c_in=512, c_out=512, ksize=41, stride=4, pad_l=20, pad_r=20, groups=4, out_slope=0.2), 500, (4, 4)),
 }
 
