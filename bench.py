@@ -111,6 +111,9 @@ def main():
                          "fp32 products; the generator computes in fp32 either way")
     ap.add_argument("--gen-bwd-math", default=None, choices=["bf16", "f32"],
                     help="generator backward contractions (default: same as --disc-math); the generator forward is always fp32")
+    ap.add_argument("--stft-math", default=None, choices=["bf16x3", "folded", "dense"],
+                    help="MRSTFT windowed-DFT contractions (default: bf16x3 -- hi/lo bf16 operand splits, ~2^-17 relative -- with "
+                         "--disc-math bf16, exact fp32 'folded' with f32)")
     ap.add_argument("--no-f32-leg", action="store_true", help="skip the extra fp32-discriminator timing reported beside a bf16 run")
     args = ap.parse_args()
 
@@ -136,6 +139,8 @@ def main():
     mod = build_module(device, 1234 + rank)
     mod.disc_math = args.disc_math
     mod.gen_backward_math = args.gen_bwd_math or args.disc_math
+    mod.stft_math = args.stft_math or ("bf16x3" if args.disc_math == "bf16" else "folded")
+    gen_bwd_math, stft_math = mod.gen_backward_math, mod.stft_math   # of the measured steps (the fp32 leg below changes the module's)
     if use_ddp:
         g_opt, d_opt = mod.optimizers()
         gs, ds = GradSync(mod.generator.parameters()), GradSync(mod.discriminator.parameters())
@@ -185,6 +190,7 @@ def main():
     dt32 = None
     if args.disc_math == "bf16" and not args.no_f32_leg:
         mod.disc_math = mod.gen_backward_math = "f32"
+        mod.stft_math = "folded"
         mod.training_step(batch)
         barrier()
         t1 = time.perf_counter()
@@ -248,7 +254,8 @@ def main():
                        "global_batch": world * args.batch, "samples_per_clip": cut, "parallelism": f"dp{world}",
                        "weights": "random init, torch.manual_seed(42)",
                        "precision": (f"discriminator contractions (91 % of the step's FLOPs): bf16 MFMA operands, fp32 accumulate; generator "
-                                     f"forward, losses, Adam, storage: fp32; generator backward contractions: {mod.gen_backward_math}"
+                                     f"forward, losses, Adam, storage: fp32; generator backward contractions: {gen_bwd_math}; MRSTFT DFT contractions: "
+                                     f"{stft_math} (bf16x3 = hi/lo bf16 operand splits, fp32 accumulate, ~2^-17 relative)"
                                      if args.disc_math == "bf16" else "fp32 throughout (exact fp32 MFMA products)")},
             "roofline": {"bound": "mfma", "kernel": f"eben::{kname} MelGAN L4 fwd (1024->1024 k41 s4 g4), {launch_batch} items per launch",
                          "achieved": round(achieved, 2) if achieved else None, "peak": peak, "unit": "TFLOP/s",

@@ -188,6 +188,18 @@ EBEN_API int eben_overlap_add(const float* frames_buf, float* x, int batch, int 
  *   eben_stft_frames: out[j, r*frames + f] = sig[r, reflect(f*hop + j - pad)]   (torch.stft(center=True, pad_mode="reflect") framing)
  *   spec (2*bins, R*frames) = basis (2*bins, win) . frames (win, R*frames)        (eben_conv1d_fwd, ksize 1, batch 1) */
 EBEN_API int eben_stft_frames(const float* sig, float* out, int rows, int t, int win, int hop, int pad, int frames, void* stream);
+/* Folded framing for a window symmetric about frame sample win/2 (hann): out holds TWO GROUPS of nsub*win/2 rows, the even
+ * part E[m] = s[h+m] + s[h-m] (E[0] = s[h]) and the odd part O[m] = s[h+m] - s[h-m] (O[0] = 0) of each frame about h = win/2, so
+ * that Re X = basis[:bins, h:] . E and Im X = basis[bins:, h:] . O is a 2-group pointwise conv with half the products of the
+ * dense one (auraloss STFTLoss.stft = torch.stft(center=True, hann) as called from eben.py:195-198).  split = 1: nsub = 3, each
+ * group written as [hi ; lo ; hi] (hi = bf16(v), lo = bf16(v - hi)) for a bf16-operand contraction against [W_hi ; W_hi ; W_lo]
+ * ("bf16x3", ~2^-17 relative); split = 0: nsub = 1, exact fp32.  eben_split3 does the same to the rows of a gradient matrix
+ * (groups * R, cols) -> (groups * 3R, cols); eben_overlap_add_folded is the adjoint of the folded framing: buf rows [dE ; dO]. */
+EBEN_API int eben_stft_frames_folded(const float* sig, float* out, int rows, int t, int win, int hop, int pad, int frames, int split,
+                            void* stream);
+EBEN_API int eben_split3(const float* in, float* out, int groups, int rows_per_group, long long cols, void* stream);
+EBEN_API int eben_overlap_add_folded(const float* frames_buf, float* x, int batch, int lx, int win, int frames, int hop, int pad,
+                            int accumulate, long long row_stride, long long j_stride, void* stream);
 EBEN_API int eben_stft_loss_sums_ex(const float* spec_x, const float* spec_y, int rows, int bins, int frames, long long row_stride,
                            long long bin_stride, long long im_off, float eps, float* partial_ws, size_t ws_bytes, float* out,
                            void* stream);

@@ -282,6 +282,7 @@ def test_bf16_discriminator_math_against_fp32_step(hip, golden):
         mod, _, _ = make_module(golden, use_mrstft=True)
         mod.disc_math = math.split("+")[0]
         mod.gen_backward_math = "bf16" if math.endswith("+gen") else "f32"
+        mod.stft_math = "bf16x3" if math.endswith("+gen") else None   # bench.py's bf16 step: MRSTFT contractions on hi/lo bf16 splits
         batch = {"audio_body_conducted": formula_audio("bf/bc", 4, 8200).to(DEV), "audio_airborne": formula_audio("bf/air", 4, 8200).to(DEV)}
         out = mod.training_step(batch)
         torch.cuda.synchronize()

@@ -420,8 +420,58 @@ def test_feature_and_hinge_losses(hip):
                 assert rel_err(t.grad, r.grad) < 1e-5
 
 
+def test_folded_framing_split_and_adjoint(hip):
+    """eben_stft_frames_folded against the dense framing (E / O parts about the window centre), its bf16x3 form
+    (hi + lo exact in bf16, hi + lo == v to 2^-17), eben_split3, and eben_overlap_add_folded as its exact adjoint."""
+    from vibravox_amd._lib import load
+    from vibravox_amd.ops import ptr, stream
+
+    lib, dev = load(), torch.device("cuda")
+    rows, t, win, hop = 3, 1000, 240, 50
+    h, pad = win // 2, win // 2
+    frames = (t + 2 * pad - win) // hop + 1
+    cols = rows * frames
+    g = torch.Generator().manual_seed(5)
+    sig = torch.randn(rows, t, generator=g).to(dev)
+    dense = torch.empty(win, cols, device=dev)
+    assert lib.eben_stft_frames(ptr(sig), ptr(dense), rows, t, win, hop, pad, frames, stream()) == 0
+    fold = torch.empty(2 * h, cols, device=dev)
+    assert lib.eben_stft_frames_folded(ptr(sig), ptr(fold), rows, t, win, hop, pad, frames, 0, stream()) == 0
+    m = torch.arange(1, h, device=dev)
+    want_e = torch.cat((dense[h:h + 1], dense[h + m] + dense[h - m]))
+    want_o = torch.cat((torch.zeros_like(dense[:1]), dense[h + m] - dense[h - m]))
+    assert torch.equal(fold[:h], want_e) and torch.equal(fold[h:], want_o)
+
+    sp = torch.empty(6 * h, cols, device=dev)
+    assert lib.eben_stft_frames_folded(ptr(sig), ptr(sp), rows, t, win, hop, pad, frames, 1, stream()) == 0
+    for grp, want in ((0, want_e), (1, want_o)):
+        hi, lo, hi2 = sp[grp * 3 * h:grp * 3 * h + h], sp[grp * 3 * h + h:grp * 3 * h + 2 * h], sp[grp * 3 * h + 2 * h:(grp + 1) * 3 * h]
+        assert torch.equal(hi, hi2)
+        assert torch.equal(hi, want.to(torch.bfloat16).float()) and torch.equal(lo, (want - hi).to(torch.bfloat16).float())
+        assert float((hi.double() + lo.double() - want.double()).abs().max()) <= 2.0 ** -16 * float(want.abs().max())
+    s3 = torch.empty(6 * h, cols, device=dev)
+    assert lib.eben_split3(ptr(fold), ptr(s3), 2, h, cols, stream()) == 0
+    assert torch.equal(s3, sp)
+
+    # adjoint: <frames_folded(sig), D> == <sig, overlap_add_folded(D)> for every D
+    d = torch.randn(2 * h, cols, generator=g).to(dev)
+    back = torch.empty(rows, t, device=dev)
+    assert lib.eben_overlap_add_folded(ptr(d), ptr(back), rows, t, win, frames, hop, pad, 0, frames, cols, stream()) == 0
+    lhs = float((fold.double() * d.double()).sum())
+    rhs = float((sig.double() * back.double()).sum())
+    assert abs(lhs - rhs) <= 1e-6 * max(1.0, abs(lhs)), (lhs, rhs)
+    twice = back.clone()
+    assert lib.eben_overlap_add_folded(ptr(d), ptr(twice), rows, t, win, frames, hop, pad, 1, frames, cols, stream()) == 0
+    assert torch.equal(twice, 2 * back)
+
+
+# "bf16x3": hi / lo bf16 operand splits on the bf16 MFMA, ~2^-17 relative per product (the bf16 train step's setting)
+STFT_MATH_TOL = {"folded": (2e-5, 2e-3), "dense": (2e-5, 2e-3), "bf16x3": (5e-5, 3e-3)}
+
+
+@pytest.mark.parametrize("stft_math", ["folded", "dense", "bf16x3"])
 @pytest.mark.parametrize("perceptual", [True, False])
-def test_mrstft_loss_and_grad(hip, perceptual):
+def test_mrstft_loss_and_grad(hip, perceptual, stft_math):
     from vibravox_amd.torch_modules.losses.mrstft_loss import MultiResolutionSTFTLoss
 
     dev = torch.device("cuda")
@@ -430,6 +480,7 @@ def test_mrstft_loss_and_grad(hip, perceptual):
     x, y = formula_audio("mr_x", 2, 4000), formula_audio("mr_y", 2, 4000)
     loss = MultiResolutionSTFTLoss(fft_sizes=(512, 1024, 2048), hop_sizes=(50, 120, 240), win_lengths=(240, 600, 1200),
                                    sample_rate=16000, perceptual_weighting=perceptual).to(dev)
+    loss.stft_math = stft_math
     xd = x.to(dev).requires_grad_(True)
     got = loss(xd, y.to(dev))
     got.backward()
@@ -437,12 +488,14 @@ def test_mrstft_loss_and_grad(hip, perceptual):
     fir = O.a_weighting_fir(16000).double() if perceptual else None
     ref = O.mrstft_loss(rx, y.double(), perceptual_weighting=perceptual, fir=fir)
     ref.backward()
-    np.testing.assert_allclose(got.item(), ref.item(), rtol=2e-5)
+    rtol, gtol = STFT_MATH_TOL[stft_math]
+    np.testing.assert_allclose(got.item(), ref.item(), rtol=rtol)
     err = float((xd.grad.double().cpu() - rx.grad).norm() / rx.grad.norm())
-    assert err < 2e-3, err  # sign(log X - log Y) flips at fp32 noise: compare in L2
+    assert err < gtol, err  # sign(log X - log Y) flips at fp32 noise: compare in L2
 
 
-def test_mrstft_ragged_length_and_batch(hip):
+@pytest.mark.parametrize("stft_math", ["folded", "bf16x3"])
+def test_mrstft_ragged_length_and_batch(hip, stft_math):
     """The flat frame matrix (win, rows*frames) at a length / batch where neither the frame count nor the column count
     is a multiple of anything convenient (3 x 4321 samples: 87 / 37 / 19 frames per item)."""
     from formula import formula_audio
@@ -453,14 +506,16 @@ def test_mrstft_ragged_length_and_batch(hip):
     x, y = formula_audio("mr2_x", 3, 4321), formula_audio("mr2_y", 3, 4321)
     loss = MultiResolutionSTFTLoss(fft_sizes=(512, 1024, 2048), hop_sizes=(50, 120, 240), win_lengths=(240, 600, 1200),
                                    sample_rate=16000, perceptual_weighting=True).to(dev)
+    loss.stft_math = stft_math
     xd = x.to(dev).requires_grad_(True)
     got = loss(xd, y.to(dev))
     got.backward()
     rx = x.double().requires_grad_(True)
     ref = O.mrstft_loss(rx, y.double(), perceptual_weighting=True, fir=O.a_weighting_fir(16000).double())
     ref.backward()
-    np.testing.assert_allclose(got.item(), ref.item(), rtol=2e-5)
-    assert float((xd.grad.double().cpu() - rx.grad).norm() / rx.grad.norm()) < 2e-3
+    rtol, gtol = STFT_MATH_TOL[stft_math]
+    np.testing.assert_allclose(got.item(), ref.item(), rtol=rtol)
+    assert float((xd.grad.double().cpu() - rx.grad).norm() / rx.grad.norm()) < gtol
 
 
 def test_adam_matches_torch(hip):

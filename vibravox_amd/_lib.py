@@ -111,6 +111,9 @@ SIGNATURES = {
     "eben_phase_vocoder": (c_int, [_P, _P, c_int, c_int, c_int, c_int, ctypes.c_double, c_float, _P]),
     "eben_resample": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "eben_stft_frames": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "eben_stft_frames_folded": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "eben_split3": (c_int, [_P, _P, c_int, c_int, c_int64, _P]),
+    "eben_overlap_add_folded": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int64, c_int64, _P]),
     "eben_stft_loss_sums_ex": (c_int, [_P, _P, c_int, c_int, c_int, c_int64, c_int64, c_int64, c_float, _P, c_size_t, _P, _P]),
     "eben_stft_loss_bwd_ex": (c_int, [_P, _P, c_int, c_int, c_int, c_int64, c_int64, c_int64, c_float, _P, _P, c_float, _P, c_int64, c_int64,
                                       c_int64, _P]),

@@ -306,6 +306,41 @@ __device__ __forceinline__ float ola_gather(const float* __restrict__ buf, int q
   for (int f = fmin; f <= fmax; ++f) acc += buf[(long long)(s - f * hop) * j_stride + f];
   return acc;
 }
+// Folded form (eben_stft_frames_folded's adjoint): buf holds 2*(win/2) rows [dE ; dO]; window sample j = h + m gets
+// dE[|m|] + sign(m) dO[|m|], the centre dE[0], sample 0 (zero window weight) nothing.
+__device__ __forceinline__ float ola_gather_folded(const float* __restrict__ buf, int q, int win, int frames, int hop, int pad, long long j_stride) {
+  const int s = q + pad;
+  if (s < 0) return 0.f;
+  const int h = win >> 1;
+  int fmax = s / hop;
+  if (fmax > frames - 1) fmax = frames - 1;
+  int fmin = s - win + 1 <= 0 ? 0 : (s - win + hop) / hop;
+  float acc = 0.f;
+  for (int f = fmin; f <= fmax; ++f) {
+    const int j = s - f * hop;
+    const int m = j - h, am = m < 0 ? -m : m;
+    if (j == 0) continue;
+    const float e = buf[(long long)am * j_stride + f];
+    const float o = m != 0 ? buf[(long long)(h + am) * j_stride + f] : 0.f;
+    acc += m < 0 ? e - o : e + o;
+  }
+  return acc;
+}
+__global__ __launch_bounds__(256) void overlap_add_folded_kernel(const float* __restrict__ buf, float* __restrict__ x, int lx, int win,
+                                                                 int frames, int hop, int pad, int accumulate,
+                                                                 long long row_stride, long long j_stride) {
+  const int b = blockIdx.y;
+  const float* bb = buf + (long long)b * row_stride;
+  for (int u = blockIdx.x * 256 + threadIdx.x; u < lx; u += gridDim.x * 256) {
+    float v = ola_gather_folded(bb, u, win, frames, hop, pad, j_stride);
+    if (u >= 1 && u <= pad) v += ola_gather_folded(bb, -u, win, frames, hop, pad, j_stride);
+    if (u <= lx - 2 && 2 * (lx - 1) - u <= lx - 1 + pad) v += ola_gather_folded(bb, 2 * (lx - 1) - u, win, frames, hop, pad, j_stride);
+    const long long i = (long long)b * lx + u;
+    if (accumulate) v += x[i];
+    x[i] = v;
+  }
+}
+
 // buf element (item b, sample j of the window, frame f) sits at b*row_stride + j*j_stride + f
 __global__ __launch_bounds__(256) void overlap_add_kernel(const float* __restrict__ buf, float* __restrict__ x, int lx, int win,
                                                           int frames, int hop, int pad, int reflect, int accumulate,
@@ -582,6 +617,16 @@ extern "C" int eben_overlap_add(const float* frames_buf, float* x, int batch, in
   return eben_overlap_add_ex(frames_buf, x, batch, lx, win, frames, hop, pad, reflect, accumulate, (long long)win * frames, frames, stream);
 }
 
+extern "C" int eben_overlap_add_folded(const float* frames_buf, float* x, int batch, int lx, int win, int frames, int hop, int pad,
+                                       int accumulate, long long row_stride, long long j_stride, void* stream) {
+  EBEN_REQUIRE(frames_buf && x && batch > 0 && lx > 0 && win > 0 && (win & 1) == 0 && frames > 0 && hop > 0 && pad >= 0 && pad < lx,
+               "bad overlap_add_folded arguments");
+  hipLaunchKernelGGL(overlap_add_folded_kernel, dim3(grid_for((size_t)lx, 256), batch), dim3(256), 0, as_stream(stream), frames_buf, x,
+                     lx, win, frames, hop, pad, accumulate, row_stride, j_stride);
+  EBEN_CHECK_LAUNCH("overlap_add_folded_kernel");
+  return EBEN_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // STFT framing (im2col of torch.stft(center=True, pad_mode="reflect")): out[j, r*frames + f] = sig[r, reflect(f*hop + j - pad)].
 // The (win, rows*frames) matrix makes the windowed DFT ONE dense GEMM over all items' frames (a pointwise tap-conv
@@ -600,6 +645,74 @@ __global__ __launch_bounds__(256) void stft_frames_kernel(const float* __restric
     o[c] = sig[(long long)r * t + q];
   }
 }
+// Folded framing.  A window symmetric about sample h = win/2 of the frame (hann, periodic: w[0] = 0, w[h+m] = w[h-m]) centred
+// in the DFT makes the real part a functional of the EVEN part of the frame about h and the imaginary part one of its ODD part:
+//   E[m] = s[h+m] + s[h-m] (m >= 1), E[0] = s[h];  O[m] = s[h+m] - s[h-m], O[0] = 0        (m < h; sample 0 has zero weight)
+//   Re X[k] = sum_m basis[k, h+m] E[m],   Im X[k] = sum_m basis[bins+k, h+m] O[m]
+// -- a pointwise conv with TWO GROUPS of h channels instead of one of win: half the products.  split = 1 writes each group as
+// 3h rows [hi ; lo ; hi] with hi = bf16(v), lo = bf16(v - hi) (both exactly representable in bf16): against weight rows
+// [W_hi ; W_hi ; W_lo] a bf16-operand MFMA contraction with fp32 accumulation returns v.W to ~2^-17 relative (the dropped
+// lo.lo and residual terms) -- "bf16x3".
+__device__ __forceinline__ float bf16_rne(float v) {
+  unsigned u = __float_as_uint(v);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return __uint_as_float(u & 0xffff0000u);
+}
+__global__ __launch_bounds__(256) void stft_frames_folded_kernel(const float* __restrict__ sig, float* __restrict__ out, int rows, int t,
+                                                                 int win, int hop, int pad, int frames, int split) {
+  const int m = blockIdx.y, h = win >> 1;
+  const long long cols = (long long)rows * frames;
+  const int nsub = split ? 3 : 1;
+  float* oe = out + (long long)m * cols;
+  float* oo = out + ((long long)nsub * h + m) * cols;
+  const long long sub = (long long)h * cols;
+  for (long long c = (long long)blockIdx.x * 256 + threadIdx.x; c < cols; c += (long long)gridDim.x * 256) {
+    const int r = (int)(c / frames), f = (int)(c - (long long)r * frames);
+    int q1 = f * hop + h + m - pad, q2 = f * hop + h - m - pad;
+    q1 = q1 < 0 ? -q1 : q1; q1 = q1 >= t ? 2 * (t - 1) - q1 : q1;
+    q2 = q2 < 0 ? -q2 : q2; q2 = q2 >= t ? 2 * (t - 1) - q2 : q2;
+    const float a = sig[(long long)r * t + q1], b = sig[(long long)r * t + q2];
+    const float e = m ? a + b : a, o = m ? a - b : 0.f;
+    if (split) {
+      const float eh = bf16_rne(e), oh = bf16_rne(o);
+      oe[c] = eh; oe[c + sub] = bf16_rne(e - eh); oe[c + 2 * sub] = eh;
+      oo[c] = oh; oo[c + sub] = bf16_rne(o - oh); oo[c + 2 * sub] = oh;
+    } else {
+      oe[c] = e; oo[c] = o;
+    }
+  }
+}
+extern "C" int eben_stft_frames_folded(const float* sig, float* out, int rows, int t, int win, int hop, int pad, int frames, int split,
+                                       void* stream) {
+  EBEN_REQUIRE(sig && out && rows > 0 && t > 1 && win > 1 && (win & 1) == 0 && hop > 0 && pad >= 0 && pad < t && frames > 0,
+               "bad stft_frames_folded arguments");
+  EBEN_REQUIRE((frames - 1) * hop + win - 1 - pad <= 2 * (t - 1), "stft_frames_folded: frames reach past the reflected signal");
+  hipLaunchKernelGGL(stft_frames_folded_kernel, dim3(grid_for((size_t)rows * frames, 64), win / 2), dim3(256), 0, as_stream(stream), sig,
+                     out, rows, t, win, hop, pad, frames, split);
+  EBEN_CHECK_LAUNCH("stft_frames_folded_kernel");
+  return EBEN_OK;
+}
+
+// out (groups * 3 * R, cols) = per group [hi ; lo ; hi] of in (groups * R, cols): the bf16x3 operand of a gradient GEMM
+__global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ in, float* __restrict__ out, int R, long long cols) {
+  const int row = blockIdx.y;               // g * R + r
+  const int g = row / R, r = row - g * R;
+  const float* src = in + (long long)row * cols;
+  float* dst = out + ((long long)g * 3 * R + r) * cols;
+  const long long sub = (long long)R * cols;
+  for (long long c = (long long)blockIdx.x * 256 + threadIdx.x; c < cols; c += (long long)gridDim.x * 256) {
+    const float v = src[c], hi = bf16_rne(v);
+    dst[c] = hi; dst[c + sub] = bf16_rne(v - hi); dst[c + 2 * sub] = hi;
+  }
+}
+extern "C" int eben_split3(const float* in, float* out, int groups, int rows_per_group, long long cols, void* stream) {
+  EBEN_REQUIRE(in && out && groups > 0 && rows_per_group > 0 && cols > 0 && (long long)groups * rows_per_group <= 65535, "bad split3 arguments");
+  hipLaunchKernelGGL(split3_kernel, dim3(grid_for((size_t)cols, 16), groups * rows_per_group), dim3(256), 0, as_stream(stream), in, out,
+                     rows_per_group, cols);
+  EBEN_CHECK_LAUNCH("split3_kernel");
+  return EBEN_OK;
+}
+
 extern "C" int eben_stft_frames(const float* sig, float* out, int rows, int t, int win, int hop, int pad, int frames, void* stream) {
   EBEN_REQUIRE(sig && out && rows > 0 && t > 1 && win > 0 && hop > 0 && pad >= 0 && pad < t && frames > 0, "bad stft_frames arguments");
   EBEN_REQUIRE((frames - 1) * hop + win - 1 - pad <= 2 * (t - 1), "stft_frames: frames reach past the reflected signal");

@@ -25,7 +25,7 @@ from __future__ import annotations
 
 import os
 from functools import partial
-from typing import Dict
+from typing import Dict, Optional
 
 import torch
 
@@ -110,6 +110,10 @@ class EBENLightningModule(BaseSELightningModule):
     #: the product's output -- is exact fp32 either way
     gen_backward_math: str = os.environ.get("EBEN_GEN_BWD_MATH", "f32")
 
+    #: arithmetic of the MRSTFT loss's windowed-DFT contractions in the engine step (mrstft_loss.MultiResolutionSTFTLoss.stft_math):
+    #: None leaves the loss module's own setting (exact fp32, folded); "bf16x3" goes with the bf16 step of BASELINE config 2
+    stft_math: Optional[str] = os.environ.get("EBEN_STEP_STFT_MATH") or None
+
     def _engine_usable(self, batch) -> bool:
         from ..disc_engine import DiscriminatorEngine
         from ..torch_modules.losses.feature_loss import FeatureLossForDiscriminatorMelganMultiScales
@@ -143,6 +147,9 @@ class EBENLightningModule(BaseSELightningModule):
         if getattr(self, "_disc_engine", None) is None or self._disc_engine.disc is not self.discriminator or self._disc_engine.math != math:
             self._disc_engine = DiscriminatorEngine(self.discriminator, math)
         engine = self._disc_engine
+
+        if self.stft_math is not None and hasattr(self.reconstructive_loss_freq_fn, "stft_math"):
+            self.reconstructive_loss_freq_fn.stft_math = self.stft_math
 
         # ---- generator phase
         ops.join_prepack()

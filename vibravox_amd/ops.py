@@ -673,6 +673,34 @@ class StftPlan:
     basis_t: torch.Tensor  # (win, 2*bins, 1) = basis transposed
     cache_fwd: PackedWeights
     cache_bwd: PackedWeights
+    #: "dense": one (2*bins x win) GEMM per resolution; "folded": even / odd parts of the frames, two groups of win/2
+    #: channels (half the products, exact fp32); "bf16x3": the folded form with hi / lo bf16 operand splits on the bf16 MFMA
+    math: str = "folded"
+    folded: Optional[dict] = None   # math -> (spec_f, basis_f, spec_t, basis_t, cache_fwd, cache_bwd), built on first use
+
+    def folded_parts(self, math: str):
+        """Weights of the folded pointwise convs (eben_stft_frames_folded): forward, 2 groups x (nsub*h -> bins) with
+        rows basis[:, h:] (x [W_hi, W_hi, W_lo] for bf16x3); backward, 2 groups x (nsub*bins -> h), its transpose."""
+        if self.folded is None:
+            self.folded = {}
+        parts = self.folded.get(math)
+        if parts is None:
+            h, bins = self.win // 2, self.bins
+            w = self.basis_f[:, h:, 0].contiguous()                       # (2*bins, h)
+            wt = w.reshape(2, bins, h).transpose(1, 2).contiguous()       # (2, h, bins): group g, output row m, reduction k
+            if math == "bf16x3":
+                def split(a, dim):
+                    hi = a.to(torch.bfloat16).to(torch.float32)
+                    lo = (a - hi).to(torch.bfloat16).to(torch.float32)
+                    return torch.cat((hi, hi, lo), dim=dim)
+                w, wt, nsub = split(w, 1), split(wt, 2), 3
+            else:
+                nsub = 1
+            parts = (ConvSpec(c_in=2 * nsub * h, c_out=2 * bins, ksize=1, groups=2), w.unsqueeze(-1).contiguous(),
+                     ConvSpec(c_in=2 * nsub * bins, c_out=2 * h, ksize=1, groups=2), wt.reshape(2 * h, nsub * bins, 1).contiguous(),
+                     PackedWeights(), PackedWeights())
+            self.folded[math] = parts
+        return parts
 
 
 class _MRSTFTFn(torch.autograd.Function):
@@ -682,7 +710,9 @@ class _MRSTFTFn(torch.autograd.Function):
     (win, R*frames) matrix, the windowed DFT is one dense GEMM over it (pointwise tap-conv, batch 1 -- a strided conv
     per item would pad every item's 134 / 267 frames to whole 128-column tiles), the loss sums read the flat
     (2*bins, R*frames) spectrum through strides; backward: d(spec) in the same flat form, d(frames) = basis^T . d(spec)
-    as one GEMM, overlap-add back onto the waveform."""
+    as one GEMM, overlap-add back onto the waveform.  ``plan.math`` "folded" / "bf16x3" (even window lengths): the frames
+    are written as their even and odd parts about the window centre and the GEMMs become 2-group contractions over
+    win/2 channels (``StftPlan.folded_parts``)."""
 
     @staticmethod
     def forward(ctx, x, y, fir, plans: List[StftPlan], eps: float):
@@ -700,10 +730,19 @@ class _MRSTFTFn(torch.autograd.Function):
         for p in plans:
             frames = (t + 2 * p.pad - p.win) // p.hop + 1
             cols = 2 * rows * frames
-            fr = torch.empty((1, p.win, cols), dtype=torch.float32, device=x.device)
-            check(lib.eben_stft_frames(ptr(sig), ptr(fr), 2 * rows, t, p.win, p.hop, p.pad, frames, st), "stft_frames")
-            d2 = conv_desc(p.spec_f, 1, cols)
-            pw = pack_weights(p.spec_f, d2, p.basis_f, None, p.cache_fwd, False)
+            math = p.math if p.win % 2 == 0 and p.pad == p.win // 2 else "dense"
+            if math == "dense":
+                fr = torch.empty((1, p.win, cols), dtype=torch.float32, device=x.device)
+                check(lib.eben_stft_frames(ptr(sig), ptr(fr), 2 * rows, t, p.win, p.hop, p.pad, frames, st), "stft_frames")
+                spec_f, basis_f, cache, cmath = p.spec_f, p.basis_f, p.cache_fwd, MATH_F32
+            else:
+                spec_f, basis_f, _, _, cache, _ = p.folded_parts(math)
+                cmath = MATH_BF16 if math == "bf16x3" else MATH_F32
+                fr = torch.empty((1, spec_f.c_in, cols), dtype=torch.float32, device=x.device)
+                check(lib.eben_stft_frames_folded(ptr(sig), ptr(fr), 2 * rows, t, p.win, p.hop, p.pad, frames, 1 if math == "bf16x3" else 0, st),
+                      "stft_frames_folded")
+            d2 = conv_desc(spec_f, 1, cols, cmath)
+            pw = pack_weights(spec_f, d2, basis_f, None, cache, False)
             spec = torch.empty((1, 2 * p.bins, cols), dtype=torch.float32, device=x.device)
             check(lib.eben_conv1d_fwd(ctypes.byref(d2), ptr(fr), ptr(pw.wp_fwd), None, None, ptr(spec), st), "stft_fwd")
             sums = torch.empty((rows, 3), dtype=torch.float32, device=x.device)
@@ -713,7 +752,7 @@ class _MRSTFTFn(torch.autograd.Function):
                                              ptr(_empty(ws_bytes, x)), ws_bytes, ptr(sums), st), "stft_loss_sums")
             term = torch.sqrt(sums[:, 0] / sums[:, 1]).mean() + sums[:, 2].sum() / float(rows * p.bins * frames)
             total = term if total is None else total + term
-            saved.append((spec, sums, frames))
+            saved.append((spec, sums, frames, math))
         ctx.plans, ctx.eps, ctx.geom, ctx.saved, ctx.fir = plans, eps, (b, c, t, rows), saved, fir
         return total / len(plans)
 
@@ -724,19 +763,32 @@ class _MRSTFTFn(torch.autograd.Function):
         b, c, t, rows = ctx.geom
         gout = gout.contiguous().reshape(1)
         dsig = torch.empty((rows, 1, t), dtype=torch.float32, device=gout.device)
-        for i, (p, (spec, sums, frames)) in enumerate(zip(ctx.plans, ctx.saved)):
+        for i, (p, (spec, sums, frames, math)) in enumerate(zip(ctx.plans, ctx.saved)):
             cols, xcols = 2 * rows * frames, rows * frames
             dspec = torch.empty((1, 2 * p.bins, xcols), dtype=torch.float32, device=gout.device)
             check(lib.eben_stft_loss_bwd_ex(ptr(spec), ptr(spec) + 4 * xcols, rows, p.bins, frames, frames, cols, p.bins * cols, ctx.eps,
                                             ptr(sums), ptr(gout), 1.0 / len(ctx.plans), ptr(dspec), frames, xcols, p.bins * xcols, st),
                   "stft_loss_bwd")
             # d(frames)[j, (r, f)] = sum_m basis[m, j] dspec[m, (r, f)]: one dense GEMM, then overlap-add
-            d1 = conv_desc(p.spec_t, 1, xcols)
-            pw = pack_weights(p.spec_t, d1, p.basis_t, None, p.cache_bwd, False)
-            dfr = torch.empty((1, p.win, xcols), dtype=torch.float32, device=gout.device)
+            if math == "dense":
+                spec_t, basis_t, cache, cmath = p.spec_t, p.basis_t, p.cache_bwd, MATH_F32
+            else:
+                _, _, spec_t, basis_t, _, cache = p.folded_parts(math)
+                cmath = MATH_BF16 if math == "bf16x3" else MATH_F32
+                if math == "bf16x3":
+                    dsplit = torch.empty((1, spec_t.c_in, xcols), dtype=torch.float32, device=gout.device)
+                    check(lib.eben_split3(ptr(dspec), ptr(dsplit), 2, p.bins, xcols, st), "split3")
+                    dspec = dsplit
+            d1 = conv_desc(spec_t, 1, xcols, cmath)
+            pw = pack_weights(spec_t, d1, basis_t, None, cache, False)
+            dfr = torch.empty((1, spec_t.c_out, xcols), dtype=torch.float32, device=gout.device)
             check(lib.eben_conv1d_fwd(ctypes.byref(d1), ptr(dspec), ptr(pw.wp_fwd), None, None, ptr(dfr), st), "stft_bwd_gemm")
-            check(lib.eben_overlap_add_ex(ptr(dfr), ptr(dsig), rows, t, p.win, frames, p.hop, p.pad, 1, 1 if i else 0, frames, xcols, st),
-                  "overlap_add")
+            if math == "dense":
+                check(lib.eben_overlap_add_ex(ptr(dfr), ptr(dsig), rows, t, p.win, frames, p.hop, p.pad, 1, 1 if i else 0, frames, xcols, st),
+                      "overlap_add")
+            else:
+                check(lib.eben_overlap_add_folded(ptr(dfr), ptr(dsig), rows, t, p.win, frames, p.hop, p.pad, 1 if i else 0, frames, xcols, st),
+                      "overlap_add_folded")
         if ctx.fir is not None:
             nt = ctx.fir.numel()
             dsig = _fir_interp_sum(dsig, ctx.fir, t, 1, nt, 1, -(nt // 2))

@@ -14,6 +14,7 @@ reflect padding reduce to frames of ``win`` samples at hop ``hop`` over the sign
 from __future__ import annotations
 
 import math
+import os
 from typing import Optional, Sequence
 
 import numpy as np
@@ -80,7 +81,16 @@ class MultiResolutionSTFTLoss(torch.nn.Module):
                                       cache_fwd=ops.PackedWeights(), cache_bwd=ops.PackedWeights()))
         return plans
 
+    #: arithmetic of the windowed-DFT contractions: "folded" (exact fp32 on the even / odd parts of the frames: half the products
+    #: of "dense"), "dense" (one win-channel GEMM), "bf16x3" (folded, hi / lo bf16 operand splits on the bf16 MFMA, ~2^-17
+    #: relative per product: the bf16 train step of BASELINE config 2 -- EBENLightningModule.stft_math)
+    stft_math: str = os.environ.get("EBEN_STFT_MATH", "folded")
+
     def forward(self, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+        if self.stft_math not in ("folded", "dense", "bf16x3"):
+            raise ValueError(f"unknown STFT math {self.stft_math!r}")
         if self._plans is None or self._plans[0].basis_f.device != x.device or self._plans[0].basis_f.data_ptr() != self.basis_0.data_ptr():
             self._plans = self._build_plans()
+        for p in self._plans:
+            p.math = self.stft_math
         return ops.mrstft(x, y, self.fir, self._plans, self.eps)
