@@ -112,8 +112,9 @@ def main():
     ap.add_argument("--gen-bwd-math", default=None, choices=["bf16", "f32"],
                     help="generator backward contractions (default: same as --disc-math); the generator forward is always fp32")
     ap.add_argument("--stft-math", default=None, choices=["bf16x3", "folded", "dense"],
-                    help="MRSTFT windowed-DFT contractions (default: bf16x3 -- hi/lo bf16 operand splits, ~2^-17 relative -- with "
-                         "--disc-math bf16, exact fp32 'folded' with f32)")
+                    help="MRSTFT windowed-DFT contractions (default: 'folded', exact fp32 on the even / odd parts of the frames; "
+                         "'bf16x3' = hi/lo bf16 operand splits on the bf16 MFMA, ~2^-17 relative: measured slower on the tap-conv "
+                         "kernel, whose tile staging dominates a pointwise contraction over 1800-3600 channels)")
     ap.add_argument("--no-f32-leg", action="store_true", help="skip the extra fp32-discriminator timing reported beside a bf16 run")
     args = ap.parse_args()
 
@@ -139,7 +140,7 @@ def main():
     mod = build_module(device, 1234 + rank)
     mod.disc_math = args.disc_math
     mod.gen_backward_math = args.gen_bwd_math or args.disc_math
-    mod.stft_math = args.stft_math or ("bf16x3" if args.disc_math == "bf16" else "folded")
+    mod.stft_math = args.stft_math or "folded"
     gen_bwd_math, stft_math = mod.gen_backward_math, mod.stft_math   # of the measured steps (the fp32 leg below changes the module's)
     if use_ddp:
         g_opt, d_opt = mod.optimizers()
@@ -255,7 +256,8 @@ def main():
                        "weights": "random init, torch.manual_seed(42)",
                        "precision": (f"discriminator contractions (91 % of the step's FLOPs): bf16 MFMA operands, fp32 accumulate; generator "
                                      f"forward, losses, Adam, storage: fp32; generator backward contractions: {gen_bwd_math}; MRSTFT DFT contractions: "
-                                     f"{stft_math} (bf16x3 = hi/lo bf16 operand splits, fp32 accumulate, ~2^-17 relative)"
+                                     + ("bf16x3 (hi/lo bf16 operand splits, fp32 accumulate, ~2^-17 relative)" if stft_math == "bf16x3"
+                                        else f"fp32 ({stft_math})")
                                      if args.disc_math == "bf16" else "fp32 throughout (exact fp32 MFMA products)")},
             "roofline": {"bound": "mfma", "kernel": f"eben::{kname} MelGAN L4 fwd (1024->1024 k41 s4 g4), {launch_batch} items per launch",
                          "achieved": round(achieved, 2) if achieved else None, "peak": peak, "unit": "TFLOP/s",

@@ -466,7 +466,9 @@ def test_folded_framing_split_and_adjoint(hip):
 
 
 # "bf16x3": hi / lo bf16 operand splits on the bf16 MFMA, ~2^-17 relative per product (the bf16 train step's setting)
-STFT_MATH_TOL = {"folded": (2e-5, 2e-3), "dense": (2e-5, 2e-3), "bf16x3": (5e-5, 3e-3)}
+# (loss rtol, gradient relative L2): the gradient of |log X - log Y| carries sign(log X - log Y), which flips wherever the two
+# magnitudes agree to within the arithmetic's noise -- 2e-3 of the gradient's L2 at fp32, 5e-3 at 2^-17
+STFT_MATH_TOL = {"folded": (2e-5, 2e-3), "dense": (2e-5, 2e-3), "bf16x3": (5e-5, 1e-2)}
 
 
 @pytest.mark.parametrize("stft_math", ["folded", "dense", "bf16x3"])

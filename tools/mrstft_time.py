@@ -4,6 +4,7 @@ from vibravox_amd.torch_modules.losses.mrstft_loss import MultiResolutionSTFTLos
 dev = torch.device("cuda")
 loss = MultiResolutionSTFTLoss(fft_sizes=(512, 1024, 2048), hop_sizes=(50, 120, 240), win_lengths=(240, 600, 1200), sample_rate=16000, perceptual_weighting=True).to(dev)
 x = (0.1 * torch.randn(32, 1, 31968, device=dev)).requires_grad_(True); y = 0.1 * torch.randn(32, 1, 31968, device=dev)
+loss.stft_math = sys.argv[1] if len(sys.argv) > 1 else loss.stft_math
 def run():
     l = loss(x, y); l.backward(); x.grad = None
 for _ in range(3): run()
@@ -13,4 +14,4 @@ tf = tb = 0
 for _ in range(10):
     e[0].record(); l = loss(x, y); e[1].record(); l.backward(); e[2].record(); torch.cuda.synchronize()
     tf += e[0].elapsed_time(e[1]); tb += e[1].elapsed_time(e[2]); x.grad = None
-print(f"mrstft fwd {tf/10:.3f} ms  bwd {tb/10:.3f} ms")
+print(f"mrstft [{loss.stft_math}] fwd {tf/10:.3f} ms  bwd {tb/10:.3f} ms")
