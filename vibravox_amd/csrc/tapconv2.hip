@@ -60,8 +60,11 @@ __device__ __forceinline__ float a_elem<1>(const float& a, int) { return a; }
 // (MelGAN layer-2 input gradient: 16 rows x 704 taps*channels): a k-step is one tap x FOUR channels, a wave
 // owns FNH = 4 fragments of 16 positions (block = 16 rows x 256 positions), everything else -- LDS-DMA weight
 // image, scalar k-step table, double-buffered input tiles -- is shared with the 32x32x2 form.
+#ifndef EBEN_T2_MINB_FM1
+#define EBEN_T2_MINB_FM1 2   // blocks per CU the register allocation of the 32-row (FM = 1) kernels is held to
+#endif
 template <int FM, int NW, int XR, bool H16 = false>
-__global__ __launch_bounds__(NW * 64, 2) void tap2_kernel(const Tap2Args P) {
+__global__ __launch_bounds__(NW * 64, (FM == 1 && XR <= 16) ? EBEN_T2_MINB_FM1 : 2) void tap2_kernel(const Tap2Args P) {
   constexpr int NT = NW * 64;
   constexpr int FNH = 4;
   constexpr int BN = H16 ? NW * 16 * FNH : NW * 32;
