@@ -87,9 +87,11 @@ __global__ __launch_bounds__(NW * 64, (FM == 1 && XR <= 16) ? EBEN_T2_MINB_FM1 :
   // (integer division runs on the VALU: readfirstlane brings the wave-uniform results back to SGPRs,
   // which is what lets the k-step table below go through the scalar cache)
   unsigned id = xcd_remap(blockIdx.x, gridDim.x);
+  // the OS phases of one output tile interleave in memory (element t*OS + phase): neighbouring block ids -- the same XCD at about
+  // the same time -- so that their partial cache lines meet in that XCD's L2 (tapconv3.hip: 10-20 % on the strided input gradients)
+  const int ph = __builtin_amdgcn_readfirstlane(id % P.nph); id /= P.nph;
   const int tt = __builtin_amdgcn_readfirstlane(id % P.ntt); id /= P.ntt;
   const int b = __builtin_amdgcn_readfirstlane(id % P.B); id /= P.B;
-  const int ph = __builtin_amdgcn_readfirstlane(id % P.nph); id /= P.nph;
   const int mt = __builtin_amdgcn_readfirstlane(id % P.nmt);
   const int g = __builtin_amdgcn_readfirstlane(id / P.nmt);
   const int t0 = tt * BN, m0 = mt * BM;

@@ -68,9 +68,20 @@ __global__ __launch_bounds__(256, 2) void tap3_kernel(const Tap3Args P) {
   const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);
 
   unsigned id = xcd_remap(blockIdx.x, gridDim.x);
+#ifndef EBEN_T3_PH_FIRST
+#define EBEN_T3_PH_FIRST 1   // MelGAN L2 / L3 / L4 input gradients at 128 items: 0.44 / 0.57 / 0.56 -> 0.36 / 0.50 / 0.46 ms
+#endif
+#if EBEN_T3_PH_FIRST
+  // the OS phases of one output tile interleave in memory (element t*OS + phase): neighbouring block ids, i.e. the same XCD at
+  // about the same time, so that their partial cache lines meet in that XCD's L2
+  const int ph = __builtin_amdgcn_readfirstlane(id % P.nph); id /= P.nph;
+  const int tt = __builtin_amdgcn_readfirstlane(id % P.ntt); id /= P.ntt;
+  const int b = __builtin_amdgcn_readfirstlane(id % P.B); id /= P.B;
+#else
   const int tt = __builtin_amdgcn_readfirstlane(id % P.ntt); id /= P.ntt;
   const int b = __builtin_amdgcn_readfirstlane(id % P.B); id /= P.B;
   const int ph = __builtin_amdgcn_readfirstlane(id % P.nph); id /= P.nph;
+#endif
   const int mt = __builtin_amdgcn_readfirstlane(id % P.nmt);
   const int g = __builtin_amdgcn_readfirstlane(id / P.nmt);
   const int t0 = tt * BN, m0 = mt * BM;
@@ -213,7 +224,7 @@ __global__ __launch_bounds__(256, 2) void tap3_kernel(const Tap3Args P) {
   for (int ks = 0; ks < KSC; ++ks) te[ks] = nch > 0 ? tab[ks] : 0;
   int pending = -1;   // tile whose global loads are issued at the top of the next chunk (not in front of the barrier)
 #ifndef EBEN_T3_DBG
-#define EBEN_T3_DBG 0   // scratch-build ablations (wrong results): 1 no weight stream, 2 no tile refresh, 4 no barrier, 8 no MFMA
+#define EBEN_T3_DBG 0   // scratch-build ablations (wrong results): 1 no weight stream, 2 no tile refresh, 4 no barrier, 8 no MFMA, 16 phase-major stores
 #endif
   for (int ch = 0; ch < nch; ++ch) {
     if ((EBEN_T3_DBG & 1) == 0 && ch + 1 < nch) issue_w(ch + 1);
@@ -264,7 +275,8 @@ __global__ __launch_bounds__(256, 2) void tap3_kernel(const Tap3Args P) {
       const int m = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
       if (m >= P.Mg) continue;
       const float bias = P.bias ? P.bias[g * P.Mg + m] : 0.f;
-      const long long idx = ((long long)b * P.Cy + (long long)g * P.Mg + m) * P.Ly + (long long)t * P.OS + oo;
+      long long idx = ((long long)b * P.Cy + (long long)g * P.Mg + m) * P.Ly + (long long)t * P.OS + oo;
+      if (EBEN_T3_DBG & 16) idx = ((long long)b * P.Cy + (long long)g * P.Mg + m) * P.Ly + (long long)ph * nt + t;   // phase-major (coalesced) stores
       float v = acc[i][r] + bias;
       v = lrelu(v, P.out_slope);
       if (use_res) v += lrelu(P.res[idx], P.res_slope);
