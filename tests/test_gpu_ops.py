@@ -128,7 +128,8 @@ BF16_CASES = {
     "dense_k5_chunks": (CONV_CASES["dense_k5_chunks"][0], 300, (4, 4)),
     "pqmf_l6_like_96rows": (CONV_CASES["pqmf_l6_like_96rows"][0], 140, (4, 4)),
     "melgan_l2_like": (CONV_CASES["melgan_l2_like"][0], 1100, (4, 4)),   # 16 rows per group on the gradient side: half-filled 32-row tiles
-    "melgan_l1_like": (CONV_CASES["melgan_l1_like"][0], 1500, (4, 4)),   # 4 channels / 4 rows per group: mostly padding, still faster
+    "melgan_l1_like": (CONV_CASES["melgan_l1_like"][0], 1500, (4, 4)),   # 4 channels / 4 rows per group: block-diagonal over the groups
+    "pqmf_l1_like_6ch": (CONV_CASES["thin_pqmf_l1"][0], 999, (4, 4)),     # 6 channels per group: the four groups as one block-diagonal contraction
     "melgan_l0_k15": (CONV_CASES["melgan_l0_k15"][0], 2014, (None, None)),   # one input channel: direct kernel, bf16 weight gradient
     "pqmf_mid_24ch": (dict(c_in=96, c_out=192, ksize=7, stride=2, dilation=3, pad_l=3, pad_r=3, groups=4, out_slope=0.2), 1001, (4, 4)),
     "pqmf_low_12ch": (dict(c_in=48, c_out=96, ksize=7, stride=2, dilation=1, pad_l=3, pad_r=3, groups=4, out_slope=0.2), 2003, (None, None)),

@@ -294,6 +294,7 @@ struct Tap3Plan {
   int ok;
   int mode, G, Cg, Mg, S, OS, dstep, kstep, nph, J, Lx, Ly, Cx, Cy, off0, nt, ps_pad;
   int FM, BM, BN, WCHU;
+  int dense;   // groups folded into ONE block-diagonal contraction (layers with a handful of channels per group)
   int CI_T, CI_B, CP, ncc, PLEN, CSTRIDE, nxbuf, XRB;
   int nmt, ntt, NCH, tab_phase;
   long long w_tile, w_phase, tab_off_floats;
@@ -327,6 +328,19 @@ static void make_plan3(const Canon& c, int dir, Tap3Plan* p) {
     p->Ly = c.reflect ? c.Lin + c.pl + c.pr : c.Lin;
     p->ps_pad = c.reflect ? 0 : c.pl;
     p->off0 = 0; p->nt = ceil_div(p->Ly, c.s);
+  }
+  // A group of <= 8 input channels fills at most half of a 16-channel k-step (forward) or 8 of a tile's 32 rows (input
+  // gradient), and one block per (group, tile) is mostly fixed cost: such layers (MelGAN L1: 4 channels per group, PQMF-disc
+  // L1: 6) run as ONE group over all channels against a block-diagonal weight image (zeros across groups) -- the same number
+  // of MFMAs or fewer, the input tile staged once instead of once per group, a quarter of the blocks.
+  // [MI355X] at 128 items: MelGAN L1 forward 0.34 -> 0.20 ms, input gradient 0.72 -> 0.38; PQMF-disc L1 0.109 -> 0.069 and
+  // 0.172 -> 0.071.  At 12 channels per group (PQMF-disc L2) the forward loses (0.064 -> 0.076: 2.2x the MFMAs) and the
+  // input gradient still wins (0.116 -> 0.092: 8 k-steps per block become 24).
+  static const int dense_max_c = env_int3("EBEN_TAP3_DENSE_MAX_C", 8);
+  static const int dense_max_c_dx = env_int3("EBEN_TAP3_DENSE_MAX_C_DX", 12);
+  p->dense = 0;
+  if (c.g > 1 && c.Cin / c.g >= 4 && c.Cin / c.g <= (dir == 0 ? dense_max_c : dense_max_c_dx) && c.Cin <= 64 && c.Cout <= 128) {
+    p->dense = 1; p->G = 1; p->Cg *= c.g; p->Mg *= c.g;
   }
   static const int enabled = env_int3("EBEN_TAP3", 1);
   static const int min_m = env_int3("EBEN_TAP3_MIN_M", 4);
@@ -416,7 +430,7 @@ struct Pack3Args {
   const float* w; const float* scale; float* wp;
   int G, Cg, Mg, nmt, BM, FM, WCHU, CI_T, CI_B, CP, ncc, NCH, nph, tab_phase;
   int mode, J0, off0, nt, dstep, OS, S, ps_pad, k, d, kstep, Ly;
-  int Cin_g, Cout_g, PLEN, CSTRIDE, nxbuf;
+  int Cin_g, Cout_g, PLEN, CSTRIDE, nxbuf, dense;
   long long w_tile, w_phase, wunits;
 };
 
@@ -453,7 +467,10 @@ __global__ __launch_bounds__(256) void pack3_kernel(const Pack3Args P) {
           const int chan = cc * P.CI_T + 16 * cp + 8 * (lane >> 5) + u;
           ok[u] = live && chan < P.Cg && m < P.Mg && (P.mode == 0 || kk < P.k);
           const int co = P.mode == 0 ? g * P.Cout_g + m : g * P.Cout_g + chan;   // mode 1: reduction channel = conv output channel
-          const long long idx = P.mode == 0 ? ((long long)co * P.Cin_g + chan) * P.k + j : ((long long)co * P.Cin_g + m) * P.k + kk;
+          // conv input channel within its group; dense form (g == 0, channels counted over all groups): zero across groups
+          const int ci = (P.mode == 0 ? chan : m) - (P.dense ? (co / P.Cout_g) * P.Cin_g : 0);
+          ok[u] = ok[u] && ci >= 0 && ci < P.Cin_g;
+          const long long idx = ((long long)co * P.Cin_g + ci) * P.k + (P.mode == 0 ? j : kk);
           v[u] = P.w[ok[u] ? idx : 0];
           sc8[u] = P.scale ? P.scale[ok[u] ? co : 0] : 1.f;
         }
@@ -522,7 +539,7 @@ int tap3_pack(const Canon& c, int dir, const float* w, const float* scale, float
   a.CI_T = p.CI_T; a.CI_B = p.CI_B; a.CP = p.CP; a.ncc = p.ncc; a.NCH = p.NCH; a.nph = p.nph; a.tab_phase = p.tab_phase;
   a.mode = p.mode; a.J0 = p.J; a.off0 = p.off0; a.nt = p.nt; a.dstep = p.dstep; a.OS = p.OS; a.S = p.S; a.ps_pad = p.ps_pad;
   a.k = c.k; a.d = c.d; a.kstep = p.kstep; a.Ly = p.Ly;
-  a.Cin_g = c.Cin / c.g; a.Cout_g = c.Cout / c.g; a.PLEN = p.PLEN; a.CSTRIDE = p.CSTRIDE; a.nxbuf = p.nxbuf;
+  a.Cin_g = c.Cin / c.g; a.Cout_g = c.Cout / c.g; a.PLEN = p.PLEN; a.CSTRIDE = p.CSTRIDE; a.nxbuf = p.nxbuf; a.dense = p.dense;
   a.w_tile = p.w_tile; a.w_phase = p.w_phase; a.wunits = p.w_phase * p.nph;
   long long blocks = (a.wunits + (long long)p.tab_phase * p.nph + 255) / 256;
   if (blocks > 8192) blocks = 8192;
