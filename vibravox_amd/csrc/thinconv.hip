@@ -34,8 +34,12 @@ struct ThinArgs {
   long long w_tile;   // floats per (phase, group, m-tile) weight panel: J0 * Cg * MT
 };
 
-template <int MT, int BN>
+// NP: output positions per thread (block = BN * NP positions, position tid + n * BN: every store stays coalesced).  A block of
+// the first discriminator layers is a few dozen FMAs per thread behind a fixed preamble (phase geometry, tile staging, barrier);
+// four positions per thread amortise it and reuse each scalar weight four times.  Same FMA order per output: same bits.
+template <int MT, int BN, int NP = 1>
 __global__ __launch_bounds__(BN) void thin_kernel(const ThinArgs P) {
+  constexpr int TILE = BN * NP;
   extern __shared__ __attribute__((aligned(16))) float Xs[];
   const int tid = threadIdx.x;
 
@@ -45,13 +49,13 @@ __global__ __launch_bounds__(BN) void thin_kernel(const ThinArgs P) {
   const int ph = __builtin_amdgcn_readfirstlane(id % P.nph); id /= P.nph;
   const int mt = __builtin_amdgcn_readfirstlane(id % P.nmt);
   const int g = __builtin_amdgcn_readfirstlane(id / P.nmt);
-  const int t0 = tt * BN, m0 = mt * MT;
+  const int t0 = tt * TILE, m0 = mt * MT;
 
   const PhaseGeom q = phase_geom(P.mode, ph, P.J0, P.off0, P.nt, P.dstep, P.OS, P.ps_pad, P.ps_k, P.ps_d, P.ps_kstep, P.Ly);
   const int J = q.J, nt = q.nt, oo = q.oo;
   if (t0 >= nt) return;
   const int adstep = P.dstep >= 0 ? P.dstep : -P.dstep;
-  const int span = J > 0 ? (BN - 1) * P.S + (J - 1) * adstep + 1 : 0;
+  const int span = J > 0 ? (TILE - 1) * P.S + (J - 1) * adstep + 1 : 0;
   const int q0 = t0 * P.S + q.minoff;
   const int xtot = P.Cg * span;
   const unsigned span_magic = span > 0 ? (unsigned)((0x100000000ull + (unsigned)span - 1) / (unsigned)span) : 0u;
@@ -91,9 +95,11 @@ __global__ __launch_bounds__(BN) void thin_kernel(const ThinArgs P) {
   }
   __syncthreads();
 
-  float acc[MT];
+  float acc[NP][MT];
 #pragma unroll
-  for (int m = 0; m < MT; ++m) acc[m] = 0.f;
+  for (int n = 0; n < NP; ++n)
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[n][m] = 0.f;
 
   // weights: [phase][group][m-tile][tap][channel][MT], wave-uniform -> constant address space -> s_load
   typedef const __attribute__((address_space(4))) float* cw_t;
@@ -106,9 +112,15 @@ __global__ __launch_bounds__(BN) void thin_kernel(const ThinArgs P) {
     cw_t wj = w + (long long)j * P.Cg * MT;
 #pragma unroll 4
     for (int c = 0; c < P.Cg; ++c) {
-      const float xv = xr[c * P.CSTRIDE];
+      float xv[NP];
 #pragma unroll
-      for (int m = 0; m < MT; ++m) acc[m] = fmaf(wj[c * MT + m], xv, acc[m]);
+      for (int n = 0; n < NP; ++n) xv[n] = xr[c * P.CSTRIDE + n * BN];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const float wv = wj[c * MT + m];
+#pragma unroll
+        for (int n = 0; n < NP; ++n) acc[n][m] = fmaf(wv, xv[n], acc[n][m]);
+      }
     }
   }
 
@@ -116,19 +128,22 @@ __global__ __launch_bounds__(BN) void thin_kernel(const ThinArgs P) {
   const bool use_res = P.res != nullptr && (P.res_rows == 0 || b < P.res_rows);
   const int eb = P.em_seg > 0 ? P.em_map[b / P.em_seg] * P.em_seg + b % P.em_seg : b;
   const long long eoff = (long long)(eb - b) * P.Cy * P.Ly;
-  const int t = t0 + tid;
-  if (t >= nt) return;
+#pragma unroll
+  for (int n = 0; n < NP; ++n) {
+  const int t = t0 + tid + n * BN;
+  if (t >= nt) continue;
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
     const int mm = m0 + m;
     if (mm >= P.Mg) continue;
     const long long idx = ((long long)b * P.Cy + (long long)g * P.Mg + mm) * P.Ly + (long long)t * P.OS + oo;
-    float v = acc[m] + (P.bias ? P.bias[g * P.Mg + mm] : 0.f);
+    float v = acc[n][m] + (P.bias ? P.bias[g * P.Mg + mm] : 0.f);
     v = lrelu(v, P.out_slope);
     if (use_res) v += lrelu(P.res[idx], P.res_slope);
     if (P.emask) v *= dlrelu(P.emask[idx + eoff], P.emask_slope);
     if (P.accumulate) v += P.y[idx];
     P.y[idx] = v;
+  }
   }
 }
 
@@ -136,7 +151,7 @@ __global__ __launch_bounds__(BN) void thin_kernel(const ThinArgs P) {
 struct ThinPlan {
   int ok;
   int mode, G, Cg, Mg, S, OS, dstep, kstep, nph, J, Lx, Ly, Cx, Cy, off0, nt, ps_pad;
-  int MT, BN, nmt, ntt, PLEN, CSTRIDE;
+  int MT, BN, NP, nmt, ntt, PLEN, CSTRIDE;
   long long w_tile;
   size_t packed_floats, lds_bytes;
 };
@@ -182,15 +197,18 @@ static void make_thin_plan(const Canon& c, int dir, ThinPlan* p) {
   const int adstep = p->dstep >= 0 ? p->dstep : -p->dstep;
   const int maxd = ((p->J - 1) * adstep) / p->S + 1;
   p->BN = p->nt <= 128 ? 128 : 256;
+  static const int np4 = thin_env("EBEN_THIN_NP", 4);
+  p->NP = (np4 == 4 && p->BN == 256 && p->nt >= 4096 &&
+           (long long)ceil_div(p->nt, 1024) * c.B * p->nph * p->nmt * p->G >= 2048) ? 4 : 1;
   for (;;) {
-    p->PLEN = p->BN + maxd + 1;
+    p->PLEN = p->BN * p->NP + maxd + 1;
     p->CSTRIDE = p->S * p->PLEN;
     p->lds_bytes = 4ull * p->Cg * p->CSTRIDE;
-    if (p->lds_bytes <= 72 * 1024 || p->BN == 128) break;
-    p->BN = 128;
+    if (p->lds_bytes <= 72 * 1024 || (p->BN == 128 && p->NP == 1)) break;
+    if (p->NP > 1) p->NP = 1; else p->BN = 128;
   }
   if (p->lds_bytes > 150 * 1024) return;
-  p->ntt = ceil_div(p->nt, p->BN);
+  p->ntt = ceil_div(p->nt, p->BN * p->NP);
   p->w_tile = (long long)p->J * p->Cg * p->MT;
   p->packed_floats = (size_t)p->w_tile * p->nmt * p->G * p->nph;
   p->ok = 1;
@@ -234,10 +252,10 @@ __global__ __launch_bounds__(256) void thin_pack_kernel(const ThinPackArgs P) {
   }
 }
 
-template <int MT, int BN>
+template <int MT, int BN, int NP = 1>
 static int launch_thin_cfg(const ThinArgs& a, int nblocks, size_t lds, hipStream_t st) {
   static bool attr_set = false;
-  auto kern = thin_kernel<MT, BN>;
+  auto kern = thin_kernel<MT, BN, NP>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(thin)");
@@ -296,6 +314,14 @@ int thin_launch(const Canon& c, int dir, const TapIO& io, int reflect, hipStream
   a.ntt = p.ntt; a.nmt = p.nmt; a.w_tile = p.w_tile;
   const long long nb = (long long)p.ntt * c.B * p.nph * p.nmt * p.G;
   if (nb <= 0 || nb > 0x7fffffffLL) return fail(EBEN_EINVAL, "thin grid of %lld blocks", nb);
+  if (p.BN == 256 && p.NP == 4) {
+    switch (p.MT) {
+      case 1: return launch_thin_cfg<1, 256, 4>(a, (int)nb, p.lds_bytes, st);
+      case 4: return launch_thin_cfg<4, 256, 4>(a, (int)nb, p.lds_bytes, st);
+      case 8: return launch_thin_cfg<8, 256, 4>(a, (int)nb, p.lds_bytes, st);
+      default: return launch_thin_cfg<16, 256, 4>(a, (int)nb, p.lds_bytes, st);
+    }
+  }
   if (p.BN == 256) {
     switch (p.MT) {
       case 1: return launch_thin_cfg<1, 256>(a, (int)nb, p.lds_bytes, st);
