@@ -18,6 +18,10 @@ import sys
 import time
 from functools import partial
 
+# RCCL's version banner (NCCL_DEBUG=VERSION in this image) goes to STDOUT, where the driver reads one JSON line
+if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
+    os.environ["NCCL_DEBUG"] = "WARN"
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -279,9 +283,15 @@ def main():
         print(f"[bench] GPU: {ms:.1f} ms/step, {value:.1f} audio-s/s", file=sys.stderr, flush=True)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_batch, args.length, args.cpu_steps)
-        print(json.dumps(line), flush=True)
+    # the JSON line is the LAST thing on stdout: the process group is torn down and every C stdio buffer (RCCL's log stream) is
+    # flushed first
     if use_ddp:
+        barrier()
         dist.destroy_process_group()
+    import ctypes
+    ctypes.CDLL(None).fflush(None)
+    if rank == 0:
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":
