@@ -22,13 +22,14 @@ along the batch axis (rows [fm | adv | fake | real], 4B rows):
 
 Same arithmetic per sample as the four separate passes (convolutions are per-sample); only the fp32
 summation order inside the weight gradients changes.  The four sub-discriminators run on their own
-HIP streams.  No autograd graph is built for the discriminator; parameter gradients are handed to
-autograd through ``inject_grads`` so that ``.grad`` accumulation hooks (``ddp.GradSync``) still fire.
+HIP streams.  No autograd graph is built for the discriminator; parameter gradients become ``.grad`` directly, or
+are handed to autograd through ``inject_grads`` where ``.grad`` accumulation hooks (torch DDP) must fire.
 """
 from __future__ import annotations
 
 import ctypes
 import dataclasses
+import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -242,6 +243,9 @@ class _Chain:
         return dv, dg, dbias
 
 
+_DIRECT_INJECT = os.environ.get("EBEN_DIRECT_INJECT", "1") != "0"
+
+
 class _InjectGrads(torch.autograd.Function):
     """Hands externally computed parameter gradients to autograd (so accumulation hooks fire)."""
 
@@ -260,6 +264,18 @@ def inject_grads(params: Sequence[torch.nn.Parameter], grads: Sequence[torch.Ten
     if not live:
         return
     ps, gs = zip(*live)
+    # Through autograd every gradient is CLONED into ``.grad`` (the list above keeps a second reference, so AccumulateGrad cannot
+    # steal it): 93 device copies in front of the discriminator's Adam.  The gradients are fresh tensors of the parameters'
+    # own layout, so without accumulation hooks to fire (torch DDP's reducer, ``register_post_accumulate_grad_hook`` users) they
+    # become ``.grad`` directly.
+    if _DIRECT_INJECT and not (torch.distributed.is_available() and torch.distributed.is_initialized()) and all(
+            not getattr(p, "_post_accumulate_grad_hooks", None) and not p._backward_hooks for p in ps):
+        for p, g in live:
+            if p.grad is None:
+                p.grad = g
+            else:
+                p.grad.add_(g)
+        return
     _InjectGrads.apply(list(gs), *ps).backward()
 
 
