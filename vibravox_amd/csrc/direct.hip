@@ -62,9 +62,10 @@ __global__ __launch_bounds__(256) void fir_interp_sum_kernel(const float* __rest
   int j0 = rel % stride;
   if (j0 < 0) j0 += stride;
   float acc = 0.f;
-  for (int j = j0; j < ntaps; j += stride) {
-    const int t = (rel - j) / stride;       // exact
-    const int tl = t - t_min;
+  // t = (rel - j) / stride is exact and falls by one per step of j: ONE division per thread (a division per tap was 101 of them
+  // per output of the A-weighting filter's adjoint); same taps in the same order
+  int tl = (rel - j0) / stride - t_min;
+  for (int j = j0; j < ntaps; j += stride, --tl) {
     if (tl < 0 || tl >= tile_t) continue;
     for (int k = 0; k < bands; ++k) acc = fmaf(ws[k * ntaps + j], ys[k * tile_t + tl], acc);
   }
