@@ -561,14 +561,50 @@ __global__ __launch_bounds__(1024) void conv_m1_fwd_kernel(const float* __restri
   const int b = blockIdx.y, t = blockIdx.x * 64 + lane;
   const float* xb = x + (long long)b * C * Lx;
   float acc = 0.f;
-  for (int c = w; c < C; c += 16) {
-    const int cc = c / CI_T, cl = c - cc * CI_T;
-    const float* xr = xb + (long long)c * Lx;
-    const float* wc = wp + ((long long)cc * KCpad + cl) * Mp;
-    for (int j = 0; j < J; ++j) {
-      const int q = t - pad + j * dil;
-      const float xv = (q >= 0 && q < Lx) ? xr[q] : 0.f;
-      acc = fmaf(wc[(long long)j * CI_T * Mp], xv, acc);
+  if (J == 3) {
+    // the two logits layers (k = 3): four channels' loads in flight per round trip, addresses clamped instead of branched on,
+    // the channel-chunk index carried instead of divided for; same FMA order as the generic loop below
+    int q[3], ok[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int qq = t - pad + j * dil;
+      ok[j] = (int)(qq >= 0) & (int)(qq < Lx);
+      q[j] = ok[j] ? qq : 0;
+    }
+    int cc = w / CI_T, cl = w - cc * CI_T;
+    for (int c = w; c < C; c += 64) {
+      float xv[4][3], wv[4][3];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int cu = c + 16 * u;
+        const bool live = cu < C;
+        const float* xr = xb + (long long)(live ? cu : w) * Lx;
+        const float* wc = wp + ((long long)cc * KCpad + cl) * Mp;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          xv[u][j] = xr[q[j]];
+          wv[u][j] = live ? wc[(long long)j * CI_T * Mp] : 0.f;
+          if (!ok[j]) xv[u][j] = 0.f;
+        }
+        cl += 16;
+        while (cl >= CI_T) { cl -= CI_T; ++cc; }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+          if (c + 16 * u < C) acc = fmaf(wv[u][j], xv[u][j], acc);
+    }
+  } else {
+    for (int c = w; c < C; c += 16) {
+      const int cc = c / CI_T, cl = c - cc * CI_T;
+      const float* xr = xb + (long long)c * Lx;
+      const float* wc = wp + ((long long)cc * KCpad + cl) * Mp;
+      for (int j = 0; j < J; ++j) {
+        const int q = t - pad + j * dil;
+        const float xv = (q >= 0 && q < Lx) ? xr[q] : 0.f;
+        acc = fmaf(wc[(long long)j * CI_T * Mp], xv, acc);
+      }
     }
   }
   part[w][lane] = acc;
