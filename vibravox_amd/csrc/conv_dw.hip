@@ -349,6 +349,65 @@ __global__ __launch_bounds__(256) void tiny_dw_kernel(const DwArgs P) {
   }
 }
 
+// ---- weight gradient of a single-output-channel conv (the logits layers: 768 -> 1 and 1024 -> 1, k = 3) -----------------
+// dw[c, j] = sum_t a[t] * x[c, t + off0 + j*d]: a matrix-vector product per batch item -- the input is read ONCE, the one
+// gradient row stays in cache.  One block = one batch item x 16 channels (4 per wave, their 12 loads in flight together),
+// lanes walk the time steps, wave_sum in a fixed order; slab b holds item b's row [c*J + j ..., bias] like tiny_dw's.
+constexpr int M1DW_CPB = 16;
+__global__ __launch_bounds__(256) void m1_dw_kernel(const DwArgs P) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int b = blockIdx.y, c0 = blockIdx.x * M1DW_CPB + w * 4;
+  const float* pa = P.a + (long long)b * P.La;
+  const float* pam = P.a_mode ? P.amask + (long long)b * P.La : pa;
+  const float* px = P.x + (long long)b * P.Cx * P.Lx;
+  float acc[4][3], asum = 0.f;
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) acc[u][j] = 0.f;
+  for (int t = lane; t < P.La; t += 64) {
+    float a = pa[t];
+    a = P.a_mode == 0 ? lrelu(a, P.a_slope) : a * dlrelu(pam[t], P.a_slope);
+    asum += a;
+    int q[3];
+    bool ok[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int p = t + P.off0 + j * P.d;
+      ok[j] = p >= 0 && p < P.Lx;
+      q[j] = ok[j] ? p : 0;
+    }
+    float xv[4][3];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int c = c0 + u < P.Cx ? c0 + u : 0;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) xv[u][j] = px[(long long)c * P.Lx + q[j]];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) acc[u][j] = fmaf(a, ok[j] ? lrelu(xv[u][j], P.x_slope) : 0.f, acc[u][j]);
+  }
+  float* o = P.slabs + (long long)b * P.slab_stride;
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const float v = wave_sum(acc[u][j]);
+      if (lane == 0 && c0 + u < P.Cx) o[(c0 + u) * 3 + j] = v;
+    }
+  if (blockIdx.x == 0 && w == 0 && P.has_bias) {
+    const float v = wave_sum(asum);
+    if (lane == 0) o[P.Ng] = v;
+  }
+}
+
+static bool m1_dw_applicable(const Canon& c, const EbenConv1dDesc* d) {
+  static const int enabled = getenv("EBEN_M1_DW") ? atoi(getenv("EBEN_M1_DW")) : 1;
+  return enabled && !d->transposed && c.Cout == 1 && c.g == 1 && c.s == 1 && c.k == 3 && !c.reflect && c.Cin >= 64;
+}
+
 static bool tiny_dw_applicable(const Canon& c, const EbenConv1dDesc* d) {
   static const int enabled = getenv("EBEN_TINY_DW") ? atoi(getenv("EBEN_TINY_DW")) : 1;
   const int Ng = (c.Cin / c.g) * c.k;
@@ -591,6 +650,12 @@ extern "C" size_t eben_conv1d_bwd_dw_workspace(const EbenConv1dDesc* d, int* nsl
     if (row_stride) *row_stride = rs;
     return sizeof(float) * (size_t)c.B * c.Cout * rs;
   }
+  if (m1_dw_applicable(c, d)) {
+    const int rs = c.Cin * c.k + 1;
+    if (nslab) *nslab = c.B;
+    if (row_stride) *row_stride = rs;
+    return sizeof(float) * (size_t)c.B * rs;
+  }
   if ((d->out_slope == 1.f || !d->transposed) && dw3_applicable(c)) return dw3_workspace(c, nslab, row_stride);   // bf16 math (no mask on the X operand)
   if (dw2_applicable(c)) return dw2_workspace(c, nslab, row_stride);
   DwPlan p;
@@ -622,6 +687,20 @@ extern "C" int eben_conv1d_bwd_dw(const EbenConv1dDesc* d, const float* dy, cons
     EBEN_REQUIRE(a.row_stride <= 4, "tiny_dw serves at most 4 columns per row");
     hipLaunchKernelGGL(tiny_dw_kernel<4>, grid, dim3(256), 0, as_stream(stream), a);
     EBEN_CHECK_LAUNCH("tiny_dw_kernel");
+    return EBEN_OK;
+  }
+  if (m1_dw_applicable(c, d)) {
+    DwArgs a{};
+    a.a = dy; a.amask = y; a.a_mode = d->out_slope != 1.f ? 1 : 0; a.a_slope = a.a_mode ? d->out_slope : 1.f;
+    a.x = x; a.xmask = nullptr; a.x_mode = 0; a.x_slope = d->in_slope;
+    a.slabs = slabs;
+    a.B = c.B; a.G = 1; a.Cg = c.Cin; a.Mg = 1; a.Ca = 1; a.Cx = c.Cin; a.La = c.Lout; a.Lx = c.Lin;
+    a.S = 1; a.d = c.d; a.off0 = -c.pl; a.J = 3; a.Ng = c.Cin * 3; a.has_bias = has_bias ? 1 : 0; a.row_stride = a.Ng + 1;
+    a.reflect = 0; a.slab_stride = a.row_stride;
+    const size_t need = sizeof(float) * (size_t)c.B * a.slab_stride;
+    if (ws_bytes < need) return fail(EBEN_EWORKSPACE, "bwd_dw needs %zu workspace bytes, got %zu", need, ws_bytes);
+    hipLaunchKernelGGL(m1_dw_kernel, dim3(ceil_div(c.Cin, M1DW_CPB), c.B), dim3(256), 0, as_stream(stream), a);
+    EBEN_CHECK_LAUNCH("m1_dw_kernel");
     return EBEN_OK;
   }
   if ((d->out_slope == 1.f || !d->transposed) && dw3_applicable(c)) {

@@ -198,8 +198,9 @@ static void make_thin_plan(const Canon& c, int dir, ThinPlan* p) {
   const int maxd = ((p->J - 1) * adstep) / p->S + 1;
   p->BN = p->nt <= 128 ? 128 : 256;
   static const int np4 = thin_env("EBEN_THIN_NP", 4);
+  static const int np_min_blocks = thin_env("EBEN_THIN_NP_MIN_BLOCKS", 2048);
   p->NP = (np4 == 4 && p->BN == 256 && p->nt >= 4096 &&
-           (long long)ceil_div(p->nt, 1024) * c.B * p->nph * p->nmt * p->G >= 2048) ? 4 : 1;
+           (long long)ceil_div(p->nt, 1024) * c.B * p->nph * p->nmt * p->G >= np_min_blocks) ? 4 : 1;
   for (;;) {
     p->PLEN = p->BN * p->NP + maxd + 1;
     p->CSTRIDE = p->S * p->PLEN;
