@@ -45,6 +45,12 @@ extern "C" {
 #define EBEN_MATH_F32 0   /* v_mfma_f32_*_f32 / fp32 FMA: bit-exact fp32 products */
 #define EBEN_MATH_BF16 1  /* both MFMA operands rounded (RNE) to bf16 -- after the fused input stage (LeakyReLU or its
                            * derivative mask) -- fp32 accumulate; layers the bf16 kernels do not cover run their fp32 kernel */
+#define EBEN_MATH_BF16X2 2 /* EBEN_MATH_BF16 with the ACTIVATION operand -- x of the layer's forward and of its weight gradient --
+                           * entering as hi + lo, hi = bf16(x), lo = bf16(x - hi): two MFMAs per k-step against the same bf16
+                           * weight / gradient fragment, x accurate to ~2^-17.  The discriminator's activations are a large
+                           * input-independent component plus a small input-dependent one; rounding them to 8 bits buries the
+                           * second, which is all that survives when the fake and real hinge gradients (eben.py:121-125) cancel.
+                           * Gradient operands and weights stay single bf16; the input-gradient launch equals EBEN_MATH_BF16. */
 
 /* One Conv1d / ConvTranspose1d layer (nn.Conv1d / nn.ConvTranspose1d semantics).
  * Replaces the F.conv1d / F.conv_transpose1d call sites behind

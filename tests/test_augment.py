@@ -75,6 +75,42 @@ def test_device_module_surface_on_cpu():
     assert a is x and b is None
 
 
+@pytest.mark.parametrize("two", [False, True])
+def test_draw_sequence_with_every_transform_enabled(monkeypatch, two):
+    """CPU: the module consumes the CPU generator exactly as the reference does when every branch fires -- including the
+    per-call ``torch.randint(len(factors), ())`` inside torchaudio's ``T.SpeedPerturbation.forward`` (one per waveform) that
+    sits between the speed factor draw and the pitch-shift decision (data_augmentation.py:52-69)."""
+    import vibravox_amd.augment as DA
+
+    monkeypatch.setattr(DA, "speed", lambda w, sr, f: w)
+    monkeypatch.setattr(DA, "pitch_shift", lambda w, sr, s: w)
+
+    def masking(x, pct):   # the draw of time_masking_waveform.py:30 without the kernel
+        t = x.shape[-1]
+        torch.randint(0, t - int(t * pct / 100), (1,))
+        return x
+
+    monkeypatch.setattr(DA, "time_masking_", masking)
+    mod = DA.WaveformDataAugmentation(16000, p_data_augmentation=1, p_speed_perturbation=1, p_pitch_shift=1, p_time_masking=1)
+    x = torch.zeros(1, 1, 1000)
+    n = 2 if two else 1
+    torch.manual_seed(7)
+    mod(x, x.clone() if two else None)
+    after = float(torch.rand(1))
+    torch.manual_seed(7)
+    torch.rand(1); torch.rand(1)                                   # apply at all?  speed?
+    torch.randint(len(mod.speed_perturbation_factors), size=(1,))
+    for _ in range(n):
+        torch.randint(1, ())                                       # SpeedPerturbation.forward, once per waveform
+    torch.rand(1)
+    torch.randint(len(mod.pitch_shift_steps), size=(1,))
+    torch.rand(1)
+    pct = mod.time_masking_percentage[torch.randint(len(mod.time_masking_percentage), size=(1,)).item()]
+    for _ in range(n):
+        torch.randint(0, 1000 - int(1000 * pct / 100), (1,))
+    assert float(torch.rand(1)) == after
+
+
 @pytest.mark.gpu
 def test_device_time_masking_matches_reference_golden(agold):
     from vibravox_amd.augment import WaveformDataAugmentation, time_masking_

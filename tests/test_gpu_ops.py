@@ -257,6 +257,82 @@ def test_bf16_math_forward_and_batched_input_gradient(hip, name):
         assert rel_err(dv, wr2.grad) < 1e-4
 
 
+@pytest.mark.parametrize("name", list(BF16_CASES))
+def test_bf16x2_math_keeps_the_activation_operand(hip, name):
+    """EBEN_MATH_BF16X2: the activation operand enters the forward and the weight gradient as hi + lo (two bf16 MFMAs per
+    k-step), weights / gradients as single bf16.  Against an fp64 conv of the EXACT x and the bf16-rounded other operand
+    the kernels must be as tight as the fp32 ones (x = hi + lo to 2^-17 per element); the input gradient is EBEN_MATH_BF16's."""
+    import ctypes
+    import dataclasses
+
+    from vibravox_amd import ops
+    from vibravox_amd._lib import check, load, ptr, stream
+
+    lib = load()
+    kw, length, _ = BF16_CASES[name]
+    spec = ops.ConvSpec(**kw)
+    wshape = spec.weight_shape()
+    w = formula_tensor(f"bf/{name}/w", wshape, 1 / math.sqrt(wshape[1] * wshape[2]))
+    bias = formula_tensor(f"bf/{name}/b", (spec.c_out,), 0.1)
+    # a large common component plus a small item-dependent one: what the discriminator's activations look like, and the
+    # case single-bf16 rounding gets wrong (the item-dependent part sits below the 2^-9 grid of the common one)
+    common = formula_tensor(f"x2/{name}/c", (1, spec.c_in, length))
+    x = common + 2e-3 * formula_tensor(f"x2/{name}/x", (4, spec.c_in, length))
+    l_out = spec.out_len(length)
+    okw = {k: v for k, v in kw.items() if k not in ("c_in", "c_out", "ksize", "in_slope", "out_slope")}
+    dev = torch.device("cuda")
+    wd, bd, xd = w.to(dev), bias.to(dev), x.to(dev)
+    d = ops.conv_desc(spec, 4, length, ops.MATH_BF16X2)
+    fgen = lib.eben_conv1d_kernel_generation(ctypes.byref(d), 0)
+    rw = _bf16 if fgen == 4 else (lambda t: t.double())
+    xin = torch.nn.functional.leaky_relu(x.double(), spec.in_slope)
+    ref = torch.nn.functional.leaky_relu(O.conv_layer(xin, rw(w), None, bias.double(), **{**okw}), spec.out_slope) if spec.in_slope == 1.0 else None
+    wp = torch.empty(lib.eben_conv1d_packed_floats(ctypes.byref(d), 0), dtype=torch.float32, device=dev)
+    check(lib.eben_conv1d_pack(ctypes.byref(d), ptr(wd), None, ptr(wp), None, stream()), "pack")
+    y = torch.empty(4, spec.c_out, l_out, dtype=torch.float32, device=dev)
+    check(lib.eben_conv1d_fwd(ctypes.byref(d), ptr(xd), ptr(wp), ptr(bd), None, ptr(y), stream()), "fwd")
+    torch.cuda.synchronize()
+    if ref is not None:
+        assert rel_err(y, ref) < 3e-5
+        # the item-dependent part of the output (differences between items) survives: single bf16 loses it
+        diff, rdiff = (y[1] - y[0]).double().cpu(), ref[1] - ref[0]
+        assert float((diff - rdiff).norm() / rdiff.norm()) < 2e-3
+        if fgen == 4:
+            d1 = ops.conv_desc(spec, 4, length, ops.MATH_BF16)
+            wp1 = torch.empty(lib.eben_conv1d_packed_floats(ctypes.byref(d1), 0), dtype=torch.float32, device=dev)
+            check(lib.eben_conv1d_pack(ctypes.byref(d1), ptr(wd), None, ptr(wp1), None, stream()), "pack")
+            y1 = torch.empty_like(y)
+            check(lib.eben_conv1d_fwd(ctypes.byref(d1), ptr(xd), ptr(wp1), ptr(bd), None, ptr(y1), stream()), "fwd")
+            torch.cuda.synchronize()
+            d1v = (y1[1] - y1[0]).double().cpu()
+            assert float((d1v - rdiff).norm() / rdiff.norm()) > 10 * float((diff - rdiff).norm() / rdiff.norm())
+
+    # weight / bias gradient: x exact, gradient operand rounded
+    lin = dataclasses.replace(spec, in_slope=1.0, out_slope=1.0)
+    nb = 24
+    d = ops.conv_desc(lin, nb, length, ops.MATH_BF16X2)
+    xb = common + 2e-3 * formula_tensor(f"x2/{name}/xb", (nb, spec.c_in, length))
+    gb = formula_tensor(f"bf/{name}/gb", (nb, spec.c_out, l_out))
+    nslab, row_stride = ctypes.c_int(0), ctypes.c_int(0)
+    ws_bytes = lib.eben_conv1d_bwd_dw_workspace(ctypes.byref(d), ctypes.byref(nslab), ctypes.byref(row_stride))
+    wr = torch.zeros(wshape, dtype=torch.float64, requires_grad=True)
+    (O.conv_layer(xb.double(), wr, None, None, **okw) * gb.double()).sum().backward()
+    exact = wr.grad.clone()
+    wr.grad = None
+    (O.conv_layer(xb.double(), wr, None, None, **okw) * _bf16(gb)).sum().backward()
+    slabs = torch.empty((ws_bytes + 3) // 4, dtype=torch.float32, device=dev)
+    xbd, gbd = xb.to(dev), gb.to(dev)
+    check(lib.eben_conv1d_bwd_dw(ctypes.byref(d), ptr(gbd), None, ptr(xbd), 1, ptr(slabs), ws_bytes, stream()), "bwd_dw")
+    rows, cols = wshape[0], wshape[1] * wshape[2]
+    dv = torch.empty(wshape, dtype=torch.float32, device=dev)
+    dbias = torch.empty(rows, dtype=torch.float32, device=dev)
+    check(lib.eben_wn_bwd(ptr(slabs), nslab.value, rows * row_stride.value, rows, cols, row_stride.value, None, None, None, None,
+                          ptr(dv), ptr(dbias), stream()), "wn_bwd")
+    torch.cuda.synchronize()
+    # either the bf16 kernel with the split X operand (== fp64 of exact x, rounded g) or the fp32 fallback (== exact)
+    assert min(rel_err(dv, wr.grad), rel_err(dv, exact)) < 1e-4
+
+
 @pytest.mark.parametrize("name", ["pqmf_disc_wide", "melgan_l2_like", "thin_pqmf_l1", "dense_k5_chunks"])
 def test_batched_input_gradient_ex(hip, name):
     """eben_conv1d_bwd_dx_ex: four stacked right-hand sides [fm | adv | fake | real] against activations

@@ -61,7 +61,7 @@ def main():
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--filter", default="")
     ap.add_argument("--min-gmacs", type=float, default=0.0)
-    ap.add_argument("--math", default="f32", choices=["f32", "bf16"], help="bf16: EBEN_MATH_BF16 descriptors; dx through eben_conv1d_bwd_dx_ex")
+    ap.add_argument("--math", default="f32", choices=["f32", "bf16", "bf16x2"], help="bf16: EBEN_MATH_BF16 descriptors; dx through eben_conv1d_bwd_dx_ex; bf16x2: EBEN_MATH_BF16X2")
     a = ap.parse_args()
     lib = load()
     dev = torch.device("cuda")
@@ -71,7 +71,7 @@ def main():
     for name, spec, l_in, has_bias in rows:
         if a.filter and a.filter not in name:
             continue
-        math = ops.MATH_BF16 if a.math == "bf16" else ops.MATH_F32
+        math = {"bf16": ops.MATH_BF16, "bf16x2": ops.MATH_BF16X2, "f32": ops.MATH_F32}[a.math]
         d = ops.conv_desc(spec, a.batch, l_in, math)
         l_out = d.l_out
         wshape = spec.weight_shape()
@@ -101,18 +101,18 @@ def main():
             check(lib.eben_conv1d_fwd(ctypes.byref(d), ptr(x), ptr(pw.wp_fwd), ptr(bias), None, ptr(y), st))
 
         def bdx():
-            if math == ops.MATH_BF16:   # the engine's form: linear conv, masks in the producer's epilogue
+            if math != ops.MATH_F32:   # the engine's form: linear conv, masks in the producer's epilogue
                 return check(lib.eben_conv1d_bwd_dx(ctypes.byref(d_lin), ptr(dy), None, ptr(pw.wp_bwd), None, ptr(dx), 0, ptr(ws), wsb, st))
             check(lib.eben_conv1d_bwd_dx(ctypes.byref(d), ptr(dy), ptr(ymask), ptr(pw.wp_bwd), ptr(xmask), ptr(dx), 0, ptr(ws), wsb, st))
 
-        if math == ops.MATH_BF16:   # the engine's form: pre-masked gradient, linear conv
+        if math != ops.MATH_F32:   # the engine's form: pre-masked gradient, linear conv
             import dataclasses
             d_lin = ops.conv_desc(dataclasses.replace(spec, in_slope=1.0, out_slope=1.0), a.batch, l_in, math)
             dwb = lib.eben_conv1d_bwd_dw_workspace(ctypes.byref(d_lin), ctypes.byref(nslab), ctypes.byref(rs))
             slabs = torch.empty(max(1, dwb // 4), device=dev)
 
         def bdw():
-            if math == ops.MATH_BF16:
+            if math != ops.MATH_F32:
                 check(lib.eben_conv1d_bwd_dw(ctypes.byref(d_lin), ptr(dy), None, ptr(x), 1 if has_bias else 0, ptr(slabs), dwb, st))
             else:
                 check(lib.eben_conv1d_bwd_dw(ctypes.byref(d), ptr(dy), ptr(ymask), ptr(x), 1 if has_bias else 0, ptr(slabs), dwb, st))

@@ -177,8 +177,12 @@ class WaveformDataAugmentation(torch.nn.Module):
         if torch.rand(1) < self.apply_data_augmentation:
             if torch.rand(1) < self.p_speed_perturbation:
                 f = self.speed_perturbation_factors[torch.randint(len(self.speed_perturbation_factors), size=(1,)).item()]
+                # torchaudio's T.SpeedPerturbation.forward picks its speeder with torch.randint(len(factors), ()) on EVERY call --
+                # one draw per waveform even with the single factor the reference constructs it with (data_augmentation.py:56-60)
+                torch.randint(1, ())
                 waveform_1 = speed(waveform_1, self.sample_rate, f)
                 if waveform_2 is not None:
+                    torch.randint(1, ())
                     waveform_2 = speed(waveform_2, self.sample_rate, f)
             if torch.rand(1) < self.p_pitch_shift:
                 steps = self.pitch_shift_steps[torch.randint(len(self.pitch_shift_steps), size=(1,)).item()]

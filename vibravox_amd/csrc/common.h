@@ -76,7 +76,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // big side X (B,Cin,Lin), small side Y (B,Cout,Lout), weight (Cout, Cin/g, k).
 struct Canon {
   int B, Cin, Cout, Lin, Lout, k, s, d, g, pl, pr, reflect;
-  int bf16;   // EbenConv1dDesc.math == EBEN_MATH_BF16: bf16 MFMA operands where tapconv3.hip covers the layer
+  int bf16;   // EbenConv1dDesc.math != EBEN_MATH_F32: bf16 MFMA operands where tapconv3.hip / conv_dw3.hip cover the layer
+  // EBEN_MATH_BF16X2: the tap-conv direction (0 gather-strided, 1 phase-scatter) whose INPUT operand is the layer's activation
+  // tensor (the layer's forward) -- staged as hi + lo bf16 tiles there and in the weight gradient; -1 otherwise
+  int xsplit_dir;
 };
 int canon_from_desc(const EbenConv1dDesc* d, Canon* c);
 

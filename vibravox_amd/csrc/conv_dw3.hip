@@ -94,7 +94,9 @@ __global__ __launch_bounds__(256) void dw3_pack_a_kernel(const Dw3Args P) {
 }
 
 // ---- main kernel ---------------------------------------------------------------------------------
-template <int FM, int FN, int WAVES_M, int XRB>
+// SP (EBEN_MATH_BF16X2): the X operand -- the layer's activations -- is staged as hi = bf16(x) and lo = bf16(x - hi) tiles and
+// every k-step issues two MFMAs per fragment pair against the same gradient fragment.
+template <int FM, int FN, int WAVES_M, int XRB, bool SP = false>
 __global__ __launch_bounds__(256, 2) void conv_dw3_kernel(const Dw3Args P) {
   constexpr int WAVES_N = 4 / WAVES_M;
   constexpr int MT = WAVES_M * FM;
@@ -109,7 +111,8 @@ __global__ __launch_bounds__(256, 2) void conv_dw3_kernel(const Dw3Args P) {
   extern __shared__ __attribute__((aligned(16))) u32x4 smem_dw3[];
   u32x4* As = smem_dw3;                          // 2 x ACHU
   const int XT = 2 * P.HS + 2;                   // X tile units (+ {zero, one} cells)
-  u32x4* Xs = smem_dw3 + 2 * ACHU;               // 2 x XT
+  u32x4* Xs = smem_dw3 + 2 * ACHU;               // 2 x XT (SP: 2 x XT hi, then 2 x XT lo)
+  const int LO = 2 * XT;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -132,6 +135,7 @@ __global__ __launch_bounds__(256, 2) void conv_dw3_kernel(const Dw3Args P) {
   if (tid < 4) {
     const unsigned v = (tid & 1) ? 0x3f803f80u : 0u;   // bf16 1.0 pairs
     Xs[(tid >> 1) * XT + cell_zero + (tid & 1)] = u32x4{v, v, v, v};
+    if constexpr (SP) Xs[LO + (tid >> 1) * XT + cell_zero + (tid & 1)] = u32x4{0u, 0u, 0u, 0u};   // lo of the constants 0 and 1
   }
 
   // per-lane column geometry: B fragment n reads unit Xs[xoff[n] + t * xstep[n]] at time step t of the chunk
@@ -209,6 +213,15 @@ __global__ __launch_bounds__(256, 2) void conv_dw3_kernel(const Dw3Args P) {
       // lanes without a unit rewrite the constant zero cell with zero
       const int sl = xpk[u] >= 0 ? ((xpk[u] >> 30) & 1) * P.HS + ((xpk[u] >> 16) & 0x3fff) * P.XSTR + (xpk[u] & 0xffff) : cell_zero;
       dst[sl] = o;
+      if constexpr (SP) {
+        u32x4 l;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float h0 = __builtin_bit_cast(float, o[e] << 16), h1 = __builtin_bit_cast(float, o[e] & 0xffff0000u);
+          l[e] = dw3_pack_bf16(t[2 * e] - h0, t[2 * e + 1] - h1);
+        }
+        dst[LO + sl] = l;
+      }
     }
   };
   const u32x4* asrc = P.ap + (((long long)g * P.nmt + mt) * P.nchunks) * (long long)BKT * (MT * 64);
@@ -238,13 +251,16 @@ __global__ __launch_bounds__(256, 2) void conv_dw3_kernel(const Dw3Args P) {
       if (sub + 1 < NSUB) issue_a(q, sub + 1, abuf ^ 1);
       else if (more) issue_a(qn, 0, abuf ^ 1);
       const u32x4* ab = As + abuf * ACHU + wm * FM * 64 + lane;
-      u32x4 av[KSC][FM], bv[KSC][FN];
+      u32x4 av[KSC][FM], bv[KSC][FN], bl[SP ? KSC : 1][FN];
       auto rd = [&](int ks) {
         const int t = sub * KSC + ks;
 #pragma unroll
         for (int i = 0; i < FM; ++i) av[ks][i] = ab[(ks * MT + i) * 64];
 #pragma unroll
-        for (int n = 0; n < FN; ++n) bv[ks][n] = xb[xoff[n] + t * xstep[n]];
+        for (int n = 0; n < FN; ++n) {
+          bv[ks][n] = xb[xoff[n] + t * xstep[n]];
+          if constexpr (SP) bl[ks][n] = xb[LO + xoff[n] + t * xstep[n]];
+        }
       };
       rd(0);
       rd(1);
@@ -258,6 +274,14 @@ __global__ __launch_bounds__(256, 2) void conv_dw3_kernel(const Dw3Args P) {
           for (int n = 0; n < FN; ++n)
             acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[ks][i]), __builtin_bit_cast(bf16x8, bv[ks][n]),
                                                                 acc[i][n], 0, 0, 0);
+        if constexpr (SP) {
+#pragma unroll
+          for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int n = 0; n < FN; ++n)
+              acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[ks][i]), __builtin_bit_cast(bf16x8, bl[ks][n]),
+                                                                  acc[i][n], 0, 0, 0);
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
       if (sub == NSUB - 1 && more) store_x(qn, xbuf ^ 1);   // the other X buffer was last read a whole chunk ago
@@ -286,7 +310,7 @@ __global__ __launch_bounds__(256, 2) void conv_dw3_kernel(const Dw3Args P) {
 // ---------------------------------------------------------------------------------------------------
 struct Dw3Plan {
   int ok;
-  int Cg, Mg, G, J, Ng, row_stride, cfg, BM, MT, nnt, nmt, nct, nbg, nchunks, nsplit, XSTR, HS, nch_max, BKT, xrb;
+  int Cg, Mg, G, J, Ng, row_stride, cfg, BM, MT, nnt, nmt, nct, nbg, nchunks, nsplit, XSTR, HS, nch_max, BKT, xrb, split;
   size_t lds_bytes, ap_units;
   long long slab_stride;
 };
@@ -300,6 +324,7 @@ static void make_dw3_plan(const Canon& c, Dw3Plan* p) {
   p->ok = 0;
   p->G = c.g; p->Cg = c.Cin / c.g; p->Mg = c.Cout / c.g; p->J = c.k;
   p->Ng = p->Cg * c.k; p->row_stride = p->Ng + 1;
+  p->split = c.xsplit_dir == 0;   // Conv1d under EBEN_MATH_BF16X2: the X operand is the activation tensor
   static const int enabled = dw3_env("EBEN_DW3", 1);
   static const int min_m = dw3_env("EBEN_DW3_MIN_M", 4);
   static const int min_n = dw3_env("EBEN_DW3_MIN_N", 12);
@@ -324,9 +349,10 @@ static void make_dw3_plan(const Canon& c, Dw3Plan* p) {
     for (int bkt : {32, 16, 8, 4}) {   // 8, 4: wide X tiles (pointwise convs over 128 channels, dilation 9): fewer time steps per chunk
       if (pass == 1 && bkt == 32) continue;
       const int span = (bkt - 1) * c.s + (c.k - 1) * c.d + 1;
-      if (span > 0xffff || 2 * p->nch_max * span > 8 * 256) continue;   // X tile must fit the register prefetch
+      // X tile must fit the register prefetch (split operand: four units per thread -- the eight-unit kernels have no registers left for the lo fragments)
+      if (span > 0xffff || 2 * p->nch_max * span > (p->split ? 4 : 8) * 256) continue;
       int xstr = span + (((c.k - span) % 16) + 16) % 16;                 // rows continue the column sequence mod 16 units
-      const size_t lds = a_bytes + 2ull * (2ull * p->nch_max * xstr + 2) * 16;
+      const size_t lds = a_bytes + 2ull * (2ull * p->nch_max * xstr + 2) * 16 * (p->split ? 2 : 1);
       if (lds > budget) continue;
       p->BKT = bkt; p->XSTR = xstr; p->HS = p->nch_max * xstr; p->lds_bytes = lds;
       p->xrb = 2 * p->nch_max * span > 4 * 256 ? 8 : 4;
@@ -349,10 +375,10 @@ static void make_dw3_plan(const Canon& c, Dw3Plan* p) {
   p->ok = 1;
 }
 
-template <int FM, int FN, int WAVES_M, int XRB>
-static int launch_dw3(const Dw3Args& a, const Dw3Plan& p, hipStream_t st) {
+template <int FM, int FN, int WAVES_M, int XRB, bool SP>
+static int launch_dw3_sp(const Dw3Args& a, const Dw3Plan& p, hipStream_t st) {
   static bool attr_set = false;
-  auto kern = conv_dw3_kernel<FM, FN, WAVES_M, XRB>;
+  auto kern = conv_dw3_kernel<FM, FN, WAVES_M, XRB, SP>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(conv_dw3)");
@@ -366,6 +392,14 @@ static int launch_dw3(const Dw3Args& a, const Dw3Plan& p, hipStream_t st) {
   hipLaunchKernelGGL(kern, dim3(nb), dim3(256), p.lds_bytes, st, a);
   EBEN_CHECK_LAUNCH("conv_dw3_kernel");
   return EBEN_OK;
+}
+
+template <int FM, int FN, int WAVES_M, int XRB>
+static int launch_dw3(const Dw3Args& a, const Dw3Plan& p, hipStream_t st) {
+  if constexpr (XRB <= 4) {
+    if (p.split) return launch_dw3_sp<FM, FN, WAVES_M, XRB, true>(a, p, st);
+  }
+  return launch_dw3_sp<FM, FN, WAVES_M, XRB, false>(a, p, st);
 }
 
 int dw3_applicable(const Canon& c) {

@@ -52,7 +52,9 @@ struct Tap3Args {
   long long w_tile, w_phase;                     // in 16-byte units
 };
 
-template <int FM, int XRB, bool IM = false>
+// SP: the input operand is staged as TWO bf16 tiles, hi = bf16(x) and lo = bf16(x - hi), and every k-step issues two MFMAs
+// against the same weight fragment (EBEN_MATH_BF16X2: x enters the product to ~2^-17 instead of 2^-9; weights single bf16).
+template <int FM, int XRB, bool IM = false, bool SP = false>
 __global__ __launch_bounds__(256, 2) void tap3_kernel(const Tap3Args P) {
   constexpr int NT = 256, BN = 128, BM = FM * 32, KSC = T3_KSC;
   constexpr int WCHU = KSC * FM * 64;       // 16-byte units per weight chunk
@@ -61,7 +63,7 @@ __global__ __launch_bounds__(256, 2) void tap3_kernel(const Tap3Args P) {
 
   extern __shared__ __attribute__((aligned(16))) u32x4 smem3[];
   u32x4* Ws = smem3;              // 2 x WCHU
-  u32x4* Xs = smem3 + 2 * WCHU;   // nxb input tiles of CI_B * CSTRIDE units + one spare unit
+  u32x4* Xs = smem3 + 2 * WCHU;   // nxb input tiles of CI_B * CSTRIDE units + one spare unit (SP: the lo tiles behind them)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -97,6 +99,7 @@ __global__ __launch_bounds__(256, 2) void tap3_kernel(const Tap3Args P) {
   const int q0 = t0 * P.S + q.minoff;
   const int xtot = P.CI_B * span;          // bundle-positions per input tile
   const int XBUF = P.CI_B * P.CSTRIDE;
+  const int LO = P.nxb * XBUF + 1;         // SP: unit offset of the lo copy of every tile slot
   const unsigned span_magic = span > 0 ? (unsigned)((0x100000000ull + (unsigned)span - 1) / (unsigned)span) : 0u;
 
   const u32x4* wsrc = P.wp + (long long)ph * P.w_phase + ((long long)g * P.nmt + mt) * P.w_tile;
@@ -133,7 +136,7 @@ __global__ __launch_bounds__(256, 2) void tap3_kernel(const Tap3Args P) {
       v[e] = base[(long long)c * P.Lx + qq];
     }
   };
-  auto cvt8 = [&](const float (&v)[8], const float (&mk)[8], int c0, int ok) -> u32x4 {
+  auto cvt8 = [&](const float (&v)[8], const float (&mk)[8], int c0, int ok, u32x4& lo) -> u32x4 {
     float t[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -142,6 +145,14 @@ __global__ __launch_bounds__(256, 2) void tap3_kernel(const Tap3Args P) {
     }
     u32x4 o;
     o[0] = pack_bf16(t[0], t[1]); o[1] = pack_bf16(t[2], t[3]); o[2] = pack_bf16(t[4], t[5]); o[3] = pack_bf16(t[6], t[7]);
+    if constexpr (SP) {
+      // residual against the rounded value (a bf16 is the upper half of its fp32): x - hi is exact in fp32
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float h0 = __builtin_bit_cast(float, o[e] << 16), h1 = __builtin_bit_cast(float, o[e] & 0xffff0000u);
+        lo[e] = pack_bf16(t[2 * e] - h0, t[2 * e + 1] - h1);
+      }
+    }
     return o;
   };
 
@@ -176,7 +187,9 @@ __global__ __launch_bounds__(256, 2) void tap3_kernel(const Tap3Args P) {
     for (int u = 0; u < XRB; ++u) {
       const int bb = xg[u] >> 16;
       const int sl = xg[u] >= 0 ? x_slot(bb, xg[u] & 0xffff) : dead_slot - bsel * XBUF;
-      dst[sl] = cvt8(xreg[u], mreg[IM ? u : 0], cc * P.CI_T + (xg[u] >= 0 ? bb * 8 : 0), (int)((okmask >> u) & 1u));
+      u32x4 lo;
+      dst[sl] = cvt8(xreg[u], mreg[IM ? u : 0], cc * P.CI_T + (xg[u] >= 0 ? bb * 8 : 0), (int)((okmask >> u) & 1u), lo);
+      if constexpr (SP) dst[sl + LO] = lo;
     }
   };
 
@@ -212,7 +225,11 @@ __global__ __launch_bounds__(256, 2) void tap3_kernel(const Tap3Args P) {
       }
 #pragma unroll
       for (int u = 0; u < 2; ++u)
-        if (sl[u] >= 0) Xs[sl[u]] = cvt8(v[u], mk[IM ? u : 0], c0[u], ok[u]);
+        if (sl[u] >= 0) {
+          u32x4 lo;
+          Xs[sl[u]] = cvt8(v[u], mk[IM ? u : 0], c0[u], ok[u], lo);
+          if constexpr (SP) Xs[sl[u] + LO] = lo;
+        }
     }
     if (P.ncc > 1) fetch_x(1);
   }
@@ -231,9 +248,10 @@ __global__ __launch_bounds__(256, 2) void tap3_kernel(const Tap3Args P) {
     if ((EBEN_T3_DBG & 2) == 0 && pending >= 0) { fetch_x(pending); pending = -1; }
     const u32x4* wb = Ws + (ch & 1) * WCHU + lane;
     const u32x4* xb = Xs + lanebase;
-    u32x4 bv[KSC], a[KSC][FM];
+    u32x4 bv[KSC], bl[SP ? KSC : 1], a[KSC][FM];
     auto rd = [&](int ks) {
       bv[ks] = xb[te[ks]];
+      if constexpr (SP) bl[ks] = xb[te[ks] + LO];
 #pragma unroll
       for (int i = 0; i < FM; ++i) a[ks][i] = wb[(ks * FM + i) * 64];
     };
@@ -247,6 +265,11 @@ __global__ __launch_bounds__(256, 2) void tap3_kernel(const Tap3Args P) {
       for (int i = 0; i < FM; ++i) {
         if (EBEN_T3_DBG & 8) acc[i][0] += __builtin_bit_cast(float, a[ks][i][0] ^ bv[ks][i & 3]);
         else acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[ks][i]), __builtin_bit_cast(bf16x8, bv[ks]), acc[i], 0, 0, 0);
+      }
+      if constexpr (SP) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[ks][i]), __builtin_bit_cast(bf16x8, bl[ks]), acc[i], 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -295,6 +318,7 @@ struct Tap3Plan {
   int mode, G, Cg, Mg, S, OS, dstep, kstep, nph, J, Lx, Ly, Cx, Cy, off0, nt, ps_pad;
   int FM, BM, BN, WCHU;
   int dense;   // groups folded into ONE block-diagonal contraction (layers with a handful of channels per group)
+  int split;   // input operand staged as hi + lo bf16 tiles (EBEN_MATH_BF16X2 on the activation side)
   int CI_T, CI_B, CP, ncc, PLEN, CSTRIDE, nxbuf, XRB;
   int nmt, ntt, NCH, tab_phase;
   long long w_tile, w_phase, tab_off_floats;
@@ -312,6 +336,8 @@ static void make_plan3(const Canon& c, int dir, Tap3Plan* p) {
   p->ok = 0;
   p->mode = dir;
   p->G = c.g;
+  p->split = c.xsplit_dir == dir;
+  const int ub = p->split ? 32 : 16;   // LDS bytes per staged bundle position
   if (dir == 0) {
     p->Cg = c.Cin / c.g; p->Mg = c.Cout / c.g;
     p->S = c.s; p->OS = 1; p->dstep = c.d; p->kstep = 1; p->nph = 1; p->J = c.k;
@@ -387,7 +413,7 @@ static void make_plan3(const Canon& c, int dir, Tap3Plan* p) {
   const int xbudget = lds_budget - wbytes - 16;
   const int Cg2 = round_up(p->Cg, 16);
   p->XRB = 2;
-  if ((long long)(Cg2 / 8) * p->CSTRIDE * 16 <= xbudget) {
+  if ((long long)(Cg2 / 8) * p->CSTRIDE * ub + (p->split ? 16 : 0) <= xbudget) {
     p->CI_T = Cg2; p->ncc = 1; p->nxbuf = 1;
   } else {
     // hand-over rule of tapconv2.hip in weight chunks of T3_KSC k-steps: the tile of the next channel chunk is
@@ -396,7 +422,7 @@ static void make_plan3(const Canon& c, int dir, Tap3Plan* p) {
     for (int nbuf = 2; nbuf <= 3 && !found; ++nbuf) {
       for (int xrb : {2, 3, 5}) {
         int cap = (xrb * NT) / span * 8;          // channels
-        const int cap_lds = (nbuf == 2 ? xbudget : 110 * 1024 - wbytes) / nbuf / (p->CSTRIDE * 16) * 8;
+        const int cap_lds = ((nbuf == 2 ? xbudget : 110 * 1024 - wbytes) - (p->split ? 16 : 0)) / nbuf / (p->CSTRIDE * ub) * 8;
         if (cap > cap_lds) cap = cap_lds;
         cap -= cap % 16;
         if (cap < 16) continue;
@@ -421,7 +447,7 @@ static void make_plan3(const Canon& c, int dir, Tap3Plan* p) {
   p->w_phase = p->w_tile * p->nmt * p->G;
   p->tab_off_floats = p->w_phase * p->nph * 4;
   p->packed_floats = (size_t)p->tab_off_floats + (size_t)p->tab_phase * p->nph;
-  p->lds_bytes = (size_t)wbytes + (size_t)p->nxbuf * p->CI_B * p->CSTRIDE * 16 + 16;   // + the spare unit
+  p->lds_bytes = (size_t)wbytes + ((size_t)p->nxbuf * p->CI_B * p->CSTRIDE * 16 + 16) * (p->split ? 2 : 1);   // + the spare unit(s)
   if (p->lds_bytes > 160 * 1024) return;
   p->ok = 1;
 }
@@ -499,10 +525,10 @@ __global__ __launch_bounds__(256) void pack3_kernel(const Pack3Args P) {
   }
 }
 
-template <int FM, int XRB, bool IM>
+template <int FM, int XRB, bool IM, bool SP = false>
 static int launch3_im(const Tap3Args& a, int nblocks, size_t lds, hipStream_t st) {
   static bool attr_set = false;
-  auto kern = tap3_kernel<FM, XRB, IM>;
+  auto kern = tap3_kernel<FM, XRB, IM, SP>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(tap3)");
@@ -513,7 +539,11 @@ static int launch3_im(const Tap3Args& a, int nblocks, size_t lds, hipStream_t st
   return EBEN_OK;
 }
 template <int FM, int XRB>
-static int launch3_cfg(const Tap3Args& a, int nblocks, size_t lds, hipStream_t st) {
+static int launch3_cfg(const Tap3Args& a, int nblocks, size_t lds, bool split, hipStream_t st) {
+  if (split) {
+    if (a.in_mode) return fail(EBEN_EUNSUPPORTED, "tap3: split operand with a mask on load");
+    return launch3_im<FM, XRB, false, true>(a, nblocks, lds, st);
+  }
   return a.in_mode ? launch3_im<FM, XRB, true>(a, nblocks, lds, st) : launch3_im<FM, XRB, false>(a, nblocks, lds, st);
 }
 
@@ -571,9 +601,9 @@ int tap3_launch(const Canon& c, int dir, const TapIO& io, int reflect, hipStream
   if (nb <= 0 || nb > 0x7fffffffLL) return fail(EBEN_EINVAL, "tap3 grid of %lld blocks", nb);
 #define EBEN_T3_CASE(FMV)                                                          \
   switch (p.XRB) {                                                                 \
-    case 2: return launch3_cfg<FMV, 2>(a, (int)nb, p.lds_bytes, st);               \
-    case 3: return launch3_cfg<FMV, 3>(a, (int)nb, p.lds_bytes, st);               \
-    default: return launch3_cfg<FMV, 5>(a, (int)nb, p.lds_bytes, st);              \
+    case 2: return launch3_cfg<FMV, 2>(a, (int)nb, p.lds_bytes, p.split, st);               \
+    case 3: return launch3_cfg<FMV, 3>(a, (int)nb, p.lds_bytes, p.split, st);               \
+    default: return launch3_cfg<FMV, 5>(a, (int)nb, p.lds_bytes, p.split, st);              \
   }
   switch (p.FM) {
     case 1: EBEN_T3_CASE(1)

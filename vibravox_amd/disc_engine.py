@@ -44,9 +44,10 @@ from ._lib import stream as _stream  # noqa: E402  (raw handle of the current HI
 class _Layer:
     """One weight-normalised conv of a sub-discriminator with the packed copies the engine needs."""
 
-    def __init__(self, conv, math: int = ops.MATH_F32):
+    def __init__(self, conv, math=ops.MATH_F32):
+        """math: one EBEN_MATH_* for every contraction of the layer, or (forward, input gradient, weight gradient)."""
         self.conv = conv
-        self.math = math
+        self.math_fwd, self.math_dx, self.math_dw = (math, math, math) if isinstance(math, int) else tuple(math)
         self.spec: ops.ConvSpec = conv.spec
         self.spec_lin = dataclasses.replace(conv.spec, in_slope=1.0, out_slope=1.0)   # gradients arrive pre-masked
         self.packs: Dict[Tuple[int, int, int], Tuple[tuple, torch.Tensor]] = {}
@@ -79,7 +80,7 @@ class _Layer:
         hit = self.packs.get(slot)
         if hit is not None and hit[0] == wkey:
             return hit[1]
-        d = ops.conv_desc(self.spec, batch, l_in, self.math)
+        d = ops.conv_desc(self.spec, batch, l_in, self.math_fwd if which == 0 else self.math_dx)
         wp = torch.empty(lib.eben_conv1d_packed_floats(ctypes.byref(d), which), dtype=torch.float32, device=v.device)
         check(lib.eben_conv1d_pack(ctypes.byref(d), ptr(v), ptr(self.scale), ptr(wp) if which == 0 else None,
                                    ptr(wp) if which == 1 else None, _stream()), "conv1d_pack")
@@ -90,19 +91,22 @@ class _Layer:
 class _Chain:
     """A sub-discriminator: ReflectionPad1d(pad) followed by the conv stack (last conv = logits)."""
 
-    def __init__(self, modules, math: int = ops.MATH_F32):
+    def __init__(self, modules, math=ops.MATH_F32):
+        """math: EBEN_MATH_* or (forward, input gradient, weight gradient), or a callable layer index -> one of those."""
         self.layers: List[_Layer] = []
         self.pad = 0
-        self.math = math
+        convs = []
         for m in modules:
             if isinstance(m, torch.nn.Sequential):
                 for sub in m:
                     if hasattr(sub, "padding") and not hasattr(sub, "spec"):
                         self.pad = int(sub.padding)
                     else:
-                        self.layers.append(_Layer(sub, math))
+                        convs.append(sub)
             else:
-                self.layers.append(_Layer(m, math))
+                convs.append(m)
+        for i, conv in enumerate(convs):
+            self.layers.append(_Layer(conv, math(i, len(convs)) if callable(math) else math))
 
     # ---- forward on a (2B, C, L) batch: returns [input, out_0, ..., logits] and the padded input
     def forward(self, x: torch.Tensor):
@@ -124,7 +128,7 @@ class _Chain:
             check(lib.eben_reflect_pad_fwd(ptr(x_full[r0:r1]), ptr(xp_full[r0:r1]), b * c, l, self.pad, self.pad, _stream()), "reflect_pad_fwd")
         cur = xp_full[r0:r1]
         for i, lay in enumerate(self.layers):
-            d = ops.conv_desc(lay.spec, b, cur.shape[2], self.math)
+            d = ops.conv_desc(lay.spec, b, cur.shape[2], lay.math_fwd)
             if bufs["outs"][i] is None:
                 bufs["outs"][i] = torch.empty((nb, lay.spec.c_out, d.l_out), dtype=torch.float32, device=x_full.device)
             y = bufs["outs"][i][r0:r1]
@@ -165,7 +169,7 @@ class _Chain:
                 jobs.append((i, g, x_in))
             if i > 0:
                 rows = 4 * half
-                d = ops.conv_desc(lay.spec_lin, rows, l_in, self.math)
+                d = ops.conv_desc(lay.spec_lin, rows, l_in, lay.math_dx)
                 gp = torch.empty((rows, lay.spec.c_in, l_in), dtype=torch.float32, device=g.device)
                 res = fm_grads[i - 1]
                 prev_slope = self.layers[i - 1].spec.out_slope
@@ -175,7 +179,7 @@ class _Chain:
                 g = gp
             else:
                 rows = 2 * half   # only the generator-side signals reach the discriminator input
-                d = ops.conv_desc(lay.spec_lin, rows, l_in, self.math)
+                d = ops.conv_desc(lay.spec_lin, rows, l_in, lay.math_dx)
                 gp = torch.empty((rows, lay.spec.c_in, l_in), dtype=torch.float32, device=g.device)
                 check(lib.eben_conv1d_bwd_dx_ex(ctypes.byref(d), ptr(g), ptr(lay.packed(1, rows, l_in)), None, 0, None, 1.0, 0, None, ptr(gp), st),
                       "conv1d_bwd_dx_ex")
@@ -223,7 +227,7 @@ class _Chain:
         lib = load()
         v, gain, bias = lay.params()
         rows_b = g2.shape[0]
-        d = ops.conv_desc(lay.spec_lin, rows_b, x_in.shape[2], lay.math)
+        d = ops.conv_desc(lay.spec_lin, rows_b, x_in.shape[2], lay.math_dw)
         nslab, row_stride = ctypes.c_int(0), ctypes.c_int(0)
         ws_bytes = lib.eben_conv1d_bwd_dw_workspace(ctypes.byref(d), ctypes.byref(nslab), ctypes.byref(row_stride))
         slabs = torch.empty(max(1, (ws_bytes + 3) // 4), dtype=torch.float32, device=g2.device)

@@ -31,6 +31,7 @@ except Exception:
             self._optimizers = None
             self._toggled: Dict[int, List[bool]] = {}
             self.grad_sync = {}  # optimizer id -> vibravox_amd.ddp.GradSync (data-parallel runs)
+            self._sync_pending: List[str] = []
 
         def optimizers(self, use_pl_optimizer: bool = True):
             if self._optimizers is None:
@@ -55,7 +56,23 @@ except Exception:
             loss.backward(*args, **kwargs)
 
         def log(self, name, value, sync_dist: bool = False, **kwargs):
+            """``sync_dist=True`` (every train-step value, eben.py:103-124): Lightning reduces each value to the rank mean
+            with a collective of its own -- 7 per step; here the names are queued and ``flush_logged`` reduces them
+            together."""
             self.logged[name] = value.detach() if torch.is_tensor(value) else torch.as_tensor(value)
+            if sync_dist and torch.distributed.is_available() and torch.distributed.is_initialized() \
+                    and torch.distributed.get_world_size() > 1 and name not in self._sync_pending:
+                self._sync_pending.append(name)
+
+        def flush_logged(self) -> None:
+            """ONE packed all-reduce(mean) for every value logged with ``sync_dist`` since the last flush (called at the end
+            of ``training_step``: off the critical path, after the last gradient exchange has been issued)."""
+            if self._sync_pending:
+                from ..ddp import all_reduce_scalars
+
+                names, self._sync_pending = self._sync_pending, []
+                for n, v in zip(names, all_reduce_scalars([self.logged[n] for n in names])):
+                    self.logged[n] = v
 
 
 class BaseSELightningModule(_Base):

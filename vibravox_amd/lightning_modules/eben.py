@@ -23,6 +23,7 @@ attribute to False for the literal as-executed order.
 """
 from __future__ import annotations
 
+import inspect
 import os
 from functools import partial
 from typing import Dict, Optional
@@ -31,6 +32,42 @@ import torch
 
 from .. import ops
 from .base_se import BaseSELightningModule
+
+
+def _takes_grad_scale(optimizer) -> bool:
+    """Whether ``optimizer.step`` accepts ``grad_scale`` -- decided from the signature of the innermost optimiser, never by
+    catching a TypeError raised somewhere inside a step that may already have updated parameters."""
+    inner = optimizer
+    while hasattr(inner, "optimizer") and not isinstance(inner, torch.optim.Optimizer):
+        inner = inner.optimizer   # ddp.BucketedZeroGrad / Lightning's optimizer wrapper
+    try:
+        return "grad_scale" in inspect.signature(type(inner).step).parameters
+    except (TypeError, ValueError):
+        return False
+
+
+#: ``disc_math`` names -> what ``DiscriminatorEngine`` runs: one EBEN_MATH_* for every contraction, or (forward, input gradient,
+#: weight gradient).  "bf16": bf16 MFMA operands with the ACTIVATION operand of the forward and of the weight gradient kept as
+#: hi + lo (EBEN_MATH_BF16X2) -- the discriminator's gradient is the difference of two nearly equal hinge branches, and the
+#: part of the activations that differs between items sits below the 2^-9 grid of their common part; with it kept the
+#: discriminator gradient stays within a few percent of the fp32 step's (tests/test_gpu_models.py), without it tens of
+#: percent ("bf16_plain": every operand single bf16).
+DISC_MATH_PLANS = {
+    "f32": ops.MATH_F32,
+    "bf16": (ops.MATH_BF16X2, ops.MATH_BF16, ops.MATH_BF16X2),
+    "bf16_plain": ops.MATH_BF16,
+}
+
+#: generator-side loss terms in the reference's insertion order (eben.py:195-211): logged name, the module attribute that holds
+#: the loss function, and what it is evaluated on
+_GENERATOR_TERMS = (
+    ("reconstructive_loss_freq", "reconstructive_loss_freq_fn", "waveforms"),
+    ("reconstructive_loss_temp", "reconstructive_loss_temp_fn", "waveforms"),
+    ("feature_matching_loss", "feature_matching_loss_fn", "both embeddings"),
+    ("adv_loss_gen", "adversarial_loss_fn", "enhanced embeddings"),
+)
+#: discriminator-side terms (eben.py:212-219): logged name, branch, hinge target
+_DISCRIMINATOR_TERMS = (("real_loss", "reference", 1), ("fake_loss", "enhanced", -1))
 
 
 class EBENLightningModule(BaseSELightningModule):
@@ -82,29 +119,35 @@ class EBENLightningModule(BaseSELightningModule):
         return sync.finish() if sync is not None else 1.0
 
     def _step(self, optimizer, grad_scale: float):
+        """optimizer.step() on gradient SUMS over ranks: ``grad_scale`` (1 / world size) is folded into the Adam kernel where
+        the optimiser takes it (``FusedAdam.step(grad_scale=)``, also behind ``BucketedZeroGrad``), else applied in place."""
         if grad_scale != 1.0:
-            try:
+            if _takes_grad_scale(optimizer):
                 optimizer.step(grad_scale=grad_scale)
                 return
-            except TypeError:
-                for grp in optimizer.param_groups:
-                    for p in grp["params"]:
-                        if p.grad is not None:
-                            p.grad.mul_(grad_scale)
+            for grp in optimizer.param_groups:
+                for p in grp["params"]:
+                    if p.grad is not None:
+                        p.grad.mul_(grad_scale)
         optimizer.step()
 
     def training_step(self, batch: Dict[str, torch.Tensor], batch_idx: int = 0):
         if (self.exploit_step_redundancy and self.adversarial_loss_fn is not None and self.feature_matching_loss_fn is not None
                 and self.dynamic_loss_balancing is not None):
-            if self._engine_usable(batch):
-                return self._training_step_engine(batch)
-            return self._training_step_fused(batch)
-        return self._training_step_literal(batch)
+            step = self._training_step_engine if self._engine_usable(batch) else self._training_step_fused
+        else:
+            step = self._training_step_literal
+        out = step(batch)
+        flush = getattr(self, "flush_logged", None)   # Lightning-free stand-in: the step's sync_dist values as one collective
+        if flush is not None:
+            flush()
+        return out
 
     #: run the discriminator passes batched and outside autograd (vibravox_amd/disc_engine.py)
     use_disc_engine: bool = os.environ.get("EBEN_DISC_ENGINE", "1") != "0"
-    #: arithmetic of the discriminator contractions inside the engine: "f32" (bit-exact fp32 products) or "bf16"
-    #: (bf16 MFMA operands, fp32 accumulate -- BASELINE config 2).  The generator always computes in fp32.
+    #: arithmetic of the discriminator contractions inside the engine: a key of DISC_MATH_PLANS -- "f32" (bit-exact fp32
+    #: products), "bf16" (bf16 MFMA operands, fp32 accumulate, activation operand split -- BASELINE config 2), "bf16_plain" --
+    #: or a plan the engine understands.  The generator's forward always computes in fp32.
     disc_math: str = os.environ.get("EBEN_DISC_MATH", "f32")
     #: arithmetic of the generator's BACKWARD contractions (input / weight gradients) in the engine step; its forward --
     #: the product's output -- is exact fp32 either way
@@ -143,7 +186,7 @@ class EBENLightningModule(BaseSELightningModule):
         reference_speech = self.generator.cut_to_valid_length(batch["audio_airborne"])
         generator_optimizer, discriminator_optimizer = self.optimizers(use_pl_optimizer=True)
         g_params = [p for p in self.generator.parameters() if p.requires_grad]
-        math = {"f32": ops.MATH_F32, "bf16": ops.MATH_BF16}[self.disc_math]
+        math = DISC_MATH_PLANS[self.disc_math] if isinstance(self.disc_math, str) else self.disc_math
         if getattr(self, "_disc_engine", None) is None or self._disc_engine.disc is not self.discriminator or self._disc_engine.math != math:
             self._disc_engine = DiscriminatorEngine(self.discriminator, math)
         engine = self._disc_engine
@@ -206,13 +249,7 @@ class EBENLightningModule(BaseSELightningModule):
             else:
                 seeds.append(own[key])
         atomic_norms = [torch.norm(torch.autograd.grad(bands, leaf, grad_outputs=s, retain_graph=True)[0]).detach() for s in seeds]
-        if self.atomic_norms_old is None or self.dynamic_loss_balancing == "simple":
-            self.atomic_norms_old = atomic_norms
-        if self.dynamic_loss_balancing == "ema":
-            self.atomic_norms_old = [self.beta_ema * old + (1 - self.beta_ema) * new
-                                     for old, new in zip(self.atomic_norms_old, atomic_norms)]
-        lambdas = [torch.clamp(1 / (norm + 1e-4), min=0.0, max=1e4) for norm in self.atomic_norms_old]
-        self.last_norms, self.last_lambdas = atomic_norms, lambdas
+        lambdas = self._update_lambdas(atomic_norms)
         backprop_loss_generator = sum(loss.detach() * lam for loss, lam in zip(losses.values(), lambdas))
         self.log("train/generator/backprop_loss", backprop_loss_generator, sync_dist=True)
         seed = None
@@ -290,13 +327,7 @@ class EBENLightningModule(BaseSELightningModule):
         with ops.weight_grads_disabled():  # only d/d(bands) is wanted from these passes
             seeds = [torch.autograd.grad(loss, bands, retain_graph=True)[0] for loss in losses.values()]
         atomic_norms = [torch.norm(torch.autograd.grad(bands, leaf, grad_outputs=s, retain_graph=True)[0]).detach() for s in seeds]
-        if self.atomic_norms_old is None or self.dynamic_loss_balancing == "simple":
-            self.atomic_norms_old = atomic_norms
-        if self.dynamic_loss_balancing == "ema":
-            self.atomic_norms_old = [self.beta_ema * old + (1 - self.beta_ema) * new
-                                     for old, new in zip(self.atomic_norms_old, atomic_norms)]
-        lambdas = [torch.clamp(1 / (norm + 1e-4), min=0.0, max=1e4) for norm in self.atomic_norms_old]
-        self.last_norms, self.last_lambdas = atomic_norms, lambdas
+        lambdas = self._update_lambdas(atomic_norms)
         backprop_loss_generator = sum(loss.detach() * lam for loss, lam in zip(losses.values(), lambdas))
         self.log("train/generator/backprop_loss", backprop_loss_generator, sync_dist=True)
         seed = None
@@ -320,44 +351,35 @@ class EBENLightningModule(BaseSELightningModule):
         return {"corrupted": corrupted_speech, "enhanced": enhanced_speech.detach(), "reference": reference_speech}
 
     def _training_step_literal(self, batch: Dict[str, torch.Tensor]):
-        corrupted_speech = self.generator.cut_to_valid_length(batch["audio_body_conducted"])
-        reference_speech = self.generator.cut_to_valid_length(batch["audio_airborne"])
+        """The reference's as-executed order (eben.py:82-130): each network's phase evaluates its own atomic losses from
+        scratch -- 4 discriminator forwards, 3 balancing backward passes + the final one."""
         generator_optimizer, discriminator_optimizer = self.optimizers(use_pl_optimizer=True)
+        corrupted = self.generator.cut_to_valid_length(batch["audio_body_conducted"])
+        reference = self.generator.cut_to_valid_length(batch["audio_airborne"])
 
-        # ---- generator phase (eben.py:96-111)
-        self.toggle_optimizer(generator_optimizer)
-        enhanced_speech, decomposed_enhanced_speech = self.generator(corrupted_speech)
-        decomposed_reference_speech = self.generator.pqmf.forward(reference_speech, "analysis")
-        atomic_losses_generator = self.compute_atomic_losses(
-            "generator", enhanced_speech, reference_speech, decomposed_enhanced_speech, decomposed_reference_speech
-        )
-        for key, value in atomic_losses_generator.items():
-            self.log(f"train/generator/{key}", value, sync_dist=True)
-        if self.dynamic_loss_balancing is not None:
-            atomic_losses_generator = self.dynamically_balance_losses(atomic_losses_generator)
-        backprop_loss_generator = sum(atomic_losses_generator.values())
-        self.log("train/generator/backprop_loss", backprop_loss_generator, sync_dist=True)
-        self.manual_backward(backprop_loss_generator)
-        self._step(generator_optimizer, self._sync_grads(generator_optimizer))
-        generator_optimizer.zero_grad()
-        self.untoggle_optimizer(generator_optimizer)
+        def phase(network, optimizer, signals, gate):
+            # one network's turn: freeze the other one, losses -> log -> (balance) -> backward -> Adam -> unfreeze.  `gate`
+            # decides, AFTER the forwards and BEFORE anything is logged, whether this phase updates at all (eben.py:118).
+            self.toggle_optimizer(optimizer)
+            terms = self.compute_atomic_losses(network, *signals)
+            if gate(terms):
+                for name, value in terms.items():
+                    self.log(f"train/{network}/{name}", value, sync_dist=True)
+                if network == "generator" and self.dynamic_loss_balancing is not None:
+                    terms = self.dynamically_balance_losses(terms)
+                total = sum(terms.values())
+                self.log(f"train/{network}/backprop_loss", total, sync_dist=True)
+                self.manual_backward(total)
+                self._step(optimizer, self._sync_grads(optimizer))
+                optimizer.zero_grad()
+            self.untoggle_optimizer(optimizer)
 
-        # ---- discriminator phase (eben.py:114-128)
-        self.toggle_optimizer(discriminator_optimizer)
-        atomic_losses_discriminator = self.compute_atomic_losses(
-            "discriminator", enhanced_speech, reference_speech, decomposed_enhanced_speech, decomposed_reference_speech
-        )
-        if atomic_losses_discriminator and torch.rand(1) < self.update_discriminator_ratio:
-            for key, value in atomic_losses_discriminator.items():
-                self.log(f"train/discriminator/{key}", value, sync_dist=True)
-            backprop_loss_discriminator = atomic_losses_discriminator["real_loss"] + atomic_losses_discriminator["fake_loss"]
-            self.log("train/discriminator/backprop_loss", backprop_loss_discriminator, sync_dist=True)
-            self.manual_backward(backprop_loss_discriminator)
-            self._step(discriminator_optimizer, self._sync_grads(discriminator_optimizer))
-            discriminator_optimizer.zero_grad()
-        self.untoggle_optimizer(discriminator_optimizer)
-
-        return {"corrupted": corrupted_speech, "enhanced": enhanced_speech, "reference": reference_speech}
+        enhanced, bands = self.generator(corrupted)   # no discriminator parameter involved: same graph inside or outside the toggle
+        signals = (enhanced, reference, bands, self.generator.pqmf.forward(reference, "analysis"))
+        phase("generator", generator_optimizer, signals, lambda terms: True)
+        phase("discriminator", discriminator_optimizer, signals,
+              lambda terms: bool(terms) and bool(torch.rand(1) < self.update_discriminator_ratio))
+        return {"corrupted": corrupted, "enhanced": enhanced, "reference": reference}
 
     # -- evaluation (SURVEY section 8 f1) -----------------------------------------------------
     def common_eval_step(self, batch: Dict[str, torch.Tensor], batch_idx: int, stage: str, dataloader_idx: int = 0):
@@ -389,44 +411,62 @@ class EBENLightningModule(BaseSELightningModule):
 
     def compute_atomic_losses(self, network, enhanced_speech, reference_speech, decomposed_enhanced_speech,
                               decomposed_reference_speech) -> Dict[str, torch.Tensor]:
-        """eben.py:184-220."""
-        atomic_losses = dict()
+        """eben.py:184-220 as two term tables: the generator's losses on the live graph, the discriminator's hinge terms on
+        detached generator outputs.  Each discriminator forward is run at most once per call and only if a term needs it."""
         assert network in {"generator", "discriminator"}
-        if network == "generator":
-            if self.reconstructive_loss_freq_fn:
-                atomic_losses["reconstructive_loss_freq"] = self.reconstructive_loss_freq_fn(enhanced_speech, reference_speech)
-            if self.reconstructive_loss_temp_fn:
-                atomic_losses["reconstructive_loss_temp"] = self.reconstructive_loss_temp_fn(enhanced_speech, reference_speech)
-            if self.feature_matching_loss_fn or self.adversarial_loss_fn:
-                enhanced_embeddings = self.discriminator(bands=decomposed_enhanced_speech, audio=enhanced_speech)
-                if self.feature_matching_loss_fn:
-                    reference_embeddings = self.discriminator(bands=decomposed_reference_speech, audio=reference_speech)
-                    atomic_losses["feature_matching_loss"] = self.feature_matching_loss_fn(enhanced_embeddings, reference_embeddings)
-                if self.adversarial_loss_fn:
-                    atomic_losses["adv_loss_gen"] = self.adversarial_loss_fn(embeddings=enhanced_embeddings, target=1)
-        else:
-            if self.adversarial_loss_fn:
-                enhanced_embeddings = self.discriminator(bands=decomposed_enhanced_speech.detach(), audio=enhanced_speech.detach())
-                reference_embeddings = self.discriminator(bands=decomposed_reference_speech, audio=reference_speech)
-                atomic_losses["real_loss"] = self.adversarial_loss_fn(embeddings=reference_embeddings, target=1)
-                atomic_losses["fake_loss"] = self.adversarial_loss_fn(embeddings=enhanced_embeddings, target=-1)
-        return atomic_losses
+        detached = network == "discriminator"
+        branch_inputs = {
+            "enhanced": (decomposed_enhanced_speech.detach() if detached else decomposed_enhanced_speech,
+                         enhanced_speech.detach() if detached else enhanced_speech),
+            "reference": (decomposed_reference_speech, reference_speech),
+        }
+        cache = {}
 
-    def dynamically_balance_losses(self, atomic_losses: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
-        """eben.py:222-240 (norms / EMA state / lambdas are rank-local, as under the reference's DDP)."""
-        loss_adjustment_layer = self.generator.last_conv.weight
-        atomic_norms = [
-            torch.norm(torch.autograd.grad(loss, loss_adjustment_layer, retain_graph=True)[0]).detach()
-            for loss in atomic_losses.values()
-        ]
+        def embeddings(branch):
+            if branch not in cache:
+                bands, audio = branch_inputs[branch]
+                cache[branch] = self.discriminator(bands=bands, audio=audio)
+            return cache[branch]
+
+        out: Dict[str, torch.Tensor] = {}
+        if network == "generator":
+            if self.feature_matching_loss_fn or self.adversarial_loss_fn:
+                embeddings("enhanced")   # the reference runs the enhanced branch first (eben.py:204)
+            for name, attr, operands in _GENERATOR_TERMS:
+                fn = getattr(self, attr)
+                if not fn:
+                    continue
+                if operands == "waveforms":
+                    out[name] = fn(enhanced_speech, reference_speech)
+                elif operands == "both embeddings":
+                    out[name] = fn(embeddings("enhanced"), embeddings("reference"))
+                else:
+                    out[name] = fn(embeddings=embeddings("enhanced"), target=1)
+        elif self.adversarial_loss_fn:
+            embeddings("enhanced")       # eben.py:214 before :217
+            for name, branch, target in _DISCRIMINATOR_TERMS:
+                out[name] = self.adversarial_loss_fn(embeddings=embeddings(branch), target=target)
+        return out
+
+    def _update_lambdas(self, atomic_norms):
+        """Loss weights from the gradient norms at ``generator.last_conv.weight`` (eben.py:229-237): the state is initialised
+        with the first norms and -- quirk kept -- the EMA update is applied on that same call; rank-local like the reference's."""
         if self.atomic_norms_old is None or self.dynamic_loss_balancing == "simple":
             self.atomic_norms_old = atomic_norms
         if self.dynamic_loss_balancing == "ema":
-            self.atomic_norms_old = [
-                self.beta_ema * old + (1 - self.beta_ema) * new for old, new in zip(self.atomic_norms_old, atomic_norms)
-            ]
+            self.atomic_norms_old = [self.beta_ema * old + (1 - self.beta_ema) * new for old, new in zip(self.atomic_norms_old, atomic_norms)]
         lambdas = [torch.clamp(1 / (norm + 1e-4), min=0.0, max=1e4) for norm in self.atomic_norms_old]
         self.last_norms, self.last_lambdas = atomic_norms, lambdas
-        for key, lambda_ in zip(atomic_losses.keys(), lambdas):
-            atomic_losses[key] = atomic_losses[key] * lambda_
-        return atomic_losses
+        return lambdas
+
+    def dynamically_balance_losses(self, atomic_losses: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        """eben.py:222-240: one partial backward per loss down to the last generator layer, then ``_update_lambdas``."""
+        leaf = self.generator.last_conv.weight
+        norms = [torch.norm(torch.autograd.grad(loss, leaf, retain_graph=True)[0]).detach() for loss in atomic_losses.values()]
+        return {name: loss * lam for (name, loss), lam in zip(atomic_losses.items(), self._update_lambdas(norms))}
+
+    def on_test_end(self) -> None:
+        """eben.py:176-181: upload the generator when asked to (needs Lightning's trainer / datamodule and network access)."""
+        if self.push_to_hub_after_testing:
+            self.generator.push_to_hub(f"Cnam-LMSSC/EBEN_{self.trainer.datamodule.sensor}",
+                                       commit_message=f"Upload EBENGenerator after {self.trainer.current_epoch} epochs")
