@@ -115,6 +115,10 @@ EBEN_API int eben_conv1d_pack(const EbenConv1dDesc* d, const float* v, const flo
 /* y = lrelu_out( conv(lrelu_in(x)) + bias ) [+ residual] */
 EBEN_API int eben_conv1d_fwd(const EbenConv1dDesc* d, const float* x, const float* wp_fwd, const float* bias,
                     const float* residual, float* y, void* stream);
+/* ... + lrelu(residual, res_slope): the ResidualUnit's skip when its input is the previous block's output seen through
+ * the shared LeakyReLU (eben_generator.py:187-189, 314-316: `x + nl(pointwise(dilated(x)))` with x = nl(previous)) */
+EBEN_API int eben_conv1d_fwd_res(const EbenConv1dDesc* d, const float* x, const float* wp_fwd, const float* bias,
+                        const float* residual, float res_slope, float* y, void* stream);
 /* workspace bytes for bwd_dx (reflect padding only) and bwd_dw (partial slabs) */
 EBEN_API size_t eben_conv1d_bwd_dx_workspace(const EbenConv1dDesc* d);
 EBEN_API size_t eben_conv1d_bwd_dw_workspace(const EbenConv1dDesc* d, int* nslab, int* row_stride);
@@ -122,6 +126,11 @@ EBEN_API size_t eben_conv1d_bwd_dw_workspace(const EbenConv1dDesc* d, int* nslab
  * accumulate!=0 adds into dx instead of overwriting. */
 EBEN_API int eben_conv1d_bwd_dx(const EbenConv1dDesc* d, const float* dy, const float* y, const float* wp_bwd,
                        const float* x, float* dx, int accumulate, void* workspace, size_t ws_bytes, void* stream);
+/* dx = ( conv^T( dy * lrelu_out'(y) ) + res_pre ) * lrelu_in'(x) + res_post  (either addend may be NULL; res_post only for
+ * reflect-padded Conv1d layers, whose fold pass applies it): the gradient joins of the generator's ResidualUnit / skip
+ * connections (eben_generator.py:251-254, 282-284, 314-316) without separate add kernels. */
+EBEN_API int eben_conv1d_bwd_dx_res(const EbenConv1dDesc* d, const float* dy, const float* y, const float* wp_bwd, const float* x,
+                           const float* res_pre, const float* res_post, float* dx, void* workspace, size_t ws_bytes, void* stream);
 /* Batched input gradient for several right-hand sides that share one set of saved activations (rows of
  * g / dx = d->batch):  dx[b] = ( conv^T(g[b]) + (b < res_rows ? res[b] : 0) ) * lrelu'(mask[map(b)], mask_slope)
  * with map(b) = seg_map[b / seg] * seg + b % seg (seg = 0: map(b) = b; seg_map = HOST array of 4 ints).
@@ -135,6 +144,19 @@ EBEN_API int eben_conv1d_bwd_dx_ex(const EbenConv1dDesc* d, const float* g, cons
  * finish with eben_wn_bwd. */
 EBEN_API int eben_conv1d_bwd_dw(const EbenConv1dDesc* d, const float* dy, const float* y, const float* x, int has_bias,
                        float* slabs, size_t ws_bytes, void* stream);
+
+/* ---- fused ResidualUnit forward (vibravox/torch_modules/dnn/eben_generator.py:287-316) ---------------------------------
+ *   y = xin + lrelu( W_pw . ( W_dil (*) xin ), out_slope ),  xin = lrelu(x, in_slope)
+ * W_dil (C, C, 3) dilation d with "same" reflect padding, W_pw (C, C, 1), C in {32, 64, 128}, no bias; x, y (batch, C, length).
+ * One launch instead of dilated conv + pointwise conv + add: x is read once.  h (nullable) receives W_dil (*) xin and u
+ * (nullable) lrelu(z) -- what the backward needs (the pointwise weight gradient, the activation mask).  eben_ru_pack writes
+ * the weight image both stages stream (eben_ru_packed_floats(C) floats) from the directions v and the weight-norm scales
+ * g/||v|| (eben_wn_scale; NULL = plain weights). */
+EBEN_API size_t eben_ru_packed_floats(int channels);
+EBEN_API int eben_ru_pack(int channels, const float* v_dil, const float* scale_dil, const float* v_pw, const float* scale_pw, float* wimg,
+                 void* stream);
+EBEN_API int eben_ru_fwd(int batch, int channels, int length, int dilation, const float* x, float in_slope, float out_slope,
+                const float* wimg, float* y, float* h, float* u, void* stream);
 
 /* ---- PQMF (vibravox/torch_modules/dsp/pqmf.py:194-213, eben_generator.py:209-211) ---------- */
 /* decimating FIR bank: y[b,k,t] = sum_j w[k*ntaps+j] * x[b,0,t*stride+off0+j], zero outside [0,lx) */

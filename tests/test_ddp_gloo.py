@@ -90,3 +90,120 @@ def test_bucketed_gradient_allreduce_two_ranks():
     for p in procs:
         p.join(timeout=30)
     assert sorted(results) == [(0, "ok"), (1, "ok")], results
+
+
+def _engine_sequence_worker(rank, world, port, q):
+    """The data-parallel call sequence of the engine train step (lightning_modules/eben.py::_training_step_engine) on CPU
+    tensors: TWO GradSyncs; the generator's gradients partly through autograd's hooks and partly through the sink
+    (grad_buffer + mark_ready at the side-stream join); the discriminator's written into the bucket views chain by chain,
+    the LAST chain first (disc_engine.backward_finish), each chain reported by its own mark_ready; finish() + the
+    optimiser's grad_scale; the step's sync_dist values reduced by ONE packed collective (base_se.flush_logged)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from vibravox_amd.ddp import BucketedZeroGrad, GradSync
+        from vibravox_amd.lightning_modules.base_se import BaseSELightningModule
+
+        torch.manual_seed(0)
+        gen = torch.nn.Sequential(torch.nn.Linear(6, 20), torch.nn.Tanh(), torch.nn.Linear(20, 4))
+        chains = [torch.nn.Sequential(torch.nn.Linear(4, 9), torch.nn.Tanh(), torch.nn.Linear(9, 1)) for _ in range(3)]
+        disc = torch.nn.ModuleList(chains)
+        g_sync, d_sync = GradSync(gen.parameters(), bucket_bytes=300), GradSync(disc.parameters(), bucket_bytes=200)
+        assert len(g_sync.buckets) >= 2 and len(d_sync.buckets) >= 3
+        # a discriminator bucket that straddles two chains must wait for both reports
+        owners = [{id(p) for p in ch.parameters()} for ch in chains]
+        assert any(sum(any(id(p) in o for p in b.params) for o in owners) > 1 for b in d_sync.buckets)
+        g_opt = BucketedZeroGrad(torch.optim.SGD(gen.parameters(), lr=0.1), g_sync)
+        d_opt = BucketedZeroGrad(torch.optim.SGD(disc.parameters(), lr=0.1), d_sync)
+        data = torch.randn(world, 5, 6, generator=torch.Generator().manual_seed(3))
+        mod = BaseSELightningModule(sample_rate=16000)
+        for step in range(2):
+            x = data[rank] + step
+            fake = gen(x)
+            # ---- discriminator gradients "outside autograd", written into the bucket views, last chain first
+            d_loss = sum(ch(fake.detach()).pow(2).mean() for ch in chains)
+            grads = torch.autograd.grad(d_loss, list(disc.parameters()))
+            by_param = {id(p): g for p, g in zip(disc.parameters(), grads)}
+            launched_before = d_sync.launched
+            for ci in (2, 0, 1):
+                plist = list(chains[ci].parameters())
+                for p in plist:
+                    d_sync.grad_buffer(p).copy_(by_param[id(p)])
+                d_sync.mark_ready(plist)
+                if ci == 2:   # only buckets that the last chain fills on its own can have left yet
+                    gone = d_sync.order[len(d_sync.order) - (d_sync.launched - launched_before):] if d_sync.launched > launched_before else []
+                    assert all(id(p) in owners[2] for i in gone for p in d_sync.buckets[i].params)
+            # ---- generator: first layer through the sink (side-stream join), the rest through autograd's hooks
+            g_loss = sum(ch(fake).mean() for ch in chains)
+            first = list(gen[0].parameters())
+            rest = [p for p in gen.parameters() if all(p is not f for f in first)]
+            g_first = torch.autograd.grad(g_loss, first, retain_graph=True)
+            torch.autograd.backward(g_loss, inputs=rest)
+            for p, g in zip(first, g_first):
+                g_sync.grad_buffer(p).copy_(g)
+            g_sync.mark_ready(first)
+            mod.log("train/generator/x", g_loss.detach(), sync_dist=True)
+            mod.log("train/discriminator/y", d_loss.detach(), sync_dist=True)
+            g_scale, d_scale = g_sync.finish(), d_sync.finish()
+            assert g_scale == d_scale == 1.0 / world
+            # reference: the mean over ranks of the per-rank gradients, computed locally from every rank's data
+            ref_g = [torch.zeros_like(p) for p in gen.parameters()]
+            ref_d = [torch.zeros_like(p) for p in disc.parameters()]
+            ref_losses = [0.0, 0.0]
+            for r in range(world):
+                f = gen(data[r] + step)
+                dl = sum(ch(f.detach()).pow(2).mean() for ch in chains)
+                gl = sum(ch(f).mean() for ch in chains)
+                for acc, g in zip(ref_d, torch.autograd.grad(dl, list(disc.parameters()))):
+                    acc += g / world
+                for acc, g in zip(ref_g, torch.autograd.grad(gl, list(gen.parameters()))):
+                    acc += g / world
+                ref_losses[0] += float(gl) / world
+                ref_losses[1] += float(dl) / world
+            for p, want in zip(gen.parameters(), ref_g):
+                assert torch.allclose(p.grad * g_scale, want, atol=1e-6)
+            for p, want in zip(disc.parameters(), ref_d):
+                assert p.grad is d_sync.grad_buffer(p) and torch.allclose(p.grad * d_scale, want, atol=1e-6)
+            for opt, scale in ((g_opt, g_scale), (d_opt, d_scale)):
+                for grp in opt.param_groups:
+                    for p in grp["params"]:
+                        p.grad.mul_(scale)
+                opt.step()
+                opt.zero_grad()
+            # the packed scalar reduction: local values until the flush, rank means after it
+            assert abs(float(mod.logged["train/generator/x"]) - float(g_loss)) < 1e-7
+            mod.flush_logged()
+            assert abs(float(mod.logged["train/generator/x"]) - ref_losses[0]) < 1e-6
+            assert abs(float(mod.logged["train/discriminator/y"]) - ref_losses[1]) < 1e-6
+            assert mod._sync_pending == []
+        # deterministic exchange order: every rank issued the same buckets in the same order
+        mine = torch.tensor(d_sync.order + [-1] + g_sync.order)
+        both = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(both, mine)
+        assert all(torch.equal(both[0], o) for o in both)
+        assert len(d_sync.order) == 2 * len(d_sync.buckets) and len(g_sync.order) == 2 * len(g_sync.buckets)
+        # replicas stayed identical
+        flat = torch.cat([p.detach().flatten() for p in list(gen.parameters()) + list(disc.parameters())])
+        other = [torch.zeros_like(flat) for _ in range(world)]
+        dist.all_gather(other, flat)
+        assert all(torch.equal(other[0], o) for o in other)
+        q.put((rank, "ok"))
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, f"{type(e).__name__}: {e}\n{traceback.format_exc()}"))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_engine_step_exchange_sequence_two_ranks():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_engine_sequence_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=100) for _ in procs]
+    for p in procs:
+        p.join(timeout=30)
+    assert sorted(results) == [(0, "ok"), (1, "ok")], results

@@ -269,46 +269,170 @@ def test_full_size_step_properties(hip, golden):
     assert all(k.endswith(".bias") for k in still) and len(still) <= 4, still
 
 
-def test_bf16_discriminator_math_against_fp32_step(hip, golden):
-    """disc_math = "bf16" (BASELINE config 2): the discriminator contractions take bf16 MFMA operands, everything
-    else -- the generator, accumulation, losses, Adam -- is unchanged fp32.  One step from the same state in both
-    modes: the generator output is IDENTICAL (it never sees the discriminator), the logged losses and balancing
-    norms move by ~1e-3, the generator gradient by < 2 % (whole-vector relative L2; Adam's first moment after one
-    step is (1 - beta1) * grad).  The discriminator gradient is the difference of two coherent sums (fake and real
-    hinge branches, opposite signs) and inherits the bf16 noise of each un-cancelled: tens of percent at
-    initialisation -- the stated cost of this mode, measured here and bounded loosely."""
-    res = {}
-    for math in ("f32", "bf16", "bf16+gen"):
-        mod, _, _ = make_module(golden, use_mrstft=True)
-        mod.disc_math = math.split("+")[0]
-        mod.gen_backward_math = "bf16" if math.endswith("+gen") else "f32"
-        mod.stft_math = "bf16x3" if math.endswith("+gen") else None   # bench.py's bf16 step: MRSTFT contractions on hi/lo bf16 splits
-        batch = {"audio_body_conducted": formula_audio("bf/bc", 4, 8200).to(DEV), "audio_airborne": formula_audio("bf/air", 4, 8200).to(DEV)}
+# ---- the bf16 step (disc_math = "bf16", BASELINE config 2) against the fp32 step ---------------------------------
+# What bf16 MFMA operands cost, measured on MI355X and bounded here (tools/bf16_where.py, tools/bf16_trajectory.py):
+#   * the generator never sees the discriminator's arithmetic in its forward: its output is IDENTICAL;
+#   * each hinge branch's discriminator gradient (fake_loss alone, real_loss alone) moves by 1e-3 relative L2;
+#   * their SUM -- the gradient Adam gets -- is what survives a cancellation of R = (|G_fake| + |G_real|) / |G_fake + G_real|
+#     = 240 (config 2, noise inputs, default init) ... 700 (two formula clips): an absolute error of 1e-3 of a branch is
+#     R * 1e-3 of the sum.  The error does not come from the gradient contractions (bf16 dX / dW: 7e-3 / 2.4e-2 of the sum at
+#     R = 232) but from the FORWARD: bf16 products move pre-activations by ~1e-3, a fraction of them changes sign, and every
+#     flipped LeakyReLU mask changes one path of the backward by a factor 5.  The same mechanism separates the reference's own
+#     fp32 and fp64 gradients by 8.5e-3 (golden check:disc_grad_fp64_floor); the error goes with sqrt(eps), so neither hi + lo
+#     activation operands (EBEN_MATH_BF16X2: measured, no gain) nor anything short of ~2^-18 products would bring it to 1e-2.
+#   * the PQMF-band discriminators (9 % of the discriminator's FLOPs) carry most of it (0.25-0.75 per tensor against MelGAN's
+#     0.03-0.07): the "bf16" plan therefore runs THEIR forward in exact fp32 (+1.6 ms on a 21.3 ms step) and everything else
+#     on bf16 operands -- 3.4e-2 of the summed gradient at config 2, against 0.18 for bf16 everywhere ("bf16_plain").
+BF16_STEP_TOLERANCES = {
+    # one step from the same state, bf16 step vs fp32 step at BASELINE config 2 (32 x 32000 noise clips, default init)
+    "loss": 2e-3,                    # every logged loss but the two below, relative
+    "feature_matching_loss": 2e-2,   # a sum of L1 distances between nearly equal embeddings
+    "backprop_loss": 2e-2,           # lambda-weighted: inherits the balancing norms
+    "balancing_norms": 3e-2,         # |d loss / d last_conv.weight| per loss, relative
+    "generator_grad": 2e-2,          # whole-vector relative L2 (bf16 critic + bf16 generator backward)
+    "discriminator_grad": 5e-2,      # whole-vector relative L2 of the summed gradient (R = 240)
+    "discriminator_branch_grad": 3e-3,   # fake_loss alone / real_loss alone
+    "discriminator_grad_vs_branches": 5e-4,   # |dG| / (|G_fake| + |G_real|): the bound that does not depend on R
+}
+
+
+def _one_step(make, disc_math, gen_bwd="f32", seed_weights=None):
+    from vibravox_amd.disc_engine import DiscriminatorEngine
+    from vibravox_amd.lightning_modules.eben import DISC_MATH_PLANS
+
+    mod, batch = make()
+    mod.disc_math, mod.gen_backward_math = disc_math, gen_bwd
+    if seed_weights is not None:
+        mod._disc_engine = DiscriminatorEngine(mod.discriminator, DISC_MATH_PLANS[disc_math])
+        mod._disc_engine.seed_weights = seed_weights
+    out = mod.training_step(batch)
+    torch.cuda.synchronize()
+    moments = []
+    for opt in mod.optimizers():   # Adam's first moment after one step = (1 - beta1) * grad
+        moments.append(torch.cat([opt.state[p]["exp_avg"].double().flatten().cpu() for grp in opt.param_groups for p in grp["params"]
+                                  if "exp_avg" in opt.state.get(p, {})]))
+    return out["enhanced"].clone(), {k: float(v) for k, v in mod.logged.items()}, torch.stack(mod.last_norms).cpu(), moments
+
+
+def _rel(a, b):
+    return float((a - b).norm() / a.norm())
+
+
+def test_bf16_step_against_fp32_step_at_config2(hip):
+    """BASELINE config 2 (batch 32 x 32000 samples, default initialisation, noise clips -- bench.py's workload): the bf16 step
+    against the fp32 step, every quantity of BF16_STEP_TOLERANCES."""
+    import bench
+
+    def make():
+        return bench.build_module(DEV, 1234), bench.synthetic_batch(32, 32000, 1234, DEV)
+
+    tol = BF16_STEP_TOLERANCES
+    f32, bf = _one_step(make, "f32"), _one_step(make, "bf16", "bf16")
+    assert torch.equal(f32[0], bf[0])   # the generator's forward is exact fp32 in every mode
+    for k, v in f32[1].items():
+        t = tol["feature_matching_loss"] if "feature_matching" in k else tol["backprop_loss"] if "backprop" in k else tol["loss"]
+        assert abs(bf[1][k] - v) <= t * abs(v), (k, v, bf[1][k])
+    assert float(((f32[2] - bf[2]).abs() / f32[2].abs()).max()) < tol["balancing_norms"]
+    g_rel, d_rel = _rel(f32[3][0], bf[3][0]), _rel(f32[3][1], bf[3][1])
+    branches = {}
+    for name, w in (("fake", (1.0, 1.0, 0.0)), ("real", (1.0, 0.0, 1.0))):
+        a, b = _one_step(make, "f32", seed_weights=w), _one_step(make, "bf16", seed_weights=w)
+        branches[name] = (float(a[3][1].norm()), _rel(a[3][1], b[3][1]))
+    vs_branches = float((f32[3][1] - bf[3][1]).norm()) / (branches["fake"][0] + branches["real"][0])
+    cancel = (branches["fake"][0] + branches["real"][0]) / float(f32[3][1].norm())
+    print(f"bf16 step at config 2: generator grad {g_rel:.3e}, discriminator grad {d_rel:.3e} (R = {cancel:.0f}), branches "
+          f"fake {branches['fake'][1]:.3e} real {branches['real'][1]:.3e}, |dG| / (|G_fake| + |G_real|) {vs_branches:.3e}")
+    assert g_rel < tol["generator_grad"] and d_rel < tol["discriminator_grad"]
+    assert max(branches["fake"][1], branches["real"][1]) < tol["discriminator_branch_grad"]
+    assert vs_branches < tol["discriminator_grad_vs_branches"]
+    assert cancel > 50   # the regime the bound is stated for: the two hinge branches cancel
+    # every contraction on single bf16 operands: the mode this build does NOT headline
+    plain = _one_step(make, "bf16_plain", "bf16")
+    assert _rel(f32[3][1], plain[3][1]) > 2 * d_rel
+
+
+def test_bf16_step_against_reference_replay_golden(hip, golden):
+    """The two-step replay of eben.py:82-130 over the reference modules (golden fixtures, two formula clips of 8200 samples)
+    with the bf16 step.  Committed tolerances: logged values as below; the discriminator's update is bounded per hinge branch
+    and against the branch magnitudes (R = 670 here: the summed gradient itself moves by ~0.3, see BF16_STEP_TOLERANCES)."""
+    table = {"train/generator/feature_matching_loss": 2e-2, "train/generator/adv_loss_gen": 2e-3, "train/generator/backprop_loss": 5e-2,
+             "train/discriminator/real_loss": 2e-3, "train/discriminator/fake_loss": 2e-3, "train/discriminator/backprop_loss": 2e-3}
+    mod, g_sd, d_sd = make_module(golden, use_mrstft=False)
+    mod.disc_math = mod.gen_backward_math = "bf16"
+    for i in range(2):
+        batch = {"audio_body_conducted": formula_audio(f"step{i}/bc", 2, 8200).to(DEV), "audio_airborne": formula_audio(f"step{i}/air", 2, 8200).to(DEV)}
         out = mod.training_step(batch)
-        torch.cuda.synchronize()
-        moments = []
-        for opt in mod.optimizers():
-            moments.append(torch.cat([opt.state[p]["exp_avg"].double().flatten().cpu() for grp in opt.param_groups for p in grp["params"]
-                                      if "exp_avg" in opt.state.get(p, {})]))
-        res[math] = (out["enhanced"].clone(), {k: float(v) for k, v in mod.logged.items()}, torch.stack(mod.last_norms).cpu(), moments)
-    # ... and with the generator's BACKWARD contractions in bf16 as well (bench.py's default): its forward is still exact
-    a, c = res["f32"], res["bf16+gen"]
-    assert torch.equal(a[0], c[0])
-    g_rel = float((a[3][0] - c[3][0]).norm() / a[3][0].norm())
-    n_rel = float(((a[2] - c[2]).abs() / a[2].abs()).max())
-    print(f"bf16 discriminator + generator-backward math: norms {n_rel:.3e}, generator grad rel-L2 {g_rel:.3e}")
-    assert n_rel < 5e-2 and g_rel < 5e-2
-    a, b = res["f32"], res["bf16"]
-    assert torch.equal(a[0], b[0])
-    rel = {k: abs(b[1][k] - v) / abs(v) for k, v in a[1].items()}
-    n_rel = float(((a[2] - b[2]).abs() / a[2].abs()).max())
-    g_rel = float((a[3][0] - b[3][0]).norm() / a[3][0].norm())
-    d_rel = float((a[3][1] - b[3][1]).norm() / a[3][1].norm())
-    print(f"bf16 discriminator math: losses {rel}, norms {n_rel:.3e}, generator grad rel-L2 {g_rel:.3e}, discriminator grad rel-L2 {d_rel:.3e}")
-    # the feature-matching loss is a sum of L1 distances between nearly equal embeddings (formula weights): percent level
-    for k, r in rel.items():
-        assert r < (5e-2 if "feature_matching" in k or "backprop" in k else 5e-3), (k, r)
-    assert n_rel < 5e-2 and g_rel < 5e-2 and d_rel < 1.0
+        check_summary(golden, f"step{i}/enhanced", out["enhanced"], rtol=2e-3 if i else 2e-4, atol=2e-4 if i else 2e-5)
+        for k, rtol in table.items():
+            np.testing.assert_allclose(mod.logged[k].item(), golden[f"step{i}/{k}"], rtol=rtol * (1 if i == 0 else 5), err_msg=f"step {i} {k}")
+        np.testing.assert_allclose(torch.stack(mod.last_norms).cpu().numpy(), golden[f"step{i}/balancing/norms"], rtol=5e-2)
+        np.testing.assert_allclose(torch.stack(mod.last_lambdas).cpu().numpy(), golden[f"step{i}/balancing/lambdas"], rtol=5e-2)
+
+    def make():
+        m, _, _ = make_module(golden, use_mrstft=False)
+        return m, {"audio_body_conducted": formula_audio("step0/bc", 2, 8200).to(DEV), "audio_airborne": formula_audio("step0/air", 2, 8200).to(DEV)}
+
+    f32, bf = _one_step(make, "f32"), _one_step(make, "bf16", "bf16")
+    norms = {}
+    for name, w in (("fake", (1.0, 1.0, 0.0)), ("real", (1.0, 0.0, 1.0))):
+        a, b = _one_step(make, "f32", seed_weights=w), _one_step(make, "bf16", seed_weights=w)
+        norms[name] = float(a[3][1].norm())
+        assert _rel(a[3][1], b[3][1]) < BF16_STEP_TOLERANCES["discriminator_branch_grad"], name
+    assert float((f32[3][1] - bf[3][1]).norm()) / (norms["fake"] + norms["real"]) < 1e-3
+    assert _rel(f32[3][0], bf[3][0]) < 2e-2
+
+
+def test_bf16_training_statistics_against_fp32(hip):
+    """Do the two arithmetic modes train the same way?  40 steps from the same state on the same sequence of noise batches
+    (4 x 16000), once in fp32, once in fp32 with every input sample perturbed by at most ONE fp32 ulp, once in bf16.
+    This GAN's training is chaotic at this scale: the one-ulp run leaves the fp32 run by > 10 % of the discriminator losses
+    within 40 steps -- a step-by-step comparison means something only for the first steps, after that only statistics do:
+      * steps 0-2: the bf16 run's discriminator losses stay within 1e-2 of the fp32 run's (measured 0, 6e-5, 5e-3);
+      * the mean over the 40 steps of the discriminator loss (real + fake) and of the feature-matching loss: the bf16 run sits
+        as close to the fp32 run as the one-ulp run does (measured: D 1.953 / 1.979 / 1.990, FM 0.178 / 0.172 / 0.165)."""
+    import bench
+
+    def run(mode, perturb):
+        mod = bench.build_module(DEV, 1234)
+        mod.disc_math = mode
+        mod.gen_backward_math = "f32" if mode == "f32" else "bf16"
+        torch.manual_seed(7)
+        rows = []
+        for i in range(40):
+            batch = bench.synthetic_batch(4, 16000, 1000 + i, DEV)
+            if perturb:
+                g = torch.Generator().manual_seed(5000 + i)
+                batch = {k: v * (1 + 2.0 ** -23 * (2 * torch.rand(v.shape, generator=g).to(DEV) - 1)) for k, v in batch.items()}
+            mod.training_step(batch)
+            rows.append([float(mod.logged[f"train/{k}"]) for k in ("discriminator/real_loss", "discriminator/fake_loss", "generator/feature_matching_loss")])
+        return np.array(rows)
+
+    f32, ulp, bf = run("f32", False), run("f32", True), run("bf16", False)
+    dev = lambda a: np.abs(a[:, :2] - f32[:, :2]).max(axis=1) / np.abs(f32[:, :2]).min(axis=1)
+    assert dev(ulp).max() > 0.1, "the chaos yardstick: one ulp on the inputs is amplified to > 10 % within 40 steps"
+    assert dev(bf)[:3].max() < 1e-2
+    d_mean = lambda a: float((a[:, 0] + a[:, 1]).mean())
+    fm_mean = lambda a: float(a[:, 2].mean())
+    print(f"mean D loss over 40 steps: fp32 {d_mean(f32):.4f}, fp32 + 1 ulp {d_mean(ulp):.4f}, bf16 {d_mean(bf):.4f}; "
+          f"mean FM: {fm_mean(f32):.4f} / {fm_mean(ulp):.4f} / {fm_mean(bf):.4f}")
+    assert abs(d_mean(bf) - d_mean(f32)) < max(0.03 * d_mean(f32), 2 * abs(d_mean(ulp) - d_mean(f32)))
+    assert abs(fm_mean(bf) - fm_mean(f32)) < max(0.12 * fm_mean(f32), 2 * abs(fm_mean(ulp) - fm_mean(f32)))
+
+
+def test_variable_clip_lengths_keep_the_pack_caches_bounded(hip, golden):
+    """``collate_strategy: "pad"`` / a short last batch give the step a new (batch, length) every time: the engine's packed
+    weight images must not pile up (one fwd + two dX images per layer and shape, re-packed after every optimiser step)."""
+    from vibravox_amd.disc_engine import _Layer
+
+    mod, _, _ = make_module(golden, use_mrstft=False)
+    seen = []
+    for i, (b, t) in enumerate([(2, 4100), (2, 8200), (1, 6000), (2, 5000), (2, 7000), (2, 4100)]):
+        mod.training_step({"audio_body_conducted": formula_audio(f"var{i}/bc", b, t).to(DEV), "audio_airborne": formula_audio(f"var{i}/air", b, t).to(DEV)})
+        layers = [lay for ch in mod._disc_engine.chains for lay in ch.layers]
+        assert max(len(lay.packs) for lay in layers) <= _Layer.MAX_PACKS
+        seen.append(float(mod.logged["train/discriminator/real_loss"]))
+    torch.cuda.synchronize()
+    assert all(np.isfinite(seen)) and max(len(lay.packs) for lay in layers) <= 3   # after prepack: only the last step's shapes
 
 
 def test_train_step_is_bitwise_reproducible(hip, golden):

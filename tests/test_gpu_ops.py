@@ -257,6 +257,100 @@ def test_bf16_math_forward_and_batched_input_gradient(hip, name):
         assert rel_err(dv, wr2.grad) < 1e-4
 
 
+@pytest.mark.parametrize("channels,dilation,length,batch,in_slope", [
+    (32, 1, 1000, 3, 1.0), (32, 3, 517, 2, 0.01), (32, 9, 8000, 2, 1.0), (64, 9, 300, 3, 0.01), (64, 1, 4000, 2, 1.0),
+    (128, 3, 1000, 2, 1.0), (128, 9, 131, 2, 0.01), (32, 9, 20, 1, 1.0)])
+def test_fused_residual_unit_forward(hip, channels, dilation, length, batch, in_slope):
+    """eben_ru_fwd: y = xin + lrelu(W_pw . (W_dil (*) xin), 0.01), xin = lrelu(x, in_slope) -- eben_generator.py:287-316 in one
+    launch -- against the fp64 oracle: tile interiors (float4 staging), both reflected ends, lengths that are not a multiple
+    of the 128-position tile or of 4, a clip shorter than one tile; plus the two tensors kept for the backward."""
+    from vibravox_amd._lib import check, load, ptr, stream
+
+    lib, dev = load(), torch.device("cuda")
+    c = channels
+    vd = formula_tensor(f"ru/{c}/{dilation}/vd", (c, c, 3), 1 / math.sqrt(3 * c))
+    vp = formula_tensor(f"ru/{c}/{dilation}/vp", (c, c, 1), 1 / math.sqrt(c))
+    sd = 0.5 + formula_tensor(f"ru/{c}/sd", (c,), 0.4).abs()
+    sp = 0.5 + formula_tensor(f"ru/{c}/sp", (c,), 0.4).abs()
+    x = formula_tensor(f"ru/{c}/{dilation}/{length}/x", (batch, c, length))
+    xin = torch.nn.functional.leaky_relu(x.double(), in_slope)
+    wd, wp_ = vd.double() * sd.double().reshape(c, 1, 1), vp.double() * sp.double().reshape(c, 1, 1)
+    h_ref = torch.nn.functional.conv1d(torch.nn.functional.pad(xin, (dilation, dilation), mode="reflect"), wd, dilation=dilation)
+    u_ref = torch.nn.functional.leaky_relu(torch.nn.functional.conv1d(h_ref, wp_), 0.01)
+    y_ref = xin + u_ref
+    img = torch.empty(lib.eben_ru_packed_floats(c), dtype=torch.float32, device=dev)
+    assert img.numel() == 4 * c * c
+    vdd, vpd, sdd, spd, xd = vd.to(dev), vp.to(dev), sd.to(dev), sp.to(dev), x.to(dev)
+    check(lib.eben_ru_pack(c, ptr(vdd), ptr(sdd), ptr(vpd), ptr(spd), ptr(img), stream()), "ru_pack")
+    y, h, u = torch.full_like(xd, float("nan")), torch.full_like(xd, float("nan")), torch.full_like(xd, float("nan"))
+    check(lib.eben_ru_fwd(batch, c, length, dilation, ptr(xd), in_slope, 0.01, ptr(img), ptr(y), ptr(h), ptr(u), stream()), "ru_fwd")
+    torch.cuda.synchronize()
+    assert rel_err(h, h_ref) < 3e-5 and rel_err(u, u_ref) < 3e-5 and rel_err(y, y_ref) < 3e-5
+    # inference form: no h / u written; same y bit for bit
+    y2 = torch.empty_like(xd)
+    check(lib.eben_ru_fwd(batch, c, length, dilation, ptr(xd), in_slope, 0.01, ptr(img), ptr(y2), None, None, stream()), "ru_fwd")
+    torch.cuda.synchronize()
+    assert torch.equal(y, y2)
+    # a 4-byte-aligned (not 16-byte-aligned) input takes the scalar staging path: same values
+    buf = torch.empty(xd.numel() + 1, dtype=torch.float32, device=dev)
+    xo = buf[1:].view_as(xd)
+    xo.copy_(xd)
+    y3 = torch.empty_like(xd)
+    check(lib.eben_ru_fwd(batch, c, length, dilation, ptr(xo), in_slope, 0.01, ptr(img), ptr(y3), None, None, stream()), "ru_fwd")
+    torch.cuda.synchronize()
+    assert torch.equal(y, y3)
+
+
+def test_fused_residual_unit_rejects_unsupported_shapes(hip):
+    from vibravox_amd._lib import load
+
+    lib = load()
+    assert lib.eben_ru_packed_floats(48) == 0
+    assert lib.eben_ru_fwd(1, 48, 100, 1, None, 1.0, 0.01, None, None, None, None, None) < 0     # channels
+    assert lib.eben_ru_fwd(1, 32, 5, 9, None, 1.0, 0.01, None, None, None, None, None) < 0       # reflect pad >= length
+
+
+def test_input_gradient_with_residual_joins(hip):
+    """eben_conv1d_bwd_dx_res: dx = (conv^T(dy * lrelu_out'(y)) + res_pre) * lrelu_in'(x) + res_post on a reflect-padded dilated
+    conv (the ResidualUnit's gradient join) and res_pre alone on a pointwise conv (no fold pass)."""
+    import ctypes
+
+    from vibravox_amd import ops
+    from vibravox_amd._lib import check, load, ptr, stream
+
+    lib, dev = load(), torch.device("cuda")
+    for name, kw, use_post in (("dil", dict(c_in=32, c_out=32, ksize=3, dilation=3, pad_l=3, pad_r=3, reflect=True, in_slope=0.01), True),
+                               ("pw", dict(c_in=64, c_out=64, ksize=1, out_slope=0.01), False)):
+        spec = ops.ConvSpec(**kw)
+        b, l = 2, 333
+        w = formula_tensor(f"dxr/{name}/w", spec.weight_shape(), 0.1)
+        x, dy = formula_tensor(f"dxr/{name}/x", (b, spec.c_in, l)), formula_tensor(f"dxr/{name}/dy", (b, spec.c_out, l))
+        pre, post = formula_tensor(f"dxr/{name}/pre", (b, spec.c_in, l)), formula_tensor(f"dxr/{name}/post", (b, spec.c_in, l))
+        yv = formula_tensor(f"dxr/{name}/y", (b, spec.c_out, l))
+        okw = {k: v for k, v in kw.items() if k not in ("c_in", "c_out", "ksize", "in_slope", "out_slope")}
+        xr = torch.zeros(b, spec.c_in, l, dtype=torch.float64, requires_grad=True)
+        masked = dy.double() * torch.where(yv.double() > 0, 1.0, spec.out_slope)
+        (O.conv_layer(xr, w.double(), None, None, **okw) * masked).sum().backward()
+        ref = (xr.grad + pre.double()) * torch.where(x.double() > 0, 1.0, spec.in_slope)
+        if use_post:
+            ref = ref + post.double()
+        d = ops.conv_desc(spec, b, l)
+        wd = w.to(dev)
+        wp = torch.empty(lib.eben_conv1d_packed_floats(ctypes.byref(d), 1), dtype=torch.float32, device=dev)
+        check(lib.eben_conv1d_pack(ctypes.byref(d), ptr(wd), None, None, ptr(wp), stream()), "pack")
+        ws_bytes = lib.eben_conv1d_bwd_dx_workspace(ctypes.byref(d))
+        ws = torch.empty(max(1, ws_bytes // 4), dtype=torch.float32, device=dev)
+        xd, dyd, pred, postd, yd = x.to(dev), dy.to(dev), pre.to(dev), post.to(dev), yv.to(dev)
+        dx = torch.empty_like(xd)
+        check(lib.eben_conv1d_bwd_dx_res(ctypes.byref(d), ptr(dyd), ptr(yd) if spec.out_slope != 1.0 else None, ptr(wp),
+                                         ptr(xd) if spec.in_slope != 1.0 else None, ptr(pred), ptr(postd) if use_post else None, ptr(dx),
+                                         ptr(ws), ws_bytes, stream()), "bwd_dx_res")
+        torch.cuda.synchronize()
+        assert rel_err(dx, ref) < 3e-5
+        if not use_post:   # an addend behind the mask needs the fold pass
+            assert lib.eben_conv1d_bwd_dx_res(ctypes.byref(d), ptr(dyd), ptr(yd), ptr(wp), None, None, ptr(postd), ptr(dx), None, 0, stream()) < 0
+
+
 @pytest.mark.parametrize("name", list(BF16_CASES))
 def test_bf16x2_math_keeps_the_activation_operand(hip, name):
     """EBEN_MATH_BF16X2: the activation operand enters the forward and the weight gradient as hi + lo (two bf16 MFMAs per

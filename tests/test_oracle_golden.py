@@ -1,11 +1,15 @@
 """CPU: the oracle restatement against the fixtures frozen from the REFERENCE modules
 (tests/golden/make_golden.py).  This is what pins the oracle."""
+import os
+
 import numpy as np
 import pytest
 import torch
 
 from formula import formula_audio, formula_state_dict, iter_embeddings, summarize
 from oracle import eben_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _check_summary(golden, prefix, t, rtol=2e-5, atol=2e-6):
@@ -162,3 +166,47 @@ def test_mrstft_against_independent_numpy_rfft():
             cnt += xm.size
         total += np.mean(sc) + lg / cnt
     np.testing.assert_allclose(got, total / 3, rtol=2e-4)
+
+
+def test_a_weighting_taps_fixture_regenerates():
+    """the 101 A-weighting taps (auraloss FIRFilter 'aw', 16 kHz) are a committed table that the product
+    loads; scipy's bilinear / freqz / firls on this box must still reproduce it, and the oracle's own design must agree."""
+    import numpy as np
+
+    from vibravox_amd.torch_modules.losses.mrstft_loss import a_weighting_taps, design_a_weighting_taps
+
+    path = os.path.join(ROOT, "vibravox_amd", "data", "a_weighting_fir_16000_101.npy")
+    committed = np.load(path)
+    assert committed.shape == (101,) and committed.dtype == np.float32
+    np.testing.assert_allclose(design_a_weighting_taps(16000, 101).numpy(), committed, rtol=0, atol=1e-7)
+    np.testing.assert_allclose(O.a_weighting_fir(16000).numpy(), committed, rtol=0, atol=1e-7)
+    assert np.array_equal(a_weighting_taps(16000, 101).numpy(), committed)          # the product loads the table
+    assert np.allclose(committed, committed[::-1], atol=1e-7)                        # type-I linear phase (firls)
+    # the response it was designed for: A-weighting is 0 dB at 1 kHz, about -19 dB at 100 Hz
+    h = np.abs(np.fft.rfft(committed.astype(np.float64), 16000))
+    assert abs(20 * np.log10(h[1000])) < 0.3 and -21.0 < 20 * np.log10(h[100]) < -17.0
+    assert a_weighting_taps(22050, 101).shape == (101,)                              # other rates are designed on the fly
+
+
+def test_resample_kernel_tables_fixture_regenerates():
+    """The windowed-sinc polyphase tables of torchaudio.functional.resample (hann, width 6, rolloff 0.99) for every rate pair
+    the default augmentation can draw: regenerated == committed to 1e-7 (tables) / 1e-6 relative (signatures)."""
+    import numpy as np
+
+    from make_third_party_fixtures import rate_pairs
+    from vibravox_amd.augment import sinc_resample_kernel
+
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "resample_kernels.npz"))
+    n_tables = 0
+    for orig, new in rate_pairs():
+        k, width, o, n = sinc_resample_kernel(orig, new)
+        sig = gold[f"{orig}_{new}:sig"]
+        assert (width, o, n) == tuple(int(v) for v in sig[:3])
+        got = np.array([float(k.double().sum()), float(k.double().pow(2).sum()), float(k[0, width]), float(k[-1, -1])])
+        np.testing.assert_allclose(got, sig[3:], rtol=1e-6, atol=1e-9)
+        if f"{orig}_{new}" in gold.files:
+            np.testing.assert_allclose(k.numpy(), gold[f"{orig}_{new}"], rtol=0, atol=1e-7)
+            n_tables += 1
+        # every polyphase row is a unit-gain low-pass: rows sum to ~1 (DC preserved)
+        assert float((k.double().sum(dim=1) - 1).abs().max()) < 5e-3
+    assert n_tables >= 5

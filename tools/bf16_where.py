@@ -25,9 +25,14 @@ def make():
     return mod, batch
 
 
-def run(plan):
+def run(plan, seed_weights=None):
     mod, batch = make()
     mod.disc_math = plan
+    if seed_weights is not None:
+        from vibravox_amd.disc_engine import DiscriminatorEngine
+        from vibravox_amd.lightning_modules.eben import DISC_MATH_PLANS
+        mod._disc_engine = DiscriminatorEngine(mod.discriminator, DISC_MATH_PLANS[plan] if isinstance(plan, str) else plan)
+        mod._disc_engine.seed_weights = seed_weights
     mod.training_step(batch)
     torch.cuda.synchronize()
     opt = mod._optimizers[1]
@@ -66,8 +71,9 @@ nf = sum(float(v.norm() ** 2) for v in br["fake"].values()) ** 0.5
 nr = sum(float(v.norm() ** 2) for v in br["real"].values()) ** 0.5
 nt = sum(float(v.norm() ** 2) for v in tot.values()) ** 0.5
 print(f"cancellation: |G_fake| {nf:.3e} |G_real| {nr:.3e} |sum| {nt:.3e}  R = {(nf + nr) / nt:.1f}")
-plans = {"bf16 all": (H, H, H), "fwd only": (H, F, F), "dx only": (F, H, F), "dw only": (F, F, H), "dx+dw": (F, H, H),
-         "x2 fwd only": (X, F, F), "x2 dw only": (F, F, X), "x2/bf16/x2": (X, H, X), "x2/bf16/bf16": (X, H, H), "x2/f32/x2": (X, F, X)}
+plans = {"bf16 all": (H, H, H), "fwd only": (H, F, F), "dx+dw": (F, H, H),
+         "pq f32fwd": {"pqmf": (F, H, H), "melgan": H}, "pq f32fwd x2dw": {"pqmf": (F, H, X), "melgan": H}, "pq f32": {"pqmf": F, "melgan": H},
+         "pq f32, mel x2dw": {"pqmf": F, "melgan": (H, H, X)}, "mel fwd only": {"pqmf": F, "melgan": (H, F, F)}}
 if os.environ.get("PLANS"):
     plans = {k: v for k, v in plans.items() if k in os.environ["PLANS"].split(",") or k == "bf16 all"}
 res = {}
@@ -79,3 +85,11 @@ print("per tensor (bf16 all):  R = (|fake|+|real|)/|sum|,  rel-L2 vs fp32")
 for n in ref:
     r = float((br["fake"][n].norm() + br["real"][n].norm()) / (tot[n].norm() + 1e-300))
     print(f"  {n:75s} R {r:8.1f}  " + "  ".join(f"{k} {dist(ref, v, lambda q: q == n):.2e}" for k, v in res.items()))
+
+# each hinge branch on its own (no cancellation): fp32 vs the step's bf16 plan
+for name, w in (("fake", (1.0, 1.0, 0.0)), ("real", (1.0, 0.0, 1.0))):
+    a, b = run("f32", w), run("bf16", w)
+    print(f"branch {name}: engine bf16 vs f32 rel-L2 {dist(a, b):.3e}   (f32 engine vs autograd: {dist({n: 0.5 * v for n, v in br[name].items()}, a):.3e})")
+tot_b = run("bf16")
+num = sum(float((ref[n] - tot_b[n]).norm() ** 2) for n in ref) ** 0.5
+print(f"'bf16' plan: |dG| / |G| = {dist(ref, tot_b):.3e};  |dG| / (|G_fake| + |G_real|) = {num / (0.5 * (nf + nr)):.3e}")

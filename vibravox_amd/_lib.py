@@ -83,11 +83,16 @@ SIGNATURES = {
     "eben_conv1d_kernel_generation": (c_int, [_D, c_int]),
     "eben_conv1d_pack": (c_int, [_D, _P, _P, _P, _P, _P]),
     "eben_conv1d_fwd": (c_int, [_D, _P, _P, _P, _P, _P, _P]),
+    "eben_conv1d_fwd_res": (c_int, [_D, _P, _P, _P, _P, c_float, _P, _P]),
+    "eben_conv1d_bwd_dx_res": (c_int, [_D, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     "eben_conv1d_bwd_dx_workspace": (c_size_t, [_D]),
     "eben_conv1d_bwd_dw_workspace": (c_size_t, [_D, POINTER(c_int), POINTER(c_int)]),
     "eben_conv1d_bwd_dx": (c_int, [_D, _P, _P, _P, _P, _P, c_int, _P, c_size_t, _P]),
     "eben_conv1d_bwd_dx_ex": (c_int, [_D, _P, _P, _P, c_int, _P, c_float, c_int, POINTER(c_int), _P, _P]),
     "eben_conv1d_bwd_dw": (c_int, [_D, _P, _P, _P, c_int, _P, c_size_t, _P]),
+    "eben_ru_packed_floats": (c_size_t, [c_int]),
+    "eben_ru_pack": (c_int, [c_int, _P, _P, _P, _P, _P, _P]),
+    "eben_ru_fwd": (c_int, [c_int, c_int, c_int, c_int, _P, c_float, c_float, _P, _P, _P, _P, _P]),
     "eben_fir_decimate": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "eben_fir_interp_sum": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "eben_lrelu_fwd": (c_int, [_P, _P, c_size_t, c_float, _P]),

@@ -618,9 +618,10 @@ __global__ __launch_bounds__(1024) void conv_m1_fwd_kernel(const float* __restri
   }
 }
 
-// reflect-pad fold: dx[u] = D[u+pl] + D[pl-u] (1<=u<=pl) + D[pl+2(L-1)-u] (L-1-pr<=u<=L-2), then mask
+// reflect-pad fold: dx[u] = D[u+pl] + D[pl-u] (1<=u<=pl) + D[pl+2(L-1)-u] (L-1-pr<=u<=L-2) (+ pre), then mask (+ post)
 __global__ __launch_bounds__(256) void fold_kernel(const float* __restrict__ D, const float* __restrict__ mask, float* __restrict__ dx,
-                                                   long long rows, int L, int pl, int pr, float slope, int accumulate) {
+                                                   long long rows, int L, int pl, int pr, float slope, int accumulate,
+                                                   const float* __restrict__ pre, const float* __restrict__ post) {
   const int Lp = L + pl + pr;
   const long long total = rows * L;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
@@ -630,7 +631,9 @@ __global__ __launch_bounds__(256) void fold_kernel(const float* __restrict__ D, 
     float v = d[u + pl];
     if (u >= 1 && u <= pl) v += d[pl - u];
     if (u >= L - 1 - pr && u <= L - 2) v += d[pl + 2 * (L - 1) - u];
+    if (pre) v += pre[i];
     if (mask) v *= dlrelu(mask[i], slope);
+    if (post) v += post[i];
     if (accumulate) v += dx[i];
     dx[i] = v;
   }
@@ -695,8 +698,8 @@ extern "C" int eben_conv1d_pack(const EbenConv1dDesc* d, const float* v, const f
   return EBEN_OK;
 }
 
-extern "C" int eben_conv1d_fwd(const EbenConv1dDesc* d, const float* x, const float* wp_fwd, const float* bias,
-                               const float* residual, float* y, void* stream) {
+static int conv1d_fwd_impl(const EbenConv1dDesc* d, const float* x, const float* wp_fwd, const float* bias,
+                           const float* residual, float res_slope, float* y, void* stream) {
   Canon c;
   int rc = canon_from_desc(d, &c);
   if (rc) return rc;
@@ -711,13 +714,24 @@ extern "C" int eben_conv1d_fwd(const EbenConv1dDesc* d, const float* x, const fl
   }
   TapIO io{};
   io.x = x; io.in_mode = 0; io.in_slope = d->in_slope; io.wp = wp_fwd; io.bias = bias;
-  io.res = residual; io.res_slope = 1.f; io.emask = nullptr; io.emask_slope = 1.f;
+  io.res = residual; io.res_slope = res_slope; io.emask = nullptr; io.emask_slope = 1.f;
   io.out_slope = d->out_slope; io.y = y; io.accumulate = 0;
   const int fgen = tap_generation(c, d->transposed ? 1 : 0);
   if (fgen == 2) return tap2_launch(c, d->transposed ? 1 : 0, io, c.reflect && !d->transposed, as_stream(stream));
   if (fgen == 3) return thin_launch(c, d->transposed ? 1 : 0, io, c.reflect && !d->transposed, as_stream(stream));
   if (fgen == 4) return tap3_launch(c, d->transposed ? 1 : 0, io, c.reflect && !d->transposed, as_stream(stream));
   return launch_tap(c, p, io, c.reflect && !d->transposed, as_stream(stream));
+}
+
+extern "C" int eben_conv1d_fwd(const EbenConv1dDesc* d, const float* x, const float* wp_fwd, const float* bias,
+                               const float* residual, float* y, void* stream) {
+  return conv1d_fwd_impl(d, x, wp_fwd, bias, residual, 1.f, y, stream);
+}
+
+extern "C" int eben_conv1d_fwd_res(const EbenConv1dDesc* d, const float* x, const float* wp_fwd, const float* bias,
+                                   const float* residual, float res_slope, float* y, void* stream) {
+  EBEN_REQUIRE(residual != nullptr, "conv1d_fwd_res without a residual");
+  return conv1d_fwd_impl(d, x, wp_fwd, bias, residual, res_slope, y, stream);
 }
 
 extern "C" size_t eben_conv1d_bwd_dx_workspace(const EbenConv1dDesc* d) {
@@ -727,8 +741,9 @@ extern "C" size_t eben_conv1d_bwd_dx_workspace(const EbenConv1dDesc* d) {
   return 0;
 }
 
-extern "C" int eben_conv1d_bwd_dx(const EbenConv1dDesc* d, const float* dy, const float* y, const float* wp_bwd,
-                                  const float* x, float* dx, int accumulate, void* workspace, size_t ws_bytes, void* stream) {
+static int conv1d_bwd_dx_impl(const EbenConv1dDesc* d, const float* dy, const float* y, const float* wp_bwd, const float* x,
+                              const float* res_pre, const float* res_post, float* dx, int accumulate, void* workspace, size_t ws_bytes,
+                              void* stream) {
   Canon c;
   int rc = canon_from_desc(d, &c);
   if (rc) return rc;
@@ -746,6 +761,8 @@ extern "C" int eben_conv1d_bwd_dx(const EbenConv1dDesc* d, const float* dy, cons
   else { io.in_mode = 0; io.in_slope = 1.f; }
   const bool fold = !d->transposed && c.reflect;
   if (!fold) {
+    if (res_post) return fail(EBEN_EUNSUPPORTED, "bwd_dx: an addend behind the input-activation mask needs the reflect-fold pass");
+    io.res = res_pre;
     io.emask = d->in_slope != 1.f ? x : nullptr; io.emask_slope = d->in_slope;
     io.y = dx; io.accumulate = accumulate;
     return gen == 2 ? tap2_launch(c, dir, io, 0, st) : gen == 3 ? thin_launch(c, dir, io, 0, st)
@@ -761,9 +778,20 @@ extern "C" int eben_conv1d_bwd_dx(const EbenConv1dDesc* d, const float* dy, cons
   long long blocks = (rows * c.Lin + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(fold_kernel, dim3((unsigned)blocks), dim3(256), 0, st, static_cast<const float*>(workspace),
-                     d->in_slope != 1.f ? x : nullptr, dx, rows, c.Lin, c.pl, c.pr, d->in_slope, accumulate);
+                     d->in_slope != 1.f ? x : nullptr, dx, rows, c.Lin, c.pl, c.pr, d->in_slope, accumulate, res_pre, res_post);
   EBEN_CHECK_LAUNCH("fold_kernel");
   return EBEN_OK;
+}
+
+extern "C" int eben_conv1d_bwd_dx(const EbenConv1dDesc* d, const float* dy, const float* y, const float* wp_bwd,
+                                  const float* x, float* dx, int accumulate, void* workspace, size_t ws_bytes, void* stream) {
+  return conv1d_bwd_dx_impl(d, dy, y, wp_bwd, x, nullptr, nullptr, dx, accumulate, workspace, ws_bytes, stream);
+}
+
+extern "C" int eben_conv1d_bwd_dx_res(const EbenConv1dDesc* d, const float* dy, const float* y, const float* wp_bwd, const float* x,
+                                      const float* res_pre, const float* res_post, float* dx, void* workspace, size_t ws_bytes,
+                                      void* stream) {
+  return conv1d_bwd_dx_impl(d, dy, y, wp_bwd, x, res_pre, res_post, dx, 0, workspace, ws_bytes, stream);
 }
 
 // Batched input gradient for several right-hand sides that share one set of saved activations

@@ -35,6 +35,7 @@ class _Bucket:
             off += p.numel()
         self.pending = len(params)
         self.work = None
+        self.events = []   # producer-stream events the exchange has to wait for (gradients written outside autograd)
         self.index = {id(p): i for i, p in enumerate(params)}
 
 
@@ -74,6 +75,10 @@ class GradSync:
                 p.grad = v  # gradient-as-bucket-view: autograd accumulates in place
                 p.register_post_accumulate_grad_hook(self._on_grad)
         self.launched = 0
+        self.order: List[int] = []   # bucket indices in the order their exchanges were issued (identical on every rank)
+        self.exposed_ms: List[float] = []   # per finish(): main-stream time spent waiting for the exchange (profile=True)
+        self.profile = False
+        self._pending_timing = []
 
     # -- hooks -------------------------------------------------------------------------------
     def grad_buffer(self, p: torch.nn.Parameter) -> Optional[torch.Tensor]:
@@ -83,14 +88,26 @@ class GradSync:
         return None if b is None else b.views[b.index[id(p)]]
 
     def mark_ready(self, params: Iterable[torch.nn.Parameter]) -> None:
-        """Gradients written straight into ``grad_buffer(p)`` (complete on the current stream): the same accounting as
-        the post-accumulate hook -- a bucket's all-reduce is issued when its last gradient is there."""
+        """Gradients written straight into ``grad_buffer(p)`` by kernels enqueued on the CURRENT stream: the same accounting
+        as the post-accumulate hook -- a bucket's all-reduce is issued when its last gradient is there.  May be called once
+        per producer stream (the discriminator engine reports each sub-discriminator chain from that chain's stream, the
+        largest layers first): a bucket filled from several streams waits for an event of each."""
+        ev = None
+        touched = []
         for p in params:
             b = self._owner.get(id(p))
             if b is None:
                 continue
             p.grad = b.views[b.index[id(p)]]
             b.pending -= 1
+            if b not in touched:
+                touched.append(b)
+        if self.on_gpu and touched:
+            ev = torch.cuda.Event()
+            ev.record()
+        for b in touched:
+            if ev is not None:
+                b.events.append(ev)
             if b.pending == 0 and self.overlap:
                 self._launch(b)
 
@@ -106,9 +123,18 @@ class GradSync:
 
     def _launch(self, b: _Bucket):
         if self.world == 1 and not dist.is_initialized():
+            b.events.clear()
             return
+        self.order.append(self.buckets.index(b))
         if self.on_gpu:
+            # the collective is ordered behind what produced the bucket: the current stream (autograd hooks, the last
+            # mark_ready) and the recorded events of the other producer streams -- not behind unrelated work queued on the
+            # side stream.  (torch's NCCL process group runs the collective on a stream of its own and orders it after the
+            # stream that is current at the call.)
             self.comm_stream.wait_stream(torch.cuda.current_stream())
+            for ev in b.events:
+                self.comm_stream.wait_event(ev)
+            b.events.clear()
             with torch.cuda.stream(self.comm_stream):
                 b.work = dist.all_reduce(b.buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         else:
@@ -118,6 +144,10 @@ class GradSync:
     # -- step API ----------------------------------------------------------------------------
     def finish(self) -> float:
         """Wait for every bucket's all-reduce; returns the factor that turns the sums into means."""
+        timing = self.on_gpu and self.profile
+        if timing:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record()
         for b in self.buckets:
             if b.work is None and b.pending < len(b.params):
                 self._launch(b)  # not launched from a hook (overlap disabled or partial bucket)
@@ -125,9 +155,23 @@ class GradSync:
                 b.work.wait()
                 b.work = None
             b.pending = len(b.params)
+            b.events.clear()
         if self.on_gpu and self.world > 1:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
+        if timing:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            self._pending_timing.append((e0, e1))
         return 1.0 / self.world
+
+    def exposed_comm_ms(self) -> Optional[float]:
+        """Mean main-stream wait per ``finish()`` since the last call (``profile = True``; synchronises)."""
+        if not self._pending_timing:
+            return None
+        torch.cuda.synchronize()
+        ms = [a.elapsed_time(b) for a, b in self._pending_timing]
+        self._pending_timing = []
+        return sum(ms) / len(ms)
 
     def zero(self):
         for b in self.buckets:

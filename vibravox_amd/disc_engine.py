@@ -44,6 +44,8 @@ from ._lib import stream as _stream  # noqa: E402  (raw handle of the current HI
 class _Layer:
     """One weight-normalised conv of a sub-discriminator with the packed copies the engine needs."""
 
+    MAX_PACKS = 6   # forward at 2B rows + input gradient at 4B / 2B rows, for two (batch, length) shapes
+
     def __init__(self, conv, math=ops.MATH_F32):
         """math: one EBEN_MATH_* for every contraction of the layer, or (forward, input gradient, weight gradient)."""
         self.conv = conv
@@ -51,6 +53,7 @@ class _Layer:
         self.spec: ops.ConvSpec = conv.spec
         self.spec_lin = dataclasses.replace(conv.spec, in_slope=1.0, out_slope=1.0)   # gradients arrive pre-masked
         self.packs: Dict[Tuple[int, int, int], Tuple[tuple, torch.Tensor]] = {}
+        self.used = set()   # slots touched since the last prepack(): the only ones it rebuilds
         self.scale_key = None
         self.scale = self.norm = None
 
@@ -77,9 +80,15 @@ class _Layer:
             check(lib.eben_wn_scale(ptr(g), ptr(v), rows, v.numel() // rows, ptr(self.scale), ptr(self.norm), _stream()), "wn_scale")
             self.scale_key = wkey
         slot = (which, batch, l_in)
+        self.used.add(slot)
         hit = self.packs.get(slot)
         if hit is not None and hit[0] == wkey:
             return hit[1]
+        if hit is None and len(self.packs) >= self.MAX_PACKS:
+            # variable clip lengths / a short last batch: every new (batch, length) would otherwise keep another packed copy of
+            # the weights alive and be re-packed after every optimiser step -- drop the slots the current step has not touched
+            for old in [k for k in self.packs if k not in self.used] or list(self.packs)[:1]:
+                del self.packs[old]
         d = ops.conv_desc(self.spec, batch, l_in, self.math_fwd if which == 0 else self.math_dx)
         wp = torch.empty(lib.eben_conv1d_packed_floats(ctypes.byref(d), which), dtype=torch.float32, device=v.device)
         check(lib.eben_conv1d_pack(ctypes.byref(d), ptr(v), ptr(self.scale), ptr(wp) if which == 0 else None,
@@ -284,22 +293,35 @@ def inject_grads(params: Sequence[torch.nn.Parameter], grads: Sequence[torch.Ten
 
 
 class DiscriminatorEngine:
-    def __init__(self, disc, math: int = ops.MATH_F32):
-        """math = ops.MATH_BF16: the contractions of the layers tapconv3.hip covers take bf16 operands (fp32
-        accumulation, storage and element-wise stages); everything else is unchanged."""
+    def __init__(self, disc, math=ops.MATH_F32):
+        """math: what the contractions of the layers tapconv3.hip / conv_dw3.hip cover compute in (fp32 accumulation, storage
+        and element-wise stages either way) -- one EBEN_MATH_* for everything, a (forward, input gradient, weight gradient)
+        triple, a callable (layer index, layers in the chain) -> one of those, or a dict {"pqmf": ..., "melgan": ...} of
+        those per sub-discriminator family."""
         self.disc = disc
         self.q = disc.q
         self.math = math
-        self.chains = [_Chain(d.discriminator, math) for d in disc.pqmf_discriminators] + [_Chain(disc.melgan_discriminator.discriminator, math)]
+        per = math if isinstance(math, dict) else {"pqmf": math, "melgan": math}
+        self.chains = [_Chain(d.discriminator, per["pqmf"]) for d in disc.pqmf_discriminators] + [
+            _Chain(disc.melgan_discriminator.discriminator, per["melgan"])]
         self._streams = None
         self._state = None
+        #: weights of the (adversarial, fake, real) hinge seeds of the stacked backward: (1, 1, 1) is the train step; (1, 1, 0) /
+        #: (1, 0, 1) give the discriminator gradient of fake_loss / real_loss alone (the parity tests bound each branch
+        #: separately -- their sum cancels to a fraction of a percent at initialisation)
+        self.seed_weights = (1.0, 1.0, 1.0)
 
     @staticmethod
     def supports(disc) -> bool:
         return hasattr(disc, "pqmf_discriminators") and hasattr(disc, "melgan_discriminator") and all(
             hasattr(m, "discriminator") for m in list(disc.pqmf_discriminators) + [disc.melgan_discriminator])
 
-    def _launch_on_streams(self, fn):
+    #: forward pass only: the last PQMF-band chain on the side stream (idle between the weight pre-packing and the generator's
+    #: weight gradients) instead of behind the other two -- the PQMF chains' exact-fp32 forward ("bf16" plan) is the longest
+    #: stream of that phase otherwise
+    spread_forward = os.environ.get("EBEN_D_FWD_SPREAD", "1") != "0"
+
+    def _launch_on_streams(self, fn, forward: bool = False):
         """fn(i) for each sub-discriminator on its own HIP stream, the longest chain (MelGAN, last) first so that it
         is never queued behind a short one; results in chain order.  The caller joins with ``_join_streams``."""
         main = torch.cuda.current_stream()
@@ -309,11 +331,15 @@ class DiscriminatorEngine:
             # and the side stream that is four streams = four hardware queues, none shared (ops.aux_stream)
             pq, mel = ops.aux_stream(1, dev), ops.aux_stream(0, dev)
             self._streams = [pq] * (len(self.chains) - 1) + [mel]
+        streams = list(self._streams)
+        if forward and self.spread_forward and len(self.chains) >= 3:
+            streams[len(self.chains) - 2] = ops.aux_stream(2, dev)
+        self._used_streams = set(streams) | set(self._streams)
         results = [None] * len(self.chains)
         n = len(self.chains)
         ev = getattr(self, "_prepack_ev", None)
         for i in [n - 1] + list(range(n - 1)):
-            st = self._streams[i]
+            st = streams[i]
             st.wait_stream(main)
             if ev is not None:
                 st.wait_event(ev)   # weight images rebuilt ahead of time on the side stream (prepack)
@@ -323,7 +349,7 @@ class DiscriminatorEngine:
 
     def _join_streams(self):
         main = torch.cuda.current_stream()
-        for st in set(self._streams):
+        for st in getattr(self, "_used_streams", None) or set(self._streams):
             main.wait_stream(st)
 
     def _on_streams(self, fn):
@@ -348,7 +374,7 @@ class DiscriminatorEngine:
         sub[half:].copy_(bands_ref[:, -self.q:, :])
         wav[half:].copy_(audio_ref)
         inputs = [sub] * (len(self.chains) - 1) + [wav]
-        bufs = self._launch_on_streams(lambda i: self.chains[i].forward_rows(inputs[i], None, half, 2 * half))
+        bufs = self._launch_on_streams(lambda i: self.chains[i].forward_rows(inputs[i], None, half, 2 * half), forward=True)
         self._partial = dict(half=half, sub=sub, wav=wav, bufs=bufs)
 
     @torch.no_grad()
@@ -363,12 +389,12 @@ class DiscriminatorEngine:
             sub[:half].copy_(bands[:, -self.q:, :])
             wav[:half].copy_(audio)
             inputs = [sub] * (len(self.chains) - 1) + [wav]
-            res = self._launch_on_streams(lambda i: self.chains[i].forward_rows(inputs[i], part["bufs"][i], 0, half))
+            res = self._launch_on_streams(lambda i: self.chains[i].forward_rows(inputs[i], part["bufs"][i], 0, half), forward=True)
         else:
             sub = torch.cat((bands[:, -self.q:, :], bands_ref[:, -self.q:, :]), dim=0).contiguous()
             wav = torch.cat((audio, audio_ref), dim=0).contiguous()
             inputs = [sub] * (len(self.chains) - 1) + [wav]
-            res = self._launch_on_streams(lambda i: self.chains[i].forward_rows(inputs[i], None, 0, 2 * half))
+            res = self._launch_on_streams(lambda i: self.chains[i].forward_rows(inputs[i], None, 0, 2 * half), forward=True)
         if join:
             self._join_streams()
         self._state = dict(half=half, emb=[r["emb"] for r in res], xp=[r["xp"] for r in res], bands_shape=tuple(bands.shape))
@@ -402,8 +428,13 @@ class DiscriminatorEngine:
             ops.wn_scale_multi(jobs)
             for ch in self.chains:
                 for lay in ch.layers:
-                    for (which, batch, l_in) in list(lay.packs):
-                        lay.packed(which, batch, l_in)
+                    used, lay.used = lay.used, set()
+                    for slot in list(lay.packs):
+                        if slot in used:
+                            lay.packed(*slot)     # what the last step launched: the next step most likely launches it again
+                        else:
+                            del lay.packs[slot]   # a shape of an earlier step: rebuilt on demand if it comes back
+                    lay.used = set()              # re-packing is not a use: the next step decides what survives the next prepack
             self._prepack_ev = torch.cuda.Event()
             self._prepack_ev.record()
 
@@ -472,7 +503,8 @@ class DiscriminatorEngine:
             per = lg[:half].numel()
             flat = seeds.reshape(-1)
             for k2, (rows, target) in enumerate(((lg[:half], 1.0), (lg[:half], -1.0), (lg[half:], 1.0))):
-                check(lib.eben_hinge_bwd(ptr(rows), rows.numel(), target, ptr(one), inv_scales, ptr(flat[(k2 + 1) * per:]), _stream()), "hinge_bwd")
+                check(lib.eben_hinge_bwd(ptr(rows), rows.numel(), target, ptr(one), inv_scales * self.seed_weights[k2],
+                                         ptr(flat[(k2 + 1) * per:]), _stream()), "hinge_bwd")
             return self.chains[i].backward(scale, s["xp"][i], fm_per_chain[i], seeds, half, want_param_grads)
 
         # `da` / `one` live on the main stream's pool and are read by the chains: keep them referenced until the join
@@ -510,6 +542,11 @@ class DiscriminatorEngine:
             for i in [n - 1] + list(range(n - 1)):   # the longest chain first
                 with torch.cuda.stream(self._streams[i]):
                     pend[i] = self.chains[i].weight_grads(res[i][1], half, self._sink)
+                    if self._sink is not None:
+                        # data-parallel run: this chain's gradients are in the buckets once its stream gets here -- report them
+                        # now, from this stream, so that the buckets they complete (MelGAN's 75 MB first) are exchanged underneath
+                        # the other chains' weight gradients and the generator backward instead of in front of Adam
+                        self._sink.mark_ready([p for lay in self.chains[i].layers for p in lay.params() if p is not None and p.requires_grad])
             self._pending = (pend, s)   # keeps the saved activations alive until the kernels have run
         self._state = None
         return gb[:half], ga[:half], gb[half:], ga[half:]
@@ -524,9 +561,8 @@ class DiscriminatorEngine:
         for st in set(self._streams):
             main.wait_stream(st)
         sink = getattr(self, "_sink", None)
-        if sink is not None:   # already in the gradient buckets: report them (the buckets' all-reduces start), nothing to inject
+        if sink is not None:   # already in the gradient buckets and reported chain by chain (backward_finish): nothing to inject
             self._pending = self._sink = None
-            sink.mark_ready([p for p in self.disc.parameters() if p.requires_grad])
             return None
         by_param = {}
         for ch, grads in zip(self.chains, pend):

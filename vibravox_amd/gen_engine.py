@@ -1,0 +1,291 @@
+"""Forward / backward of the EBEN generator's convolutional core as explicit kernel chains.
+
+``EBENGenerator.forward`` (``vibravox/torch_modules/dnn/eben_generator.py:168-213``) is a chain of 45 small-channel conv
+layers; through ``torch.autograd`` every ResidualUnit (:287-316) costs three launches and seven tensor passes forward
+(dilated conv, pointwise conv, add) and, backward, two input-gradient launches, a reflect fold, two weight-gradient
+launches and the adds autograd inserts where a gradient fans in.  This engine runs the core -- PQMF analysis, first conv,
+encoder blocks, latent convs, decoder blocks: everything up to the input of ``last_conv`` -- outside autograd:
+
+  * forward: one fused launch per ResidualUnit (``eben_ru_fwd``: x read once; h = dilated(x) and u = lrelu(pointwise(h)) kept
+    for the backward), the shared LeakyReLU of the block inputs (:187-189) folded into that launch's tile staging;
+  * backward: per ResidualUnit ``g_h = pointwise^T(g_y * lrelu'(u))`` and ``g_x = (g_y + fold(dilated^T(g_h))) * lrelu'(x) +
+    skip`` -- the residual / skip joins ride in the reflect-fold pass (``eben_conv1d_bwd_dx_res``), no add kernel runs; the
+    weight gradients are launched beside the input-gradient chain (``ops.weight_grads``: side stream, straight into ``.grad``
+    or the data-parallel buckets);
+  * ``last_conv`` (the leaf of the loss balancing, eben.py:223), the tanh recomposition and the PQMF synthesis stay in
+    autograd: the step differentiates them three extra times with ``retain_graph`` and they are cheap.
+
+Same kernels' arithmetic as the layer-by-layer path (exact fp32 forward; the fused unit sums its products in a different
+order); the module tree, parameters and ``state_dict`` are untouched -- this is only how ``EBENGenerator.forward`` executes.
+"""
+from __future__ import annotations
+
+import ctypes
+import dataclasses
+import os
+from typing import Dict, List, Optional
+
+import torch
+
+from . import ops
+from ._lib import check, load, ptr, stream
+
+USE_FUSED_RU = os.environ.get("EBEN_RU_FUSED", "1") != "0"
+
+
+def _params(m):
+    if m.weight_norm:
+        prm = m.parametrizations["weight"]
+        return prm.original1, prm.original0
+    return m.weight, None
+
+
+class _ConvRec:
+    """What the backward of one conv launch needs."""
+
+    __slots__ = ("m", "spec", "d", "x", "y", "wp_bwd", "norm")
+
+    def __init__(self, m, spec, d, x, y, wp_bwd, norm):
+        self.m, self.spec, self.d, self.x, self.y, self.wp_bwd, self.norm = m, spec, d, x, y, wp_bwd, norm
+
+
+class GeneratorEngine:
+    def __init__(self, gen):
+        self.gen = gen
+        self._spec_cache: Dict[tuple, ops.ConvSpec] = {}
+        self._ru_images: Dict[int, tuple] = {}   # id(ResidualUnit) -> (weights key, image)
+
+    # ---- helpers ------------------------------------------------------------------------------------
+    def _spec(self, m, in_slope=None, out_slope=None) -> ops.ConvSpec:
+        if in_slope is None and out_slope is None:
+            return m.spec
+        key = (id(m), in_slope, out_slope)
+        s = self._spec_cache.get(key)
+        if s is None:
+            kw = {}
+            if in_slope is not None:
+                kw["in_slope"] = float(in_slope)
+            if out_slope is not None:
+                kw["out_slope"] = float(out_slope)
+            s = self._spec_cache[key] = dataclasses.replace(m.spec, **kw)
+        return s
+
+    def _pack(self, m, spec, batch, l_in, train):
+        d = ops.conv_desc(spec, batch, l_in)
+        bm = ops._backward_math[0]
+        d_bwd = ops.conv_desc(spec, batch, l_in, bm) if bm != ops.MATH_F32 else d
+        v, g = _params(m)
+        pw = ops.pack_weights(m.spec, d, v.detach(), None if g is None else g.detach(), m._packed, train, d_bwd)
+        return d, d_bwd, pw
+
+    def _conv(self, m, x, train, in_slope=None, recs=None):
+        """y = conv layer ``m`` on x (its own fused output activation; ``in_slope``: LeakyReLU on load)."""
+        spec = self._spec(m, in_slope=in_slope)
+        b, _, l_in = x.shape
+        d, d_bwd, pw = self._pack(m, spec, b, l_in, train)
+        y = torch.empty((b, spec.c_out, d.l_out), dtype=torch.float32, device=x.device)
+        check(load().eben_conv1d_fwd(ctypes.byref(d), ptr(x), ptr(pw.wp_fwd), ptr(m.bias), None, ptr(y), stream()), "conv1d_fwd")
+        if recs is not None:
+            recs.append(_ConvRec(m, spec, d_bwd, x, y if spec.out_slope != 1.0 else None, pw.wp_bwd, pw.norm))
+        return y
+
+    def _ru_image(self, ru) -> torch.Tensor:
+        """Weight image of the fused unit (both convs, weight-norm scales folded in), rebuilt when a parameter changed."""
+        lib = load()
+        vd, gd = _params(ru.dilated_conv)
+        vp, gp = _params(ru.pointwise_conv)
+        e = ops._storage_epoch
+        key = tuple((t.data_ptr(), t._version, e.get(t.data_ptr(), 0)) for t in (vd, gd, vp, gp)) + (e.get(-1, 0),)
+        hit = self._ru_images.get(id(ru))
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        c = vd.shape[0]
+        dev = vd.device
+        scales = torch.empty((4, c), dtype=torch.float32, device=dev)   # scale / norm of the dilated, then of the pointwise conv
+        ops.wn_scale_multi([(gd.detach(), vd.detach(), c, vd.numel() // c, scales[0], scales[1]), (gp.detach(), vp.detach(), c, vp.numel() // c, scales[2], scales[3])])
+        img = torch.empty(lib.eben_ru_packed_floats(c), dtype=torch.float32, device=dev)
+        check(lib.eben_ru_pack(c, ptr(vd.detach()), ptr(scales[0]), ptr(vp.detach()), ptr(scales[2]), ptr(img), stream()), "ru_pack")
+        self._ru_images[id(ru)] = (key, img)
+        return img
+
+    def prepack(self) -> None:
+        """Rebuilds the fused units' weight images on the side stream (called with ``ops.prepack`` after the optimiser step)."""
+        if not self._ru_images:
+            return
+        units = [ru for blk in list(self.gen.encoder_blocks) + list(self.gen.decoder_blocks) for ru in blk.residuals]
+        dev = _params(units[0].dilated_conv)[0].device
+        main = torch.cuda.current_stream(dev)
+        side = ops._side_stream(dev)
+        side.wait_stream(main)
+        with torch.cuda.stream(side), torch.no_grad():
+            for ru in units:
+                self._ru_image(ru)
+            ev = torch.cuda.Event()
+            ev.record()
+        self._prepacked = ev
+
+    def _residual_unit(self, ru, x, in_slope, train, recs):
+        """y = xin + lrelu(pointwise(dilated(xin))), xin = lrelu(x, in_slope).  Returns y; records (x, h, u) for the backward."""
+        lib = load()
+        b, c, l = x.shape
+        dil, pwc = ru.dilated_conv, ru.pointwise_conv
+        if train:
+            # the backward images of the two convs (and their weight-norm norms) come from the per-layer caches
+            spec_d = self._spec(dil, in_slope=in_slope if in_slope != 1.0 else None)
+            _, dd_bwd, pw_d = self._pack(dil, spec_d, b, l, True)
+            _, dp_bwd, pw_p = self._pack(pwc, pwc.spec, b, l, True)
+        if USE_FUSED_RU and c in (32, 64, 128) and dil.spec.ksize == 3 and dil.spec.reflect:
+            img = self._ru_image(ru)
+            y = torch.empty_like(x)
+            h = torch.empty_like(x) if train else None
+            u = torch.empty_like(x) if train else None
+            check(lib.eben_ru_fwd(b, c, l, dil.spec.dilation, ptr(x), float(in_slope), float(pwc.spec.out_slope), ptr(img), ptr(y), ptr(h), ptr(u),
+                                  stream()), "ru_fwd")
+        else:   # layer by layer (bisecting aid, EBEN_RU_FUSED=0)
+            xin = x
+            if in_slope != 1.0:
+                xin = torch.empty_like(x)
+                check(lib.eben_lrelu_fwd(ptr(x), ptr(xin), x.numel(), float(in_slope), stream()), "lrelu_fwd")
+            h = self._conv(dil, xin, train)
+            u = self._conv(pwc, h, train)
+            y = torch.empty_like(x)
+            check(lib.eben_add(ptr(xin), ptr(u), ptr(y), x.numel(), stream()), "add")
+        if train:
+            recs.append(("ru", _ConvRec(dil, spec_d, dd_bwd, x, None, pw_d.wp_bwd, pw_d.norm), _ConvRec(pwc, pwc.spec, dp_bwd, h, u, pw_p.wp_bwd, pw_p.norm)))
+        return y
+
+    # ---- forward -------------------------------------------------------------------------------------
+    def forward(self, cut_audio: torch.Tensor, train: bool):
+        """Returns (input of last_conv, first_bands, records for ``backward`` or None)."""
+        gen = self.gen
+        lib = load()
+        ev = getattr(self, "_prepacked", None)
+        if ev is not None:
+            self._prepacked = None
+            torch.cuda.current_stream().wait_event(ev)
+        slope = gen.nl.negative_slope
+        first_bands = gen.pqmf(cut_audio, "analysis", bands=gen.p).detach()
+        saved = {"enc": [], "dec": [], "misc": []} if train else None
+        a = self._conv(gen.first_conv, first_bands, train, recs=saved["misc"] if train else None)
+        skips = []
+        for blk in gen.encoder_blocks:
+            recs = [] if train else None
+            cur = a
+            for k, ru in enumerate(blk.residuals):
+                cur = self._residual_unit(ru, cur, slope if k == 0 else 1.0, train, recs)
+            a = self._conv(blk.conv, cur, train, recs=recs)
+            skips.append(a)
+            if train:
+                saved["enc"].append(recs)
+        lat = [] if train else None
+        l1 = self._conv(gen.latent_conv[1], a, train, in_slope=slope, recs=lat)
+        cur = self._conv(gen.latent_conv[3], l1, train, recs=lat)
+        if train:
+            saved["latent"] = lat
+        for blk, skip in zip(gen.decoder_blocks, reversed(skips)):
+            recs = [] if train else None
+            s = torch.empty_like(cur)
+            check(lib.eben_add(ptr(cur), ptr(skip), ptr(s), cur.numel(), stream()), "add")
+            cur = self._conv(blk.conv_trans, s, train, recs=recs)
+            for ru in blk.residuals:
+                cur = self._residual_unit(ru, cur, 1.0, train, recs)
+            if train:
+                saved["dec"].append(recs)
+        return cur, first_bands, saved
+
+    # ---- backward ------------------------------------------------------------------------------------
+    @staticmethod
+    def _dx(rec: _ConvRec, dy, res_pre=None, res_post=None):
+        lib = load()
+        d = rec.d
+        ws_bytes = lib.eben_conv1d_bwd_dx_workspace(ctypes.byref(d))
+        ws = ops._empty(ws_bytes, dy) if ws_bytes else None
+        dx = torch.empty_like(rec.x)
+        xmask = rec.x if rec.spec.in_slope != 1.0 else None
+        check(lib.eben_conv1d_bwd_dx_res(ctypes.byref(d), ptr(dy), ptr(rec.y), ptr(rec.wp_bwd), ptr(xmask), ptr(res_pre), ptr(res_post), ptr(dx),
+                                         ptr(ws), ws_bytes, stream()), "conv1d_bwd_dx_res")
+        return dx
+
+    @staticmethod
+    def _dw(rec: _ConvRec, dy):
+        if ops._skip_weight_grads[0]:
+            return
+        v, g = _params(rec.m)
+        if not v.requires_grad:
+            return
+        grads = ops.weight_grads(rec.d, dy, rec.y, rec.x, v, g, rec.m.bias, rec.norm)
+        for p, t in zip((v, g, rec.m.bias), grads):   # not deferred (no side-stream context): accumulate like autograd would
+            if p is not None and t is not None:
+                p.grad = t if p.grad is None else p.grad.add_(t)
+                for hook in list((getattr(p, "_post_accumulate_grad_hooks", None) or {}).values()):
+                    hook(p)   # e.g. ddp.GradSync's bucket accounting
+
+    def _ru_backward(self, rec, gy, res_post=None):
+        _, dil, pwc = rec
+        gh = self._dx(pwc, gy)                       # pointwise^T(gy * lrelu'(u))
+        self._dw(pwc, gy)
+        gx = self._dx(dil, gh, res_pre=gy, res_post=res_post)   # (gy + fold(dilated^T gh)) * lrelu'(x) + skip gradient
+        self._dw(dil, gh)
+        return gx
+
+    @torch.no_grad()
+    def backward(self, saved, g_pre: torch.Tensor) -> None:
+        """Input-gradient chain on the current stream, weight gradients through ``ops.weight_grads`` (inside
+        ``ops.weight_grads_on_side_stream()``: beside the chain, joined by the caller)."""
+        g = g_pre.contiguous()
+        skip_grads: List[Optional[torch.Tensor]] = []
+        for recs in reversed(saved["dec"]):           # decoder blocks, last first: [conv_trans, ru, ru, ru]
+            for rec in reversed(recs[1:]):
+                g = self._ru_backward(rec, g)
+            ct = recs[0]
+            gs = self._dx(ct, g)                      # gradient at (x + skip)
+            self._dw(ct, g)
+            skip_grads.append(gs)                     # dec2 -> a1, dec1 -> a2, dec0 -> a3
+            g = gs
+        c1, c2 = saved["latent"]
+        gl1 = self._dx(c2, g)
+        self._dw(c2, g)
+        g = self._dx(c1, gl1, res_post=skip_grads[-1])   # a3: latent path (masked by lrelu'(a3)) + the decoder's skip
+        self._dw(c1, gl1)
+        n_enc = len(saved["enc"])
+        for i in range(n_enc - 1, -1, -1):            # encoder blocks, last first: [ru, ru, ru, conv]
+            recs = saved["enc"][i]
+            conv = recs[-1]
+            gy = self._dx(conv, g)
+            self._dw(conv, g)
+            for rec in reversed(recs[1:-1]):
+                gy = self._ru_backward(rec, gy)
+            # the block's input a_i is also a decoder block's skip: that gradient joins behind the activation mask
+            post = skip_grads[i - 1] if i >= 1 else None   # skip_grads: [a1 (dec2), a2 (dec1), a3 (dec0)]
+            g = self._ru_backward(recs[0], gy, res_post=post)
+        self._dw(saved["misc"][0], g)                 # first_conv: its input is data, only the weight gradient
+
+
+class _CoreFn(torch.autograd.Function):
+    """The engine behind autograd: outputs (input of last_conv, first_bands); the parameters are arguments only so that the
+    graph knows the output depends on them -- their gradients are produced by the engine, not returned."""
+
+    @staticmethod
+    def forward(ctx, x, engine, *params):
+        pre, first_bands, saved = engine.forward(x, True)
+        ctx.engine, ctx.saved = engine, saved
+        ctx.mark_non_differentiable(first_bands)
+        return pre, first_bands
+
+    @staticmethod
+    def backward(ctx, g_pre, _g_fb):
+        ctx.engine.backward(ctx.saved, g_pre)
+        return (None, None) + (None,) * (len(ctx.needs_input_grad) - 2)
+
+
+def core(gen, cut_audio: torch.Tensor):
+    """(input of ``gen.last_conv``, first_bands) through the engine; differentiable w.r.t. the generator's parameters."""
+    engine = getattr(gen, "_engine", None)
+    if engine is None:
+        engine = GeneratorEngine(gen)
+        object.__setattr__(gen, "_engine", engine)   # not a submodule / buffer: invisible to state_dict
+    params = [p for p in gen.parameters() if p.requires_grad]
+    if torch.is_grad_enabled() and params:
+        return _CoreFn.apply(cut_audio.contiguous(), engine, *params)
+    pre, first_bands, _ = engine.forward(cut_audio.contiguous(), False)
+    return pre, first_bands

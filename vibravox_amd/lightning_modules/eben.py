@@ -46,16 +46,12 @@ def _takes_grad_scale(optimizer) -> bool:
         return False
 
 
-#: ``disc_math`` names -> what ``DiscriminatorEngine`` runs: one EBEN_MATH_* for every contraction, or (forward, input gradient,
-#: weight gradient).  "bf16": bf16 MFMA operands with the ACTIVATION operand of the forward and of the weight gradient kept as
-#: hi + lo (EBEN_MATH_BF16X2) -- the discriminator's gradient is the difference of two nearly equal hinge branches, and the
-#: part of the activations that differs between items sits below the 2^-9 grid of their common part; with it kept the
-#: discriminator gradient stays within a few percent of the fp32 step's (tests/test_gpu_models.py), without it tens of
-#: percent ("bf16_plain": every operand single bf16).
+#: ``disc_math`` names -> what ``DiscriminatorEngine`` runs (see its ``math`` argument).
 DISC_MATH_PLANS = {
     "f32": ops.MATH_F32,
-    "bf16": (ops.MATH_BF16X2, ops.MATH_BF16, ops.MATH_BF16X2),
     "bf16_plain": ops.MATH_BF16,
+    "bf16": {"pqmf": (ops.MATH_F32, ops.MATH_BF16, ops.MATH_BF16), "melgan": ops.MATH_BF16},
+    "bf16x2": (ops.MATH_BF16X2, ops.MATH_BF16, ops.MATH_BF16X2),
 }
 
 #: generator-side loss terms in the reference's insertion order (eben.py:195-211): logged name, the module attribute that holds
@@ -266,6 +262,8 @@ class EBENLightningModule(BaseSELightningModule):
         self._mark("generator Adam")
         if self.prepack_weights:
             ops.prepack(self._hip_convs(self.generator))   # next step's generator images, under the discriminator phase
+            if getattr(self.generator, "_engine", None) is not None:
+                self.generator._engine.prepack()
 
         # ---- discriminator phase: the gradients of real_loss + fake_loss are already there
         if update_discriminator:

@@ -52,12 +52,17 @@ class weight_grads_disabled:
 # weight-norm chain rule.  Inside `weight_grads_on_side_stream()` the second group is issued on a side
 # stream, so the input-gradient chain of the whole network is not held up by it (generator backward:
 # ~2.9 ms of dX launches instead of ~8.6 ms of everything in series).  The caller must `join()` before
-# anything on the main stream reads the parameter gradients (the optimiser step); only valid while
-# `.grad` is None for the parameters involved (AccumulateGrad then just stores the tensor).
-# `keep` holds a reference to every upstream gradient a side-stream kernel reads until `join()`: autograd
-# sums gradients IN PLACE into a buffer it holds the only reference to (a residual add hands the same
-# tensor to both branches), which would rewrite the gradient on the main stream under the kernel reading it.
-_side = {"enabled": False, "stream": None, "keep": [], "prepacked": None, "wn_jobs": [], "sink": None, "sunk": []}
+# anything on the main stream reads the parameter gradients (the optimiser step); only used while
+# `.grad` is None for the parameters involved and no accumulation hook hangs on them: the deferred gradients never pass through
+# autograd -- backward() returns None for them and `join()` assigns `p.grad` itself once the side stream is done.
+# `keep` holds a reference to every upstream gradient a side-stream kernel reads until `join()`: autograd sums gradients IN PLACE
+# into a buffer it holds the only reference to (a residual add hands the same tensor to both branches), which would rewrite the
+# gradient on the main stream under the kernel reading it.
+_side = {"enabled": False, "stream": None, "keep": [], "prepacked": None, "wn_jobs": [], "sink": None, "sunk": [], "assign": []}
+
+
+def _no_grad_hooks(p) -> bool:
+    return p is None or (not getattr(p, "_post_accumulate_grad_hooks", None) and not p._backward_hooks)
 
 
 class weight_grads_on_side_stream:
@@ -74,8 +79,16 @@ class weight_grads_on_side_stream:
         _side["enabled"], _side["sink"] = True, self.sink
         return self
 
-    def __exit__(self, *exc):
+    def __exit__(self, exc_type, *exc):
         _side["enabled"], _side["sink"] = self.prev
+        if exc_type is not None:
+            # a backward that raised half-way leaves jobs pointing at tensors nobody will hand over: wait for what was
+            # launched, then drop everything instead of letting the next join() write through stale pointers
+            st = _side["stream"]
+            if st is not None:
+                torch.cuda.current_stream(st.device).wait_stream(st)
+            for key in ("wn_jobs", "keep", "sunk", "assign"):
+                _side[key] = []
 
     def join(self):
         st = _side["stream"]
@@ -86,6 +99,14 @@ class weight_grads_on_side_stream:
                 _side["wn_jobs"] = []
             torch.cuda.current_stream(st.device).wait_stream(st)
         _side["keep"].clear()
+        assign, _side["assign"] = _side["assign"], []
+        for p, t in assign:   # complete on this stream from here on (allocated on the side stream's pool: tell the allocator)
+            if st is not None:
+                t.record_stream(torch.cuda.current_stream(st.device))
+            if p.grad is None:
+                p.grad = t
+            else:
+                p.grad.add_(t)
         if _side["sunk"]:
             sunk, _side["sunk"] = _side["sunk"], []
             self.sink.mark_ready(sunk)
@@ -220,6 +241,8 @@ def conv_desc(spec: ConvSpec, batch: int, l_in: int, math: int = MATH_F32) -> Eb
     key = (spec, batch, l_in, math)
     d = _desc_cache.get(key)
     if d is None:
+        if len(_desc_cache) >= 4096:   # variable clip lengths ("pad" collation): do not grow without bound
+            _desc_cache.clear()
         d = EbenConv1dDesc(
             batch, spec.c_in, spec.c_out, l_in, spec.out_len(l_in), spec.ksize, spec.stride, spec.dilation, spec.groups,
             spec.pad_l, spec.pad_r, 1 if spec.reflect else 0, 1 if spec.transposed else 0, spec.in_slope, spec.out_slope, math,
@@ -321,6 +344,67 @@ def join_prepack() -> None:
         torch.cuda.current_stream().wait_event(ev)
 
 
+def weight_grads(d: EbenConv1dDesc, dy: torch.Tensor, y: Optional[torch.Tensor], x: torch.Tensor, v: torch.Tensor,
+                 g: Optional[torch.Tensor], bias: Optional[torch.Tensor], norm: Optional[torch.Tensor]):
+    """Weight (+ bias) gradient of one conv layer: ``eben_conv1d_bwd_dw`` into split-K slabs, then the slab sum and the
+    weight-norm chain rule.  dy: gradient at the layer output (``y``: the saved output when a fused output activation has to
+    be differentiated, else None); x: the layer input; v / g / bias: the PARAMETERS (g, bias may be None); norm: ||v|| rows.
+    Returns (dv, dg, dbias) -- or Nones for gradients that were deferred: inside ``weight_grads_on_side_stream()`` the work is
+    issued on the side stream, and the results are either written straight into the sink's buckets (reported at ``join()``)
+    or assigned to ``.grad`` by ``join()`` (never handed to autograd: it may clone what it is given, and the deferred
+    kernels would then fill a tensor nobody reads)."""
+    lib = load()
+    has_g, has_bias = g is not None, bias is not None
+    is_param = isinstance(v, torch.nn.Parameter)
+    use_side = (_side["enabled"] and is_param and v.grad is None and (g is None or g.grad is None) and (bias is None or bias.grad is None)
+                and _no_grad_hooks(v) and _no_grad_hooks(g) and _no_grad_hooks(bias))
+    sunk = None
+    if _side["enabled"] and not use_side and _side["sink"] is not None:
+        # data-parallel run: p.grad is a view of a gradient bucket -- write the results there directly
+        sk = _side["sink"]
+        sunk = (sk.grad_buffer(v), sk.grad_buffer(g) if has_g else None, sk.grad_buffer(bias) if has_bias else None)
+        if sunk[0] is None or (has_g and sunk[1] is None) or (has_bias and sunk[2] is None):
+            sunk = None
+        use_side = sunk is not None
+    if use_side:
+        main = torch.cuda.current_stream(x.device)
+        side = _side_stream(x.device)
+        side.wait_stream(main)   # dy (and everything saved by the forward) is complete on the main stream
+        for t in (dy, x, y, v, g, norm):
+            if t is not None:
+                t.record_stream(side)
+        _side["keep"].append(dy)
+        stream_ctx = torch.cuda.stream(side)
+    else:
+        stream_ctx = contextlib.nullcontext()
+    with stream_ctx:
+        sw = stream()
+        nslab, row_stride = ctypes.c_int(0), ctypes.c_int(0)
+        ws_bytes = lib.eben_conv1d_bwd_dw_workspace(ctypes.byref(d), ctypes.byref(nslab), ctypes.byref(row_stride))
+        slabs = _empty(ws_bytes, x)
+        check(lib.eben_conv1d_bwd_dw(ctypes.byref(d), ptr(dy), ptr(y), ptr(x), 1 if has_bias else 0, ptr(slabs), ws_bytes, sw), "conv1d_bwd_dw")
+        rows = v.shape[0]
+        cols = v.numel() // rows
+        if sunk is not None:
+            dv, dg, dbias = sunk
+        else:
+            dv = torch.empty_like(v)
+            dg = torch.empty_like(g) if has_g else None
+            dbias = torch.empty(rows, dtype=torch.float32, device=x.device) if has_bias else None
+        job = (slabs, nslab.value, rows * row_stride.value, rows, cols, row_stride.value, g.detach() if has_g else None, v.detach(),
+               norm if has_g else None, dg, dv, dbias)
+        if use_side:
+            # the slab sums and the weight-norm chain rule of ALL layers are issued as one multi-tensor launch at join()
+            _side["wn_jobs"].append(job)
+            if sunk is None:
+                _side["assign"].extend((p, t) for p, t in ((v, dv), (g, dg), (bias, dbias)) if p is not None and t is not None)
+            else:
+                _side["sunk"].extend(p for p in (v, g, bias) if p is not None)
+            return None, None, None
+        wn_bwd_multi([job])
+    return dv, dg, dbias
+
+
 class _ConvLayerFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, v, g, bias, spec: ConvSpec, cache):
@@ -347,7 +431,10 @@ class _ConvLayerFn(torch.autograd.Function):
         ctx.spec, ctx.d = spec, d_bwd   # the descriptor the backward launches use
         ctx.wp_bwd, ctx.norm = pw.wp_bwd, pw.norm
         ctx.has_g, ctx.has_bias = g is not None, bias is not None
-        ctx.bias_param = bias   # identity only: the gradient sink looks its bucket view up by parameter
+        # identities only: the gradient sink looks its bucket views up by parameter, join() assigns .grad to them
+        ctx.bias_param = bias
+        ctx.v_param = v if isinstance(v, torch.nn.Parameter) else None
+        ctx.g_param = g if isinstance(g, torch.nn.Parameter) else None
         ctx.save_for_backward(x, v, g, y if spec.out_slope != 1.0 else None)
         return y
 
@@ -367,54 +454,9 @@ class _ConvLayerFn(torch.autograd.Function):
                   "conv1d_bwd_dx")
         want_w = ctx.needs_input_grad[1] or (ctx.has_g and ctx.needs_input_grad[2]) or (ctx.has_bias and ctx.needs_input_grad[3])
         if want_w and not _skip_weight_grads[0]:
-            use_side = _side["enabled"] and v.grad is None and (g is None or g.grad is None)
-            sunk = None
-            if _side["enabled"] and not use_side and _side["sink"] is not None:
-                # data-parallel run: p.grad is a view of a gradient bucket -- write the results there directly
-                sk = _side["sink"]
-                sunk = (sk.grad_buffer(v), sk.grad_buffer(g) if ctx.has_g else None, sk.grad_buffer(ctx.bias_param) if ctx.has_bias else None)
-                if sunk[0] is None or (ctx.has_g and sunk[1] is None) or (ctx.has_bias and sunk[2] is None):
-                    sunk = None
-                use_side = sunk is not None
-            if use_side:
-                main = torch.cuda.current_stream(x.device)
-                side = _side_stream(x.device)
-                side.wait_stream(main)   # dy (and everything saved by the forward) is complete on the main stream
-                for t in (dy, x, y, v, g, ctx.norm):
-                    if t is not None:
-                        t.record_stream(side)
-                _side["keep"].append(dy)
-                stream_ctx = torch.cuda.stream(side)
-            else:
-                stream_ctx = contextlib.nullcontext()
-            with stream_ctx:
-                sw = stream()
-                nslab, row_stride = ctypes.c_int(0), ctypes.c_int(0)
-                ws_bytes = lib.eben_conv1d_bwd_dw_workspace(ctypes.byref(d), ctypes.byref(nslab), ctypes.byref(row_stride))
-                slabs = _empty(ws_bytes, x)
-                check(lib.eben_conv1d_bwd_dw(ctypes.byref(d), ptr(dy), ptr(y), ptr(x), 1 if ctx.has_bias else 0, ptr(slabs), ws_bytes, sw),
-                      "conv1d_bwd_dw")
-                rows = v.shape[0]
-                cols = v.numel() // rows
-                if sunk is not None:
-                    dv, dg, dbias = sunk
-                else:
-                    dv = torch.empty_like(v)
-                    dg = torch.empty_like(g) if ctx.has_g else None
-                    dbias = torch.empty(rows, dtype=torch.float32, device=x.device) if ctx.has_bias else None
-                job = (slabs, nslab.value, rows * row_stride.value, rows, cols, row_stride.value, g if ctx.has_g else None, v,
-                       ctx.norm if ctx.has_g else None, dg, dv, dbias)
-                if use_side:
-                    # .grad is None for these parameters: AccumulateGrad just stores dv / dg / dbias -- PROVIDED nothing else
-                    # references them (it clones a gradient it does not own exclusively), so the deferred job keeps their
-                    # device pointers, not the tensors.  The slab sums and the weight-norm chain rule of ALL layers are
-                    # then issued as one multi-tensor launch at join().
-                    _side["wn_jobs"].append(job[:9] + (ptr(dg), ptr(dv), ptr(dbias)))
-                else:
-                    wn_bwd_multi([job])
-            if sunk is not None:   # autograd gets nothing for these parameters; join() reports them to the sink
-                _side["sunk"].extend(p for p in (v, g if ctx.has_g else None, ctx.bias_param if ctx.has_bias else None) if p is not None)
-                dv = dg = dbias = None
+            dv, dg, dbias = weight_grads(d, dy, y, x, ctx.v_param if ctx.v_param is not None else v,
+                                         (ctx.g_param if ctx.g_param is not None else g) if ctx.has_g else None,
+                                         ctx.bias_param if ctx.has_bias else None, ctx.norm)
         return dx, dv, dg, dbias, None, None
 
 

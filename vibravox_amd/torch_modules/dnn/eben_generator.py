@@ -9,6 +9,8 @@ so the default-init RNG stream under ``torch.manual_seed``) matches the referenc
 """
 from __future__ import annotations
 
+import os
+
 import torch
 from torch import nn
 
@@ -112,7 +114,18 @@ class EBENGenerator(nn.Module, PyTorchModelHubMixin):
         self.decoder_blocks = nn.ModuleList([DecBlock(out_channels=c, stride=s, nl=self.nl) for c, s in DECODER])
         self.last_conv = HipConv1d(32, 4, 3, padding="same", bias=False, padding_mode="reflect", weight_norm=False)
 
+    #: run everything up to ``last_conv`` through ``vibravox_amd.gen_engine`` (fused ResidualUnit launches, explicit backward
+    #: chain) instead of module by module through autograd; same parameters, same values
+    use_engine: bool = os.environ.get("EBEN_GEN_ENGINE", "1") != "0"
+
     def forward(self, cut_audio):
+        if self.use_engine and cut_audio.is_cuda:
+            from ... import gen_engine
+
+            x, first_bands = gen_engine.core(self, cut_audio)
+            x = self.last_conv(x)
+            enhanced_speech_decomposed = ops.tanh_lift(x, first_bands)
+            return self.pqmf.synthesis_sum(enhanced_speech_decomposed), enhanced_speech_decomposed
         first_bands = self.pqmf(cut_audio, "analysis", bands=self.p)
         x = self.first_conv(first_bands)
         skips = []

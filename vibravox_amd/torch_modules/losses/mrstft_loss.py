@@ -23,7 +23,20 @@ import torch
 from ... import ops
 
 
+_DATA = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "data")
+
+
 def a_weighting_taps(fs: float, ntaps: int = 101) -> torch.Tensor:
+    """The A-weighting FIR of auraloss ``FIRFilter("aw")``.  For the reference's configuration (16 kHz, 101 taps:
+    multi_stft.yaml:15,18) the committed table is loaded -- the design runs through scipy's ``firls`` and must not move with
+    the scipy installed on the box; ``tests/test_oracle_golden.py`` checks that it still regenerates to 1e-7."""
+    path = os.path.join(_DATA, f"a_weighting_fir_{int(fs)}_{int(ntaps)}.npy")
+    if float(fs) == int(fs) and os.path.exists(path):
+        return torch.from_numpy(np.load(path).astype("float32"))
+    return design_a_weighting_taps(fs, ntaps)
+
+
+def design_a_weighting_taps(fs: float, ntaps: int = 101) -> torch.Tensor:
     """IEC A-weighting prototype -> bilinear -> freqz(512) -> firls(ntaps) (auraloss FIRFilter 'aw')."""
     import scipy.signal
 
