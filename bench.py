@@ -56,14 +56,29 @@ def build_module(device, batch_seed):
 
 
 def pmc_traffic(batch, math):
-    """HBM bytes per launch of the roofline kernel from the committed rocprofv3 PMC passes
-    (profiles/r01_pmc_melgan_l4_fwd[_bf16].json; collected by tools/pmc_traffic.sh at the batch the step launches)."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_melgan_l4_fwd_bf16.json" if math == "bf16" else "r01_pmc_melgan_l4_fwd.json")
+    """HBM bytes per launch of the roofline kernel from this round's rocprofv3 PMC passes (profiles/r02_pmc_melgan_l4_fwd_<math>.json,
+    written by tools/pmc_traffic.sh + tools/pmc_summary.py for the build whose commit it records, at the batch the step launches;
+    FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  None when the record is missing or of another batch."""
+    path = os.path.join(ROOT, "profiles", f"r02_pmc_melgan_l4_fwd_{math}.json")
     if not os.path.exists(path):
         return None
     with open(path) as f:
         rec = json.load(f)
     return rec.get("traffic_bytes_per_launch") if rec.get("launch_batch") == batch else None
+
+
+def noisy_bwe_source(device, n_items=64, seed=4321):
+    """BASELINE config 4: a resident pool of synthetic (speech, airborne, speechless-noise) clips of ragged lengths (1.9-3.4 s at
+    16 kHz, the noise at least as long as its speech), from which every step assembles its batch ON THE DEVICE: the reference's
+    collator arithmetic (noisybwe.py:219-291: random noise slice, add, random crop / pad to 2.5 s) as one gather kernel, then the
+    waveform augmentation (data_augmentation.py:38-71; time masking only: the other two transforms change the clip length)."""
+    g = torch.Generator().manual_seed(seed)
+    items = []
+    for _ in range(n_items):
+        n = int(torch.randint(30400, 54400, (1,), generator=g))
+        items.append({"audio_body_conducted": (0.1 * torch.randn(n, generator=g)).to(device), "audio_airborne": (0.1 * torch.randn(n, generator=g)).to(device),
+                      "audio_body_conducted_speechless_noisy": (0.05 * torch.randn(n + int(torch.randint(1, 16000, (1,), generator=g)), generator=g)).to(device)})
+    return items
 
 
 def synthetic_batch(batch, length, seed, device):
@@ -72,54 +87,81 @@ def synthetic_batch(batch, length, seed, device):
             "audio_airborne": (0.1 * torch.randn(batch, 1, length, generator=g)).to(device)}
 
 
-def cpu_baseline(batch, length, steps):
-    """The CPU oracle (oracle/eben_oracle.py, a restatement pinned to the reference by golden
-    fixtures) running the reference's as-executed step order on the host cores."""
+def cpu_baseline(batch, length, steps, threads):
+    """The CPU oracle (oracle/eben_oracle.py, a restatement pinned to the reference by golden fixtures) running the
+    reference's as-executed step order on the host cores: `steps` timed steps after one warm-up."""
     from oracle import eben_oracle as O
     from vibravox_amd.torch_modules.dnn.eben_discriminator import DiscriminatorEBENMultiScales
     from vibravox_amd.torch_modules.dnn.eben_generator import EBENGenerator
 
-    # torch's intra-op pool.  Measured on the GPU host (2 x EPYC 9575F, 256 hardware threads) at the
-    # full batch 32: 8 threads 9.9, 16 threads 14.8, 32 threads 10.6 audio-s/s, 256 threads > 20x slower
-    # -- these convolutions do not scale past ~16 threads, so 16 is the fairest setting.
-    avail = len(os.sched_getaffinity(0))
-    cores = int(os.environ.get("EBEN_CPU_THREADS", "0")) or max(1, min(16, avail))
-    torch.set_num_threads(cores)
+    torch.set_num_threads(threads)
     torch.manual_seed(42)
     gen, disc = EBENGenerator(m=4, n=32, p=2), DiscriminatorEBENMultiScales(q=4, min_channels=24)
     trainer = O.OracleTrainer({k: v.detach() for k, v in gen.state_dict().items()}, {k: v.detach() for k, v in disc.state_dict().items()})
     data = synthetic_batch(batch, length, 1234, "cpu")
     trainer.step(data["audio_body_conducted"], data["audio_airborne"])  # warm-up (first call is ~17x slower)
-    t0 = time.perf_counter()
+    times = []
     for _ in range(steps):
+        t0 = time.perf_counter()
         trainer.step(data["audio_body_conducted"], data["audio_airborne"])
-    dt = (time.perf_counter() - t0) / steps
+        times.append(time.perf_counter() - t0)
     cut = length - (length + 32) % 256
-    return {"value": round(batch * cut / 16000 / dt, 3), "unit": "audio-seconds/sec", "cores": cores, "kind": "port",
-            "sample": f"{steps} timed step(s) after 1 warm-up, batch {batch} x {length} samples, fp32, reference as-executed order, {dt:.2f} s/step"}
+    dt = sum(times) / len(times)
+    return batch * cut / 16000 / dt, dt, times
+
+
+def percentile(sorted_vals, q):
+    if not sorted_vals:
+        return None
+    k = (len(sorted_vals) - 1) * q
+    lo, hi = int(k), min(int(k) + 1, len(sorted_vals) - 1)
+    return sorted_vals[lo] + (sorted_vals[hi] - sorted_vals[lo]) * (k - lo)
+
+
+# SURVEY.md section 8d: MACs of ONE forward pass at batch 32 x 31968 samples (both scale with batch x length)
+G_MACS, D_MACS = 4.3008e10, 1.6147e11
+D_PQMF_MACS = 1.398e10 + 1.361e10 + 1.324e10   # the three PQMF-band discriminators (section 8a, row a10)
+G_BYTES = 2.318e9                              # generator activations in + out, one pass, fp32
+HBM_PEAK = 8.0e12
+
+
+def step_roofline_ms(disc_math, scale):
+    """Mixed roofline of the minimal step F_min = 2 (3 G + 8 D): sum over the parts of max(FLOP / peak(dtype), bytes / HBM).
+    fp32: everything on the fp32 MFMA peak.  bf16: the discriminator passes on the bf16 MFMA peak except the PQMF-band forwards (2 of
+    the 8 passes of those three chains), which this build keeps in fp32; the generator's forward is fp32 compute, its backward
+    (2 G, bf16 operands) is bound by its activation traffic."""
+    f32, bf16 = MFMA_F32_PEAK_TFLOPS * 1e12, MFMA_BF16_PEAK_TFLOPS * 1e12
+    if disc_math == "f32":
+        t = 2 * (3 * G_MACS + 8 * D_MACS) / f32
+    else:
+        t = 2 * (8 * D_MACS - 2 * D_PQMF_MACS) / bf16 + 2 * 2 * D_PQMF_MACS / f32
+        t += max(2 * G_MACS / f32, G_BYTES / HBM_PEAK) + max(2 * 2 * G_MACS / bf16, 2 * G_BYTES / HBM_PEAK)
+    return t * scale * 1e3
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32, help="clips per GPU (BASELINE config 2: 32)")
     ap.add_argument("--length", type=int, default=32000)
+    ap.add_argument("--workload", default="bwe", choices=["bwe", "noisybwe"],
+                    help="bwe: BASELINE config 2 (resident synthetic batch); noisybwe: config 4 (every step assembles its batch on the "
+                         "device from a resident pool of ragged clips: noise mixing + crop/pad to 2.5 s + time masking, then the same step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=32)
-    ap.add_argument("--cpu-steps", type=int, default=1)
+    ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--force-ddp", action="store_true", help="run the bucketed RCCL gradient path even with one rank")
-    ap.add_argument("--disc-math", default=os.environ.get("EBEN_DISC_MATH", "bf16"), choices=["bf16", "f32"],
-                    help="discriminator contractions: bf16 MFMA operands with fp32 accumulate (BASELINE config 2 names bf16) or exact "
-                         "fp32 products; the generator computes in fp32 either way")
+    ap.add_argument("--disc-math", default=os.environ.get("EBEN_DISC_MATH", "bf16"), choices=["bf16", "f32", "bf16_plain"],
+                    help="discriminator contractions: 'bf16' = bf16 MFMA operands with fp32 accumulate (BASELINE config 2 names bf16; the "
+                         "PQMF-band discriminators' forward stays fp32, see DESIGN.md), 'f32' = exact fp32 products, 'bf16_plain' = every "
+                         "contraction on single bf16 operands; the generator's forward computes in fp32 either way")
     ap.add_argument("--gen-bwd-math", default=None, choices=["bf16", "f32"],
-                    help="generator backward contractions (default: same as --disc-math); the generator forward is always fp32")
+                    help="generator backward contractions (default: bf16 with a bf16 discriminator, else f32)")
     ap.add_argument("--stft-math", default=None, choices=["bf16x3", "folded", "dense"],
-                    help="MRSTFT windowed-DFT contractions (default: 'folded', exact fp32 on the even / odd parts of the frames; "
-                         "'bf16x3' = hi/lo bf16 operand splits on the bf16 MFMA, ~2^-17 relative: measured slower on the tap-conv "
-                         "kernel, whose tile staging dominates a pointwise contraction over 1800-3600 channels)")
-    ap.add_argument("--no-f32-leg", action="store_true", help="skip the extra fp32-discriminator timing reported beside a bf16 run")
+                    help="MRSTFT windowed-DFT contractions (default: 'folded', exact fp32 on the even / odd parts of the frames)")
+    ap.add_argument("--no-f32-leg", action="store_true", help="skip the extra fp32 timing reported beside a bf16 run")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -142,32 +184,80 @@ def main():
     from vibravox_amd.ddp import BucketedZeroGrad, GradSync
 
     mod = build_module(device, 1234 + rank)
+    bf16 = args.disc_math != "f32"
     mod.disc_math = args.disc_math
-    mod.gen_backward_math = args.gen_bwd_math or args.disc_math
+    mod.gen_backward_math = args.gen_bwd_math or ("bf16" if bf16 else "f32")
     mod.stft_math = args.stft_math or "folded"
     gen_bwd_math, stft_math = mod.gen_backward_math, mod.stft_math   # of the measured steps (the fp32 leg below changes the module's)
+    syncs = []
     if use_ddp:
         g_opt, d_opt = mod.optimizers()
         gs, ds = GradSync(mod.generator.parameters()), GradSync(mod.discriminator.parameters())
+        gs.profile = ds.profile = True
         g_w, d_w = BucketedZeroGrad(g_opt, gs), BucketedZeroGrad(d_opt, ds)
         mod._optimizers = [g_w, d_w]
         mod.grad_sync = {id(g_w): gs, id(d_w): ds}
-    batch = synthetic_batch(args.batch, args.length, 1234 + rank, device)
-    cut = args.length - (args.length + 32) % 256
+        syncs = [("generator", gs), ("discriminator", ds)]
 
-    # dominant kernel: MelGAN layer 4 (1024->1024, k41, s4, g4) forward, 52 % of conv MACs sit in L3-L5
-    layer = mod.discriminator.melgan_discriminator.discriminator[4][0]
-    timer = ops.KernelTimer(layer.spec)
-    ops.set_kernel_timer(timer)
+    if args.workload == "noisybwe":
+        from vibravox_amd.augment import WaveformDataAugmentation
+        from vibravox_amd.collate import noisy_bwe_collate
+
+        pool = noisy_bwe_source(device, seed=4321 + rank)
+        augment = WaveformDataAugmentation(16000, p_data_augmentation=1.0, p_speed_perturbation=0.0, p_pitch_shift=0.0, p_time_masking=1.0)
+        length = 40000   # collate_strategy constant_length-2500-ms (noisybwe.yaml:7)
+        counter = [0]
+
+        def next_batch():
+            i = counter[0]
+            counter[0] += 1
+            items = [pool[(i * args.batch + k) % len(pool)] for k in range(args.batch)]
+            batch = noisy_bwe_collate(items, 16000, "constant_length-2500-ms")
+            bc, air = augment(batch["audio_body_conducted"], batch["audio_airborne"])
+            return {"audio_body_conducted": bc, "audio_airborne": air}
+    else:
+        length = args.length
+        resident = synthetic_batch(args.batch, args.length, 1234 + rank, device)
+
+        def next_batch():
+            return resident
+    cut = length - (length + 32) % 256
+    scale = world * args.batch * cut / (32 * 31968.0)   # work relative to SURVEY's batch 32 x 31968 figures
+
+    # roofline kernels: MelGAN layer 4 forward (1024->1024, k41, s4, g4: the launch with the most FLOPs; L3-L5 hold 52 % of the conv
+    # MACs) and MelGAN layer 3's input gradient over the four stacked right-hand sides (the longest single launch of the step)
+    mel = mod.discriminator.melgan_discriminator.discriminator
+    layer, layer_t = mel[4][0], mel[3][0]
+    timer, timer_t = ops.KernelTimer(layer.spec, "fwd"), ops.KernelTimer(layer_t.spec, "dx")
+    ops.set_kernel_timers([timer, timer_t])
 
     def barrier():
         if use_ddp:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed_steps(n):
+        """EXACTLY n steps between two barrier + synchronize brackets (wall clock), with a HIP event at every step boundary on the main
+        stream for the per-step distribution."""
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
+        barrier()
+        t0 = time.perf_counter()
+        evs[0].record()
+        for i in range(n):
+            mod.training_step(next_batch())
+            evs[i + 1].record()
+        barrier()
+        dt = time.perf_counter() - t0
+        per = sorted(a.elapsed_time(b) for a, b in zip(evs[:-1], evs[1:]))
+        if world > 1:
+            t = torch.tensor([dt], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, per
+
     for i in range(args.warmup):
         tw = time.perf_counter()
-        mod.training_step(batch)
+        mod.training_step(next_batch())
         torch.cuda.synchronize()
         if rank == 0:
             print(f"[bench] warm-up step {i}: {(time.perf_counter() - tw) * 1e3:.1f} ms", file=sys.stderr, flush=True)
@@ -177,36 +267,20 @@ def main():
     import gc
     gc.collect()
     gc.freeze()
-    barrier()
-    timer.enabled = True
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        mod.training_step(batch)
-    barrier()
-    dt = time.perf_counter() - t0
-    timer.enabled = False
-    if world > 1:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    for _, sy in syncs:
+        sy.exposed_comm_ms()   # drop the warm-up's samples
+    timer.enabled = timer_t.enabled = True
+    dt, per_step = timed_steps(args.steps)
+    timer.enabled = timer_t.enabled = False
+    exposed = {name: sy.exposed_comm_ms() for name, sy in syncs}
 
-    # beside a bf16 run: the same K steps with exact-fp32 discriminator products (the parity mode of tests/), reported
-    # as `f32_discriminator` -- never as `value`
-    dt32 = None
-    if args.disc_math == "bf16" and not args.no_f32_leg:
+    # beside a bf16 run: the same K steps in exact fp32 (the arithmetic of the reference), reported as value_f32 -- never as `value`
+    dt32 = per32 = None
+    if bf16 and not args.no_f32_leg:
         mod.disc_math = mod.gen_backward_math = "f32"
         mod.stft_math = "folded"
-        mod.training_step(batch)
-        barrier()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            mod.training_step(batch)
-        barrier()
-        dt32 = time.perf_counter() - t1
-        if world > 1:
-            t = torch.tensor([dt32], device=device, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt32 = float(t.item())
+        mod.training_step(next_batch())
+        dt32, per32 = timed_steps(args.steps)
 
     # the roofline kernel once more, ALONE on the device (inside the step it shares the GPU with the three other
     # discriminator chains and the MRSTFT GEMMs, which stretches its launch-to-finish time): reported as `isolated`
@@ -214,8 +288,11 @@ def main():
     if rank == 0:
         import ctypes
         from vibravox_amd._lib import check, load, ptr, stream
+        from vibravox_amd.lightning_modules.eben import DISC_MATH_PLANS
         lib = load()
-        math = ops.MATH_BF16 if args.disc_math == "bf16" else ops.MATH_F32
+        plan = DISC_MATH_PLANS[args.disc_math]
+        plan = plan["melgan"] if isinstance(plan, dict) else plan
+        math = plan if isinstance(plan, int) else plan[0]
         lb = timer.batch or 2 * args.batch
         lx = cut
         for (k, s_, p_) in [(15, 1, 7), (41, 4, 20), (41, 4, 20), (41, 4, 20)]:
@@ -238,51 +315,88 @@ def main():
 
     if rank == 0:
         ms = dt / args.steps * 1e3
-        value = world * args.batch * cut / 16000 / (dt / args.steps)
-        sp = layer.spec
-        lx = cut
-        for (_, _, k, s, p, _) in [(1, 16, 15, 1, 7, 1), (16, 64, 41, 4, 20, 4), (64, 256, 41, 4, 20, 4), (256, 1024, 41, 4, 20, 4)]:
-            lx = (lx + 2 * p - (k - 1) - 1) // s + 1
-        l_out = sp.out_len(lx)
-        launch_batch = timer.batch or args.batch   # the discriminator engine runs enhanced + reference as one batch-2B launch
-        flops = 2.0 * launch_batch * sp.c_out * (sp.c_in // sp.groups) * sp.ksize * l_out
-        kms = timer.mean_ms()
-        achieved = flops / (kms * 1e-3) / 1e12 if kms else None
-        peak = MFMA_BF16_PEAK_TFLOPS if args.disc_math == "bf16" else MFMA_F32_PEAK_TFLOPS
-        kname = "tap3_kernel<4,*> (v_mfma_f32_32x32x16_bf16)" if args.disc_math == "bf16" else "tap2_kernel<4,4,16> (v_mfma_f32_32x32x2_f32)"
+        audio_s = world * args.batch * cut / 16000
+        value = audio_s / (dt / args.steps)
+        peak = MFMA_BF16_PEAK_TFLOPS if bf16 else MFMA_F32_PEAK_TFLOPS
+
+        def launch_record(tm, which, kname):
+            sp = tm.spec
+            lx = cut
+            chain = [(15, 1, 7), (41, 4, 20), (41, 4, 20), (41, 4, 20)]
+            depth = 4 if tm is timer else 3
+            for (k, s_, p_) in chain[:depth]:
+                lx = (lx + 2 * p_ - (k - 1) - 1) // s_ + 1
+            l_out = sp.out_len(lx)
+            items = tm.batch or args.batch
+            flops = 2.0 * items * sp.c_out * (sp.c_in // sp.groups) * sp.ksize * l_out
+            kms = tm.mean_ms()
+            ach = flops / (kms * 1e-3) / 1e12 if kms else None
+            return {"bound": "mfma", "kernel": f"eben::{kname} MelGAN L{depth} {which} ({sp.c_in}->{sp.c_out} k{sp.ksize} s{sp.stride} g{sp.groups}), {items} items per launch",
+                    "achieved": round(ach, 2) if ach else None, "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4) if ach else None,
+                    "launch_ms": round(kms, 4) if kms else None, "flops_per_launch": flops, "launches_timed": len(tm.events)}, flops
+
+        kn = "tap3_kernel<4,*> (v_mfma_f32_32x32x16_bf16)" if bf16 else "tap2_kernel<4,4,16> (v_mfma_f32_32x32x2_f32)"
+        roof, flops = launch_record(timer, "fwd", kn)
+        roof["traffic"] = pmc_traffic(timer.batch or 2 * args.batch, "bf16" if bf16 else "f32")
+        if iso_ms:
+            roof["isolated"] = {"launch_ms": round(iso_ms, 4), "achieved": round(flops / (iso_ms * 1e-3) / 1e12, 2),
+                                "frac": round(flops / (iso_ms * 1e-3) / 1e12 / peak, 4),
+                                "note": "same launch alone on the device, 20 back-to-back launches after the timed region"}
+        roof_t, _ = launch_record(timer_t, "input gradient, rows [fm | adv | fake | real]", kn)
+        ideal = step_roofline_ms("f32" if not bf16 else "bf16", scale)
         line = {
             "metric": "EBEN train-step audio-seconds/sec (gen+disc)", "value": round(value, 2), "unit": "audio-seconds/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": args.disc_math, "data": "synthetic",
-            "config": {"workload": f"EBEN full GAN train step (gen+disc+MRSTFT+feature-matching+hinge, EMA balancing, Adam), "
-                                   f"batch {args.batch} x {args.length} samples @16kHz per GPU (cut to {cut})",
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
+            "config": {"workload": (f"EBEN full GAN train step (gen+disc+MRSTFT+feature-matching+hinge, EMA balancing, Adam), batch {args.batch} x "
+                                    f"{length} samples @16kHz per GPU (cut to {cut})"
+                                    + ("; BASELINE config 4: each step's batch assembled on the device from a resident pool of ragged clips "
+                                       "(noise slice + mix + crop/pad to 2.5 s + time masking)" if args.workload == "noisybwe" else "")),
                        "global_batch": world * args.batch, "samples_per_clip": cut, "parallelism": f"dp{world}",
-                       "weights": "random init, torch.manual_seed(42)",
-                       "precision": (f"discriminator contractions (91 % of the step's FLOPs): bf16 MFMA operands, fp32 accumulate; generator "
-                                     f"forward, losses, Adam, storage: fp32; generator backward contractions: {gen_bwd_math}; MRSTFT DFT contractions: "
-                                     + ("bf16x3 (hi/lo bf16 operand splits, fp32 accumulate, ~2^-17 relative)" if stft_math == "bf16x3"
-                                        else f"fp32 ({stft_math})")
-                                     if args.disc_math == "bf16" else "fp32 throughout (exact fp32 MFMA products)")},
-            "roofline": {"bound": "mfma", "kernel": f"eben::{kname} MelGAN L4 fwd (1024->1024 k41 s4 g4), {launch_batch} items per launch",
-                         "achieved": round(achieved, 2) if achieved else None, "peak": peak, "unit": "TFLOP/s",
-                         "frac": round(achieved / peak, 4) if achieved else None, "traffic": pmc_traffic(launch_batch, args.disc_math),
-                         "launch_ms": round(kms, 4) if kms else None, "flops_per_launch": flops,
-                         "launches_timed": len(timer.events),
-                         "isolated": {"launch_ms": round(iso_ms, 4), "achieved": round(flops / (iso_ms * 1e-3) / 1e12, 2),
-                                      "frac": round(flops / (iso_ms * 1e-3) / 1e12 / peak, 4),
-                                      "note": "same launch alone on the device, 20 back-to-back launches after the timed region"}},
+                       "weights": "random init, torch.manual_seed(42)", "disc_math": args.disc_math,
+                       "precision": (f"discriminator contractions on bf16 MFMA operands with fp32 accumulate (MelGAN: every pass; PQMF-band "
+                                     f"discriminators: input / weight gradients -- their forward stays fp32, which keeps the discriminator "
+                                     f"gradient within 3.4e-2 of the fp32 step's, tests/test_gpu_models.py); generator forward, losses, Adam, "
+                                     f"storage: fp32; generator backward contractions: {gen_bwd_math}; MRSTFT DFT contractions: fp32 ({stft_math})"
+                                     if args.disc_math == "bf16" else
+                                     "every contraction on single bf16 MFMA operands (bf16_plain)" if bf16 else "fp32 throughout (exact fp32 MFMA products)")},
+            "step_ms": {"median": round(percentile(per_step, 0.5), 3), "p10": round(percentile(per_step, 0.1), 3),
+                        "p90": round(percentile(per_step, 0.9), 3), "clock": "HIP events at the step boundaries on the main stream"},
+            "roofline": roof,
+            "roofline_time_dominant": roof_t,
+            "step_roofline": {"ideal_ms": round(ideal, 3), "frac": round(ideal / ms, 4),
+                              "note": "sum over the parts of F_min = 2(3G+8D) of max(FLOP / MFMA peak of the part's dtype, bytes / 8 TB/s) / measured ms per step "
+                                      "(SURVEY 8d; G = 6.727e8, D = 2.5255e9 MACs per audio-second)"},
         }
         # whole-step arithmetic rate on SURVEY section 8d's minimal algorithmic count F_min = 2*(3G + 8D) (no credit for redundant passes)
-        f_min = 2.0 * (3 * 6.727e8 + 8 * 2.5255e9) * (world * args.batch * cut / 16000.0)
-        line["step_work"] = {"f_min_flop": f_min, "achieved_tflops": round(f_min / (dt / args.steps) / 1e12, 1),
-                             "note": "F_min = 2*(3G+8D), G = 6.727e8 and D = 2.5255e9 MACs per audio-second; 91 % of it (the discriminator passes) "
-                                     "runs on bf16 MFMA operands in this mode" if args.disc_math == "bf16" else "F_min = 2*(3G+8D), all fp32"}
+        f_min = 2.0 * (3 * 6.727e8 + 8 * 2.5255e9) * audio_s
+        line["step_work"] = {"f_min_flop": f_min, "achieved_tflops": round(f_min / (dt / args.steps) / 1e12, 1)}
         if dt32 is not None:
-            line["f32_discriminator"] = {"ms_per_step": round(dt32 / args.steps * 1e3, 3), "steps": args.steps,
-                                         "value": round(world * args.batch * cut / 16000 / (dt32 / args.steps), 2), "unit": "audio-seconds/sec"}
+            ms32 = dt32 / args.steps * 1e3
+            line["value_f32"] = round(audio_s / (dt32 / args.steps), 2)
+            line["ms_per_step_f32"] = round(ms32, 3)
+            line["step_ms_f32"] = {"median": round(percentile(per32, 0.5), 3), "p10": round(percentile(per32, 0.1), 3), "p90": round(percentile(per32, 0.9), 3)}
+            line["step_roofline_f32"] = {"ideal_ms": round(step_roofline_ms("f32", scale), 3), "frac": round(step_roofline_ms("f32", scale) / ms32, 4)}
+        if use_ddp:
+            line["comm"] = {"backend": dist.get_backend(), "ranks": world,
+                            "exposed_ms_per_step": {k: (round(v, 4) if v is not None else None) for k, v in exposed.items()},
+                            "grad_bytes": {name: sum(b.numel for b in sy.buckets) * 4 for name, sy in syncs},
+                            "buckets": {name: len(sy.buckets) for name, sy in syncs},
+                            "note": "exposed = main-stream time spent waiting for the bucket all-reduces in front of each Adam"}
         print(f"[bench] GPU: {ms:.1f} ms/step, {value:.1f} audio-s/s", file=sys.stderr, flush=True)
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.cpu_batch, args.length, args.cpu_steps)
+            # torch's intra-op pool.  Measured on the GPU host (2 x EPYC 9575F, 256 hardware threads) at the full batch 32: 8 threads 9.9,
+            # 16 threads 14.8, 32 threads 10.6 audio-s/s, 256 threads > 20x slower -- these convolutions do not scale past ~16 threads, so
+            # 16 is the setting that is fair to the CPU; the 8-thread leg is comparable with the survey's measurement of the reference.
+            avail = len(os.sched_getaffinity(0))
+            cores = int(os.environ.get("EBEN_CPU_THREADS", "0")) or max(1, min(16, avail))
+            v16, dt16, times = cpu_baseline(args.cpu_batch, args.length, args.cpu_steps, cores)
+            v8, dt8, _ = cpu_baseline(args.cpu_batch, args.length, 1, min(8, avail))
+            line["cpu_baseline"] = {"value": round(v16, 3), "unit": "audio-seconds/sec", "cores": cores, "kind": "port",
+                                    "sample": f"{args.cpu_steps} timed steps after 1 warm-up ({', '.join(f'{t:.2f}' for t in times)} s), batch {args.cpu_batch} x "
+                                              f"{args.length} samples, fp32, reference as-executed order; host has {avail} hardware threads "
+                                              f"(more than ~16 threads is slower for these convolutions)",
+                                    "threads_8": {"value": round(v8, 3), "s_per_step": round(dt8, 2), "steps": 1}}
     # the JSON line is the LAST thing on stdout: the process group is torn down and every C stdio buffer (RCCL's log stream) is
     # flushed first
     if use_ddp:

@@ -157,6 +157,15 @@ EBEN_API int eben_ru_pack(int channels, const float* v_dil, const float* scale_d
                  void* stream);
 EBEN_API int eben_ru_fwd(int batch, int channels, int length, int dilation, const float* x, float in_slope, float out_slope,
                 const float* wimg, float* y, float* h, float* u, void* stream);
+/* Input-gradient chain of the same unit in one launch (the reflect padding folds onto the end positions inside the kernel):
+ *   g_h = W_pw^T ( g_y * lrelu'(u, out_slope) ),   g_x = ( g_y + fold(W_dil^T (*) g_h) ) * lrelu'(x, in_slope) + post
+ * u: the forward's lrelu(z); x: the unit's input (needed when in_slope != 1), post: nullable addend behind the mask (a skip
+ * connection's gradient); g_h is written out for the dilated conv's weight gradient.  eben_ru_pack_bwd writes the transposed
+ * weight image (eben_ru_packed_floats(C) floats). */
+EBEN_API int eben_ru_pack_bwd(int channels, const float* v_dil, const float* scale_dil, const float* v_pw, const float* scale_pw,
+                     float* wimg_bwd, void* stream);
+EBEN_API int eben_ru_bwd(int batch, int channels, int length, int dilation, const float* gy, const float* u, float out_slope,
+                const float* x, float in_slope, const float* post, const float* wimg_bwd, float* gx, float* gh, void* stream);
 
 /* ---- PQMF (vibravox/torch_modules/dsp/pqmf.py:194-213, eben_generator.py:209-211) ---------- */
 /* decimating FIR bank: y[b,k,t] = sum_j w[k*ntaps+j] * x[b,0,t*stride+off0+j], zero outside [0,lx) */

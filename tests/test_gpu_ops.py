@@ -301,6 +301,45 @@ def test_fused_residual_unit_forward(hip, channels, dilation, length, batch, in_
     assert torch.equal(y, y3)
 
 
+@pytest.mark.parametrize("channels,dilation,length,batch,in_slope,post", [
+    (32, 1, 1000, 3, 1.0, False), (32, 3, 517, 2, 0.01, True), (32, 9, 8000, 2, 1.0, False), (64, 9, 300, 3, 0.01, True),
+    (64, 1, 4000, 2, 1.0, False), (128, 3, 1000, 2, 1.0, True), (128, 9, 131, 2, 0.01, False), (32, 9, 20, 1, 1.0, False),
+    (32, 9, 110, 1, 1.0, False), (64, 3, 123, 2, 1.0, False)])
+def test_fused_residual_unit_backward(hip, channels, dilation, length, batch, in_slope, post):
+    """eben_ru_bwd: g_h = W_pw^T (g_y * lrelu'(u)) and g_x = (g_y + fold(W_dil^T g_h)) * lrelu'(x) + post in one launch, against
+    fp64 autograd of the unit: interior tiles, both reflect folds (also when they land in the same or in neighbouring tiles),
+    windows that overhang the signal, clips of exactly one tile and shorter."""
+    from vibravox_amd._lib import check, load, ptr, stream
+
+    lib, dev = load(), torch.device("cuda")
+    c = channels
+    vd = formula_tensor(f"rub/{c}/{dilation}/vd", (c, c, 3), 1 / math.sqrt(3 * c))
+    vp = formula_tensor(f"rub/{c}/{dilation}/vp", (c, c, 1), 1 / math.sqrt(c))
+    sd = 0.5 + formula_tensor(f"rub/{c}/sd", (c,), 0.4).abs()
+    sp = 0.5 + formula_tensor(f"rub/{c}/sp", (c,), 0.4).abs()
+    x = formula_tensor(f"rub/{c}/{dilation}/{length}/x", (batch, c, length))
+    gy = formula_tensor(f"rub/{c}/{dilation}/{length}/gy", (batch, c, length))
+    pt = formula_tensor(f"rub/{c}/{dilation}/{length}/post", (batch, c, length))
+    xr = x.double().requires_grad_(True)
+    xin = torch.nn.functional.leaky_relu(xr, in_slope)
+    wd, wp_ = vd.double() * sd.double().reshape(c, 1, 1), vp.double() * sp.double().reshape(c, 1, 1)
+    h = torch.nn.functional.conv1d(torch.nn.functional.pad(xin, (dilation, dilation), mode="reflect"), wd, dilation=dilation)
+    h.retain_grad()
+    u = torch.nn.functional.leaky_relu(torch.nn.functional.conv1d(h, wp_), 0.01)
+    ((xin + u) * gy.double()).sum().backward()
+    gx_ref = xr.grad + (pt.double() if post else 0.0)
+    img = torch.empty(lib.eben_ru_packed_floats(c), dtype=torch.float32, device=dev)
+    vdd, vpd, sdd, spd = vd.to(dev), vp.to(dev), sd.to(dev), sp.to(dev)
+    check(lib.eben_ru_pack_bwd(c, ptr(vdd), ptr(sdd), ptr(vpd), ptr(spd), ptr(img), stream()), "ru_pack_bwd")
+    xd, gyd, ud, ptd = x.to(dev), gy.to(dev), u.detach().float().to(dev), pt.to(dev)
+    gx, gh = torch.full_like(xd, float("nan")), torch.full_like(xd, float("nan"))
+    check(lib.eben_ru_bwd(batch, c, length, dilation, ptr(gyd), ptr(ud), 0.01, ptr(xd) if in_slope != 1.0 else None, in_slope,
+                          ptr(ptd) if post else None, ptr(img), ptr(gx), ptr(gh), stream()), "ru_bwd")
+    torch.cuda.synchronize()
+    assert rel_err(gh, h.grad) < 3e-5
+    assert rel_err(gx, gx_ref) < 3e-5
+
+
 def test_fused_residual_unit_rejects_unsupported_shapes(hip):
     from vibravox_amd._lib import load
 

@@ -24,6 +24,7 @@ def collect(batch, length):
     """(name, spec, l_in) for every conv, by tracing one forward with hooks on the CPU-side modules."""
     dev = torch.device("cuda")
     gen, disc = EBENGenerator(4, 32, 2).to(dev), DiscriminatorEBENMultiScales(q=4, min_channels=24).to(dev)
+    gen.use_engine = False   # module by module: the hooks below see every conv
     rows = []
 
     def hook(name):

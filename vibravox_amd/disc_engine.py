@@ -143,16 +143,11 @@ class _Chain:
             y = bufs["outs"][i][r0:r1]
             _, _, bias = lay.params()
             wp = lay.packed(0, b, cur.shape[2])
-            tm = ops._timer[0]
-            timed = tm is not None and tm.enabled and tm.spec == lay.spec
-            if timed:   # bench.py: HIP events around the roofline kernel, on the stream it is launched on
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
+            tm = ops.kernel_timer_for(lay.spec, "fwd")   # bench.py: HIP events around the roofline kernel, on the stream it is launched on
+            e0 = tm.start() if tm is not None else None
             check(lib.eben_conv1d_fwd(ctypes.byref(d), ptr(cur), ptr(wp), ptr(bias), None, ptr(y), _stream()), "conv1d_fwd")
-            if timed:
-                e1.record()
-                tm.events.append((e0, e1))
-                tm.batch = b
+            if tm is not None:
+                tm.stop(e0, b)
             cur = y
         bufs["emb"] = [x_full] + bufs["outs"]
         return bufs
@@ -182,9 +177,14 @@ class _Chain:
                 gp = torch.empty((rows, lay.spec.c_in, l_in), dtype=torch.float32, device=g.device)
                 res = fm_grads[i - 1]
                 prev_slope = self.layers[i - 1].spec.out_slope
-                check(lib.eben_conv1d_bwd_dx_ex(ctypes.byref(d), ptr(g), ptr(lay.packed(1, rows, l_in)), ptr(res), half if res is not None else 0,
+                wp = lay.packed(1, rows, l_in)
+                tm = ops.kernel_timer_for(lay.spec, "dx")
+                e0 = tm.start() if tm is not None else None
+                check(lib.eben_conv1d_bwd_dx_ex(ctypes.byref(d), ptr(g), ptr(wp), ptr(res), half if res is not None else 0,
                                                 ptr(outs[i - 1]) if prev_slope != 1.0 else None, prev_slope, half, seg_map, ptr(gp), st),
                       "conv1d_bwd_dx_ex")
+                if tm is not None:
+                    tm.stop(e0, rows)
                 g = gp
             else:
                 rows = 2 * half   # only the generator-side signals reach the discriminator input

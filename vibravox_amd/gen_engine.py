@@ -31,6 +31,7 @@ from . import ops
 from ._lib import check, load, ptr, stream
 
 USE_FUSED_RU = os.environ.get("EBEN_RU_FUSED", "1") != "0"
+USE_FUSED_RU_BWD = os.environ.get("EBEN_RU_FUSED_BWD", "1") != "0"
 
 
 def _params(m):
@@ -89,8 +90,9 @@ class GeneratorEngine:
             recs.append(_ConvRec(m, spec, d_bwd, x, y if spec.out_slope != 1.0 else None, pw.wp_bwd, pw.norm))
         return y
 
-    def _ru_image(self, ru) -> torch.Tensor:
-        """Weight image of the fused unit (both convs, weight-norm scales folded in), rebuilt when a parameter changed."""
+    def _ru_image(self, ru, which: int = 0) -> torch.Tensor:
+        """Weight images of the fused unit (both convs, weight-norm scales folded in): 0 forward, 1 backward (transposed);
+        rebuilt together when a parameter changed."""
         lib = load()
         vd, gd = _params(ru.dilated_conv)
         vp, gp = _params(ru.pointwise_conv)
@@ -98,15 +100,17 @@ class GeneratorEngine:
         key = tuple((t.data_ptr(), t._version, e.get(t.data_ptr(), 0)) for t in (vd, gd, vp, gp)) + (e.get(-1, 0),)
         hit = self._ru_images.get(id(ru))
         if hit is not None and hit[0] == key:
-            return hit[1]
+            return hit[1 + which]
         c = vd.shape[0]
         dev = vd.device
         scales = torch.empty((4, c), dtype=torch.float32, device=dev)   # scale / norm of the dilated, then of the pointwise conv
         ops.wn_scale_multi([(gd.detach(), vd.detach(), c, vd.numel() // c, scales[0], scales[1]), (gp.detach(), vp.detach(), c, vp.numel() // c, scales[2], scales[3])])
         img = torch.empty(lib.eben_ru_packed_floats(c), dtype=torch.float32, device=dev)
+        img_b = torch.empty_like(img)
         check(lib.eben_ru_pack(c, ptr(vd.detach()), ptr(scales[0]), ptr(vp.detach()), ptr(scales[2]), ptr(img), stream()), "ru_pack")
-        self._ru_images[id(ru)] = (key, img)
-        return img
+        check(lib.eben_ru_pack_bwd(c, ptr(vd.detach()), ptr(scales[0]), ptr(vp.detach()), ptr(scales[2]), ptr(img_b), stream()), "ru_pack_bwd")
+        self._ru_images[id(ru)] = (key, img, img_b)
+        return (img, img_b)[which]
 
     def prepack(self) -> None:
         """Rebuilds the fused units' weight images on the side stream (called with ``ops.prepack`` after the optimiser step)."""
@@ -151,7 +155,9 @@ class GeneratorEngine:
             y = torch.empty_like(x)
             check(lib.eben_add(ptr(xin), ptr(u), ptr(y), x.numel(), stream()), "add")
         if train:
-            recs.append(("ru", _ConvRec(dil, spec_d, dd_bwd, x, None, pw_d.wp_bwd, pw_d.norm), _ConvRec(pwc, pwc.spec, dp_bwd, h, u, pw_p.wp_bwd, pw_p.norm)))
+            fused = USE_FUSED_RU_BWD and c in (32, 64, 128) and dil.spec.ksize == 3 and dil.spec.reflect
+            recs.append((self._ru_image(ru, 1) if fused else None, _ConvRec(dil, spec_d, dd_bwd, x, None, pw_d.wp_bwd, pw_d.norm),
+                         _ConvRec(pwc, pwc.spec, dp_bwd, h, u, pw_p.wp_bwd, pw_p.norm)))
         return y
 
     # ---- forward -------------------------------------------------------------------------------------
@@ -198,7 +204,9 @@ class GeneratorEngine:
     def _dx(rec: _ConvRec, dy, res_pre=None, res_post=None):
         lib = load()
         d = rec.d
-        ws_bytes = lib.eben_conv1d_bwd_dx_workspace(ctypes.byref(d))
+        ws_bytes = getattr(d, "_dx_ws", None)
+        if ws_bytes is None:
+            ws_bytes = d._dx_ws = lib.eben_conv1d_bwd_dx_workspace(ctypes.byref(d))
         ws = ops._empty(ws_bytes, dy) if ws_bytes else None
         dx = torch.empty_like(rec.x)
         xmask = rec.x if rec.spec.in_slope != 1.0 else None
@@ -221,7 +229,16 @@ class GeneratorEngine:
                     hook(p)   # e.g. ddp.GradSync's bucket accounting
 
     def _ru_backward(self, rec, gy, res_post=None):
-        _, dil, pwc = rec
+        img_b, dil, pwc = rec
+        if img_b is not None:   # one launch: g_h and g_x = (g_y + fold(dilated^T g_h)) * lrelu'(x) + skip gradient
+            b, c, l = gy.shape
+            gx, gh = torch.empty_like(gy), torch.empty_like(gy)
+            ins = dil.spec.in_slope
+            check(load().eben_ru_bwd(b, c, l, dil.spec.dilation, ptr(gy), ptr(pwc.y), float(pwc.spec.out_slope), ptr(dil.x) if ins != 1.0 else None,
+                                     float(ins), ptr(res_post), ptr(img_b), ptr(gx), ptr(gh), stream()), "ru_bwd")
+            self._dw(pwc, gy)
+            self._dw(dil, gh)
+            return gx
         gh = self._dx(pwc, gy)                       # pointwise^T(gy * lrelu'(u))
         self._dw(pwc, gy)
         gx = self._dx(dil, gh, res_pre=gy, res_post=res_post)   # (gy + fold(dilated^T gh)) * lrelu'(x) + skip gradient
@@ -284,7 +301,9 @@ def core(gen, cut_audio: torch.Tensor):
     if engine is None:
         engine = GeneratorEngine(gen)
         object.__setattr__(gen, "_engine", engine)   # not a submodule / buffer: invisible to state_dict
-    params = [p for p in gen.parameters() if p.requires_grad]
+    # the parameters the core owns: NOT last_conv's -- the balancing passes differentiate the losses w.r.t. last_conv.weight alone
+    # (eben.py:223-227) and must not reach into the core
+    params = [p for m in (gen.first_conv, gen.encoder_blocks, gen.latent_conv, gen.decoder_blocks) for p in m.parameters() if p.requires_grad]
     if torch.is_grad_enabled() and params:
         return _CoreFn.apply(cut_audio.contiguous(), engine, *params)
     pre, first_bands, _ = engine.forward(cut_audio.contiguous(), False)

@@ -98,11 +98,8 @@ class weight_grads_on_side_stream:
                     wn_bwd_multi(_side["wn_jobs"])   # slab sums + weight-norm chain rule of every layer: two launches
                 _side["wn_jobs"] = []
             torch.cuda.current_stream(st.device).wait_stream(st)
-        _side["keep"].clear()
         assign, _side["assign"] = _side["assign"], []
-        for p, t in assign:   # complete on this stream from here on (allocated on the side stream's pool: tell the allocator)
-            if st is not None:
-                t.record_stream(torch.cuda.current_stream(st.device))
+        for p, t in assign:   # complete on this stream from here on
             if p.grad is None:
                 p.grad = t
             else:
@@ -110,6 +107,7 @@ class weight_grads_on_side_stream:
         if _side["sunk"]:
             sunk, _side["sunk"] = _side["sunk"], []
             self.sink.mark_ready(sunk)
+        _side["keep"].clear()   # the current stream has waited for the side stream: what its kernels read may be reused from here on
 
 
 # The HIP runtime multiplexes streams onto FOUR hardware queues (GPU_MAX_HW_QUEUES; 8 measured 50 % slower): a fifth
@@ -159,10 +157,21 @@ def wn_scale_multi(jobs) -> None:
 
 
 class KernelTimer:
-    """HIP-event timing of one layer's forward kernel on the stream it is launched on (bench.py)."""
+    """HIP-event timing of one layer's forward ("fwd") or input-gradient ("dx") launch on the stream it is launched on (bench.py)."""
 
-    def __init__(self, spec: "ConvSpec"):
-        self.spec, self.enabled, self.events, self.batch = spec, False, [], None
+    def __init__(self, spec: "ConvSpec", which: str = "fwd"):
+        self.spec, self.which, self.enabled, self.events, self.batch = spec, which, False, [], None
+
+    def start(self):
+        e0 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        return e0
+
+    def stop(self, e0, batch: int) -> None:
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        self.events.append((e0, e1))
+        self.batch = batch
 
     def mean_ms(self) -> Optional[float]:
         if not self.events:
@@ -170,11 +179,22 @@ class KernelTimer:
         return sum(a.elapsed_time(b) for a, b in self.events) / len(self.events)
 
 
-_timer: List[Optional[KernelTimer]] = [None]
+_timers: List[KernelTimer] = []
+
+
+def set_kernel_timers(timers: Sequence[KernelTimer]) -> None:
+    _timers[:] = list(timers)
 
 
 def set_kernel_timer(t: Optional[KernelTimer]) -> None:
-    _timer[0] = t
+    set_kernel_timers([] if t is None else [t])
+
+
+def kernel_timer_for(spec: "ConvSpec", which: str) -> Optional[KernelTimer]:
+    for t in _timers:
+        if t.enabled and t.which == which and t.spec == spec:
+            return t
+    return None
 
 
 def _empty(n_bytes: int, like: torch.Tensor) -> torch.Tensor:
@@ -366,42 +386,38 @@ def weight_grads(d: EbenConv1dDesc, dy: torch.Tensor, y: Optional[torch.Tensor],
         if sunk[0] is None or (has_g and sunk[1] is None) or (has_bias and sunk[2] is None):
             sunk = None
         use_side = sunk is not None
-    if use_side:
-        main = torch.cuda.current_stream(x.device)
-        side = _side_stream(x.device)
-        side.wait_stream(main)   # dy (and everything saved by the forward) is complete on the main stream
-        for t in (dy, x, y, v, g, norm):
-            if t is not None:
-                t.record_stream(side)
-        _side["keep"].append(dy)
-        stream_ctx = torch.cuda.stream(side)
-    else:
-        stream_ctx = contextlib.nullcontext()
-    with stream_ctx:
-        sw = stream()
+    ws = getattr(d, "_dw_ws", None)   # (bytes, slabs, row stride) of this descriptor: asked once
+    if ws is None:
         nslab, row_stride = ctypes.c_int(0), ctypes.c_int(0)
-        ws_bytes = lib.eben_conv1d_bwd_dw_workspace(ctypes.byref(d), ctypes.byref(nslab), ctypes.byref(row_stride))
-        slabs = _empty(ws_bytes, x)
-        check(lib.eben_conv1d_bwd_dw(ctypes.byref(d), ptr(dy), ptr(y), ptr(x), 1 if has_bias else 0, ptr(slabs), ws_bytes, sw), "conv1d_bwd_dw")
-        rows = v.shape[0]
-        cols = v.numel() // rows
-        if sunk is not None:
-            dv, dg, dbias = sunk
+        ws = d._dw_ws = (lib.eben_conv1d_bwd_dw_workspace(ctypes.byref(d), ctypes.byref(nslab), ctypes.byref(row_stride)), nslab.value, row_stride.value)
+    ws_bytes, nslab, row_stride = ws
+    # Every buffer is allocated on the CURRENT stream's pool; on the deferred path the kernels are launched on the side stream through
+    # its raw handle (no torch stream switch) and everything they touch stays referenced until join(), after which the current
+    # stream -- which waits for the side stream there -- may reuse it.
+    slabs = _empty(ws_bytes, x)
+    rows = v.shape[0]
+    cols = v.numel() // rows
+    if sunk is not None:
+        dv, dg, dbias = sunk
+    else:
+        dv = torch.empty_like(v)
+        dg = torch.empty_like(g) if has_g else None
+        dbias = torch.empty(rows, dtype=torch.float32, device=x.device) if has_bias else None
+    job = (slabs, nslab, rows * row_stride, rows, cols, row_stride, g.detach() if has_g else None, v.detach(), norm if has_g else None, dg, dv, dbias)
+    if use_side:
+        side = _side_stream(x.device)
+        side.wait_stream(torch.cuda.current_stream(x.device))   # dy (and everything saved by the forward) is complete on the main stream
+        check(lib.eben_conv1d_bwd_dw(ctypes.byref(d), ptr(dy), ptr(y), ptr(x), 1 if has_bias else 0, ptr(slabs), ws_bytes, side.cuda_stream), "conv1d_bwd_dw")
+        _side["keep"].append((dy, x, y, norm, slabs))
+        # the slab sums and the weight-norm chain rule of ALL layers are issued as one multi-tensor launch at join()
+        _side["wn_jobs"].append(job)
+        if sunk is None:
+            _side["assign"].extend((p, t) for p, t in ((v, dv), (g, dg), (bias, dbias)) if p is not None and t is not None)
         else:
-            dv = torch.empty_like(v)
-            dg = torch.empty_like(g) if has_g else None
-            dbias = torch.empty(rows, dtype=torch.float32, device=x.device) if has_bias else None
-        job = (slabs, nslab.value, rows * row_stride.value, rows, cols, row_stride.value, g.detach() if has_g else None, v.detach(),
-               norm if has_g else None, dg, dv, dbias)
-        if use_side:
-            # the slab sums and the weight-norm chain rule of ALL layers are issued as one multi-tensor launch at join()
-            _side["wn_jobs"].append(job)
-            if sunk is None:
-                _side["assign"].extend((p, t) for p, t in ((v, dv), (g, dg), (bias, dbias)) if p is not None and t is not None)
-            else:
-                _side["sunk"].extend(p for p in (v, g, bias) if p is not None)
-            return None, None, None
-        wn_bwd_multi([job])
+            _side["sunk"].extend(p for p in (v, g, bias) if p is not None)
+        return None, None, None
+    check(lib.eben_conv1d_bwd_dw(ctypes.byref(d), ptr(dy), ptr(y), ptr(x), 1 if has_bias else 0, ptr(slabs), ws_bytes, stream()), "conv1d_bwd_dw")
+    wn_bwd_multi([job])
     return dv, dg, dbias
 
 
@@ -418,16 +434,11 @@ class _ConvLayerFn(torch.autograd.Function):
         need_dx = ctx.needs_input_grad[0]
         pw = pack_weights(spec, d, v.detach(), None if g is None else g.detach(), cache, need_dx, d_bwd)
         y = torch.empty((b, spec.c_out, d.l_out), dtype=torch.float32, device=x.device)
-        tm = _timer[0]
-        timed = tm is not None and tm.enabled and tm.spec == spec
-        if timed:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
+        tm = kernel_timer_for(spec, "fwd")
+        e0 = tm.start() if tm is not None else None
         check(lib.eben_conv1d_fwd(ctypes.byref(d), ptr(x), ptr(pw.wp_fwd), ptr(bias), None, ptr(y), stream()), "conv1d_fwd")
-        if timed:
-            e1.record()
-            tm.events.append((e0, e1))
-            tm.batch = b
+        if tm is not None:
+            tm.stop(e0, b)
         ctx.spec, ctx.d = spec, d_bwd   # the descriptor the backward launches use
         ctx.wp_bwd, ctx.norm = pw.wp_bwd, pw.norm
         ctx.has_g, ctx.has_bias = g is not None, bias is not None
