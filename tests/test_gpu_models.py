@@ -497,3 +497,72 @@ def test_bucketed_grad_sync_path_on_gpu_matches_plain_step(hip, golden):
             assert torch.allclose(a, b, rtol=0, atol=1e-6), k
     finally:
         dist.destroy_process_group()
+
+
+def test_noisy_bwe_chain_collate_augment_step_against_oracle(hip, golden):
+    """BASELINE config 4 end to end at oracle size: ragged resident clips -> device collator (noise slice + mix + crop / pad,
+    noisybwe.py:219-291) -> WaveformDataAugmentation (time masking, data_augmentation.py:38-71) -> EBEN training_step, against the same
+    chain made of the CPU oracles (collate_oracle + augment_oracle + OracleTrainer) under the same torch seed: the assembled batch
+    bit for bit, the step's logged losses / balancing norms at the train-step tolerances, for two consecutive steps."""
+    from oracle import augment_oracle as A
+    from oracle import collate_oracle as C
+    from vibravox_amd.augment import WaveformDataAugmentation
+    from vibravox_amd.collate import noisy_bwe_collate
+
+    mod, g_sd, d_sd = make_module(golden, use_mrstft=True)
+    trainer = O.OracleTrainer(g_sd, d_sd, p=2, q=4, use_mrstft=True)
+    kw = dict(p_data_augmentation=1.0, p_speed_perturbation=0.0, p_pitch_shift=0.0, p_time_masking=1.0, time_masking_percentage=(1, 2, 3))
+    dev_aug, ora_aug = WaveformDataAugmentation(16000, **kw), A.WaveformDataAugmentation(16000, **kw)
+    lengths = [(7000, 9100), (9500, 9600), (8192, 12000), (10100, 10101)]   # speech / noise samples: shorter and longer than the 512 ms target
+    strategy = "constant_length-512-ms"                                      # 8192 samples
+    for step in range(2):
+        items = []
+        for i, (ls, ln) in enumerate(lengths):
+            items.append({"audio_body_conducted": formula_audio(f"nbwe/{step}/{i}/bc", 1, ls).reshape(-1),
+                          "audio_airborne": formula_audio(f"nbwe/{step}/{i}/air", 1, ls).reshape(-1),
+                          "audio_body_conducted_speechless_noisy": 0.3 * formula_audio(f"nbwe/{step}/{i}/noise", 1, ln).reshape(-1)})
+        torch.manual_seed(100 + step)
+        ref = C.noisy_bwe_collate([dict(it) for it in items], 16000, strategy, False)
+        rbc, rair = ora_aug(ref["audio_body_conducted"].clone(), ref["audio_airborne"].clone())
+        state = float(torch.rand(1))
+        torch.manual_seed(100 + step)
+        got = noisy_bwe_collate([{k: v.to(DEV) for k, v in it.items()} for it in items], 16000, strategy, False)
+        gbc, gair = dev_aug(got["audio_body_conducted"], got["audio_airborne"])
+        assert float(torch.rand(1)) == state                                 # same draws consumed
+        assert gbc.shape == (4, 1, 8192) and torch.equal(gbc.cpu(), rbc) and torch.equal(gair.cpu(), rair)
+        assert float((gbc == 0).float().mean()) > 0.009                      # the time mask is in
+        mod.training_step({"audio_body_conducted": gbc, "audio_airborne": gair})
+        logs = trainer.step(rbc, rair)
+        for k in ("train/generator/reconstructive_loss_freq", "train/generator/feature_matching_loss", "train/generator/adv_loss_gen",
+                  "train/generator/backprop_loss", "train/discriminator/real_loss", "train/discriminator/fake_loss"):
+            np.testing.assert_allclose(mod.logged[k].item(), logs[k].item(), rtol=1e-3, err_msg=k)
+        np.testing.assert_allclose(torch.stack(mod.last_norms).cpu().numpy(), logs["balancing/norms"].numpy(), rtol=5e-3)
+
+
+def test_noisy_bwe_chain_at_config4_size(hip, golden):
+    """The same chain at BASELINE config 4's size (batch 32, constant_length-2500-ms = 40000 samples, bench.py --workload noisybwe):
+    size-independent properties -- the collated clips are sums / crops of their sources, the mask zeroes the drawn share, the step's
+    outputs and losses are finite and every parameter moved by at most one Adam step."""
+    import bench
+    from vibravox_amd.augment import WaveformDataAugmentation
+    from vibravox_amd.collate import noisy_bwe_collate
+
+    mod, _, _ = make_module(golden, use_mrstft=True)
+    pool = bench.noisy_bwe_source(DEV, n_items=32, seed=99)
+    aug = WaveformDataAugmentation(16000, p_data_augmentation=1.0, p_speed_perturbation=0.0, p_pitch_shift=0.0, p_time_masking=1.0)
+    torch.manual_seed(5)
+    batch = noisy_bwe_collate(pool, 16000, "constant_length-2500-ms")
+    assert batch["audio_body_conducted"].shape == (32, 1, 40000)
+    bc, air = aug(batch["audio_body_conducted"], batch["audio_airborne"])
+    energy = float(bc.pow(2).mean())
+    assert 0.008 < energy < 0.014     # speech (sigma 0.1) + noise (sigma 0.05): 0.0125 where the clip covers the window, 0 in the padding / mask
+    params = [p for p in mod.generator.parameters() if p.requires_grad]
+    before = [p.detach().clone() for p in params]
+    out = mod.training_step({"audio_body_conducted": bc, "audio_airborne": air})
+    torch.cuda.synchronize()
+    cut = 40000 - (40000 + 32) % 256
+    assert out["enhanced"].shape == (32, 1, cut) and torch.isfinite(out["enhanced"]).all()
+    for k, v in mod.logged.items():
+        assert np.isfinite(float(v)), k
+    steps = [float((p.detach() - b).abs().max()) for p, b in zip(params, before)]
+    assert max(steps) <= 3e-4 * 1.001 + 1e-7 and sum(st > 0.0 for st in steps) >= len(steps) - 2, sorted(steps)[:4]

@@ -750,3 +750,44 @@ def test_adam_matches_torch(hip):
         assert rel_err(g, r) < 1e-6
     sd = o_got.state_dict()
     assert set(sd["state"][0].keys()) >= {"step", "exp_avg", "exp_avg_sq"}
+
+
+@pytest.mark.parametrize("math_name", ["f32", "bf16"])
+def test_full_size_melgan_layer4_forward_against_fp64(hip, math_name):
+    """One full-size layer of BASELINE config 2 against the fp64 oracle: MelGAN layer 4 (1024 -> 1024, k 41, stride 4, 4 groups,
+    melgan_discriminator.py:89-156) on the 32 x 1024 x 500 activations the step feeds it -- the launch bench.py quotes its roofline
+    on.  fp32: 3e-5 of max|ref| (the fp32-GEMM bound of the small cases, K = 10 496); bf16: the same bound against an fp64
+    convolution of the bf16-rounded operands (what the kernel is specified to compute) and 1e-2 against the exact one."""
+    import ctypes
+
+    from vibravox_amd import ops
+    from vibravox_amd._lib import check, load, ptr, stream
+
+    lib, dev = load(), torch.device("cuda")
+    spec = ops.ConvSpec(c_in=1024, c_out=1024, ksize=41, stride=4, pad_l=20, pad_r=20, groups=4, out_slope=0.2)
+    b, l_in = 32, 500
+    v = formula_tensor("full/l4/v", (1024, 256, 41), 1 / math.sqrt(256 * 41))
+    g = 0.5 + formula_tensor("full/l4/g", (1024, 1, 1), 0.4).abs()
+    bias = formula_tensor("full/l4/b", (1024,), 0.1)
+    x = formula_tensor("full/l4/x", (b, 1024, l_in))
+    math_id = ops.MATH_F32 if math_name == "f32" else ops.MATH_BF16
+    d = ops.conv_desc(spec, b, l_in, math_id)
+    vd, gd, bd, xd = v.to(dev), g.to(dev), bias.to(dev), x.to(dev)
+    pw = ops.pack_weights(spec, d, vd, gd, None, False)
+    y = torch.empty((b, 1024, d.l_out), dtype=torch.float32, device=dev)
+    check(lib.eben_conv1d_fwd(ctypes.byref(d), ptr(xd), ptr(pw.wp_fwd), ptr(bd), None, ptr(y), stream()), "conv1d_fwd")
+    torch.cuda.synchronize()
+    w = (v.double() * (g.double() / v.double().flatten(1).norm(dim=1).reshape(-1, 1, 1)))
+
+    def ref_conv(xx, ww):
+        return torch.nn.functional.leaky_relu(torch.nn.functional.conv1d(xx, ww, bias.double(), stride=4, padding=20, groups=4), 0.2)
+
+    exact = ref_conv(x.double(), w)
+    assert tuple(y.shape) == tuple(exact.shape) == (b, 1024, 125)
+    scale = float(exact.abs().max())
+    if math_name == "f32":
+        assert float((y.cpu().double() - exact).abs().max()) < 3e-5 * scale
+    else:
+        rounded = ref_conv(x.bfloat16().double(), w.float().bfloat16().double())
+        assert float((y.cpu().double() - rounded).abs().max()) < 3e-5 * scale
+        assert float((y.cpu().double() - exact).abs().max()) < 1e-2 * scale

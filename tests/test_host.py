@@ -40,6 +40,34 @@ def test_library_exports_every_declared_symbol(lib):
     assert lib.eben_version() >= 1
 
 
+def test_no_kernel_of_the_library_spills(lib, tmp_path):
+    """Every gfx950 kernel of libeben_hip.so runs out of registers only: the code objects' notes (llvm-readelf, no GPU needed) report a
+    zero private segment (scratch) for each of them -- a spill in a hot loop is a silent 2-5x (round 1 shipped five such kernels)."""
+    import shutil
+    import subprocess
+
+    llvm = "/opt/rocm/lib/llvm/bin"
+    if not os.path.exists(os.path.join(llvm, "llvm-objdump")):
+        pytest.skip("ROCm llvm tools not installed")
+    so = shutil.copy(os.path.join(ROOT, "vibravox_amd", "lib", "libeben_hip.so"), tmp_path / "lib.so")
+    subprocess.run([os.path.join(llvm, "llvm-objdump"), "--offloading", str(so)], check=True, capture_output=True, cwd=tmp_path)
+    objs = [f for f in os.listdir(tmp_path) if "gfx950" in f]
+    assert objs, "no gfx950 code object in the library"
+    kernels, spilling = 0, []
+    for f in objs:
+        notes = subprocess.run([os.path.join(llvm, "llvm-readelf"), "--notes", str(tmp_path / f)], check=True, capture_output=True, text=True).stdout
+        for blk in notes.split(".agpr_count:")[1:]:
+            name = re.search(r"\.name:\s+(\S+)", blk)
+            scratch = re.search(r"\.private_segment_fixed_size:\s+(\d+)", blk)
+            if name is None or scratch is None:
+                continue
+            kernels += 1
+            if int(scratch.group(1)) != 0:
+                spilling.append((name.group(1), int(scratch.group(1))))
+    assert kernels > 100, kernels
+    assert not spilling, spilling
+
+
 def test_descriptor_validation_without_gpu(lib):
     """Pure host logic of the ABI: bad descriptors are rejected with a negative code and a message."""
     from vibravox_amd._lib import EbenConv1dDesc

@@ -144,18 +144,27 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, WAVES_M * WAVES_N == 8 ? 4 
   constexpr int XCAP = XR * NT;
   const int xtot = P.CI_T * span;
   const bool xpre = xtot <= XCAP && span < 65536;
-  int xg[XR];
   float xreg[XR];
+  // tile coordinates of this thread's elements: held in registers by the light variants, recomputed at every use (from a copy of
+  // the thread id the compiler cannot see through, so nothing is hoisted back) by the 16-fragment ones, which otherwise spill
+  constexpr bool XG_REG = FM * FN < 8;
+  const unsigned span_magic = span > 1 ? (unsigned)((0x100000000ull + (unsigned)span - 1) / (unsigned)span) : 0u;
+  auto xg_make = [&](int t, int u) -> int {
+    const int i = t + u * NT;
+    if (!(xpre && i < xtot)) return -1;
+    const int c = span > 1 ? (int)__umulhi((unsigned)i, span_magic) : i;
+    return (c << 16) | (i - c * span);
+  };
+  int xg_r[XG_REG ? XR : 1];
+  if constexpr (XG_REG) {
 #pragma unroll
-  for (int u = 0; u < XR; ++u) {
-    const int i = tid + u * NT;
-    if (xpre && i < xtot) {
-      const int c = i / span;
-      xg[u] = (c << 16) | (i - c * span);
-    } else {
-      xg[u] = -1;
-    }
+    for (int u = 0; u < XR; ++u) xg_r[u] = xg_make(tid, u);
   }
+  auto opaque_tid = [&]() -> int {
+    int t = tid;
+    if constexpr (!XG_REG) asm volatile("" : "+v"(t));
+    return t;
+  };
   auto fetch_x = [&](int r, long long row, bool cv) -> float {
     int q = q0 + r;
     if (P.reflect) {
@@ -176,20 +185,25 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, WAVES_M * WAVES_N == 8 ? 4 
     return c * P.CSTRIDE + p * P.PLEN + i;
   };
   auto load_x = [&](int cc) {
+    const int tq = opaque_tid();
 #pragma unroll
     for (int u = 0; u < XR; ++u) {
       float v = 0.f;
-      if (xg[u] >= 0) {
-        const int chan = cc * P.CI_T + (xg[u] >> 16);
-        v = fetch_x(xg[u] & 0xffff, ((long long)b * P.Cx + (long long)g * P.Cg + chan) * P.Lx, chan < P.Cg);
+      const int g_ = XG_REG ? xg_r[XG_REG ? u : 0] : xg_make(tq, u);
+      if (g_ >= 0) {
+        const int chan = cc * P.CI_T + (g_ >> 16);
+        v = fetch_x(g_ & 0xffff, ((long long)b * P.Cx + (long long)g * P.Cg + chan) * P.Lx, chan < P.Cg);
       }
       xreg[u] = v;
     }
   };
   auto store_x = [&]() {
+    const int tq = opaque_tid();
 #pragma unroll
-    for (int u = 0; u < XR; ++u)
-      if (xg[u] >= 0) Xs[lds_x(xg[u] >> 16, xg[u] & 0xffff)] = xreg[u];
+    for (int u = 0; u < XR; ++u) {
+      const int g_ = XG_REG ? xg_r[XG_REG ? u : 0] : xg_make(tq, u);
+      if (g_ >= 0) Xs[lds_x(g_ >> 16, g_ & 0xffff)] = xreg[u];
+    }
   };
   auto stage_x_direct = [&](int cc) {
     for (int c = 0; c < P.CI_T; ++c) {

@@ -63,8 +63,11 @@ __device__ __forceinline__ float a_elem<1>(const float& a, int) { return a; }
 #ifndef EBEN_T2_MINB_FM1
 #define EBEN_T2_MINB_FM1 2   // blocks per CU the register allocation of the 32-row (FM = 1) kernels is held to
 #endif
-template <int FM, int NW, int XR, bool H16 = false>
+// IMT: -1 the mask-on-load mode (Tap2Args.in_mode) is a run-time switch; 0 / 1 compiled in -- the 28-element variants, which would
+// otherwise hold 28 mask registers they never use and spill past the 256 registers of two blocks per CU
+template <int FM, int NW, int XR, bool H16 = false, int IMT = -1>
 __global__ __launch_bounds__(NW * 64, (FM == 1 && XR <= 16) ? EBEN_T2_MINB_FM1 : 2) void tap2_kernel(const Tap2Args P) {
+  const bool im_on = IMT < 0 ? P.in_mode != 0 : IMT == 1;
   constexpr int NT = NW * 64;
   constexpr int FNH = 4;
   constexpr int BN = H16 ? NW * 16 * FNH : NW * 32;
@@ -149,28 +152,42 @@ __global__ __launch_bounds__(NW * 64, (FM == 1 && XR <= 16) ? EBEN_T2_MINB_FM1 :
     return c * P.CSTRIDE + p * P.PLEN + d;
   };
   // coordinates of the XR tile elements this thread fetches for every channel chunk after the first
-  int xg[XR];
-#pragma unroll
-  for (int u = 0; u < XR; ++u) {
-    const int i = tid + u * NT;
+  // (registers for the 16-element tiles; the 28-element variants recompute them at every use from a copy of the thread id the
+  // compiler cannot see through -- two VALU ops per element instead of 28 registers held across the whole k loop, which is what
+  // keeps those kernels inside the 256 registers of two blocks per CU without scratch)
+  constexpr bool XG_REG = XR <= T2_XR;
+  auto xg_make = [&](int t, int u) -> int {
+    const int i = t + u * NT;
     const int c = (int)__umulhi((unsigned)i, span_magic);
-    xg[u] = (P.ncc > 1 && i < xtot) ? ((c << 16) | (i - c * span)) : -1;
+    return (P.ncc > 1 && i < xtot) ? ((c << 16) | (i - c * span)) : -1;
+  };
+  int xg_r[XG_REG ? XR : 1];
+  if constexpr (XG_REG) {
+#pragma unroll
+    for (int u = 0; u < XR; ++u) xg_r[u] = xg_make(tid, u);
   }
+  auto opaque_tid = [&]() -> int {
+    int t = tid;
+    if constexpr (!XG_REG) asm volatile("" : "+v"(t));
+    return t;
+  };
   // fetch_x only ISSUES the loads (raw values stay in flight in xreg / mreg under the MFMAs);
   // store_x applies the fused input stage and the zero fill when it writes the tile to LDS
-  float xreg[XR], mreg[XR];
+  float xreg[XR], mreg[IMT == 0 ? 1 : XR];
   unsigned okmask = 0;
   auto fetch_x = [&](int cc) {
     const float* xp = P.x + xrow0 + (long long)cc * P.CI_T * P.Lx;
     const float* mp = P.xmask + xrow0 + (long long)cc * P.CI_T * P.Lx;
     okmask = 0;
+    const int tq = opaque_tid();
 #pragma unroll
     for (int u = 0; u < XR; ++u) {
       int ok;
-      const int o = x_off(xg[u] >> 16, xg[u] & 0xffff, cc, (int)(xg[u] >= 0), ok);
+      const int g_ = XG_REG ? xg_r[XG_REG ? u : 0] : xg_make(tq, u);
+      const int o = x_off(g_ >> 16, g_ & 0xffff, cc, (int)(g_ >= 0), ok);
       okmask |= (unsigned)ok << u;
       xreg[u] = xp[o];
-      if (P.in_mode != 0) mreg[u] = mp[o];
+      if constexpr (IMT != 0) { if (im_on) mreg[u] = mp[o]; }
     }
   };
   const int dead_slot = P.nxb * XBUF;   // one spare float behind the tiles: lanes without an element store there
@@ -178,16 +195,18 @@ __global__ __launch_bounds__(NW * 64, (FM == 1 && XR <= 16) ? EBEN_T2_MINB_FM1 :
     const int bsel = cc % P.nxb;
     float* dst = Xs + bsel * XBUF;
     float t[XR];
-    if (P.in_mode == 0) {
+    if (!im_on) {
 #pragma unroll
       for (int u = 0; u < XR; ++u) t[u] = lrelu(xreg[u], P.in_slope);
-    } else {
+    } else if constexpr (IMT != 0) {
 #pragma unroll
       for (int u = 0; u < XR; ++u) t[u] = xreg[u] * dlrelu(mreg[u], P.in_slope);
     }
+    const int tq = opaque_tid();
 #pragma unroll
     for (int u = 0; u < XR; ++u) {
-      const int sl = xg[u] >= 0 ? x_slot(xg[u] >> 16, xg[u] & 0xffff) : dead_slot - bsel * XBUF;
+      const int g_ = XG_REG ? xg_r[XG_REG ? u : 0] : xg_make(tq, u);
+      const int sl = g_ >= 0 ? x_slot(g_ >> 16, g_ & 0xffff) : dead_slot - bsel * XBUF;
       dst[sl] = ((okmask >> u) & 1u) ? t[u] : 0.f;
     }
   };
@@ -211,7 +230,7 @@ __global__ __launch_bounds__(NW * 64, (FM == 1 && XR <= 16) ? EBEN_T2_MINB_FM1 :
       const int tot4 = P.CI_T * span4;
       const unsigned s4_magic = (unsigned)((0x100000000ull + (unsigned)span4 - 1) / (unsigned)span4);
       const float* xp = P.x + xrow0 + (q0 - xshift);
-      const float* mp = P.in_mode ? P.xmask + xrow0 + (q0 - xshift) : xp;
+      const float* mp = im_on ? P.xmask + xrow0 + (q0 - xshift) : xp;
       for (int base = 0; base < tot4; base += 4 * NT) {
         f32x4 v[4], mk[4];
         int sl[4], ok[4];
@@ -231,7 +250,7 @@ __global__ __launch_bounds__(NW * 64, (FM == 1 && XR <= 16) ? EBEN_T2_MINB_FM1 :
           f32x4 t;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const float w = P.in_mode == 0 ? lrelu(v[u][e], P.in_slope) : v[u][e] * dlrelu(mk[u][e], P.in_slope);
+            const float w = !im_on ? lrelu(v[u][e], P.in_slope) : v[u][e] * dlrelu(mk[u][e], P.in_slope);
             t[e] = ok[u] ? w : 0.f;
           }
           if (sl[u] >= 0) *reinterpret_cast<f32x4*>(Xa + sl[u]) = t;
@@ -239,7 +258,7 @@ __global__ __launch_bounds__(NW * 64, (FM == 1 && XR <= 16) ? EBEN_T2_MINB_FM1 :
       }
     } else {
       const float* xp = P.x + xrow0;
-      const float* mp = P.in_mode ? P.xmask + xrow0 : xp;
+      const float* mp = im_on ? P.xmask + xrow0 : xp;
       for (int base = 0; base < xtot; base += 8 * NT) {
         float v[8], mk[8];
         int sl[8], ok[8];
@@ -255,7 +274,7 @@ __global__ __launch_bounds__(NW * 64, (FM == 1 && XR <= 16) ? EBEN_T2_MINB_FM1 :
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-          const float t = P.in_mode == 0 ? lrelu(v[u], P.in_slope) : v[u] * dlrelu(mk[u], P.in_slope);
+          const float t = !im_on ? lrelu(v[u], P.in_slope) : v[u] * dlrelu(mk[u], P.in_slope);
           if (sl[u] >= 0) Xs[sl[u]] = ok[u] ? t : 0.f;
         }
       }
@@ -593,10 +612,10 @@ __global__ __launch_bounds__(256) void pack2_kernel(const Pack2Args P) {
   }
 }
 
-template <int FM, int NW, int XR, bool H16 = false>
+template <int FM, int NW, int XR, bool H16 = false, int IMT = -1>
 static int launch2_cfg(const Tap2Args& a, int nblocks, size_t lds, hipStream_t st) {
   static bool attr_set = false;
-  auto kern = tap2_kernel<FM, NW, XR, H16>;
+  auto kern = tap2_kernel<FM, NW, XR, H16, IMT>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(tap2)");
@@ -659,15 +678,20 @@ int tap2_launch(const Canon& c, int dir, const TapIO& io, int reflect, hipStream
   a.w_tile = p.w_tile; a.w_phase = p.w_phase;
   const long long nb = (long long)p.ntt * c.B * p.nph * p.nmt * p.G;
   if (nb <= 0 || nb > 0x7fffffffLL) return fail(EBEN_EINVAL, "tap2 grid of %lld blocks", nb);
-  if (p.H16) return p.XR == T2_XR_BIG ? launch2_cfg<1, 4, T2_XR_BIG, true>(a, (int)nb, p.lds_bytes, st)
+  const bool im = io.in_mode != 0;
+  if (p.H16) return p.XR == T2_XR_BIG ? (im ? launch2_cfg<1, 4, T2_XR_BIG, true, 1>(a, (int)nb, p.lds_bytes, st)
+                                            : launch2_cfg<1, 4, T2_XR_BIG, true, 0>(a, (int)nb, p.lds_bytes, st))
                                        : launch2_cfg<1, 4, T2_XR, true>(a, (int)nb, p.lds_bytes, st);
   if (p.XR == T2_XR_BIG) {
+#define EBEN_T2_BIG(FMV) return im ? launch2_cfg<FMV, 4, T2_XR_BIG, false, 1>(a, (int)nb, p.lds_bytes, st) \
+                                   : launch2_cfg<FMV, 4, T2_XR_BIG, false, 0>(a, (int)nb, p.lds_bytes, st)
     switch (p.FM) {
-      case 1: return launch2_cfg<1, 4, T2_XR_BIG>(a, (int)nb, p.lds_bytes, st);
-      case 2: return launch2_cfg<2, 4, T2_XR_BIG>(a, (int)nb, p.lds_bytes, st);
-      case 3: return launch2_cfg<3, 4, T2_XR_BIG>(a, (int)nb, p.lds_bytes, st);
-      default: return launch2_cfg<4, 4, T2_XR_BIG>(a, (int)nb, p.lds_bytes, st);
+      case 1: EBEN_T2_BIG(1);
+      case 2: EBEN_T2_BIG(2);
+      case 3: EBEN_T2_BIG(3);
+      default: EBEN_T2_BIG(4);
     }
+#undef EBEN_T2_BIG
   }
   switch (p.FM) {
     case 1: return launch2_cfg<1, 4, T2_XR>(a, (int)nb, p.lds_bytes, st);
