@@ -51,6 +51,8 @@ extern "C" {
                            * input-independent component plus a small input-dependent one; rounding them to 8 bits buries the
                            * second, which is all that survives when the fake and real hinge gradients (eben.py:121-125) cancel.
                            * Gradient operands and weights stay single bf16; the input-gradient launch equals EBEN_MATH_BF16. */
+#define EBEN_MATH_BF16X3 3 /* fused ResidualUnit launches (eben_ru_*_ex): both operands as hi + lo bf16, three MFMAs per product */
+#define EBEN_MATH_BF16X6 4 /* ... as three bf16 pieces each, six MFMAs: every mantissa bit of the fp32 operands, fp32-grade products */
 
 /* One Conv1d / ConvTranspose1d layer (nn.Conv1d / nn.ConvTranspose1d semantics).
  * Replaces the F.conv1d / F.conv_transpose1d call sites behind
@@ -166,6 +168,22 @@ EBEN_API int eben_ru_pack_bwd(int channels, const float* v_dil, const float* sca
                      float* wimg_bwd, void* stream);
 EBEN_API int eben_ru_bwd(int batch, int channels, int length, int dilation, const float* gy, const float* u, float out_slope,
                 const float* x, float in_slope, const float* post, const float* wimg_bwd, float* gx, float* gh, void* stream);
+
+/* The same two launches on the bf16 matrix pipe with SPLIT operands (csrc/ru_split.hip): every fp32 operand enters as a sum of
+ * bf16 pieces and a product is the sum of the piece products that matter.  math:
+ *   EBEN_MATH_F32     the exact-fp32 MFMA kernels above;
+ *   EBEN_MATH_BF16X6  three pieces per operand, six products: all 24 mantissa bits, dropped terms <= 2^-26 -- fp32 arithmetic at
+ *                     6/16 of the fp32 MFMA cost (the generator forward's mode);
+ *   EBEN_MATH_BF16X3  two pieces, three products, ~2^-17 per product;   EBEN_MATH_BF16  plain bf16 operands.
+ * which: 0 forward image, 1 backward (transposed) image; eben_ru_packed_floats_ex(C, math) floats each.  Dilation <= 9. */
+EBEN_API size_t eben_ru_packed_floats_ex(int channels, int math);
+EBEN_API int eben_ru_supported(int channels, int dilation, int math);
+EBEN_API int eben_ru_pack_ex(int channels, int math, int which, const float* v_dil, const float* scale_dil, const float* v_pw,
+                    const float* scale_pw, float* wimg, void* stream);
+EBEN_API int eben_ru_fwd_ex(int math, int batch, int channels, int length, int dilation, const float* x, float in_slope, float out_slope,
+                   const float* wimg, float* y, float* h, float* u, void* stream);
+EBEN_API int eben_ru_bwd_ex(int math, int batch, int channels, int length, int dilation, const float* gy, const float* u, float out_slope,
+                   const float* x, float in_slope, const float* post, const float* wimg_bwd, float* gx, float* gh, void* stream);
 
 /* ---- PQMF (vibravox/torch_modules/dsp/pqmf.py:194-213, eben_generator.py:209-211) ---------- */
 /* decimating FIR bank: y[b,k,t] = sum_j w[k*ntaps+j] * x[b,0,t*stride+off0+j], zero outside [0,lx) */

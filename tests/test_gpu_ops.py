@@ -257,11 +257,18 @@ def test_bf16_math_forward_and_batched_input_gradient(hip, name):
         assert rel_err(dv, wr2.grad) < 1e-4
 
 
+# max |got - ref| / max |ref| against the fp64 unit, per math mode of the fused ResidualUnit launches: exact fp32 (0) and three bf16
+# pieces per operand (4) at the fp32 bound of the conv tests; two pieces (3): 2^-17 per product; one (1): plain bf16 operands
+RU_TOL = {0: 3e-5, 4: 3e-5, 3: 1e-4, 1: 2e-2}
+
+
 @pytest.mark.parametrize("channels,dilation,length,batch,in_slope", [
     (32, 1, 1000, 3, 1.0), (32, 3, 517, 2, 0.01), (32, 9, 8000, 2, 1.0), (64, 9, 300, 3, 0.01), (64, 1, 4000, 2, 1.0),
     (128, 3, 1000, 2, 1.0), (128, 9, 131, 2, 0.01), (32, 9, 20, 1, 1.0)])
-def test_fused_residual_unit_forward(hip, channels, dilation, length, batch, in_slope):
-    """eben_ru_fwd: y = xin + lrelu(W_pw . (W_dil (*) xin), 0.01), xin = lrelu(x, in_slope) -- eben_generator.py:287-316 in one
+@pytest.mark.parametrize("math_mode", [0, 4, 3, 1])
+def test_fused_residual_unit_forward(hip, channels, dilation, length, batch, in_slope, math_mode):
+    """eben_ru_fwd_ex (math 0 = eben_ru_fwd, the exact-fp32 MFMA kernel; 4 / 3 / 1 = the split-bf16 kernels with three / two / one
+    piece per operand, tolerances RU_TOL): y = xin + lrelu(W_pw . (W_dil (*) xin), 0.01), xin = lrelu(x, in_slope) -- eben_generator.py:287-316 in one
     launch -- against the fp64 oracle: tile interiors (float4 staging), both reflected ends, lengths that are not a multiple
     of the 128-position tile or of 4, a clip shorter than one tile; plus the two tensors kept for the backward."""
     from vibravox_amd._lib import check, load, ptr, stream
@@ -278,17 +285,27 @@ def test_fused_residual_unit_forward(hip, channels, dilation, length, batch, in_
     h_ref = torch.nn.functional.conv1d(torch.nn.functional.pad(xin, (dilation, dilation), mode="reflect"), wd, dilation=dilation)
     u_ref = torch.nn.functional.leaky_relu(torch.nn.functional.conv1d(h_ref, wp_), 0.01)
     y_ref = xin + u_ref
-    img = torch.empty(lib.eben_ru_packed_floats(c), dtype=torch.float32, device=dev)
-    assert img.numel() == 4 * c * c
+    mm = math_mode
+    assert lib.eben_ru_supported(c, dilation, mm) == 1
+    img = torch.empty(lib.eben_ru_packed_floats_ex(c, mm), dtype=torch.float32, device=dev)
+    assert img.numel() == {0: 4, 1: 2, 3: 4, 4: 6}[mm] * c * c
     vdd, vpd, sdd, spd, xd = vd.to(dev), vp.to(dev), sd.to(dev), sp.to(dev), x.to(dev)
-    check(lib.eben_ru_pack(c, ptr(vdd), ptr(sdd), ptr(vpd), ptr(spd), ptr(img), stream()), "ru_pack")
+    check(lib.eben_ru_pack_ex(c, mm, 0, ptr(vdd), ptr(sdd), ptr(vpd), ptr(spd), ptr(img), stream()), "ru_pack")
     y, h, u = torch.full_like(xd, float("nan")), torch.full_like(xd, float("nan")), torch.full_like(xd, float("nan"))
-    check(lib.eben_ru_fwd(batch, c, length, dilation, ptr(xd), in_slope, 0.01, ptr(img), ptr(y), ptr(h), ptr(u), stream()), "ru_fwd")
+    check(lib.eben_ru_fwd_ex(mm, batch, c, length, dilation, ptr(xd), in_slope, 0.01, ptr(img), ptr(y), ptr(h), ptr(u), stream()), "ru_fwd")
     torch.cuda.synchronize()
-    assert rel_err(h, h_ref) < 3e-5 and rel_err(u, u_ref) < 3e-5 and rel_err(y, y_ref) < 3e-5
+    tol = RU_TOL[mm]
+    assert rel_err(h, h_ref) < tol and rel_err(u, u_ref) < tol and rel_err(y, y_ref) < tol
+    if mm == 4:   # three pieces per operand: as close to the fp64 result as the exact-fp32 kernel, not just inside its bound
+        img0 = torch.empty(lib.eben_ru_packed_floats(c), dtype=torch.float32, device=dev)
+        check(lib.eben_ru_pack(c, ptr(vdd), ptr(sdd), ptr(vpd), ptr(spd), ptr(img0), stream()), "ru_pack")
+        y0, h0 = torch.empty_like(xd), torch.empty_like(xd)
+        check(lib.eben_ru_fwd(batch, c, length, dilation, ptr(xd), in_slope, 0.01, ptr(img0), ptr(y0), ptr(h0), None, stream()), "ru_fwd")
+        torch.cuda.synchronize()
+        assert rel_err(h, h_ref) < 2 * rel_err(h0, h_ref) + 1e-7 and rel_err(y, y_ref) < 2 * rel_err(y0, y_ref) + 1e-7
     # inference form: no h / u written; same y bit for bit
     y2 = torch.empty_like(xd)
-    check(lib.eben_ru_fwd(batch, c, length, dilation, ptr(xd), in_slope, 0.01, ptr(img), ptr(y2), None, None, stream()), "ru_fwd")
+    check(lib.eben_ru_fwd_ex(mm, batch, c, length, dilation, ptr(xd), in_slope, 0.01, ptr(img), ptr(y2), None, None, stream()), "ru_fwd")
     torch.cuda.synchronize()
     assert torch.equal(y, y2)
     # a 4-byte-aligned (not 16-byte-aligned) input takes the scalar staging path: same values
@@ -296,7 +313,7 @@ def test_fused_residual_unit_forward(hip, channels, dilation, length, batch, in_
     xo = buf[1:].view_as(xd)
     xo.copy_(xd)
     y3 = torch.empty_like(xd)
-    check(lib.eben_ru_fwd(batch, c, length, dilation, ptr(xo), in_slope, 0.01, ptr(img), ptr(y3), None, None, stream()), "ru_fwd")
+    check(lib.eben_ru_fwd_ex(mm, batch, c, length, dilation, ptr(xo), in_slope, 0.01, ptr(img), ptr(y3), None, None, stream()), "ru_fwd")
     torch.cuda.synchronize()
     assert torch.equal(y, y3)
 
@@ -304,9 +321,10 @@ def test_fused_residual_unit_forward(hip, channels, dilation, length, batch, in_
 @pytest.mark.parametrize("channels,dilation,length,batch,in_slope,post", [
     (32, 1, 1000, 3, 1.0, False), (32, 3, 517, 2, 0.01, True), (32, 9, 8000, 2, 1.0, False), (64, 9, 300, 3, 0.01, True),
     (64, 1, 4000, 2, 1.0, False), (128, 3, 1000, 2, 1.0, True), (128, 9, 131, 2, 0.01, False), (32, 9, 20, 1, 1.0, False),
-    (32, 9, 110, 1, 1.0, False), (64, 3, 123, 2, 1.0, False)])
-def test_fused_residual_unit_backward(hip, channels, dilation, length, batch, in_slope, post):
-    """eben_ru_bwd: g_h = W_pw^T (g_y * lrelu'(u)) and g_x = (g_y + fold(W_dil^T g_h)) * lrelu'(x) + post in one launch, against
+    (32, 9, 110, 1, 1.0, False), (64, 3, 123, 2, 1.0, False), (128, 9, 999, 2, 1.0, False), (128, 1, 47, 1, 1.0, True)])
+@pytest.mark.parametrize("math_mode", [0, 4, 3, 1])
+def test_fused_residual_unit_backward(hip, channels, dilation, length, batch, in_slope, post, math_mode):
+    """eben_ru_bwd_ex (math modes as the forward's): g_h = W_pw^T (g_y * lrelu'(u)) and g_x = (g_y + fold(W_dil^T g_h)) * lrelu'(x) + post in one launch, against
     fp64 autograd of the unit: interior tiles, both reflect folds (also when they land in the same or in neighbouring tiles),
     windows that overhang the signal, clips of exactly one tile and shorter."""
     from vibravox_amd._lib import check, load, ptr, stream
@@ -328,16 +346,17 @@ def test_fused_residual_unit_backward(hip, channels, dilation, length, batch, in
     u = torch.nn.functional.leaky_relu(torch.nn.functional.conv1d(h, wp_), 0.01)
     ((xin + u) * gy.double()).sum().backward()
     gx_ref = xr.grad + (pt.double() if post else 0.0)
-    img = torch.empty(lib.eben_ru_packed_floats(c), dtype=torch.float32, device=dev)
+    mm = math_mode
+    img = torch.empty(lib.eben_ru_packed_floats_ex(c, mm), dtype=torch.float32, device=dev)
     vdd, vpd, sdd, spd = vd.to(dev), vp.to(dev), sd.to(dev), sp.to(dev)
-    check(lib.eben_ru_pack_bwd(c, ptr(vdd), ptr(sdd), ptr(vpd), ptr(spd), ptr(img), stream()), "ru_pack_bwd")
+    check(lib.eben_ru_pack_ex(c, mm, 1, ptr(vdd), ptr(sdd), ptr(vpd), ptr(spd), ptr(img), stream()), "ru_pack_bwd")
     xd, gyd, ud, ptd = x.to(dev), gy.to(dev), u.detach().float().to(dev), pt.to(dev)
     gx, gh = torch.full_like(xd, float("nan")), torch.full_like(xd, float("nan"))
-    check(lib.eben_ru_bwd(batch, c, length, dilation, ptr(gyd), ptr(ud), 0.01, ptr(xd) if in_slope != 1.0 else None, in_slope,
-                          ptr(ptd) if post else None, ptr(img), ptr(gx), ptr(gh), stream()), "ru_bwd")
+    check(lib.eben_ru_bwd_ex(mm, batch, c, length, dilation, ptr(gyd), ptr(ud), 0.01, ptr(xd) if in_slope != 1.0 else None, in_slope,
+                             ptr(ptd) if post else None, ptr(img), ptr(gx), ptr(gh), stream()), "ru_bwd")
     torch.cuda.synchronize()
-    assert rel_err(gh, h.grad) < 3e-5
-    assert rel_err(gx, gx_ref) < 3e-5
+    assert rel_err(gh, h.grad) < RU_TOL[mm]
+    assert rel_err(gx, gx_ref) < RU_TOL[mm]
 
 
 def test_fused_residual_unit_rejects_unsupported_shapes(hip):
@@ -347,6 +366,10 @@ def test_fused_residual_unit_rejects_unsupported_shapes(hip):
     assert lib.eben_ru_packed_floats(48) == 0
     assert lib.eben_ru_fwd(1, 48, 100, 1, None, 1.0, 0.01, None, None, None, None, None) < 0     # channels
     assert lib.eben_ru_fwd(1, 32, 5, 9, None, 1.0, 0.01, None, None, None, None, None) < 0       # reflect pad >= length
+    assert lib.eben_ru_packed_floats_ex(48, 4) == 0 and lib.eben_ru_packed_floats_ex(64, 9) == 0
+    assert lib.eben_ru_supported(64, 12, 4) == 0 and lib.eben_ru_supported(64, 12, 0) == 1   # split kernels: dilation <= 9
+    assert lib.eben_ru_fwd_ex(4, 1, 64, 100, 12, None, 1.0, 0.01, None, None, None, None, None) < 0
+    assert lib.eben_ru_bwd_ex(7, 1, 64, 100, 3, None, None, 0.01, None, 1.0, None, None, None, None, None) < 0   # unknown math
 
 
 def test_input_gradient_with_residual_joins(hip):

@@ -32,6 +32,12 @@ from ._lib import check, load, ptr, stream
 
 USE_FUSED_RU = os.environ.get("EBEN_RU_FUSED", "1") != "0"
 USE_FUSED_RU_BWD = os.environ.get("EBEN_RU_FUSED_BWD", "1") != "0"
+# arithmetic of the fused ResidualUnit launches (include/eben_hip.h, eben_ru_*_ex): the forward and the fp32 backward run on the bf16
+# matrix pipe with three bf16 pieces per operand (EBEN_MATH_BF16X6: every mantissa bit of the fp32 operands, fp32 accumulate --
+# fp32 arithmetic at 6/16 of the fp32 MFMA's cost); "f32" selects the v_mfma_f32_32x32x2_f32 kernels (bisecting aid).
+_RU_MATH = {"f32": ops.MATH_F32, "bf16x6": ops.MATH_BF16X6, "bf16x3": ops.MATH_BF16X3, "bf16": ops.MATH_BF16}
+RU_FWD_MATH = _RU_MATH[os.environ.get("EBEN_RU_FWD_MATH", "bf16x6")]
+RU_BWD_F32_MATH = _RU_MATH[os.environ.get("EBEN_RU_BWD_F32_MATH", "bf16x6")]
 
 
 def _params(m):
@@ -90,27 +96,45 @@ class GeneratorEngine:
             recs.append(_ConvRec(m, spec, d_bwd, x, y if spec.out_slope != 1.0 else None, pw.wp_bwd, pw.norm))
         return y
 
+    @staticmethod
+    def _ru_bwd_math() -> int:
+        """Math of the fused backward launch: plain bf16 operands next to a bf16 generator backward (``ops.backward_math``), else
+        the fp32-grade split."""
+        return ops.MATH_BF16 if ops._backward_math[0] != ops.MATH_F32 else RU_BWD_F32_MATH
+
     def _ru_image(self, ru, which: int = 0) -> torch.Tensor:
-        """Weight images of the fused unit (both convs, weight-norm scales folded in): 0 forward, 1 backward (transposed);
-        rebuilt together when a parameter changed."""
+        """Weight images of the fused unit (both convs, weight-norm scales folded in): 0 forward, 1 backward (transposed, in the
+        math of the current backward).  Rebuilt when a parameter changed: the forward image and the backward image of every math
+        this unit has been differentiated in (so that ``prepack``, which runs outside the step's math context, rebuilds the
+        right ones)."""
         lib = load()
         vd, gd = _params(ru.dilated_conv)
         vp, gp = _params(ru.pointwise_conv)
         e = ops._storage_epoch
         key = tuple((t.data_ptr(), t._version, e.get(t.data_ptr(), 0)) for t in (vd, gd, vp, gp)) + (e.get(-1, 0),)
         hit = self._ru_images.get(id(ru))
-        if hit is not None and hit[0] == key:
-            return hit[1 + which]
+        bm = self._ru_bwd_math() if which == 1 else None
+        if hit is not None and hit["key"] == key and (bm is None or bm in hit["bwd"]):
+            return hit["fwd"] if which == 0 else hit["bwd"][bm]
         c = vd.shape[0]
         dev = vd.device
-        scales = torch.empty((4, c), dtype=torch.float32, device=dev)   # scale / norm of the dilated, then of the pointwise conv
-        ops.wn_scale_multi([(gd.detach(), vd.detach(), c, vd.numel() // c, scales[0], scales[1]), (gp.detach(), vp.detach(), c, vp.numel() // c, scales[2], scales[3])])
-        img = torch.empty(lib.eben_ru_packed_floats(c), dtype=torch.float32, device=dev)
-        img_b = torch.empty_like(img)
-        check(lib.eben_ru_pack(c, ptr(vd.detach()), ptr(scales[0]), ptr(vp.detach()), ptr(scales[2]), ptr(img), stream()), "ru_pack")
-        check(lib.eben_ru_pack_bwd(c, ptr(vd.detach()), ptr(scales[0]), ptr(vp.detach()), ptr(scales[2]), ptr(img_b), stream()), "ru_pack_bwd")
-        self._ru_images[id(ru)] = (key, img, img_b)
-        return (img, img_b)[which]
+        if hit is None or hit["key"] != key:
+            scales = torch.empty((4, c), dtype=torch.float32, device=dev)   # scale / norm of the dilated, then of the pointwise conv
+            ops.wn_scale_multi([(gd.detach(), vd.detach(), c, vd.numel() // c, scales[0], scales[1]), (gp.detach(), vp.detach(), c, vp.numel() // c, scales[2], scales[3])])
+            img = torch.empty(lib.eben_ru_packed_floats_ex(c, RU_FWD_MATH), dtype=torch.float32, device=dev)
+            check(lib.eben_ru_pack_ex(c, RU_FWD_MATH, 0, ptr(vd.detach()), ptr(scales[0]), ptr(vp.detach()), ptr(scales[2]), ptr(img), stream()), "ru_pack")
+            maths = set(hit["bwd"]) if hit is not None else set()
+            hit = self._ru_images[id(ru)] = {"key": key, "fwd": img, "bwd": {}, "scales": scales}
+        else:
+            maths = set()
+        if bm is not None:
+            maths.add(bm)
+        scales = hit["scales"]
+        for m in maths:
+            img_b = torch.empty(lib.eben_ru_packed_floats_ex(c, m), dtype=torch.float32, device=dev)
+            check(lib.eben_ru_pack_ex(c, m, 1, ptr(vd.detach()), ptr(scales[0]), ptr(vp.detach()), ptr(scales[2]), ptr(img_b), stream()), "ru_pack_bwd")
+            hit["bwd"][m] = img_b
+        return hit["fwd"] if which == 0 else hit["bwd"][bm]
 
     def prepack(self) -> None:
         """Rebuilds the fused units' weight images on the side stream (called with ``ops.prepack`` after the optimiser step)."""
@@ -138,13 +162,14 @@ class GeneratorEngine:
             spec_d = self._spec(dil, in_slope=in_slope if in_slope != 1.0 else None)
             _, dd_bwd, pw_d = self._pack(dil, spec_d, b, l, True)
             _, dp_bwd, pw_p = self._pack(pwc, pwc.spec, b, l, True)
-        if USE_FUSED_RU and c in (32, 64, 128) and dil.spec.ksize == 3 and dil.spec.reflect:
+        fusable = dil.spec.ksize == 3 and dil.spec.reflect and lib.eben_ru_supported(c, dil.spec.dilation, RU_FWD_MATH) == 1
+        if USE_FUSED_RU and fusable:
             img = self._ru_image(ru)
             y = torch.empty_like(x)
             h = torch.empty_like(x) if train else None
             u = torch.empty_like(x) if train else None
-            check(lib.eben_ru_fwd(b, c, l, dil.spec.dilation, ptr(x), float(in_slope), float(pwc.spec.out_slope), ptr(img), ptr(y), ptr(h), ptr(u),
-                                  stream()), "ru_fwd")
+            check(lib.eben_ru_fwd_ex(RU_FWD_MATH, b, c, l, dil.spec.dilation, ptr(x), float(in_slope), float(pwc.spec.out_slope), ptr(img), ptr(y),
+                                     ptr(h), ptr(u), stream()), "ru_fwd")
         else:   # layer by layer (bisecting aid, EBEN_RU_FUSED=0)
             xin = x
             if in_slope != 1.0:
@@ -155,8 +180,9 @@ class GeneratorEngine:
             y = torch.empty_like(x)
             check(lib.eben_add(ptr(xin), ptr(u), ptr(y), x.numel(), stream()), "add")
         if train:
-            fused = USE_FUSED_RU_BWD and c in (32, 64, 128) and dil.spec.ksize == 3 and dil.spec.reflect
-            recs.append((self._ru_image(ru, 1) if fused else None, _ConvRec(dil, spec_d, dd_bwd, x, None, pw_d.wp_bwd, pw_d.norm),
+            bm = self._ru_bwd_math()
+            fused = USE_FUSED_RU_BWD and dil.spec.ksize == 3 and dil.spec.reflect and lib.eben_ru_supported(c, dil.spec.dilation, bm) == 1
+            recs.append(((self._ru_image(ru, 1), bm) if fused else None, _ConvRec(dil, spec_d, dd_bwd, x, None, pw_d.wp_bwd, pw_d.norm),
                          _ConvRec(pwc, pwc.spec, dp_bwd, h, u, pw_p.wp_bwd, pw_p.norm)))
         return y
 
@@ -229,13 +255,14 @@ class GeneratorEngine:
                     hook(p)   # e.g. ddp.GradSync's bucket accounting
 
     def _ru_backward(self, rec, gy, res_post=None):
-        img_b, dil, pwc = rec
-        if img_b is not None:   # one launch: g_h and g_x = (g_y + fold(dilated^T g_h)) * lrelu'(x) + skip gradient
+        fused, dil, pwc = rec
+        if fused is not None:   # one launch: g_h and g_x = (g_y + fold(dilated^T g_h)) * lrelu'(x) + skip gradient
             b, c, l = gy.shape
             gx, gh = torch.empty_like(gy), torch.empty_like(gy)
             ins = dil.spec.in_slope
-            check(load().eben_ru_bwd(b, c, l, dil.spec.dilation, ptr(gy), ptr(pwc.y), float(pwc.spec.out_slope), ptr(dil.x) if ins != 1.0 else None,
-                                     float(ins), ptr(res_post), ptr(img_b), ptr(gx), ptr(gh), stream()), "ru_bwd")
+            img_b, bm = fused
+            check(load().eben_ru_bwd_ex(bm, b, c, l, dil.spec.dilation, ptr(gy), ptr(pwc.y), float(pwc.spec.out_slope),
+                                        ptr(dil.x) if ins != 1.0 else None, float(ins), ptr(res_post), ptr(img_b), ptr(gx), ptr(gh), stream()), "ru_bwd")
             self._dw(pwc, gy)
             self._dw(dil, gh)
             return gx

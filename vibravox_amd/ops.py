@@ -236,7 +236,7 @@ class ConvSpec:
 _desc_cache: Dict[Tuple[ConvSpec, int, int], EbenConv1dDesc] = {}
 
 
-MATH_F32, MATH_BF16, MATH_BF16X2 = 0, 1, 2   # EBEN_MATH_* of include/eben_hip.h
+MATH_F32, MATH_BF16, MATH_BF16X2, MATH_BF16X3, MATH_BF16X6 = 0, 1, 2, 3, 4   # EBEN_MATH_* of include/eben_hip.h
 
 # Arithmetic of the BACKWARD contractions (input and weight gradients) of `conv_layer`; the forward is always exact fp32.
 # Read when the forward runs (the backward image of the weights is packed then).
