@@ -127,15 +127,15 @@ HBM_PEAK = 8.0e12
 
 def step_roofline_ms(disc_math, scale):
     """Mixed roofline of the minimal step F_min = 2 (3 G + 8 D): sum over the parts of max(FLOP / peak(dtype), bytes / HBM).
-    fp32: everything on the fp32 MFMA peak.  bf16: the discriminator passes on the bf16 MFMA peak except the PQMF-band forwards (2 of
-    the 8 passes of those three chains), which this build keeps in fp32; the generator's forward is fp32 compute, its backward
-    (2 G, bf16 operands) is bound by its activation traffic."""
+    fp32: everything on the fp32 MFMA peak.  bf16: the discriminator passes on the bf16 MFMA peak, the PQMF-band forwards (2 of
+    the 8 passes of those three chains) at three bf16 MFMAs per product; the generator's forward is fp32-grade (six bf16 MFMAs per
+    product), its backward (2 G, bf16 operands) is bound by its activation traffic."""
     f32, bf16 = MFMA_F32_PEAK_TFLOPS * 1e12, MFMA_BF16_PEAK_TFLOPS * 1e12
     if disc_math == "f32":
         t = 2 * (3 * G_MACS + 8 * D_MACS) / f32
     else:
-        t = 2 * (8 * D_MACS - 2 * D_PQMF_MACS) / bf16 + 2 * 2 * D_PQMF_MACS / f32
-        t += max(2 * G_MACS / f32, G_BYTES / HBM_PEAK) + max(2 * 2 * G_MACS / bf16, 2 * G_BYTES / HBM_PEAK)
+        t = 2 * (8 * D_MACS - 2 * D_PQMF_MACS) / bf16 + 3 * 2 * 2 * D_PQMF_MACS / bf16
+        t += max(6 * 2 * G_MACS / bf16, G_BYTES / HBM_PEAK) + max(2 * 2 * G_MACS / bf16, 2 * G_BYTES / HBM_PEAK)
     return t * scale * 1e3
 
 
@@ -355,7 +355,7 @@ def main():
                        "global_batch": world * args.batch, "samples_per_clip": cut, "parallelism": f"dp{world}",
                        "weights": "random init, torch.manual_seed(42)", "disc_math": args.disc_math,
                        "precision": (f"discriminator contractions on bf16 MFMA operands with fp32 accumulate (MelGAN: every pass; PQMF-band "
-                                     f"discriminators: input / weight gradients -- their forward stays fp32, which keeps the discriminator "
+                                     f"discriminators: input / weight gradients -- their forward takes hi + lo bf16 operands (3 MFMAs per product), which keeps the discriminator "
                                      f"gradient within 3.4e-2 of the fp32 step's, tests/test_gpu_models.py); generator forward, losses, Adam, "
                                      f"storage: fp32; generator backward contractions: {gen_bwd_math}; MRSTFT DFT contractions: fp32 ({stft_math})"
                                      if args.disc_math == "bf16" else

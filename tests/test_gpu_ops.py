@@ -257,6 +257,88 @@ def test_bf16_math_forward_and_batched_input_gradient(hip, name):
         assert rel_err(dv, wr2.grad) < 1e-4
 
 
+@pytest.mark.parametrize("math_name", ["bf16x6", "bf16x3"])
+@pytest.mark.parametrize("name", [n for n, c in BF16_CASES.items() if c[2][0] == 4])
+def test_split_bf16_math_forward_and_batched_input_gradient(hip, name, math_name):
+    """EBEN_MATH_BF16X6 / BF16X3 (tapconv3.hip with split operands): both MFMA operands enter as three / two bf16 pieces and a
+    product is the sum of the six / three piece products that matter.  Against the fp64 conv of the EXACT operands:
+    X6 at the bound of the fp32 kernels (3e-5) and within 2x of what the exact-fp32 kernel itself achieves on the same inputs --
+    it is fp32 arithmetic; X3 at 2^-17 per product (1e-4).  Weight gradients of these modes run on the fp32 kernels."""
+    import ctypes
+    import dataclasses
+
+    from vibravox_amd import ops
+    from vibravox_amd._lib import check, load, ptr, stream
+
+    lib = load()
+    kw, length, _ = BF16_CASES[name]
+    spec = ops.ConvSpec(**kw)
+    mm, tol = (ops.MATH_BF16X6, 3e-5) if math_name == "bf16x6" else (ops.MATH_BF16X3, 1e-4)
+    S = 2
+    wshape = spec.weight_shape()
+    w = formula_tensor(f"bf/{name}/w", wshape, 1 / math.sqrt(wshape[1] * wshape[2]))
+    bias = formula_tensor(f"bf/{name}/b", (spec.c_out,), 0.1)
+    x = formula_tensor(f"bf/{name}/x", (2 * S, spec.c_in, length))
+    l_out = spec.out_len(length)
+    okw = {k: v for k, v in kw.items() if k not in ("c_in", "c_out", "ksize", "in_slope", "out_slope")}
+    dev = torch.device("cuda")
+    wd, bd, xd = w.to(dev), bias.to(dev), x.to(dev)
+
+    def forward(math_id):
+        d = ops.conv_desc(spec, 2 * S, length, math_id)
+        gen = lib.eben_conv1d_kernel_generation(ctypes.byref(d), 0)
+        wp = torch.empty(lib.eben_conv1d_packed_floats(ctypes.byref(d), 0), dtype=torch.float32, device=dev)
+        check(lib.eben_conv1d_pack(ctypes.byref(d), ptr(wd), None, ptr(wp), None, stream()), "pack")
+        y = torch.full((2 * S, spec.c_out, l_out), float("nan"), dtype=torch.float32, device=dev)
+        check(lib.eben_conv1d_fwd(ctypes.byref(d), ptr(xd), ptr(wp), ptr(bd), None, ptr(y), stream()), "fwd")
+        torch.cuda.synchronize()
+        return y, gen
+
+    exact = torch.nn.functional.leaky_relu(O.conv_layer(x.double(), w.double(), None, bias.double(), **okw), spec.out_slope)
+    y, gen = forward(mm)
+    assert gen == 4
+    assert rel_err(y, exact) < tol
+    if mm == ops.MATH_BF16X6:
+        y32, _ = forward(ops.MATH_F32)
+        assert rel_err(y, exact) < 2 * rel_err(y32, exact) + 2e-7
+
+    lin = dataclasses.replace(spec, in_slope=1.0, out_slope=1.0)
+    g = formula_tensor(f"bf/{name}/g", (4 * S, spec.c_out, l_out))
+    act = formula_tensor(f"bf/{name}/act", (2 * S, spec.c_in, length))
+    res = formula_tensor(f"bf/{name}/res", (S, spec.c_in, length))
+    xr = torch.zeros(4 * S, spec.c_in, length, dtype=torch.float64, requires_grad=True)
+    (O.conv_layer(xr, w.double(), None, None, **okw) * g.double()).sum().backward()
+    ref = xr.grad.clone()
+    ref[:S] += res.double()
+    rows = torch.tensor([0, 1, 0, 1, 0, 1, 2, 3])
+    ref = ref * torch.where(act.double()[rows] > 0, 1.0, 0.2)
+    gd, rd, ad = g.to(dev), res.to(dev), act.to(dev)
+    seg_map = (ctypes.c_int * 4)(0, 0, 0, 1)
+
+    def input_gradient(math_id):
+        d = ops.conv_desc(lin, 4 * S, length, math_id)
+        gen = lib.eben_conv1d_kernel_generation(ctypes.byref(d), 1)
+        wp = torch.empty(lib.eben_conv1d_packed_floats(ctypes.byref(d), 1), dtype=torch.float32, device=dev)
+        check(lib.eben_conv1d_pack(ctypes.byref(d), ptr(wd), None, None, ptr(wp), stream()), "pack")
+        dx = torch.full((4 * S, spec.c_in, length), float("nan"), dtype=torch.float32, device=dev)
+        check(lib.eben_conv1d_bwd_dx_ex(ctypes.byref(d), ptr(gd), ptr(wp), ptr(rd), S, ptr(ad), 0.2, S, seg_map, ptr(dx), stream()), "bwd_dx_ex")
+        torch.cuda.synchronize()
+        return dx, gen
+
+    dx, gen = input_gradient(mm)
+    assert gen == 4
+    assert rel_err(dx, ref) < tol
+    if mm == ops.MATH_BF16X6:
+        dx32, _ = input_gradient(ops.MATH_F32)
+        assert rel_err(dx, ref) < 2 * rel_err(dx32, ref) + 2e-7
+    # the weight gradient of these modes is the exact-fp32 kernels' (generation 2 / 1)
+    d = ops.conv_desc(lin, 24, length, mm)
+    nslab, row_stride = ctypes.c_int(0), ctypes.c_int(0)
+    d32 = ops.conv_desc(lin, 24, length, ops.MATH_F32)
+    assert lib.eben_conv1d_bwd_dw_workspace(ctypes.byref(d), ctypes.byref(nslab), ctypes.byref(row_stride)) == \
+        lib.eben_conv1d_bwd_dw_workspace(ctypes.byref(d32), ctypes.byref(nslab), ctypes.byref(row_stride))
+
+
 # max |got - ref| / max |ref| against the fp64 unit, per math mode of the fused ResidualUnit launches: exact fp32 (0) and three bf16
 # pieces per operand (4) at the fp32 bound of the conv tests; two pieces (3): 2^-17 per product; one (1): plain bf16 operands
 RU_TOL = {0: 3e-5, 4: 3e-5, 3: 1e-4, 1: 2e-2}

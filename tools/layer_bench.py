@@ -62,7 +62,7 @@ def main():
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--filter", default="")
     ap.add_argument("--min-gmacs", type=float, default=0.0)
-    ap.add_argument("--math", default="f32", choices=["f32", "bf16", "bf16x2"], help="bf16: EBEN_MATH_BF16 descriptors; dx through eben_conv1d_bwd_dx_ex; bf16x2: EBEN_MATH_BF16X2")
+    ap.add_argument("--math", default="f32", choices=["f32", "bf16", "bf16x2", "bf16x3", "bf16x6"], help="bf16: EBEN_MATH_BF16 descriptors; dx through eben_conv1d_bwd_dx_ex; bf16x2: EBEN_MATH_BF16X2")
     a = ap.parse_args()
     lib = load()
     dev = torch.device("cuda")
@@ -72,7 +72,7 @@ def main():
     for name, spec, l_in, has_bias in rows:
         if a.filter and a.filter not in name:
             continue
-        math = {"bf16": ops.MATH_BF16, "bf16x2": ops.MATH_BF16X2, "f32": ops.MATH_F32}[a.math]
+        math = {"bf16": ops.MATH_BF16, "bf16x2": ops.MATH_BF16X2, "f32": ops.MATH_F32, "bf16x3": ops.MATH_BF16X3, "bf16x6": ops.MATH_BF16X6}[a.math]
         d = ops.conv_desc(spec, a.batch, l_in, math)
         l_out = d.l_out
         wshape = spec.weight_shape()

@@ -80,6 +80,7 @@ struct Canon {
   // EBEN_MATH_BF16X2: the tap-conv direction (0 gather-strided, 1 phase-scatter) whose INPUT operand is the layer's activation
   // tensor (the layer's forward) -- staged as hi + lo bf16 tiles there and in the weight gradient; -1 otherwise
   int xsplit_dir;
+  int np;     // pieces per MFMA operand in the bf16 tap-conv: 1 (EBEN_MATH_BF16 / BF16X2), 2 (BF16X3), 3 (BF16X6)
 };
 int canon_from_desc(const EbenConv1dDesc* d, Canon* c);
 

@@ -328,7 +328,8 @@ static void make_dw3_plan(const Canon& c, Dw3Plan* p) {
   static const int enabled = dw3_env("EBEN_DW3", 1);
   static const int min_m = dw3_env("EBEN_DW3_MIN_M", 4);
   static const int min_n = dw3_env("EBEN_DW3_MIN_N", 12);
-  if (!enabled || !c.bf16 || p->Mg < min_m || p->Ng < min_n || c.B < 8) return;
+  // split operands on BOTH sides (EBEN_MATH_BF16X3 / X6) are a tap-conv form: those weight gradients take the exact-fp32 kernels
+  if (!enabled || !c.bf16 || c.np > 1 || p->Mg < min_m || p->Ng < min_n || c.B < 8) return;
   const int cand[4] = {128, 96, 64, 32};
   int best = 0, best_pad = 1 << 30;
   for (int i = 0; i < 4; ++i) {

@@ -325,8 +325,9 @@ int canon_from_desc(const EbenConv1dDesc* d, Canon* c) {
   EBEN_REQUIRE(d->stride <= 1024 && d->pad_l >= 0 && d->pad_r >= 0, "bad stride / padding");
   c->B = d->batch; c->k = d->ksize; c->s = d->stride; c->d = d->dilation; c->g = d->groups;
   c->pl = d->pad_l; c->pr = d->pad_r;
-  EBEN_REQUIRE(d->math == EBEN_MATH_F32 || d->math == EBEN_MATH_BF16 || d->math == EBEN_MATH_BF16X2, "unknown math mode %d", d->math);
+  EBEN_REQUIRE(d->math >= EBEN_MATH_F32 && d->math <= EBEN_MATH_BF16X6, "unknown math mode %d", d->math);
   c->bf16 = d->math != EBEN_MATH_F32;
+  c->np = d->math == EBEN_MATH_BF16X3 ? 2 : (d->math == EBEN_MATH_BF16X6 ? 3 : 1);
   c->xsplit_dir = d->math == EBEN_MATH_BF16X2 ? (d->transposed ? 1 : 0) : -1;
   if (!d->transposed) {
     c->Cin = d->c_in; c->Cout = d->c_out; c->Lin = d->l_in; c->Lout = d->l_out;

@@ -35,7 +35,10 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
 #ifndef EBEN_T3_KSC
 #define EBEN_T3_KSC 4
 #endif
-constexpr int T3_KSC = EBEN_T3_KSC;   // k-steps (of 16 reduction elements) per weight chunk
+constexpr int T3_KSC = EBEN_T3_KSC;   // k-steps (of 16 reduction elements) per weight chunk (single-piece weights)
+// split weights (NPW pieces per weight, EBEN_MATH_BF16X3 / X6): a k-step carries NPW times the weight bytes and 3 / 6 times the
+// MFMAs, so two k-steps per chunk keep the chunk at 4-6 KB per 32 rows and the barrier at >= 24 MFMAs per wave
+__host__ __device__ constexpr int t3_ksc(int npw) { return npw == 1 ? T3_KSC : 2; }
 
 struct Tap3Args {
   const float* x; const float* xmask; const u32x4* wp; const int* tab;
@@ -52,14 +55,20 @@ struct Tap3Args {
   long long w_tile, w_phase;                     // in 16-byte units
 };
 
-// SP: the input operand is staged as TWO bf16 tiles, hi = bf16(x) and lo = bf16(x - hi), and every k-step issues two MFMAs
-// against the same weight fragment (EBEN_MATH_BF16X2: x enters the product to ~2^-17 instead of 2^-9; weights single bf16).
-template <int FM, int XRB, bool IM = false, bool SP = false>
-__global__ __launch_bounds__(256, 2) void tap3_kernel(const Tap3Args P) {
-  constexpr int NT = 256, BN = 128, BM = FM * 32, KSC = T3_KSC;
-  constexpr int WCHU = KSC * FM * 64;       // 16-byte units per weight chunk
-  constexpr int PIECES = WCHU / NT;
-  static_assert(PIECES >= 1 && PIECES * NT == WCHU, "weight chunk must split into whole LDS-DMA pieces");
+// NPX / NPW: pieces per operand.  The input operand is staged as NPX bf16 tiles, piece q = bf16(x - p0 - .. - p(q-1)) (every
+// residual exact in fp32), the weights arrive as NPW pieces from the pack kernel, and a k-step issues the piece products
+// a_q * b_s with q + s < max(NPW, NPX):
+//   (1, 1) EBEN_MATH_BF16;   (1, 2) EBEN_MATH_BF16X2: x to ~2^-17, weights single bf16;
+//   (2, 2) EBEN_MATH_BF16X3: three products, ~2^-17 per product;
+//   (3, 3) EBEN_MATH_BF16X6: six products, all 24 mantissa bits of both operands, dropped terms <= 2^-26: fp32-grade products at
+//          6/16 of the fp32 MFMA's cost (and 0.6 LDS fragment reads per MFMA instead of 1.25: this form is MFMA-bound).
+template <int FM, int XRB, bool IM = false, int NPW = 1, int NPX = 1>
+__global__ __launch_bounds__(256, NPW >= 2 ? 1 : 2) void tap3_kernel(const Tap3Args P) {
+  constexpr int NT = 256, BN = 128, BM = FM * 32, KSC = t3_ksc(NPW);
+  constexpr bool SP = NPX > 1;
+  constexpr int NPM = NPW > NPX ? NPW : NPX;
+  constexpr int WCHU = KSC * NPW * FM * 64;       // 16-byte units per weight chunk
+  static_assert(WCHU % 64 == 0, "weight chunk must split into whole wave pieces");
 
   extern __shared__ __attribute__((aligned(16))) u32x4 smem3[];
   u32x4* Ws = smem3;              // 2 x WCHU
@@ -99,7 +108,7 @@ __global__ __launch_bounds__(256, 2) void tap3_kernel(const Tap3Args P) {
   const int q0 = t0 * P.S + q.minoff;
   const int xtot = P.CI_B * span;          // bundle-positions per input tile
   const int XBUF = P.CI_B * P.CSTRIDE;
-  const int LO = P.nxb * XBUF + 1;         // SP: unit offset of the lo copy of every tile slot
+  const int LO = SP ? P.nxb * XBUF + 1 : 0;   // split input: unit offset from piece q to piece q + 1 of every tile slot
   const unsigned span_magic = span > 0 ? (unsigned)((0x100000000ull + (unsigned)span - 1) / (unsigned)span) : 0u;
 
   const u32x4* wsrc = P.wp + (long long)ph * P.w_phase + ((long long)g * P.nmt + mt) * P.w_tile;
@@ -136,24 +145,27 @@ __global__ __launch_bounds__(256, 2) void tap3_kernel(const Tap3Args P) {
       v[e] = base[(long long)c * P.Lx + qq];
     }
   };
-  auto cvt8 = [&](const float (&v)[8], const float (&mk)[8], int c0, int ok, u32x4& lo) -> u32x4 {
+  auto cvt8 = [&](const float (&v)[8], const float (&mk)[8], int c0, int ok, u32x4 (&pc)[NPX]) {
     float t[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const float w = IM ? v[e] * dlrelu(mk[e], P.in_slope) : lrelu(v[e], P.in_slope);
       t[e] = (ok && c0 + e < P.Cg) ? w : 0.f;
     }
-    u32x4 o;
-    o[0] = pack_bf16(t[0], t[1]); o[1] = pack_bf16(t[2], t[3]); o[2] = pack_bf16(t[4], t[5]); o[3] = pack_bf16(t[6], t[7]);
-    if constexpr (SP) {
-      // residual against the rounded value (a bf16 is the upper half of its fp32): x - hi is exact in fp32
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float h0 = __builtin_bit_cast(float, o[e] << 16), h1 = __builtin_bit_cast(float, o[e] & 0xffff0000u);
-        lo[e] = pack_bf16(t[2 * e] - h0, t[2 * e + 1] - h1);
+    for (int q = 0; q < NPX; ++q) {
+      u32x4 o;
+      o[0] = pack_bf16(t[0], t[1]); o[1] = pack_bf16(t[2], t[3]); o[2] = pack_bf16(t[4], t[5]); o[3] = pack_bf16(t[6], t[7]);
+      pc[q] = o;
+      if (q + 1 < NPX) {
+        // residual against the rounded value (a bf16 is the upper half of its fp32): exact in fp32
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          t[2 * e] -= __builtin_bit_cast(float, o[e] << 16);
+          t[2 * e + 1] -= __builtin_bit_cast(float, o[e] & 0xffff0000u);
+        }
       }
     }
-    return o;
   };
 
   int xg[XRB];
@@ -187,9 +199,10 @@ __global__ __launch_bounds__(256, 2) void tap3_kernel(const Tap3Args P) {
     for (int u = 0; u < XRB; ++u) {
       const int bb = xg[u] >> 16;
       const int sl = xg[u] >= 0 ? x_slot(bb, xg[u] & 0xffff) : dead_slot - bsel * XBUF;
-      u32x4 lo;
-      dst[sl] = cvt8(xreg[u], mreg[IM ? u : 0], cc * P.CI_T + (xg[u] >= 0 ? bb * 8 : 0), (int)((okmask >> u) & 1u), lo);
-      if constexpr (SP) dst[sl + LO] = lo;
+      u32x4 pc[NPX];
+      cvt8(xreg[u], mreg[IM ? u : 0], cc * P.CI_T + (xg[u] >= 0 ? bb * 8 : 0), (int)((okmask >> u) & 1u), pc);
+#pragma unroll
+      for (int q = 0; q < NPX; ++q) dst[sl + q * LO] = pc[q];
     }
   };
 
@@ -197,9 +210,11 @@ __global__ __launch_bounds__(256, 2) void tap3_kernel(const Tap3Args P) {
     const u32x4* src = wsrc + (long long)ch * WCHU;
     u32x4* dst = Ws + (ch & 1) * WCHU;
 #pragma unroll
-    for (int u = 0; u < PIECES; ++u) {
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (u * NT + tid)),
-                                       (__attribute__((address_space(3))) void*)(dst + (u * NT + (tid & ~63))), 16, 0, 0);
+    for (int u = 0; u * NT < WCHU; ++u) {
+      const int idx = u * NT + tid;
+      if (WCHU % NT == 0 || idx < WCHU)   // wave-uniform
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + idx),
+                                         (__attribute__((address_space(3))) void*)(dst + (idx & ~63)), 16, 0, 0);
     }
   };
 
@@ -226,9 +241,10 @@ __global__ __launch_bounds__(256, 2) void tap3_kernel(const Tap3Args P) {
 #pragma unroll
       for (int u = 0; u < 2; ++u)
         if (sl[u] >= 0) {
-          u32x4 lo;
-          Xs[sl[u]] = cvt8(v[u], mk[IM ? u : 0], c0[u], ok[u], lo);
-          if constexpr (SP) Xs[sl[u] + LO] = lo;
+          u32x4 pc[NPX];
+          cvt8(v[u], mk[IM ? u : 0], c0[u], ok[u], pc);
+#pragma unroll
+          for (int q = 0; q < NPX; ++q) Xs[sl[u] + q * LO] = pc[q];
         }
     }
     if (P.ncc > 1) fetch_x(1);
@@ -248,29 +264,34 @@ __global__ __launch_bounds__(256, 2) void tap3_kernel(const Tap3Args P) {
     if ((EBEN_T3_DBG & 2) == 0 && pending >= 0) { fetch_x(pending); pending = -1; }
     const u32x4* wb = Ws + (ch & 1) * WCHU + lane;
     const u32x4* xb = Xs + lanebase;
-    u32x4 bv[KSC], bl[SP ? KSC : 1], a[KSC][FM];
+    u32x4 bv[KSC][NPX], a[KSC][NPW][FM];
     auto rd = [&](int ks) {
-      bv[ks] = xb[te[ks]];
-      if constexpr (SP) bl[ks] = xb[te[ks] + LO];
 #pragma unroll
-      for (int i = 0; i < FM; ++i) a[ks][i] = wb[(ks * FM + i) * 64];
+      for (int q = 0; q < NPX; ++q) bv[ks][q] = xb[te[ks] + q * LO];
+#pragma unroll
+      for (int q = 0; q < NPW; ++q)
+#pragma unroll
+        for (int i = 0; i < FM; ++i) a[ks][q][i] = wb[((ks * NPW + q) * FM + i) * 64];
     };
     rd(0);
-    rd(1);
+    if (KSC > 1) rd(1);
 #pragma unroll
     for (int ks = 0; ks < KSC; ++ks) {
       if (ks + 2 < KSC) rd(ks + 2);
       __builtin_amdgcn_sched_barrier(0);
+      // piece products, smallest first: (qw, qx) with qw + qx = lvl
 #pragma unroll
-      for (int i = 0; i < FM; ++i) {
-        if (EBEN_T3_DBG & 8) acc[i][0] += __builtin_bit_cast(float, a[ks][i][0] ^ bv[ks][i & 3]);
-        else acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[ks][i]), __builtin_bit_cast(bf16x8, bv[ks]), acc[i], 0, 0, 0);
-      }
-      if constexpr (SP) {
+      for (int lvl = NPM - 1; lvl >= 0; --lvl)
 #pragma unroll
-        for (int i = 0; i < FM; ++i)
-          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[ks][i]), __builtin_bit_cast(bf16x8, bl[ks]), acc[i], 0, 0, 0);
-      }
+        for (int qw = 0; qw < NPW; ++qw) {
+          const int qx = lvl - qw;
+          if (qx < 0 || qx >= NPX) continue;
+#pragma unroll
+          for (int i = 0; i < FM; ++i) {
+            if (EBEN_T3_DBG & 8) acc[i][0] += __builtin_bit_cast(float, a[ks][qw][i][0] ^ bv[ks][qx][i & 3]);
+            else acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[ks][qw][i]), __builtin_bit_cast(bf16x8, bv[ks][qx]), acc[i], 0, 0, 0);
+          }
+        }
       __builtin_amdgcn_sched_barrier(0);
     }
     if (ch + 1 < nch) {
@@ -318,7 +339,7 @@ struct Tap3Plan {
   int mode, G, Cg, Mg, S, OS, dstep, kstep, nph, J, Lx, Ly, Cx, Cy, off0, nt, ps_pad;
   int FM, BM, BN, WCHU;
   int dense;   // groups folded into ONE block-diagonal contraction (layers with a handful of channels per group)
-  int split;   // input operand staged as hi + lo bf16 tiles (EBEN_MATH_BF16X2 on the activation side)
+  int npw, npx, KSC;   // pieces per weight / per input element (tap3_kernel), k-steps per weight chunk
   int CI_T, CI_B, CP, ncc, PLEN, CSTRIDE, nxbuf, XRB;
   int nmt, ntt, NCH, tab_phase;
   long long w_tile, w_phase, tab_off_floats;
@@ -336,8 +357,11 @@ static void make_plan3(const Canon& c, int dir, Tap3Plan* p) {
   p->ok = 0;
   p->mode = dir;
   p->G = c.g;
-  p->split = c.xsplit_dir == dir;
-  const int ub = p->split ? 32 : 16;   // LDS bytes per staged bundle position
+  p->npw = c.np;
+  p->npx = c.np > 1 ? c.np : (c.xsplit_dir == dir ? 2 : 1);
+  p->KSC = t3_ksc(p->npw);
+  const int ub = 16 * p->npx;          // LDS bytes per staged bundle position
+  const int spare = p->npx > 1 ? 16 * p->npx : 0;   // one spare unit per piece region
   if (dir == 0) {
     p->Cg = c.Cin / c.g; p->Mg = c.Cout / c.g;
     p->S = c.s; p->OS = 1; p->dstep = c.d; p->kstep = 1; p->nph = 1; p->J = c.k;
@@ -397,7 +421,7 @@ static void make_plan3(const Canon& c, int dir, Tap3Plan* p) {
   static const int force_bm = env_int3("EBEN_TAP3_BM", 0);
   if (force_bm == 32 || force_bm == 64 || force_bm == 96 || force_bm == 128) best = force_bm;
   p->BM = best; p->FM = best / 32; p->BN = 128;
-  p->WCHU = T3_KSC * p->FM * 64;
+  p->WCHU = p->KSC * p->npw * p->FM * 64;
   p->nmt = ceil_div(p->Mg, p->BM);
   p->ntt = ceil_div(p->nt, p->BN);
 
@@ -408,12 +432,14 @@ static void make_plan3(const Canon& c, int dir, Tap3Plan* p) {
   const int span = (p->BN - 1) * p->S + (p->J - 1) * adstep + 1;
   if (span > 0xffff) return;
   const int NT = 256;
-  static const int lds_budget = env_int3("EBEN_TAP3_LDS_KB", 78) * 1024;   // two blocks per CU
+  static const int lds_budget1 = env_int3("EBEN_TAP3_LDS_KB", 78) * 1024;   // two blocks per CU
+  static const int lds_budget_split = env_int3("EBEN_TAP3_SPLIT_LDS_KB", 150) * 1024;   // split weights: one MFMA-bound block per CU
+  const int lds_budget = p->npw > 1 ? lds_budget_split : lds_budget1;
   const int wbytes = 2 * p->WCHU * 16;
   const int xbudget = lds_budget - wbytes - 16;
   const int Cg2 = round_up(p->Cg, 16);
   p->XRB = 2;
-  if ((long long)(Cg2 / 8) * p->CSTRIDE * ub + (p->split ? 16 : 0) <= xbudget) {
+  if ((long long)(Cg2 / 8) * p->CSTRIDE * ub + spare <= xbudget) {
     p->CI_T = Cg2; p->ncc = 1; p->nxbuf = 1;
   } else {
     // hand-over rule of tapconv2.hip in weight chunks of T3_KSC k-steps: the tile of the next channel chunk is
@@ -422,7 +448,7 @@ static void make_plan3(const Canon& c, int dir, Tap3Plan* p) {
     for (int nbuf = 2; nbuf <= 3 && !found; ++nbuf) {
       for (int xrb : {2, 3, 5}) {
         int cap = (xrb * NT) / span * 8;          // channels
-        const int cap_lds = ((nbuf == 2 ? xbudget : 110 * 1024 - wbytes) - (p->split ? 16 : 0)) / nbuf / (p->CSTRIDE * ub) * 8;
+        const int cap_lds = ((nbuf == 2 ? xbudget : (p->npw > 1 ? lds_budget : 110 * 1024) - wbytes) - spare) / nbuf / (p->CSTRIDE * ub) * 8;
         if (cap > cap_lds) cap = cap_lds;
         cap -= cap % 16;
         if (cap < 16) continue;
@@ -431,7 +457,7 @@ static void make_plan3(const Canon& c, int dir, Tap3Plan* p) {
         p->ncc = ceil_div(p->Cg, p->CI_T);
         p->nxbuf = nbuf;
         p->XRB = xrb;
-        if (p->ncc > 1 && Jmin * (p->CI_T / 16) < (nbuf == 2 ? 2 * T3_KSC : T3_KSC)) continue;
+        if (p->ncc > 1 && Jmin * (p->CI_T / 16) < (nbuf == 2 ? 2 * p->KSC : p->KSC)) continue;
         found = true;
         break;
       }
@@ -441,13 +467,13 @@ static void make_plan3(const Canon& c, int dir, Tap3Plan* p) {
   p->CI_B = p->CI_T / 8;
   p->CP = p->CI_T / 16;
   const int KSmax = p->ncc * p->J * p->CP;
-  p->NCH = ceil_div(KSmax, T3_KSC);
-  p->tab_phase = p->NCH * T3_KSC;
+  p->NCH = ceil_div(KSmax, p->KSC);
+  p->tab_phase = p->NCH * p->KSC;
   p->w_tile = (long long)p->NCH * p->WCHU;
   p->w_phase = p->w_tile * p->nmt * p->G;
   p->tab_off_floats = p->w_phase * p->nph * 4;
   p->packed_floats = (size_t)p->tab_off_floats + (size_t)p->tab_phase * p->nph;
-  p->lds_bytes = (size_t)wbytes + ((size_t)p->nxbuf * p->CI_B * p->CSTRIDE * 16 + 16) * (p->split ? 2 : 1);   // + the spare unit(s)
+  p->lds_bytes = (size_t)wbytes + ((size_t)p->nxbuf * p->CI_B * p->CSTRIDE * 16 + 16) * p->npx;   // + the spare unit of every piece
   if (p->lds_bytes > 160 * 1024) return;
   p->ok = 1;
 }
@@ -456,7 +482,7 @@ struct Pack3Args {
   const float* w; const float* scale; float* wp;
   int G, Cg, Mg, nmt, BM, FM, WCHU, CI_T, CI_B, CP, ncc, NCH, nph, tab_phase;
   int mode, J0, off0, nt, dstep, OS, S, ps_pad, k, d, kstep, Ly;
-  int Cin_g, Cout_g, PLEN, CSTRIDE, nxbuf, dense;
+  int Cin_g, Cout_g, PLEN, CSTRIDE, nxbuf, dense, NPW, KSC;
   long long w_tile, w_phase, wunits;
 };
 
@@ -470,11 +496,12 @@ __global__ __launch_bounds__(256) void pack3_kernel(const Pack3Args P) {
       const int g = tile / P.nmt, mt = tile - g * P.nmt;
       const int ch = (int)(r / P.WCHU);
       const int e = (int)(r - (long long)ch * P.WCHU);
-      const int ks = e / (64 * P.FM);
+      const int ks = e / (64 * P.FM * P.NPW);
+      const int piece = (e / (64 * P.FM)) % P.NPW;
       const int fm = (e / 64) % P.FM;
       const int lane = e & 63;
       const PhaseGeom q = phase_geom(P.mode, ph, P.J0, P.off0, P.nt, P.dstep, P.OS, P.ps_pad, P.k, P.d, P.kstep, P.Ly);
-      const int s = ch * T3_KSC + ks;
+      const int s = ch * P.KSC + ks;
       const int KS_CC = q.J * P.CP;
       float v[8];
       {
@@ -504,7 +531,15 @@ __global__ __launch_bounds__(256) void pack3_kernel(const Pack3Args P) {
         for (int u = 0; u < 8; ++u) v[u] = ok[u] ? v[u] * sc8[u] : 0.f;
       }
       u32x4 o;
-      o[0] = pack_bf16(v[0], v[1]); o[1] = pack_bf16(v[2], v[3]); o[2] = pack_bf16(v[4], v[5]); o[3] = pack_bf16(v[6], v[7]);
+      for (int qq = 0;; ++qq) {   // piece `piece` of the split w = p0 + p1 + ..: p_q = bf16(w - p0 - .. - p(q-1))
+        o[0] = pack_bf16(v[0], v[1]); o[1] = pack_bf16(v[2], v[3]); o[2] = pack_bf16(v[4], v[5]); o[3] = pack_bf16(v[6], v[7]);
+        if (qq == piece) break;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          v[2 * u] -= __builtin_bit_cast(float, o[u] << 16);
+          v[2 * u + 1] -= __builtin_bit_cast(float, o[u] & 0xffff0000u);
+        }
+      }
       reinterpret_cast<u32x4*>(P.wp)[i] = o;
     } else {
       const long long r = i - P.wunits;
@@ -525,10 +560,10 @@ __global__ __launch_bounds__(256) void pack3_kernel(const Pack3Args P) {
   }
 }
 
-template <int FM, int XRB, bool IM, bool SP = false>
+template <int FM, int XRB, bool IM, int NPW = 1, int NPX = 1>
 static int launch3_im(const Tap3Args& a, int nblocks, size_t lds, hipStream_t st) {
   static bool attr_set = false;
-  auto kern = tap3_kernel<FM, XRB, IM, SP>;
+  auto kern = tap3_kernel<FM, XRB, IM, NPW, NPX>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(tap3)");
@@ -539,10 +574,12 @@ static int launch3_im(const Tap3Args& a, int nblocks, size_t lds, hipStream_t st
   return EBEN_OK;
 }
 template <int FM, int XRB>
-static int launch3_cfg(const Tap3Args& a, int nblocks, size_t lds, bool split, hipStream_t st) {
-  if (split) {
+static int launch3_cfg(const Tap3Args& a, int nblocks, size_t lds, int npw, int npx, hipStream_t st) {
+  if (npx > 1) {
     if (a.in_mode) return fail(EBEN_EUNSUPPORTED, "tap3: split operand with a mask on load");
-    return launch3_im<FM, XRB, false, true>(a, nblocks, lds, st);
+    if (npw == 1) return launch3_im<FM, XRB, false, 1, 2>(a, nblocks, lds, st);
+    if (npw == 2) return launch3_im<FM, XRB, false, 2, 2>(a, nblocks, lds, st);
+    return launch3_im<FM, XRB, false, 3, 3>(a, nblocks, lds, st);
   }
   return a.in_mode ? launch3_im<FM, XRB, true>(a, nblocks, lds, st) : launch3_im<FM, XRB, false>(a, nblocks, lds, st);
 }
@@ -570,6 +607,7 @@ int tap3_pack(const Canon& c, int dir, const float* w, const float* scale, float
   a.mode = p.mode; a.J0 = p.J; a.off0 = p.off0; a.nt = p.nt; a.dstep = p.dstep; a.OS = p.OS; a.S = p.S; a.ps_pad = p.ps_pad;
   a.k = c.k; a.d = c.d; a.kstep = p.kstep; a.Ly = p.Ly;
   a.Cin_g = c.Cin / c.g; a.Cout_g = c.Cout / c.g; a.PLEN = p.PLEN; a.CSTRIDE = p.CSTRIDE; a.nxbuf = p.nxbuf; a.dense = p.dense;
+  a.NPW = p.npw; a.KSC = p.KSC;
   a.w_tile = p.w_tile; a.w_phase = p.w_phase; a.wunits = p.w_phase * p.nph;
   long long blocks = (a.wunits + (long long)p.tab_phase * p.nph + 255) / 256;
   if (blocks > 8192) blocks = 8192;
@@ -601,9 +639,9 @@ int tap3_launch(const Canon& c, int dir, const TapIO& io, int reflect, hipStream
   if (nb <= 0 || nb > 0x7fffffffLL) return fail(EBEN_EINVAL, "tap3 grid of %lld blocks", nb);
 #define EBEN_T3_CASE(FMV)                                                          \
   switch (p.XRB) {                                                                 \
-    case 2: return launch3_cfg<FMV, 2>(a, (int)nb, p.lds_bytes, p.split, st);               \
-    case 3: return launch3_cfg<FMV, 3>(a, (int)nb, p.lds_bytes, p.split, st);               \
-    default: return launch3_cfg<FMV, 5>(a, (int)nb, p.lds_bytes, p.split, st);              \
+    case 2: return launch3_cfg<FMV, 2>(a, (int)nb, p.lds_bytes, p.npw, p.npx, st);               \
+    case 3: return launch3_cfg<FMV, 3>(a, (int)nb, p.lds_bytes, p.npw, p.npx, st);               \
+    default: return launch3_cfg<FMV, 5>(a, (int)nb, p.lds_bytes, p.npw, p.npx, st);              \
   }
   switch (p.FM) {
     case 1: EBEN_T3_CASE(1)

@@ -50,8 +50,18 @@ def _takes_grad_scale(optimizer) -> bool:
 DISC_MATH_PLANS = {
     "f32": ops.MATH_F32,
     "bf16_plain": ops.MATH_BF16,
-    "bf16": {"pqmf": (ops.MATH_F32, ops.MATH_BF16, ops.MATH_BF16), "melgan": ops.MATH_BF16},
+    # BASELINE config 2: bf16 MFMA operands everywhere except the FORWARD of the three PQMF-band discriminators, whose operands
+    # enter as hi + lo bf16 pieces (three piece products, ~2^-17: EBEN_MATH_BF16X3).  [MI355X] discriminator gradient against the
+    # fp32 step at config 2: 3.378e-2 with that forward in exact fp32, in six-piece (fp32-grade) or in three-piece products alike --
+    # what is left comes from MelGAN's bf16 forward and the bf16 gradient contractions; 0.18 with every contraction on single bf16.
+    "bf16": {"pqmf": (ops.MATH_BF16X3, ops.MATH_BF16, ops.MATH_BF16), "melgan": ops.MATH_BF16},
+    "bf16_f32fwd": {"pqmf": (ops.MATH_F32, ops.MATH_BF16, ops.MATH_BF16), "melgan": ops.MATH_BF16},
     "bf16x2": (ops.MATH_BF16X2, ops.MATH_BF16, ops.MATH_BF16X2),
+    # fp32 arithmetic on the bf16 matrix pipe: forward and input gradients with both operands as three bf16 pieces (six piece
+    # products, dropped terms <= 2^-26: tapconv3.hip), weight gradients on the exact-fp32 kernels
+    "bf16x6": (ops.MATH_BF16X6, ops.MATH_BF16X6, ops.MATH_F32),
+    # the "bf16" plan with the PQMF-band forwards in that fp32-grade split form instead of the fp32 MFMA
+    "bf16_x6fwd": {"pqmf": (ops.MATH_BF16X6, ops.MATH_BF16, ops.MATH_BF16), "melgan": ops.MATH_BF16},
 }
 
 #: generator-side loss terms in the reference's insertion order (eben.py:195-211): logged name, the module attribute that holds
