@@ -159,7 +159,7 @@ def main():
                          "contraction on single bf16 operands; the generator's forward computes in fp32 either way")
     ap.add_argument("--gen-bwd-math", default=None, choices=["bf16", "f32"],
                     help="generator backward contractions (default: bf16 with a bf16 discriminator, else f32)")
-    ap.add_argument("--stft-math", default=None, choices=["bf16x3", "folded", "dense"],
+    ap.add_argument("--stft-math", default=None, choices=["bf16x3", "folded", "dense", "folded_x3", "folded_x6"],
                     help="MRSTFT windowed-DFT contractions (default: 'folded', exact fp32 on the even / odd parts of the frames)")
     ap.add_argument("--no-f32-leg", action="store_true", help="skip the extra fp32 timing reported beside a bf16 run")
     args = ap.parse_args()
@@ -187,7 +187,7 @@ def main():
     bf16 = args.disc_math != "f32"
     mod.disc_math = args.disc_math
     mod.gen_backward_math = args.gen_bwd_math or ("bf16" if bf16 else "f32")
-    mod.stft_math = args.stft_math or "folded"
+    mod.stft_math = args.stft_math or ("folded_x6" if bf16 else "folded")
     gen_bwd_math, stft_math = mod.gen_backward_math, mod.stft_math   # of the measured steps (the fp32 leg below changes the module's)
     syncs = []
     if use_ddp:
@@ -357,7 +357,7 @@ def main():
                        "precision": (f"discriminator contractions on bf16 MFMA operands with fp32 accumulate (MelGAN: every pass; PQMF-band "
                                      f"discriminators: input / weight gradients -- their forward takes hi + lo bf16 operands (3 MFMAs per product), which keeps the discriminator "
                                      f"gradient within 3.4e-2 of the fp32 step's, tests/test_gpu_models.py); generator forward, losses, Adam, "
-                                     f"storage: fp32; generator backward contractions: {gen_bwd_math}; MRSTFT DFT contractions: fp32 ({stft_math})"
+                                     f"storage: fp32; generator backward contractions: {gen_bwd_math}; MRSTFT DFT contractions: {'fp32-grade (three bf16 pieces per operand, ' + stft_math + ')' if stft_math == 'folded_x6' else 'fp32 (' + stft_math + ')'}"
                                      if args.disc_math == "bf16" else
                                      "every contraction on single bf16 MFMA operands (bf16_plain)" if bf16 else "fp32 throughout (exact fp32 MFMA products)")},
             "step_ms": {"median": round(percentile(per_step, 0.5), 3), "p10": round(percentile(per_step, 0.1), 3),

@@ -15,3 +15,9 @@ for _ in range(10):
     e[0].record(); l = loss(x, y); e[1].record(); l.backward(); e[2].record(); torch.cuda.synchronize()
     tf += e[0].elapsed_time(e[1]); tb += e[1].elapsed_time(e[2]); x.grad = None
 print(f"mrstft [{loss.stft_math}] fwd {tf/10:.3f} ms  bwd {tb/10:.3f} ms")
+# value and gradient against the exact-fp32 folded form
+if loss.stft_math != "folded":
+    l = loss(x, y); l.backward(); g = x.grad.clone(); x.grad = None
+    loss.stft_math = "folded"
+    l0 = loss(x, y); l0.backward()
+    print(f"  vs folded: loss rel {abs(float(l) - float(l0)) / abs(float(l0)):.2e}, gradient rel L2 {float((g - x.grad).norm() / x.grad.norm()):.2e}")

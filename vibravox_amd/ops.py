@@ -756,6 +756,11 @@ class StftPlan:
         return parts
 
 
+#: StftPlan.math -> EBEN_MATH_* of the folded windowed-DFT contractions ("bf16x3": single bf16 operands over the concatenated
+#: [hi ; lo ; hi] x [W_hi ; W_hi ; W_lo] reduction; "folded_x3" / "folded_x6": the tap-conv's own split operands, tapconv3.hip)
+_STFT_CONV_MATH = {"bf16x3": MATH_BF16, "folded_x3": MATH_BF16X3, "folded_x6": MATH_BF16X6}
+
+
 class _MRSTFTFn(torch.autograd.Function):
     """auraloss MultiResolutionSTFTLoss(x, y) as configured by multi_stft.yaml (see mrstft_loss.py).
 
@@ -790,7 +795,7 @@ class _MRSTFTFn(torch.autograd.Function):
                 spec_f, basis_f, cache, cmath = p.spec_f, p.basis_f, p.cache_fwd, MATH_F32
             else:
                 spec_f, basis_f, _, _, cache, _ = p.folded_parts(math)
-                cmath = MATH_BF16 if math == "bf16x3" else MATH_F32
+                cmath = _STFT_CONV_MATH.get(math, MATH_F32)
                 fr = torch.empty((1, spec_f.c_in, cols), dtype=torch.float32, device=x.device)
                 check(lib.eben_stft_frames_folded(ptr(sig), ptr(fr), 2 * rows, t, p.win, p.hop, p.pad, frames, 1 if math == "bf16x3" else 0, st),
                       "stft_frames_folded")
@@ -827,7 +832,7 @@ class _MRSTFTFn(torch.autograd.Function):
                 spec_t, basis_t, cache, cmath = p.spec_t, p.basis_t, p.cache_bwd, MATH_F32
             else:
                 _, _, spec_t, basis_t, _, cache = p.folded_parts(math)
-                cmath = MATH_BF16 if math == "bf16x3" else MATH_F32
+                cmath = _STFT_CONV_MATH.get(math, MATH_F32)
                 if math == "bf16x3":
                     dsplit = torch.empty((1, spec_t.c_in, xcols), dtype=torch.float32, device=gout.device)
                     check(lib.eben_split3(ptr(dspec), ptr(dsplit), 2, p.bins, xcols, st), "split3")

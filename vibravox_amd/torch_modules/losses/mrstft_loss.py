@@ -96,11 +96,12 @@ class MultiResolutionSTFTLoss(torch.nn.Module):
 
     #: arithmetic of the windowed-DFT contractions: "folded" (exact fp32 on the even / odd parts of the frames: half the products
     #: of "dense"), "dense" (one win-channel GEMM), "bf16x3" (folded, hi / lo bf16 operand splits on the bf16 MFMA, ~2^-17
-    #: relative per product: the bf16 train step of BASELINE config 2 -- EBENLightningModule.stft_math)
+    #: relative per product), "folded_x6" / "folded_x3" (folded, the tap-conv's split bf16 operands: three pieces per operand =
+    #: fp32-grade products at 6/16 of the fp32 MFMA's cost / two pieces, ~2^-17 -- EBENLightningModule.stft_math)
     stft_math: str = os.environ.get("EBEN_STFT_MATH", "folded")
 
     def forward(self, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
-        if self.stft_math not in ("folded", "dense", "bf16x3"):
+        if self.stft_math not in ("folded", "dense", "bf16x3", "folded_x3", "folded_x6"):
             raise ValueError(f"unknown STFT math {self.stft_math!r}")
         if self._plans is None or self._plans[0].basis_f.device != x.device or self._plans[0].basis_f.data_ptr() != self.basis_0.data_ptr():
             self._plans = self._build_plans()
