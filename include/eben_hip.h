@@ -185,6 +185,15 @@ EBEN_API int eben_ru_fwd_ex(int math, int batch, int channels, int length, int d
 EBEN_API int eben_ru_bwd_ex(int math, int batch, int channels, int length, int dilation, const float* gy, const float* u, float out_slope,
                    const float* x, float in_slope, const float* post, const float* wimg_bwd, float* gx, float* gh, void* stream);
 
+/* Both weight gradients of the unit in one launch (csrc/ru_dw.hip): split-K slabs [eben_ru_dw_slabs(batch, C, length)][C][C] for the
+ * pointwise conv and [..][C][3 C] for the dilated one (row strides C and 3 C), to be summed by eben_wn_bwd / eben_wn_bwd_multi:
+ *   dW_pw[m][c] = sum g_z[m] h[c],  g_z = g_y * lrelu'(u, out_slope);   dW_dil[m][c][j] = sum g_h[m] xin[c](. + (j - 1) d, reflected)
+ * The reduction runs along time, so the operands are read straight from the (batch, channel, time) tensors (no packing pass).
+ * math: EBEN_MATH_BF16 (single bf16 operands) or EBEN_MATH_BF16X6 (three pieces per operand: fp32-grade). */
+EBEN_API int eben_ru_dw_slabs(int batch, int channels, int length);
+EBEN_API int eben_ru_dw(int math, int batch, int channels, int length, int dilation, const float* gy, const float* u, float out_slope,
+               const float* h, const float* gh, const float* x, float in_slope, float* slabs_pw, float* slabs_dil, void* stream);
+
 /* ---- PQMF (vibravox/torch_modules/dsp/pqmf.py:194-213, eben_generator.py:209-211) ---------- */
 /* decimating FIR bank: y[b,k,t] = sum_j w[k*ntaps+j] * x[b,0,t*stride+off0+j], zero outside [0,lx) */
 EBEN_API int eben_fir_decimate(const float* x, const float* w, float* y, int batch, int lx, int ly, int bands, int ntaps,

@@ -441,6 +441,52 @@ def test_fused_residual_unit_backward(hip, channels, dilation, length, batch, in
     assert rel_err(gx, gx_ref) < RU_TOL[mm]
 
 
+@pytest.mark.parametrize("channels,dilation,length,batch,in_slope", [
+    (32, 1, 1000, 3, 1.0), (32, 3, 517, 2, 0.01), (32, 9, 2100, 2, 1.0), (64, 9, 300, 3, 0.01), (64, 1, 1999, 2, 1.0),
+    (128, 3, 1000, 2, 1.0), (128, 9, 131, 2, 0.01), (32, 9, 20, 1, 1.0), (64, 3, 15, 2, 1.0)])
+@pytest.mark.parametrize("math_mode", [4, 1])
+def test_fused_residual_unit_weight_gradients(hip, channels, dilation, length, batch, in_slope, math_mode):
+    """eben_ru_dw: dW_pw = sum g_z h^T and dW_dil[j] = sum g_h xin(. + (j - 1) d)^T (reflected ends) of one unit in one launch, summed by
+    eben_wn_bwd, against fp64 autograd of the weight-normalised unit (dv and dg of both convs): K slabs that end inside a row, rows
+    whose length is not a multiple of 4 or 16 (unaligned 16-byte operand loads), clips shorter than one k-step, the fused input
+    activation.  math 4: three bf16 pieces per operand (fp32 bound); 1: single bf16 operands."""
+    from vibravox_amd._lib import check, load, ptr, stream
+
+    lib, dev = load(), torch.device("cuda")
+    c = channels
+    vd = formula_tensor(f"rudw/{c}/{dilation}/vd", (c, c, 3), 1 / math.sqrt(3 * c))
+    vp = formula_tensor(f"rudw/{c}/{dilation}/vp", (c, c, 1), 1 / math.sqrt(c))
+    gd = vd.reshape(c, -1).norm(dim=1).reshape(c, 1, 1) * (1 + 0.3 * formula_tensor(f"rudw/{c}/gd", (c, 1, 1)))
+    gp = vp.reshape(c, -1).norm(dim=1).reshape(c, 1, 1) * (1 + 0.3 * formula_tensor(f"rudw/{c}/gp", (c, 1, 1)))
+    x = formula_tensor(f"rudw/{c}/{dilation}/{length}/x", (batch, c, length))
+    gy = formula_tensor(f"rudw/{c}/{dilation}/{length}/gy", (batch, c, length))
+    rvd, rvp, rgd, rgp = (t.double().requires_grad_(True) for t in (vd, vp, gd, gp))
+    wd = rvd * (rgd / rvd.flatten(1).norm(dim=1).reshape(c, 1, 1))
+    wp_ = rvp * (rgp / rvp.flatten(1).norm(dim=1).reshape(c, 1, 1))
+    xin = torch.nn.functional.leaky_relu(x.double(), in_slope)
+    h = torch.nn.functional.conv1d(torch.nn.functional.pad(xin, (dilation, dilation), mode="reflect"), wd, dilation=dilation)
+    h.retain_grad()
+    u = torch.nn.functional.leaky_relu(torch.nn.functional.conv1d(h, wp_), 0.01)
+    ((xin + u) * gy.double()).sum().backward()
+    mm = math_mode
+    nslab = lib.eben_ru_dw_slabs(batch, c, length)
+    assert nslab >= batch
+    sp = torch.full((nslab * c * c,), float("nan"), dtype=torch.float32, device=dev)
+    sdil = torch.full((nslab * c * 3 * c,), float("nan"), dtype=torch.float32, device=dev)
+    xd, gyd, ud, hd, ghd = x.to(dev), gy.to(dev), u.detach().float().to(dev), h.detach().float().to(dev), h.grad.float().to(dev)
+    check(lib.eben_ru_dw(mm, batch, c, length, dilation, ptr(gyd), ptr(ud), 0.01, ptr(hd), ptr(ghd), ptr(xd), in_slope, ptr(sp), ptr(sdil), stream()), "ru_dw")
+    tol = {4: 3e-5, 1: 2e-2}[mm]
+    for slabs, cols, v, g, rv, rg in ((sp, c, vp, gp, rvp, rgp), (sdil, 3 * c, vd, gd, rvd, rgd)):
+        vdev, gdev = v.to(dev), g.to(dev)
+        scale, norm = torch.empty(c, device=dev), torch.empty(c, device=dev)
+        check(lib.eben_wn_scale(ptr(gdev), ptr(vdev), c, cols, ptr(scale), ptr(norm), stream()), "wn_scale")
+        dv, dg = torch.empty_like(vdev), torch.empty_like(gdev)
+        check(lib.eben_wn_bwd(ptr(slabs), nslab, c * cols, c, cols, cols, ptr(gdev), ptr(vdev), ptr(norm), ptr(dg), ptr(dv), None, stream()), "wn_bwd")
+        torch.cuda.synchronize()
+        assert rel_err(dv, rv.grad) < 2 * tol, (cols, rel_err(dv, rv.grad))
+        assert rel_err(dg, rg.grad) < 2 * tol, (cols, rel_err(dg, rg.grad))
+
+
 def test_fused_residual_unit_rejects_unsupported_shapes(hip):
     from vibravox_amd._lib import load
 
@@ -452,6 +498,8 @@ def test_fused_residual_unit_rejects_unsupported_shapes(hip):
     assert lib.eben_ru_supported(64, 12, 4) == 0 and lib.eben_ru_supported(64, 12, 0) == 1   # split kernels: dilation <= 9
     assert lib.eben_ru_fwd_ex(4, 1, 64, 100, 12, None, 1.0, 0.01, None, None, None, None, None) < 0
     assert lib.eben_ru_bwd_ex(7, 1, 64, 100, 3, None, None, 0.01, None, 1.0, None, None, None, None, None) < 0   # unknown math
+    assert lib.eben_ru_dw_slabs(2, 48, 100) == 0
+    assert lib.eben_ru_dw(0, 2, 64, 100, 3, None, None, 0.01, None, None, None, 1.0, None, None, None) < 0         # fp32 MFMA form: not built
 
 
 def test_input_gradient_with_residual_joins(hip):

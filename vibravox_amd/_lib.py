@@ -100,6 +100,8 @@ SIGNATURES = {
     "eben_ru_pack_ex": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P, _P]),
     "eben_ru_fwd_ex": (c_int, [c_int, c_int, c_int, c_int, c_int, _P, c_float, c_float, _P, _P, _P, _P, _P]),
     "eben_ru_bwd_ex": (c_int, [c_int, c_int, c_int, c_int, c_int, _P, _P, c_float, _P, c_float, _P, _P, _P, _P, _P]),
+    "eben_ru_dw_slabs": (c_int, [c_int, c_int, c_int]),
+    "eben_ru_dw": (c_int, [c_int, c_int, c_int, c_int, c_int, _P, _P, c_float, _P, _P, _P, c_float, _P, _P, _P]),
     "eben_fir_decimate": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "eben_fir_interp_sum": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "eben_lrelu_fwd": (c_int, [_P, _P, c_size_t, c_float, _P]),

@@ -32,6 +32,7 @@ from ._lib import check, load, ptr, stream
 
 USE_FUSED_RU = os.environ.get("EBEN_RU_FUSED", "1") != "0"
 USE_FUSED_RU_BWD = os.environ.get("EBEN_RU_FUSED_BWD", "1") != "0"
+USE_FUSED_RU_DW = os.environ.get("EBEN_RU_FUSED_DW", "1") != "0"
 # arithmetic of the fused ResidualUnit launches (include/eben_hip.h, eben_ru_*_ex): the forward and the fp32 backward run on the bf16
 # matrix pipe with three bf16 pieces per operand (EBEN_MATH_BF16X6: every mantissa bit of the fp32 operands, fp32 accumulate --
 # fp32 arithmetic at 6/16 of the fp32 MFMA's cost); "f32" selects the v_mfma_f32_32x32x2_f32 kernels (bisecting aid).
@@ -254,6 +255,33 @@ class GeneratorEngine:
                 for hook in list((getattr(p, "_post_accumulate_grad_hooks", None) or {}).values()):
                     hook(p)   # e.g. ddp.GradSync's bucket accounting
 
+    @staticmethod
+    def _accumulate(params, grads) -> None:
+        for p, t in zip(params, grads):   # not deferred (no side-stream context): accumulate like autograd would
+            if p is not None and t is not None:
+                p.grad = t if p.grad is None else p.grad.add_(t)
+                for hook in list((getattr(p, "_post_accumulate_grad_hooks", None) or {}).values()):
+                    hook(p)   # e.g. ddp.GradSync's bucket accounting
+
+    def _ru_dw(self, dil: _ConvRec, pwc: _ConvRec, gy, gh, bm: int) -> None:
+        """Weight gradients of both convs of a fused unit: one ``eben_ru_dw`` launch (reduction along time, operands straight from
+        the activation tensors) where both are weight-normalised bias-free parameters, else layer by layer."""
+        if ops._skip_weight_grads[0]:
+            return
+        (vd, gd), (vp, gp) = _params(dil.m), _params(pwc.m)
+        fusable = (USE_FUSED_RU_DW and gd is not None and gp is not None and dil.m.bias is None and pwc.m.bias is None
+                   and vd.requires_grad and vp.requires_grad and gd.requires_grad and gp.requires_grad and bm in (ops.MATH_BF16, ops.MATH_BF16X6))
+        res = False
+        if fusable:
+            res = ops.weight_grads_ru(bm, dil.spec.dilation, gy, pwc.y, float(pwc.spec.out_slope), pwc.x, gh, dil.x, float(dil.spec.in_slope),
+                                      (vp, gp, pwc.norm), (vd, gd, dil.norm))
+        if res is False:
+            self._dw(pwc, gy)
+            self._dw(dil, gh)
+            return
+        self._accumulate((vp, gp, None), res[0])
+        self._accumulate((vd, gd, None), res[1])
+
     def _ru_backward(self, rec, gy, res_post=None):
         fused, dil, pwc = rec
         if fused is not None:   # one launch: g_h and g_x = (g_y + fold(dilated^T g_h)) * lrelu'(x) + skip gradient
@@ -263,8 +291,7 @@ class GeneratorEngine:
             img_b, bm = fused
             check(load().eben_ru_bwd_ex(bm, b, c, l, dil.spec.dilation, ptr(gy), ptr(pwc.y), float(pwc.spec.out_slope),
                                         ptr(dil.x) if ins != 1.0 else None, float(ins), ptr(res_post), ptr(img_b), ptr(gx), ptr(gh), stream()), "ru_bwd")
-            self._dw(pwc, gy)
-            self._dw(dil, gh)
+            self._ru_dw(dil, pwc, gy, gh, bm)
             return gx
         gh = self._dx(pwc, gy)                       # pointwise^T(gy * lrelu'(u))
         self._dw(pwc, gy)

@@ -375,6 +375,32 @@ def weight_grads(d: EbenConv1dDesc, dy: torch.Tensor, y: Optional[torch.Tensor],
     kernels would then fill a tensor nobody reads)."""
     lib = load()
     has_g, has_bias = g is not None, bias is not None
+    use_side, sunk = _wg_route(v, g, bias)
+    ws = getattr(d, "_dw_ws", None)   # (bytes, slabs, row stride) of this descriptor: asked once
+    if ws is None:
+        nslab, row_stride = ctypes.c_int(0), ctypes.c_int(0)
+        ws = d._dw_ws = (lib.eben_conv1d_bwd_dw_workspace(ctypes.byref(d), ctypes.byref(nslab), ctypes.byref(row_stride)), nslab.value, row_stride.value)
+    ws_bytes, nslab, row_stride = ws
+    # Every buffer is allocated on the CURRENT stream's pool; on the deferred path the kernels are launched on the side stream through
+    # its raw handle (no torch stream switch) and everything they touch stays referenced until join(), after which the current
+    # stream -- which waits for the side stream there -- may reuse it.
+    slabs = _empty(ws_bytes, x)
+    job, outs = _wg_job(slabs, nslab, row_stride, v, g, bias, norm, sunk, x.device)
+    if use_side:
+        side = _side_stream(x.device)
+        side.wait_stream(torch.cuda.current_stream(x.device))   # dy (and everything saved by the forward) is complete on the main stream
+        check(lib.eben_conv1d_bwd_dw(ctypes.byref(d), ptr(dy), ptr(y), ptr(x), 1 if has_bias else 0, ptr(slabs), ws_bytes, side.cuda_stream), "conv1d_bwd_dw")
+        _side["keep"].append((dy, x, y, norm, slabs))
+        _wg_defer(job, outs, v, g, bias, sunk)
+        return None, None, None
+    check(lib.eben_conv1d_bwd_dw(ctypes.byref(d), ptr(dy), ptr(y), ptr(x), 1 if has_bias else 0, ptr(slabs), ws_bytes, stream()), "conv1d_bwd_dw")
+    wn_bwd_multi([job])
+    return outs
+
+
+def _wg_route(v, g, bias):
+    """Where a layer's weight gradients go: (issue on the side stream?, bucket views of a data-parallel sink or None)."""
+    has_g, has_bias = g is not None, bias is not None
     is_param = isinstance(v, torch.nn.Parameter)
     use_side = (_side["enabled"] and is_param and v.grad is None and (g is None or g.grad is None) and (bias is None or bias.grad is None)
                 and _no_grad_hooks(v) and _no_grad_hooks(g) and _no_grad_hooks(bias))
@@ -386,15 +412,12 @@ def weight_grads(d: EbenConv1dDesc, dy: torch.Tensor, y: Optional[torch.Tensor],
         if sunk[0] is None or (has_g and sunk[1] is None) or (has_bias and sunk[2] is None):
             sunk = None
         use_side = sunk is not None
-    ws = getattr(d, "_dw_ws", None)   # (bytes, slabs, row stride) of this descriptor: asked once
-    if ws is None:
-        nslab, row_stride = ctypes.c_int(0), ctypes.c_int(0)
-        ws = d._dw_ws = (lib.eben_conv1d_bwd_dw_workspace(ctypes.byref(d), ctypes.byref(nslab), ctypes.byref(row_stride)), nslab.value, row_stride.value)
-    ws_bytes, nslab, row_stride = ws
-    # Every buffer is allocated on the CURRENT stream's pool; on the deferred path the kernels are launched on the side stream through
-    # its raw handle (no torch stream switch) and everything they touch stays referenced until join(), after which the current
-    # stream -- which waits for the side stream there -- may reuse it.
-    slabs = _empty(ws_bytes, x)
+    return use_side, sunk
+
+
+def _wg_job(slabs, nslab, row_stride, v, g, bias, norm, sunk, device):
+    """The ``eben_wn_bwd`` job that sums a layer's split-K slabs and applies the weight-norm chain rule, and its outputs."""
+    has_g, has_bias = g is not None, bias is not None
     rows = v.shape[0]
     cols = v.numel() // rows
     if sunk is not None:
@@ -402,23 +425,53 @@ def weight_grads(d: EbenConv1dDesc, dy: torch.Tensor, y: Optional[torch.Tensor],
     else:
         dv = torch.empty_like(v)
         dg = torch.empty_like(g) if has_g else None
-        dbias = torch.empty(rows, dtype=torch.float32, device=x.device) if has_bias else None
+        dbias = torch.empty(rows, dtype=torch.float32, device=device) if has_bias else None
     job = (slabs, nslab, rows * row_stride, rows, cols, row_stride, g.detach() if has_g else None, v.detach(), norm if has_g else None, dg, dv, dbias)
+    return job, (dv, dg, dbias)
+
+
+def _wg_defer(job, outs, v, g, bias, sunk) -> None:
+    """Deferred path: the slab sums and the weight-norm chain rule of ALL layers are one multi-tensor launch at join()."""
+    _side["wn_jobs"].append(job)
+    if sunk is None:
+        _side["assign"].extend((p, t) for p, t in zip((v, g, bias), outs) if p is not None and t is not None)
+    else:
+        _side["sunk"].extend(p for p in (v, g, bias) if p is not None)
+
+
+def weight_grads_ru(math: int, dilation: int, gy: torch.Tensor, u: torch.Tensor, out_slope: float, h: torch.Tensor, gh: torch.Tensor,
+                    x: torch.Tensor, in_slope: float, pw_params, dil_params):
+    """Both weight gradients of a fused ResidualUnit in one launch (``eben_ru_dw``: the reduction runs along time, no packing
+    pass): ``*_params`` = (v, g, norm) of the pointwise / dilated conv (weight-normalised, no bias).  Routed like ``weight_grads``
+    (side stream / gradient buckets / immediate); returns False when the two layers would be routed differently (the caller then
+    takes the per-layer path), else a pair of (dv, dg, None) results -- Nones where deferred."""
+    lib = load()
+    (vp, gp, np_), (vd, gd, nd) = pw_params, dil_params
+    route_p, route_d = _wg_route(vp, gp, None), _wg_route(vd, gd, None)
+    if route_p[0] != route_d[0] or (route_p[1] is None) != (route_d[1] is None):
+        return False
+    use_side = route_p[0]
+    b, c, l = gy.shape
+    nslab = lib.eben_ru_dw_slabs(b, c, l)
+    slabs_p = torch.empty(nslab * c * c, dtype=torch.float32, device=gy.device)
+    slabs_d = torch.empty(nslab * c * 3 * c, dtype=torch.float32, device=gy.device)
+    job_p, outs_p = _wg_job(slabs_p, nslab, c, vp, gp, None, np_, route_p[1], gy.device)
+    job_d, outs_d = _wg_job(slabs_d, nslab, 3 * c, vd, gd, None, nd, route_d[1], gy.device)
     if use_side:
-        side = _side_stream(x.device)
-        side.wait_stream(torch.cuda.current_stream(x.device))   # dy (and everything saved by the forward) is complete on the main stream
-        check(lib.eben_conv1d_bwd_dw(ctypes.byref(d), ptr(dy), ptr(y), ptr(x), 1 if has_bias else 0, ptr(slabs), ws_bytes, side.cuda_stream), "conv1d_bwd_dw")
-        _side["keep"].append((dy, x, y, norm, slabs))
-        # the slab sums and the weight-norm chain rule of ALL layers are issued as one multi-tensor launch at join()
-        _side["wn_jobs"].append(job)
-        if sunk is None:
-            _side["assign"].extend((p, t) for p, t in ((v, dv), (g, dg), (bias, dbias)) if p is not None and t is not None)
-        else:
-            _side["sunk"].extend(p for p in (v, g, bias) if p is not None)
-        return None, None, None
-    check(lib.eben_conv1d_bwd_dw(ctypes.byref(d), ptr(dy), ptr(y), ptr(x), 1 if has_bias else 0, ptr(slabs), ws_bytes, stream()), "conv1d_bwd_dw")
-    wn_bwd_multi([job])
-    return dv, dg, dbias
+        side = _side_stream(gy.device)
+        side.wait_stream(torch.cuda.current_stream(gy.device))
+        st = side.cuda_stream
+    else:
+        st = stream()
+    check(lib.eben_ru_dw(math, b, c, l, dilation, ptr(gy), ptr(u), float(out_slope), ptr(h), ptr(gh), ptr(x), float(in_slope), ptr(slabs_p), ptr(slabs_d), st),
+          "ru_dw")
+    if use_side:
+        _side["keep"].append((gy, u, h, gh, x, np_, nd, slabs_p, slabs_d))
+        _wg_defer(job_p, outs_p, vp, gp, None, route_p[1])
+        _wg_defer(job_d, outs_d, vd, gd, None, route_d[1])
+        return (None, None, None), (None, None, None)
+    wn_bwd_multi([job_p, job_d])
+    return outs_p, outs_d
 
 
 class _ConvLayerFn(torch.autograd.Function):
