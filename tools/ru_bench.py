@@ -33,5 +33,16 @@ for c, l in ((32, 7992), (64, 3996), (128, 999)):
                 for _ in range(args.iters): run()
                 e1.record(); torch.cuda.synchronize()
                 row[(which, mm)] = e0.elapsed_time(e1) / args.iters * 1e3
+        nslab = lib.eben_ru_dw_slabs(b, c, l)
+        sp = torch.empty(nslab * c * c, device=dev); sd = torch.empty(nslab * 3 * c * c, device=dev)
+        for mm in (1, 4):
+            def run_dw():
+                check(lib.eben_ru_dw(mm, b, c, l, d, ptr(gy), ptr(u), 0.01, ptr(h), ptr(gh), ptr(x), 1.0, ptr(sp), ptr(sd), stream()))
+            for _ in range(3): run_dw()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(args.iters): run_dw()
+            e1.record(); torch.cuda.synchronize()
+            row[("dw", mm)] = e0.elapsed_time(e1) / args.iters * 1e3
         ideal = 4 * x.numel() * 4 / 6.3e12 * 1e6
-        print(f"C {c:3d} L {l:5d} d {d}      " + " ".join(f"{row[('fwd', m)]:12.1f}" for m in names) + "   " + " ".join(f"{row[('bwd', m)]:12.1f}" for m in names) + f"   ({ideal:.1f})")
+        print(f"C {c:3d} L {l:5d} d {d}      " + " ".join(f"{row[('fwd', m)]:12.1f}" for m in names) + "   " + " ".join(f"{row[('bwd', m)]:12.1f}" for m in names) + f"   ({ideal:.1f})   dw bf16 {row[('dw', 1)]:.1f} x6 {row[('dw', 4)]:.1f} (5 reads: {1.25 * ideal:.1f})")

@@ -39,6 +39,8 @@ USE_FUSED_RU_DW = os.environ.get("EBEN_RU_FUSED_DW", "1") != "0"
 _RU_MATH = {"f32": ops.MATH_F32, "bf16x6": ops.MATH_BF16X6, "bf16x3": ops.MATH_BF16X3, "bf16": ops.MATH_BF16}
 RU_FWD_MATH = _RU_MATH[os.environ.get("EBEN_RU_FWD_MATH", "bf16x6")]
 RU_BWD_F32_MATH = _RU_MATH[os.environ.get("EBEN_RU_BWD_F32_MATH", "bf16x6")]
+# forward of the other conv layers of the core (first / strided / latent / transposed convs): the same fp32-grade split form
+CONV_FWD_MATH = _RU_MATH[os.environ.get("EBEN_GEN_CONV_FWD_MATH", "bf16x6")]
 
 
 def _params(m):
@@ -79,9 +81,8 @@ class GeneratorEngine:
         return s
 
     def _pack(self, m, spec, batch, l_in, train):
-        d = ops.conv_desc(spec, batch, l_in)
-        bm = ops._backward_math[0]
-        d_bwd = ops.conv_desc(spec, batch, l_in, bm) if bm != ops.MATH_F32 else d
+        d = ops.conv_desc(spec, batch, l_in, CONV_FWD_MATH)   # layers the split bf16 tap-conv does not cover run their fp32 kernel
+        d_bwd = ops.conv_desc(spec, batch, l_in, ops._backward_math[0])
         v, g = _params(m)
         pw = ops.pack_weights(m.spec, d, v.detach(), None if g is None else g.detach(), m._packed, train, d_bwd)
         return d, d_bwd, pw

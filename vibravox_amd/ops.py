@@ -289,7 +289,7 @@ def pack_weights(spec: ConvSpec, d: EbenConv1dDesc, v: torch.Tensor, g: Optional
     lib = load()
     d_bwd = d if d_bwd is None else d_bwd
     key = (v.data_ptr(), v._version, _storage_epoch.get(v.data_ptr(), 0), _storage_epoch.get(-1, 0),
-           None if g is None else (g.data_ptr(), g._version, _storage_epoch.get(g.data_ptr(), 0)), d.batch, d.l_in, d_bwd.math)
+           None if g is None else (g.data_ptr(), g._version, _storage_epoch.get(g.data_ptr(), 0)), d.batch, d.l_in, d.math, d_bwd.math)
     pw = cache if cache is not None else PackedWeights()
     if _side["prepacked"] is not None and torch.cuda.current_stream() != _side["stream"]:
         join_prepack()   # images built ahead of time on the side stream: first consumer waits for them
