@@ -4,7 +4,7 @@ FETCH_SIZE is doubled as MI355X_MICROARCH.md (HBM section) prescribes for gfx950
 import json, os, subprocess, sys
 R = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 tag, math, batch, commit = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
-match = "tap3_kernel<4" if math == "bf16" else "tap2_kernel<4"
+match = "tap3_kernelILi4ELi5ELb0E" if math == "bf16" else "tap2_kernelILi4E"   # mangled: FM = 4 (bf16: the 5-unit tile prefetch = the forward launch of this layer)
 
 
 def agg(db):

@@ -306,6 +306,7 @@ class DiscriminatorEngine:
             _Chain(disc.melgan_discriminator.discriminator, per["melgan"])]
         self._streams = None
         self._state = None
+        self._prepack_graph = ops.ReplayedPrepack()
         #: weights of the (adversarial, fake, real) hinge seeds of the stacked backward: (1, 1, 1) is the train step; (1, 1, 0) /
         #: (1, 0, 1) give the discriminator gradient of fake_loss / real_loss alone (the parity tests bound each branch
         #: separately -- their sum cancels to a fraction of a percent at initialisation)
@@ -413,28 +414,41 @@ class DiscriminatorEngine:
         main = torch.cuda.current_stream(dev)
         side = ops._side_stream(dev)
         side.wait_stream(main)
-        with torch.cuda.stream(side), torch.no_grad():
+        layers = [lay for ch in self.chains for lay in ch.layers]
+
+        def body():
             jobs = []
-            for ch in self.chains:   # weight-norm scales of all layers: one multi-tensor launch
-                for lay in ch.layers:
-                    wkey = lay._weights_key()
-                    if lay.packs and lay.scale_key != wkey:
-                        v, g, _ = lay.params()
-                        rows = v.shape[0]
-                        lay.scale = torch.empty(rows, dtype=torch.float32, device=dev)
-                        lay.norm = torch.empty(rows, dtype=torch.float32, device=dev)
-                        lay.scale_key = wkey
-                        jobs.append((g.detach(), v.detach(), rows, v.numel() // rows, lay.scale, lay.norm))
+            for lay in layers:   # weight-norm scales of all layers: one multi-tensor launch
+                wkey = lay._weights_key()
+                if lay.packs and lay.scale_key != wkey:
+                    v, g, _ = lay.params()
+                    rows = v.shape[0]
+                    lay.scale = torch.empty(rows, dtype=torch.float32, device=dev)
+                    lay.norm = torch.empty(rows, dtype=torch.float32, device=dev)
+                    lay.scale_key = wkey
+                    jobs.append((g.detach(), v.detach(), rows, v.numel() // rows, lay.scale, lay.norm))
             ops.wn_scale_multi(jobs)
-            for ch in self.chains:
-                for lay in ch.layers:
-                    used, lay.used = lay.used, set()
-                    for slot in list(lay.packs):
-                        if slot in used:
-                            lay.packed(*slot)     # what the last step launched: the next step most likely launches it again
-                        else:
-                            del lay.packs[slot]   # a shape of an earlier step: rebuilt on demand if it comes back
-                    lay.used = set()              # re-packing is not a use: the next step decides what survives the next prepack
+            for lay in layers:
+                used, lay.used = lay.used, set()
+                for slot in list(lay.packs):
+                    if slot in used:
+                        lay.packed(*slot)     # what the last step launched: the next step most likely launches it again
+                    else:
+                        del lay.packs[slot]   # a shape of an earlier step: rebuilt on demand if it comes back
+                lay.used = set()              # re-packing is not a use: the next step decides what survives the next prepack
+
+        # the launch sequence as a function of everything but the weights' values (ops.ReplayedPrepack): layers, the slots the last
+        # step used (= all the slots held, or the eager path prunes), parameter storage, and that every image is stale
+        sig = tuple((id(lay), tuple(sorted(lay.packs)), tuple(sorted(lay.used)) == tuple(sorted(lay.packs)), lay.params()[0].data_ptr(),
+                     lay.scale_key != lay._weights_key()) for lay in layers) + (ops._storage_epoch.get(-1, 0),)
+        with torch.cuda.stream(side), torch.no_grad():
+            if self._prepack_graph.run(sig, body, side):
+                for lay in layers:   # replayed: images and scales are current, the cache keys are not
+                    wkey = lay._weights_key()
+                    lay.scale_key = wkey
+                    for slot, (_, wp) in list(lay.packs.items()):
+                        lay.packs[slot] = (wkey, wp)
+                    lay.used = set()
             self._prepack_ev = torch.cuda.Event()
             self._prepack_ev.record()
 

@@ -63,7 +63,8 @@ class GeneratorEngine:
     def __init__(self, gen):
         self.gen = gen
         self._spec_cache: Dict[tuple, ops.ConvSpec] = {}
-        self._ru_images: Dict[int, tuple] = {}   # id(ResidualUnit) -> (weights key, image)
+        self._ru_images: Dict[int, dict] = {}   # id(ResidualUnit) -> {key, fwd image, bwd images per math, scales}
+        self._prepack_graph = ops.ReplayedPrepack()
 
     # ---- helpers ------------------------------------------------------------------------------------
     def _spec(self, m, in_slope=None, out_slope=None) -> ops.ConvSpec:
@@ -139,7 +140,8 @@ class GeneratorEngine:
         return hit["fwd"] if which == 0 else hit["bwd"][bm]
 
     def prepack(self) -> None:
-        """Rebuilds the fused units' weight images on the side stream (called with ``ops.prepack`` after the optimiser step)."""
+        """Rebuilds the fused units' weight images on the side stream (called with ``ops.prepack`` after the optimiser step);
+        replayed as a graph once the sequence has settled (``ops.ReplayedPrepack``)."""
         if not self._ru_images:
             return
         units = [ru for blk in list(self.gen.encoder_blocks) + list(self.gen.decoder_blocks) for ru in blk.residuals]
@@ -147,9 +149,25 @@ class GeneratorEngine:
         main = torch.cuda.current_stream(dev)
         side = ops._side_stream(dev)
         side.wait_stream(main)
-        with torch.cuda.stream(side), torch.no_grad():
+
+        def key_of(ru):
+            e = ops._storage_epoch
+            ts = _params(ru.dilated_conv) + _params(ru.pointwise_conv)
+            return tuple((t.data_ptr(), t._version, e.get(t.data_ptr(), 0)) for t in ts) + (e.get(-1, 0),)
+
+        def body():
             for ru in units:
                 self._ru_image(ru)
+
+        def entry(ru):
+            hit = self._ru_images.get(id(ru))
+            return (id(ru), _params(ru.dilated_conv)[0].data_ptr(), None if hit is None else (tuple(sorted(hit["bwd"])), hit["key"] != key_of(ru)))
+
+        sig = tuple(entry(ru) for ru in units) + (ops._storage_epoch.get(-1, 0),)
+        with torch.cuda.stream(side), torch.no_grad():
+            if self._prepack_graph.run(sig, body, side):
+                for ru in units:   # replayed: the images are current, the cache keys are not
+                    self._ru_images[id(ru)]["key"] = key_of(ru)
             ev = torch.cuda.Event()
             ev.record()
         self._prepacked = ev

@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import contextlib
 import ctypes
+import os
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -282,14 +283,18 @@ class PackedWeights:
         self.last = None   # (spec, descriptor) of the latest pack: what `prepack` rebuilds ahead of the next step
 
 
+def _pack_key(v, g, d, d_bwd):
+    return (v.data_ptr(), v._version, _storage_epoch.get(v.data_ptr(), 0), _storage_epoch.get(-1, 0),
+            None if g is None else (g.data_ptr(), g._version, _storage_epoch.get(g.data_ptr(), 0)), d.batch, d.l_in, d.math, d_bwd.math)
+
+
 def pack_weights(spec: ConvSpec, d: EbenConv1dDesc, v: torch.Tensor, g: Optional[torch.Tensor],
                  cache: Optional[PackedWeights], need_bwd: bool, d_bwd: Optional[EbenConv1dDesc] = None, pre_scale=None) -> PackedWeights:
     """d_bwd: descriptor of the backward launches when it differs from the forward's (bf16 backward math);
     pre_scale: (scale, norm) already computed for the current weights (multi-tensor launch in `prepack`)."""
     lib = load()
     d_bwd = d if d_bwd is None else d_bwd
-    key = (v.data_ptr(), v._version, _storage_epoch.get(v.data_ptr(), 0), _storage_epoch.get(-1, 0),
-           None if g is None else (g.data_ptr(), g._version, _storage_epoch.get(g.data_ptr(), 0)), d.batch, d.l_in, d.math, d_bwd.math)
+    key = _pack_key(v, g, d, d_bwd)
     pw = cache if cache is not None else PackedWeights()
     if _side["prepacked"] is not None and torch.cuda.current_stream() != _side["stream"]:
         join_prepack()   # images built ahead of time on the side stream: first consumer waits for them
@@ -320,6 +325,53 @@ def pack_weights(spec: ConvSpec, d: EbenConv1dDesc, v: torch.Tensor, g: Optional
     return pw
 
 
+class ReplayedPrepack:
+    """Graph replay of a prepack sequence.  Rebuilding the packed weight images after an optimiser step is ~150 tiny launches per
+    step (one or two per layer and direction) whose cost is entirely host-side: ~3 ms of Python / launch time per step during which
+    the GPU has nothing else queued -- on a 19 ms step.  The sequence is static (same kernels, same parameter storage, same image
+    buffers every step), so after two eager rounds it is captured into a HIP graph and replayed: one launch call.  ``sig`` names
+    everything the launches depend on besides the weights' values (layers, shapes, storage); a new signature falls back to eager
+    rounds and a new capture.  Tensors allocated by the body while capturing live in the graph's pool for as long as the graph."""
+
+    enabled = os.environ.get("EBEN_PREPACK_GRAPH", "1") != "0"
+
+    def __init__(self):
+        self.graph, self.sig, self.rounds = None, None, 0
+
+    def run(self, sig, body, stream_) -> bool:
+        """Runs (or replays) ``body`` on ``stream_`` (a torch side stream, current on entry); True when it was a replay, in which
+        case the caller refreshes its own cache keys (the body's bookkeeping did not run)."""
+        if not self.enabled:
+            body()
+            return False
+        if sig != self.sig:
+            self.graph, self.sig, self.rounds = None, sig, 0
+        self.rounds += 1
+        if self.graph is not None:
+            self.graph.replay()
+            return True
+        if self.rounds < 3:
+            body()
+            return False
+        graph = torch.cuda.CUDAGraph()
+        try:
+            with torch.cuda.graph(graph, stream=stream_, capture_error_mode="thread_local"):
+                body()
+        except Exception as exc:   # capture is an optimisation: fall back to eager launches for good
+            import warnings
+
+            warnings.warn(f"prepack graph capture failed ({exc!r}): staying with eager launches")
+            ReplayedPrepack.enabled = False
+            body()
+            return False
+        self.graph = graph
+        graph.replay()
+        return False   # the body ran (under capture): its bookkeeping is current
+
+
+_conv_prepack_graph = ReplayedPrepack()
+
+
 def prepack(layers) -> None:
     """Rebuilds the packed weights of ``layers`` (modules with ``_packed`` / ``spec`` / weight-norm parameters, i.e.
     ``torch_modules.utils.HipConv1d``) for the descriptors of their latest forward, on the side stream: called right
@@ -332,12 +384,17 @@ def prepack(layers) -> None:
     main = torch.cuda.current_stream(dev)
     side = _side_stream(dev)
     side.wait_stream(main)   # the step that used the old images (and the optimiser that changed the weights) is complete
-    with torch.cuda.stream(side), torch.no_grad():
+    def params_of(m):
+        if m.weight_norm:
+            prm = m.parametrizations["weight"]
+            return prm.original1.detach(), prm.original0.detach()
+        return m.weight.detach(), None
+
+    def body():
         scales, jobs = {}, []
         for m in todo:   # weight-norm scales of every layer: one multi-tensor launch
             if m.weight_norm:
-                prm = m.parametrizations["weight"]
-                v, g = prm.original1.detach(), prm.original0.detach()
+                v, g = params_of(m)
                 rows = v.shape[0]
                 sc = torch.empty(rows, dtype=torch.float32, device=dev)
                 nm = torch.empty(rows, dtype=torch.float32, device=dev)
@@ -346,11 +403,19 @@ def prepack(layers) -> None:
         wn_scale_multi(jobs)
         for m in todo:
             spec, d, d_bwd = m._packed.last
-            if m.weight_norm:
-                prm = m.parametrizations["weight"]
-                pack_weights(spec, d, prm.original1.detach(), prm.original0.detach(), m._packed, True, d_bwd, scales[id(m)])
-            else:
-                pack_weights(spec, d, m.weight.detach(), None, m._packed, True, d_bwd)
+            v, g = params_of(m)
+            pack_weights(spec, d, v, g, m._packed, True, d_bwd, scales.get(id(m)))
+
+    # everything the launch sequence depends on besides the weights' values: the layers, their descriptors, the parameter storage,
+    # and WHICH layers are stale (a layer skipped while capturing would never be rebuilt by the replays)
+    sig = tuple((id(m), m._packed.last[1].batch, m._packed.last[1].l_in, m._packed.last[1].math, m._packed.last[2].math, params_of(m)[0].data_ptr(),
+                 m._packed.key != _pack_key(*params_of(m), m._packed.last[1], m._packed.last[2])) for m in todo) + (_storage_epoch.get(-1, 0),)
+    with torch.cuda.stream(side), torch.no_grad():
+        if _conv_prepack_graph.run(sig, body, side):
+            for m in todo:   # replayed: the images are current, the cache keys are not
+                spec, d, d_bwd = m._packed.last
+                v, g = params_of(m)
+                m._packed.key = _pack_key(v, g, d, d_bwd)
         ev = torch.cuda.Event()
         ev.record()
     _side["prepacked"] = ev

@@ -20,6 +20,7 @@ class FusedAdam(torch.optim.Optimizer):
         if amsgrad:
             raise NotImplementedError("amsgrad is not used by the EBEN configuration")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=False))
+        self._tables = {}   # group index -> (parameter identities, largest numel, EbenAdamTensor table with the static columns filled)
 
     @torch.no_grad()
     def step(self, closure=None, grad_scale: float = 1.0):
@@ -28,11 +29,11 @@ class FusedAdam(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         lib = load()
-        for group in self.param_groups:
+        for gi, group in enumerate(self.param_groups):
             live = [p for p in group["params"] if p.grad is not None]
             if not live:
                 continue
-            by_step = {}
+            steps = set()
             for p in live:
                 st = self.state[p]
                 if not st:
@@ -40,8 +41,36 @@ class FusedAdam(torch.optim.Optimizer):
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 st["step"] += 1
-                by_step.setdefault(int(st["step"].item()), []).append(p)
+                steps.add(float(st["step"]))
             beta1, beta2 = group["betas"]
+            if len(steps) == 1:
+                # the usual case: every parameter of the group at the same step.  The table's static columns (parameter and
+                # moment pointers, sizes) are kept from step to step; only the gradient pointers are refreshed (this loop runs
+                # at the end of every train step with the GPU idle behind it)
+                cache = self._tables.get(gi)
+                ident = tuple(id(p) for p in live)
+                if cache is None or cache[0] != ident or any(p.data_ptr() != cache[2][i].param for i, p in enumerate(live)):
+                    table = (EbenAdamTensor * len(live))()
+                    for i, p in enumerate(live):
+                        st = self.state[p]
+                        table[i] = EbenAdamTensor(ptr(p.data), 0, ptr(st["exp_avg"]), ptr(st["exp_avg_sq"]), p.numel())
+                    cache = self._tables[gi] = (ident, max(p.numel() for p in live), table)
+                table = cache[2]
+                keep = []
+                for i, p in enumerate(live):
+                    g = p.grad
+                    if not g.is_contiguous() or g.dtype is not torch.float32 or not g.is_cuda:
+                        g = g.contiguous()
+                        keep.append(g)
+                        table[i].grad = ptr(g)
+                    else:
+                        table[i].grad = g.data_ptr()
+                check(lib.eben_adam_step(table, len(live), cache[1], group["lr"], beta1, beta2, group["eps"], group["weight_decay"],
+                                         int(next(iter(steps))), grad_scale, stream()), "adam_step")
+                continue
+            by_step = {}
+            for p in live:
+                by_step.setdefault(int(self.state[p]["step"].item()), []).append(p)
             for step, plist in by_step.items():
                 table = (EbenAdamTensor * len(plist))()
                 grads = []
