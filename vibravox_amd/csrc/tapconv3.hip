@@ -432,23 +432,28 @@ static void make_plan3(const Canon& c, int dir, Tap3Plan* p) {
   const int span = (p->BN - 1) * p->S + (p->J - 1) * adstep + 1;
   if (span > 0xffff) return;
   const int NT = 256;
-  static const int lds_budget1 = env_int3("EBEN_TAP3_LDS_KB", 78) * 1024;   // two blocks per CU
+  // [MI355X] alone on the device the kernel is fastest with the largest tile that leaves two blocks per CU (78 KB: whole discriminator
+  // forward at 64 items 1.81 ms against 2.03 at 52 KB); inside the step, where three or four streams share the CUs, smaller blocks
+  // co-reside with the other streams' kernels: 19.1 / 18.9 / 18.8 ms per step at 78 / 52 / 39 KB, 19.2 at 26 KB
+  static const int lds_budget1 = env_int3("EBEN_TAP3_LDS_KB", 48) * 1024;
   static const int lds_budget_split = env_int3("EBEN_TAP3_SPLIT_LDS_KB", 150) * 1024;   // split weights: one MFMA-bound block per CU
-  const int lds_budget = p->npw > 1 ? lds_budget_split : lds_budget1;
+  static const int lds_budget_x3 = env_int3("EBEN_TAP3_X3_LDS_KB", 64) * 1024;
   const int wbytes = 2 * p->WCHU * 16;
-  const int xbudget = lds_budget - wbytes - 16;
   const int Cg2 = round_up(p->Cg, 16);
-  p->XRB = 2;
-  if ((long long)(Cg2 / 8) * p->CSTRIDE * ub + spare <= xbudget) {
-    p->CI_T = Cg2; p->ncc = 1; p->nxbuf = 1;
-  } else {
-    // hand-over rule of tapconv2.hip in weight chunks of T3_KSC k-steps: the tile of the next channel chunk is
+  // input tiles inside `lds_budget` bytes per block (weights included); a three-buffer scheme may go up to `big`
+  auto size_tiles = [&](int lds_budget, int big) -> bool {
+    const int xbudget = lds_budget - wbytes - 16;
+    p->XRB = 2;
+    if ((long long)(Cg2 / 8) * p->CSTRIDE * ub + spare <= xbudget) {
+      p->CI_T = Cg2; p->ncc = 1; p->nxbuf = 1;
+      return true;
+    }
+    // hand-over rule of tapconv2.hip in weight chunks of KSC k-steps: the tile of the next channel chunk is
     // written one weight chunk before its first use into the buffer of the tile `nxbuf` chunks back
-    bool found = false;
-    for (int nbuf = 2; nbuf <= 3 && !found; ++nbuf) {
+    for (int nbuf = 2; nbuf <= 3; ++nbuf) {
       for (int xrb : {2, 3, 5}) {
         int cap = (xrb * NT) / span * 8;          // channels
-        const int cap_lds = ((nbuf == 2 ? xbudget : (p->npw > 1 ? lds_budget : 110 * 1024) - wbytes) - spare) / nbuf / (p->CSTRIDE * ub) * 8;
+        const int cap_lds = ((nbuf == 2 ? xbudget : big - wbytes) - spare) / nbuf / (p->CSTRIDE * ub) * 8;
         if (cap > cap_lds) cap = cap_lds;
         cap -= cap % 16;
         if (cap < 16) continue;
@@ -458,12 +463,16 @@ static void make_plan3(const Canon& c, int dir, Tap3Plan* p) {
         p->nxbuf = nbuf;
         p->XRB = xrb;
         if (p->ncc > 1 && Jmin * (p->CI_T / 16) < (nbuf == 2 ? 2 * p->KSC : p->KSC)) continue;
-        found = true;
-        break;
+        return true;
       }
     }
-    if (!found) return;
-  }
+    return false;
+  };
+  bool sized;
+  if (p->npw == 1) sized = size_tiles(lds_budget1, 110 * 1024);
+  else if (p->npw == 2) sized = size_tiles(lds_budget_x3, 110 * 1024) || size_tiles(lds_budget_split, lds_budget_split);
+  else sized = size_tiles(lds_budget_split, lds_budget_split);
+  if (!sized) return;
   p->CI_B = p->CI_T / 8;
   p->CP = p->CI_T / 16;
   const int KSmax = p->ncc * p->J * p->CP;
