@@ -346,7 +346,8 @@ static void make_dw3_plan(const Canon& c, Dw3Plan* p) {
   const size_t a_bytes = 2ull * DW3_KSC * p->MT * 64 * 16;
   int chosen = 0;
   for (int pass = 0; pass < 2 && !chosen; ++pass) {
-    const size_t budget = pass == 0 ? 78 * 1024 : 156 * 1024;   // two blocks per CU, else one
+    static const size_t budget0 = (size_t)(getenv("EBEN_DW3_LDS_KB") ? atoi(getenv("EBEN_DW3_LDS_KB")) : 48) * 1024;   // [MI355X] in-step 18.8 -> 18.7 ms at 48 KB (co-residency with the other streams)
+    const size_t budget = pass == 0 ? budget0 : 156 * 1024;   // two (or more) blocks per CU, else one
     for (int bkt : {32, 16, 8, 4}) {   // 8, 4: wide X tiles (pointwise convs over 128 channels, dilation 9): fewer time steps per chunk
       if (pass == 1 && bkt == 32) continue;
       const int span = (bkt - 1) * c.s + (c.k - 1) * c.d + 1;
