@@ -35,6 +35,9 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
 #ifndef EBEN_T3_KSC
 #define EBEN_T3_KSC 4
 #endif
+#ifndef EBEN_T3_DBG
+#define EBEN_T3_DBG 0   // scratch-build ablations (wrong results): 1 no weight stream, 2 no tile refresh, 4 no barrier, 8 no MFMA, 16 phase-major stores
+#endif
 constexpr int T3_KSC = EBEN_T3_KSC;   // k-steps (of 16 reduction elements) per weight chunk (single-piece weights)
 // split weights (NPW pieces per weight, EBEN_MATH_BF16X3 / X6): a k-step carries NPW times the weight bytes and 3 / 6 times the
 // MFMAs, so two k-steps per chunk keep the chunk at 4-6 KB per 32 rows and the barrier at >= 24 MFMAs per wave
@@ -221,6 +224,9 @@ __global__ __launch_bounds__(256, NPW >= 2 ? 1 : 2) void tap3_kernel(const Tap3A
   int written = 0;
   if (nch > 0) {
     issue_w(0);
+    // the second chunk too (its buffer is free until the loop's first barrier): its LDS-DMA round trip then runs under the tile
+    // staging instead of under the four k-steps of chunk 0 -- short reductions (the PQMF-band layers: 2-6 chunks) are bound by it
+    if ((EBEN_T3_DBG & 1) == 0 && nch > 1) issue_w(1);
     const float* xp = P.x + xrow0;
     const float* mp = P.xmask + xrow0;
     for (int base = 0; base < xtot; base += 2 * NT) {
@@ -256,11 +262,8 @@ __global__ __launch_bounds__(256, NPW >= 2 ? 1 : 2) void tap3_kernel(const Tap3A
 #pragma unroll
   for (int ks = 0; ks < KSC; ++ks) te[ks] = nch > 0 ? tab[ks] : 0;
   int pending = -1;   // tile whose global loads are issued at the top of the next chunk (not in front of the barrier)
-#ifndef EBEN_T3_DBG
-#define EBEN_T3_DBG 0   // scratch-build ablations (wrong results): 1 no weight stream, 2 no tile refresh, 4 no barrier, 8 no MFMA, 16 phase-major stores
-#endif
   for (int ch = 0; ch < nch; ++ch) {
-    if ((EBEN_T3_DBG & 1) == 0 && ch + 1 < nch) issue_w(ch + 1);
+    if ((EBEN_T3_DBG & 1) == 0 && ch > 0 && ch + 1 < nch) issue_w(ch + 1);
     if ((EBEN_T3_DBG & 2) == 0 && pending >= 0) { fetch_x(pending); pending = -1; }
     const u32x4* wb = Ws + (ch & 1) * WCHU + lane;
     const u32x4* xb = Xs + lanebase;
@@ -308,25 +311,51 @@ __global__ __launch_bounds__(256, NPW >= 2 ? 1 : 2) void tap3_kernel(const Tap3A
 
   const bool use_res = P.res != nullptr && (P.res_rows == 0 || b < P.res_rows);
   const int eb = P.em_seg > 0 ? P.em_map[b / P.em_seg] * P.em_seg + b % P.em_seg : b;
-  const long long eoff = (long long)(eb - b) * P.Cy * P.Ly;
   // ---- epilogue: 32x32 D tile: column = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) ----
+  // Every operand of the fused stages (bias, residual, activation mask, accumulate target) is read for all 16 rows of a tile in ONE
+  // batch of loads (clamped addresses, no per-value branch), then the 16 values are formed and stored: written value by value the
+  // compiler waits for each load in turn -- ~32 exposed round trips per lane, several times the whole reduction of a short layer.
   const int t = t0 + wn * 32 + (lane & 31);
   if (t >= nt) return;
+  const long long col = (long long)t * P.OS + oo;
+  if (EBEN_T3_DBG & 16) { /* phase-major (coalesced) stores: scratch ablation */ }
+  const long long ybase = ((long long)b * P.Cy + (long long)g * P.Mg) * P.Ly + ((EBEN_T3_DBG & 16) ? (long long)ph * nt + t : col);
+  const long long ebase = ((long long)eb * P.Cy + (long long)g * P.Mg) * P.Ly + col;
+  const int mlane = m0 + 4 * (lane >> 5);
+  const int mlast = P.Mg - 1;
 #pragma unroll
-  for (int i = 0; i < FM; ++i) {
+  for (int ih = 0; ih < 2 * FM; ++ih) {   // eight rows (half an accumulator tile) per batch of loads: registers stay below the main loop's
+    const int i = ih >> 1, r0 = (ih & 1) * 8;
+    float bz[8], rz[8], ez[8], az[8];
+    int off[8];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      if (m >= P.Mg) continue;
-      const float bias = P.bias ? P.bias[g * P.Mg + m] : 0.f;
-      long long idx = ((long long)b * P.Cy + (long long)g * P.Mg + m) * P.Ly + (long long)t * P.OS + oo;
-      if (EBEN_T3_DBG & 16) idx = ((long long)b * P.Cy + (long long)g * P.Mg + m) * P.Ly + (long long)ph * nt + t;   // phase-major (coalesced) stores
-      float v = acc[i][r] + bias;
+    for (int r = 0; r < 8; ++r) {
+      const int m = mlane + i * 32 + (r & 3) + 8 * ((r0 + r) >> 2);
+      const int mc = m < mlast ? m : mlast;   // rows beyond the group re-read its last row and are not stored
+      off[r] = mc * P.Ly;
+      bz[r] = P.bias ? P.bias[g * P.Mg + mc] : 0.f;
+    }
+    if (use_res) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) rz[r] = P.res[ybase + off[r]];
+    }
+    if (P.emask) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) ez[r] = P.emask[ebase + off[r]];
+    }
+    if (P.accumulate) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) az[r] = P.y[ybase + off[r]];
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int m = mlane + i * 32 + (r & 3) + 8 * ((r0 + r) >> 2);
+      float v = acc[i][r0 + r] + bz[r];
       v = lrelu(v, P.out_slope);
-      if (use_res) v += lrelu(P.res[idx], P.res_slope);
-      if (P.emask) v *= dlrelu(P.emask[idx + eoff], P.emask_slope);
-      if (P.accumulate) v += P.y[idx];
-      P.y[idx] = v;
+      if (use_res) v += lrelu(rz[r], P.res_slope);
+      if (P.emask) v *= dlrelu(ez[r], P.emask_slope);
+      if (P.accumulate) v += az[r];
+      if (m < P.Mg) P.y[ybase + off[r]] = v;
     }
   }
 }
