@@ -498,7 +498,12 @@ static void make_plan3(const Canon& c, int dir, Tap3Plan* p) {
     return false;
   };
   bool sized;
-  if (p->npw == 1) sized = size_tiles(lds_budget1, 110 * 1024);
+  // long reductions (MelGAN L3-L5: >= EBEN_TAP3_BIG_KS k-steps per block) keep the two-blocks-per-CU tiles: they are the launches
+  // that fill the device by themselves, and lose 40-50 % stand-alone on the small budget
+  static const int big_ks = env_int3("EBEN_TAP3_BIG_KS", 1 << 30);
+  static const int lds_budget_big = env_int3("EBEN_TAP3_BIG_LDS_KB", 78) * 1024;
+  const long long ks_total = (long long)ceil_div(p->Cg, 16) * p->J;
+  if (p->npw == 1) sized = size_tiles(ks_total >= big_ks ? lds_budget_big : lds_budget1, 110 * 1024);
   else if (p->npw == 2) sized = size_tiles(lds_budget_x3, 110 * 1024) || size_tiles(lds_budget_split, lds_budget_split);
   else sized = size_tiles(lds_budget_split, lds_budget_split);
   if (!sized) return;
