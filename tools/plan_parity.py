@@ -6,7 +6,7 @@ import torch
 import bench
 
 DEV = torch.device("cuda")
-plans = sys.argv[1:] or ["bf16", "bf16_x6fwd", "bf16_x3fwd", "bf16x6", "bf16_plain"]
+plans = sys.argv[1:] or ["bf16", "bf16_x6fwd", "bf16_f32fwd", "bf16x6", "bf16_plain"]
 
 
 def one_step(plan, gen_bwd):

@@ -500,7 +500,7 @@ static void make_plan3(const Canon& c, int dir, Tap3Plan* p) {
   bool sized;
   // long reductions (MelGAN L3-L5: >= EBEN_TAP3_BIG_KS k-steps per block) keep the two-blocks-per-CU tiles: they are the launches
   // that fill the device by themselves, and lose 40-50 % stand-alone on the small budget
-  static const int big_ks = env_int3("EBEN_TAP3_BIG_KS", 1 << 30);
+  static const int big_ks = env_int3("EBEN_TAP3_BIG_KS", 128);   // [MI355X] neutral in the step (18.0-18.3 ms either way), MelGAN L4 forward alone 0.30 -> 0.20 ms
   static const int lds_budget_big = env_int3("EBEN_TAP3_BIG_LDS_KB", 78) * 1024;
   const long long ks_total = (long long)ceil_div(p->Cg, 16) * p->J;
   if (p->npw == 1) sized = size_tiles(ks_total >= big_ks ? lds_budget_big : lds_budget1, 110 * 1024);
