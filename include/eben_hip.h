@@ -108,6 +108,14 @@ EBEN_API int eben_wn_bwd_multi(const EbenWnBwdItem* items, int n, void* stream);
 /* ---- conv layers ------------------------------------------------------------------------ */
 /* floats needed for the packed weights of the forward (which=0) / input-gradient (which=1) pass */
 EBEN_API size_t eben_conv1d_packed_floats(const EbenConv1dDesc* d, int which);
+/* Many layers' images in few launches (the step rebuilds ~150 images after its two optimiser steps): as eben_conv1d_pack per job
+ * (wp_fwd / wp_bwd nullable); `jobs` is a HOST array. */
+typedef struct EbenPackJob {
+  EbenConv1dDesc desc;
+  const float* v; const float* scale;
+  float* wp_fwd; float* wp_bwd;
+} EbenPackJob;
+EBEN_API int eben_conv1d_pack_multi(const EbenPackJob* jobs, int n, void* stream);
 /* which tap-conv kernel generation serves the forward (which=0) / input-gradient (which=1) pass of
  * this layer: 1 = tapconv.hip (16x16x4 tiles, any shape), 2 = tapconv2.hip (32x32x2 tiles, LDS-DMA
  * weight stream; deep reductions).  The packed layouts differ; pack / fwd / bwd_dx agree by construction. */
@@ -180,6 +188,11 @@ EBEN_API size_t eben_ru_packed_floats_ex(int channels, int math);
 EBEN_API int eben_ru_supported(int channels, int dilation, int math);
 EBEN_API int eben_ru_pack_ex(int channels, int math, int which, const float* v_dil, const float* scale_dil, const float* v_pw,
                     const float* scale_pw, float* wimg, void* stream);
+typedef struct EbenRuPackJob {   /* one image of eben_ru_pack_ex (math != EBEN_MATH_F32); `jobs` is a HOST array */
+  int32_t channels, math, which, pad_;
+  const float* v_dil; const float* scale_dil; const float* v_pw; const float* scale_pw; float* wimg;
+} EbenRuPackJob;
+EBEN_API int eben_ru_pack_multi(const EbenRuPackJob* jobs, int n, void* stream);
 EBEN_API int eben_ru_fwd_ex(int math, int batch, int channels, int length, int dilation, const float* x, float in_slope, float out_slope,
                    const float* wimg, float* y, float* h, float* u, void* stream);
 EBEN_API int eben_ru_bwd_ex(int math, int batch, int channels, int length, int dilation, const float* gy, const float* u, float out_slope,

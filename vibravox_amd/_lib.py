@@ -42,6 +42,15 @@ class EbenConv1dDesc(ctypes.Structure):
     ]
 
 
+class EbenPackJob(ctypes.Structure):
+    _fields_ = [("desc", EbenConv1dDesc), ("v", c_void_p), ("scale", c_void_p), ("wp_fwd", c_void_p), ("wp_bwd", c_void_p)]
+
+
+class EbenRuPackJob(ctypes.Structure):
+    _fields_ = [("channels", c_int32), ("math", c_int32), ("which", c_int32), ("pad_", c_int32),
+                ("v_dil", c_void_p), ("scale_dil", c_void_p), ("v_pw", c_void_p), ("scale_pw", c_void_p), ("wimg", c_void_p)]
+
+
 class EbenWnScaleItem(ctypes.Structure):
     _fields_ = [("g", c_void_p), ("v", c_void_p), ("scale", c_void_p), ("norm", c_void_p), ("rows", c_int32), ("cols", c_int32)]
 
@@ -82,6 +91,7 @@ SIGNATURES = {
     "eben_conv1d_packed_floats": (c_size_t, [_D, c_int]),
     "eben_conv1d_kernel_generation": (c_int, [_D, c_int]),
     "eben_conv1d_pack": (c_int, [_D, _P, _P, _P, _P, _P]),
+    "eben_conv1d_pack_multi": (c_int, [POINTER(EbenPackJob), c_int, _P]),
     "eben_conv1d_fwd": (c_int, [_D, _P, _P, _P, _P, _P, _P]),
     "eben_conv1d_fwd_res": (c_int, [_D, _P, _P, _P, _P, c_float, _P, _P]),
     "eben_conv1d_bwd_dx_res": (c_int, [_D, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
@@ -98,6 +108,7 @@ SIGNATURES = {
     "eben_ru_packed_floats_ex": (c_size_t, [c_int, c_int]),
     "eben_ru_supported": (c_int, [c_int, c_int, c_int]),
     "eben_ru_pack_ex": (c_int, [c_int, c_int, c_int, _P, _P, _P, _P, _P, _P]),
+    "eben_ru_pack_multi": (c_int, [POINTER(EbenRuPackJob), c_int, _P]),
     "eben_ru_fwd_ex": (c_int, [c_int, c_int, c_int, c_int, c_int, _P, c_float, c_float, _P, _P, _P, _P, _P]),
     "eben_ru_bwd_ex": (c_int, [c_int, c_int, c_int, c_int, c_int, _P, _P, c_float, _P, c_float, _P, _P, _P, _P, _P]),
     "eben_ru_dw_slabs": (c_int, [c_int, c_int, c_int]),

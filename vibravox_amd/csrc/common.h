@@ -135,6 +135,7 @@ int tap2_launch(const Canon& c, int dir, const TapIO& io, int reflect, hipStream
 int tap3_applicable(const Canon& c, int dir);
 size_t tap3_packed_floats(const Canon& c, int dir);
 int tap3_pack(const Canon& c, int dir, const float* w, const float* scale, float* wp, hipStream_t st);
+int tap3_pack_multi(const Canon* cs, const int* dirs, const float* const* ws, const float* const* scales, float* const* wps, int n, hipStream_t st);
 int tap3_launch(const Canon& c, int dir, const TapIO& io, int reflect, hipStream_t st);
 
 // direct (VALU) tap-conv for layers with a handful of output channels per group (thinconv.hip)

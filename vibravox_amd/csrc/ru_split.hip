@@ -253,11 +253,11 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && CT < 4) ? 2 : 1) void ru3_fwd_
 
 // forward weight image: unit ((ks NP + q) CT + i) 64 + lane; ks < 3 KB: tap ks / KB, channels 16 (ks % KB) + 8 (lane >> 5) + e;
 // then the pointwise k-steps in the accumulator order (see the header)
-__global__ __launch_bounds__(256) void ru3_pack_fwd_kernel(const float* __restrict__ vd, const float* __restrict__ sd, const float* __restrict__ vp,
-                                                           const float* __restrict__ sp, u32x4* __restrict__ img, int CT, int NP) {
+__device__ __forceinline__ void ru3_pack_fwd_body(const float* __restrict__ vd, const float* __restrict__ sd, const float* __restrict__ vp,
+                                                  const float* __restrict__ sp, u32x4* __restrict__ img, int CT, int NP, unsigned bid, unsigned nblk) {
   const int C = 32 * CT, KB = C / 16;
   const int total = 4 * KB * CT * 64;   // (k-step, row tile, lane)
-  for (int t = blockIdx.x * 256 + threadIdx.x; t < total; t += gridDim.x * 256) {
+  for (int t = bid * 256 + threadIdx.x; t < total; t += nblk * 256) {
     const int lane = t & 63;
     const int i = (t >> 6) % CT;
     const int ks = t / (64 * CT);
@@ -515,11 +515,11 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && CT < 4) ? 2 : 1) void ru3_bwd_
 
 // backward weight image: entry en = 32 reduction channels: unit (((en 2 + kk) NP + q) CT + i) 64 + lane.
 // en < CT: W_pw^T (row = pointwise input channel, reduction = its output channel); en = CT + jj CT + cb: W_dil[2 - jj]^T
-__global__ __launch_bounds__(256) void ru3_pack_bwd_kernel(const float* __restrict__ vd, const float* __restrict__ sd, const float* __restrict__ vp,
-                                                           const float* __restrict__ sp, u32x4* __restrict__ img, int CT, int NP) {
+__device__ __forceinline__ void ru3_pack_bwd_body(const float* __restrict__ vd, const float* __restrict__ sd, const float* __restrict__ vp,
+                                                  const float* __restrict__ sp, u32x4* __restrict__ img, int CT, int NP, unsigned bid, unsigned nblk) {
   const int C = 32 * CT;
   const int total = 4 * CT * 2 * CT * 64;   // (entry, k-step of the entry, row tile, lane)
-  for (int t = blockIdx.x * 256 + threadIdx.x; t < total; t += gridDim.x * 256) {
+  for (int t = bid * 256 + threadIdx.x; t < total; t += nblk * 256) {
     const int lane = t & 63;
     const int i = (t >> 6) % CT;
     const int kk = (t / (64 * CT)) & 1;
@@ -552,6 +552,29 @@ __global__ __launch_bounds__(256) void ru3_pack_bwd_kernel(const float* __restri
       }
     }
   }
+}
+
+__global__ __launch_bounds__(256) void ru3_pack_fwd_kernel(const float* vd, const float* sd, const float* vp, const float* sp, u32x4* img, int CT, int NP) {
+  ru3_pack_fwd_body(vd, sd, vp, sp, img, CT, NP, blockIdx.x, gridDim.x);
+}
+__global__ __launch_bounds__(256) void ru3_pack_bwd_kernel(const float* vd, const float* sd, const float* vp, const float* sp, u32x4* img, int CT, int NP) {
+  ru3_pack_bwd_body(vd, sd, vp, sp, img, CT, NP, blockIdx.x, gridDim.x);
+}
+
+// the images of many units in one launch (eben_ru_pack_multi): block -> job by the prefix sums of the jobs' block counts
+constexpr int RU_PACK_MULTI = 48;
+struct RuPackTable {
+  int n;
+  unsigned short first[RU_PACK_MULTI + 1];
+  struct { const float* vd; const float* sd; const float* vp; const float* sp; u32x4* img; short CT, NP, which, pad; } job[RU_PACK_MULTI];
+};
+__global__ __launch_bounds__(256) void ru3_pack_multi_kernel(const RuPackTable T) {
+  int j = 0;
+#pragma unroll 1
+  while (j + 1 < T.n && blockIdx.x >= T.first[j + 1]) ++j;
+  const unsigned bid = blockIdx.x - T.first[j], nblk = T.first[j + 1] - T.first[j];
+  if (T.job[j].which == 0) ru3_pack_fwd_body(T.job[j].vd, T.job[j].sd, T.job[j].vp, T.job[j].sp, T.job[j].img, T.job[j].CT, T.job[j].NP, bid, nblk);
+  else ru3_pack_bwd_body(T.job[j].vd, T.job[j].sd, T.job[j].vp, T.job[j].sp, T.job[j].img, T.job[j].CT, T.job[j].NP, bid, nblk);
 }
 
 // ---- host side ----------------------------------------------------------------------------------------------------------
@@ -705,6 +728,28 @@ extern "C" int eben_ru_pack_ex(int channels, int math, int which, const float* v
   EBEN_REQUIRE(ru3_supported(channels, 1, math), "fused ResidualUnit: 32, 64 or 128 channels and a known math mode (got %d, %d)", channels, math);
   EBEN_REQUIRE(v_dil && v_pw && wimg, "null pointer in ru_pack_ex");
   return ru3_pack(channels, math, which, v_dil, scale_dil, v_pw, scale_pw, wimg, as_stream(stream));
+}
+
+extern "C" int eben_ru_pack_multi(const EbenRuPackJob* jobs, int n, void* stream) {
+  EBEN_REQUIRE(n >= 0 && (n == 0 || jobs != nullptr), "bad ru pack job list");
+  for (int base = 0; base < n; base += RU_PACK_MULTI) {
+    RuPackTable T;
+    T.n = n - base < RU_PACK_MULTI ? n - base : RU_PACK_MULTI;
+    T.first[0] = 0;
+    for (int j = 0; j < T.n; ++j) {
+      const EbenRuPackJob& jb = jobs[base + j];
+      EBEN_REQUIRE(jb.math != EBEN_MATH_F32, "ru_pack_multi: the split-operand images only (pack the fp32 MFMA images with eben_ru_pack)");
+      EBEN_REQUIRE(ru3_supported(jb.channels, 1, jb.math) && (jb.which == 0 || jb.which == 1) && jb.v_dil && jb.v_pw && jb.wimg, "bad ru pack job %d", base + j);
+      const int CT = jb.channels / 32;
+      T.job[j].vd = jb.v_dil; T.job[j].sd = jb.scale_dil; T.job[j].vp = jb.v_pw; T.job[j].sp = jb.scale_pw;
+      T.job[j].img = reinterpret_cast<u32x4*>(jb.wimg);
+      T.job[j].CT = (short)CT; T.job[j].NP = (short)rs_pieces(jb.math); T.job[j].which = (short)jb.which; T.job[j].pad = 0;
+      T.first[j + 1] = (unsigned short)(T.first[j] + ceil_div(8 * CT * CT * 64, 256));
+    }
+    hipLaunchKernelGGL(ru3_pack_multi_kernel, dim3(T.first[T.n]), dim3(256), 0, as_stream(stream), T);
+    EBEN_CHECK_LAUNCH("ru3_pack_multi_kernel");
+  }
+  return EBEN_OK;
 }
 
 extern "C" int eben_ru_fwd_ex(int math, int batch, int channels, int length, int dilation, const float* x, float in_slope, float out_slope,

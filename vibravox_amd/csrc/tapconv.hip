@@ -713,6 +713,45 @@ extern "C" int eben_conv1d_pack(const EbenConv1dDesc* d, const float* v, const f
   return EBEN_OK;
 }
 
+extern "C" int eben_conv1d_pack_multi(const EbenPackJob* jobs, int n, void* stream) {
+  EBEN_REQUIRE(n >= 0 && (n == 0 || jobs != nullptr), "bad pack job list");
+  // images of the bf16 tap-conv family (most of a step's ~150 pack launches) are gathered into launches of 16 jobs; the other
+  // families keep their own launches
+  constexpr int CAP = 512;
+  static thread_local Canon cs[CAP];
+  static thread_local int dirs[CAP];
+  static thread_local const float* ws[CAP];
+  static thread_local const float* scs[CAP];
+  static thread_local float* wps[CAP];
+  int m = 0;
+  auto flush = [&]() -> int {
+    const int rc = m ? tap3_pack_multi(cs, dirs, ws, scs, wps, m, as_stream(stream)) : EBEN_OK;
+    m = 0;
+    return rc;
+  };
+  for (int i = 0; i < n; ++i) {
+    const EbenPackJob& jb = jobs[i];
+    Canon c;
+    int rc = canon_from_desc(&jb.desc, &c);
+    if (rc) return rc;
+    EBEN_REQUIRE(jb.v != nullptr, "null weight");
+    for (int which = 0; which < 2; ++which) {
+      float* dst = which == 0 ? jb.wp_fwd : jb.wp_bwd;
+      if (!dst) continue;
+      const int dir = jb.desc.transposed ? 1 - which : which;
+      if (tap_generation(c, dir) == 4) {
+        if (m == CAP && (rc = flush())) return rc;
+        cs[m] = c; dirs[m] = dir; ws[m] = jb.v; scs[m] = jb.scale; wps[m] = dst;
+        ++m;
+      } else {
+        rc = eben_conv1d_pack(&jb.desc, jb.v, jb.scale, which == 0 ? dst : nullptr, which == 1 ? dst : nullptr, stream);
+        if (rc) return rc;
+      }
+    }
+  }
+  return flush();
+}
+
 static int conv1d_fwd_impl(const EbenConv1dDesc* d, const float* x, const float* wp_fwd, const float* bias,
                            const float* residual, float res_slope, float* y, void* stream) {
   Canon c;

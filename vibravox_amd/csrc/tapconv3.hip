@@ -529,9 +529,9 @@ struct Pack3Args {
   long long w_tile, w_phase, wunits;
 };
 
-__global__ __launch_bounds__(256) void pack3_kernel(const Pack3Args P) {
+__device__ __forceinline__ void pack3_body(const Pack3Args& P, unsigned bid, unsigned nblk) {
   const long long total = P.wunits + (long long)P.tab_phase * P.nph;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+  for (long long i = (long long)bid * 256 + threadIdx.x; i < total; i += (long long)nblk * 256) {
     if (i < P.wunits) {
       long long r = i;
       const int ph = (int)(r / P.w_phase); r -= (long long)ph * P.w_phase;
@@ -603,6 +603,22 @@ __global__ __launch_bounds__(256) void pack3_kernel(const Pack3Args P) {
   }
 }
 
+__global__ __launch_bounds__(256) void pack3_kernel(const Pack3Args P) { pack3_body(P, blockIdx.x, gridDim.x); }
+
+// several layers' images in one launch (eben_conv1d_pack_multi): block -> job by the prefix sums of the jobs' block counts
+constexpr int PACK3_MULTI = 16;
+struct Pack3Table {
+  int n;
+  unsigned first[PACK3_MULTI + 1];
+  Pack3Args job[PACK3_MULTI];
+};
+__global__ __launch_bounds__(256) void pack3_multi_kernel(const Pack3Table T) {
+  int j = 0;
+#pragma unroll 1
+  while (j + 1 < T.n && blockIdx.x >= T.first[j + 1]) ++j;
+  pack3_body(T.job[j], blockIdx.x - T.first[j], T.first[j + 1] - T.first[j]);
+}
+
 template <int FM, int XRB, bool IM, int NPW = 1, int NPX = 1>
 static int launch3_im(const Tap3Args& a, int nblocks, size_t lds, hipStream_t st) {
   static bool attr_set = false;
@@ -639,7 +655,7 @@ size_t tap3_packed_floats(const Canon& c, int dir) {
   return p.ok ? p.packed_floats : 0;
 }
 
-int tap3_pack(const Canon& c, int dir, const float* w, const float* scale, float* wp, hipStream_t st) {
+static int tap3_pack_args(const Canon& c, int dir, const float* w, const float* scale, float* wp, Pack3Args* out, unsigned* blocks_out) {
   Tap3Plan p;
   make_plan3(c, dir, &p);
   if (!p.ok) return fail(EBEN_EUNSUPPORTED, "tap3_pack on a layer the bf16 kernel does not cover");
@@ -655,8 +671,37 @@ int tap3_pack(const Canon& c, int dir, const float* w, const float* scale, float
   long long blocks = (a.wunits + (long long)p.tab_phase * p.nph + 255) / 256;
   if (blocks > 8192) blocks = 8192;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(pack3_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
+  *out = a;
+  *blocks_out = (unsigned)blocks;
+  return EBEN_OK;
+}
+
+int tap3_pack(const Canon& c, int dir, const float* w, const float* scale, float* wp, hipStream_t st) {
+  Pack3Args a;
+  unsigned blocks;
+  const int rc = tap3_pack_args(c, dir, w, scale, wp, &a, &blocks);
+  if (rc) return rc;
+  hipLaunchKernelGGL(pack3_kernel, dim3(blocks), dim3(256), 0, st, a);
   EBEN_CHECK_LAUNCH("pack3_kernel");
+  return EBEN_OK;
+}
+
+// jobs[i] = (canonical conv, direction, weights, scale, image) of layers this kernel family covers: ceil(n / 16) launches
+int tap3_pack_multi(const Canon* cs, const int* dirs, const float* const* ws, const float* const* scales, float* const* wps, int n, hipStream_t st) {
+  for (int base = 0; base < n; base += PACK3_MULTI) {
+    Pack3Table T;
+    T.n = n - base < PACK3_MULTI ? n - base : PACK3_MULTI;
+    T.first[0] = 0;
+    for (int j = 0; j < T.n; ++j) {
+      unsigned blocks;
+      const int rc = tap3_pack_args(cs[base + j], dirs[base + j], ws[base + j], scales[base + j], wps[base + j], &T.job[j], &blocks);
+      if (rc) return rc;
+      if (blocks > 512) blocks = 512;   // many jobs share the launch: the grid-stride loop takes the rest
+      T.first[j + 1] = T.first[j] + blocks;
+    }
+    hipLaunchKernelGGL(pack3_multi_kernel, dim3(T.first[T.n]), dim3(256), 0, st, T);
+    EBEN_CHECK_LAUNCH("pack3_multi_kernel");
+  }
   return EBEN_OK;
 }
 

@@ -91,8 +91,7 @@ class _Layer:
                 del self.packs[old]
         d = ops.conv_desc(self.spec, batch, l_in, self.math_fwd if which == 0 else self.math_dx)
         wp = torch.empty(lib.eben_conv1d_packed_floats(ctypes.byref(d), which), dtype=torch.float32, device=v.device)
-        check(lib.eben_conv1d_pack(ctypes.byref(d), ptr(v), ptr(self.scale), ptr(wp) if which == 0 else None,
-                                   ptr(wp) if which == 1 else None, _stream()), "conv1d_pack")
+        ops.conv1d_pack(d, v, self.scale, wp if which == 0 else None, wp if which == 1 else None)
         self.packs[slot] = (wkey, wp)
         return wp
 
@@ -429,14 +428,15 @@ class DiscriminatorEngine:
                     lay.scale_key = wkey
                     jobs.append((g.detach(), v.detach(), rows, v.numel() // rows, lay.scale, lay.norm))
             ops.wn_scale_multi(jobs)
-            for lay in layers:
-                used, lay.used = lay.used, set()
-                for slot in list(lay.packs):
-                    if slot in used:
-                        lay.packed(*slot)     # what the last step launched: the next step most likely launches it again
-                    else:
-                        del lay.packs[slot]   # a shape of an earlier step: rebuilt on demand if it comes back
-                lay.used = set()              # re-packing is not a use: the next step decides what survives the next prepack
+            with ops.pack_batch():
+                for lay in layers:
+                    used, lay.used = lay.used, set()
+                    for slot in list(lay.packs):
+                        if slot in used:
+                            lay.packed(*slot)     # what the last step launched: the next step most likely launches it again
+                        else:
+                            del lay.packs[slot]   # a shape of an earlier step: rebuilt on demand if it comes back
+                    lay.used = set()              # re-packing is not a use: the next step decides what survives the next prepack
 
         # the launch sequence as a function of everything but the weights' values (ops.ReplayedPrepack): layers, the slots the last
         # step used (= all the slots held, or the eager path prunes), parameter storage, and that every image is stale

@@ -65,6 +65,7 @@ class GeneratorEngine:
         self._spec_cache: Dict[tuple, ops.ConvSpec] = {}
         self._ru_images: Dict[int, dict] = {}   # id(ResidualUnit) -> {key, fwd image, bwd images per math, scales}
         self._prepack_graph = ops.ReplayedPrepack()
+        self._ru_batch = None
 
     # ---- helpers ------------------------------------------------------------------------------------
     def _spec(self, m, in_slope=None, out_slope=None) -> ops.ConvSpec:
@@ -121,11 +122,16 @@ class GeneratorEngine:
             return hit["fwd"] if which == 0 else hit["bwd"][bm]
         c = vd.shape[0]
         dev = vd.device
+        batch = self._ru_batch   # inside prepack(): the launches of all units are gathered into one wn_scale / one pack call
         if hit is None or hit["key"] != key:
             scales = torch.empty((4, c), dtype=torch.float32, device=dev)   # scale / norm of the dilated, then of the pointwise conv
-            ops.wn_scale_multi([(gd.detach(), vd.detach(), c, vd.numel() // c, scales[0], scales[1]), (gp.detach(), vp.detach(), c, vp.numel() // c, scales[2], scales[3])])
+            wn = [(gd.detach(), vd.detach(), c, vd.numel() // c, scales[0], scales[1]), (gp.detach(), vp.detach(), c, vp.numel() // c, scales[2], scales[3])]
+            if batch is not None:
+                batch["wn"].extend(wn)
+            else:
+                ops.wn_scale_multi(wn)
             img = torch.empty(lib.eben_ru_packed_floats_ex(c, RU_FWD_MATH), dtype=torch.float32, device=dev)
-            check(lib.eben_ru_pack_ex(c, RU_FWD_MATH, 0, ptr(vd.detach()), ptr(scales[0]), ptr(vp.detach()), ptr(scales[2]), ptr(img), stream()), "ru_pack")
+            self._ru_pack(c, RU_FWD_MATH, 0, vd, scales[0], vp, scales[2], img)
             maths = set(hit["bwd"]) if hit is not None else set()
             hit = self._ru_images[id(ru)] = {"key": key, "fwd": img, "bwd": {}, "scales": scales}
         else:
@@ -135,9 +141,30 @@ class GeneratorEngine:
         scales = hit["scales"]
         for m in maths:
             img_b = torch.empty(lib.eben_ru_packed_floats_ex(c, m), dtype=torch.float32, device=dev)
-            check(lib.eben_ru_pack_ex(c, m, 1, ptr(vd.detach()), ptr(scales[0]), ptr(vp.detach()), ptr(scales[2]), ptr(img_b), stream()), "ru_pack_bwd")
+            self._ru_pack(c, m, 1, vd, scales[0], vp, scales[2], img_b)
             hit["bwd"][m] = img_b
         return hit["fwd"] if which == 0 else hit["bwd"][bm]
+
+    def _ru_pack(self, c, math, which, vd, sd, vp, sp, img) -> None:
+        if self._ru_batch is not None and math != ops.MATH_F32:
+            self._ru_batch["packs"].append((c, math, which, vd.detach(), sd, vp.detach(), sp, img))
+            return
+        check(load().eben_ru_pack_ex(c, math, which, ptr(vd.detach()), ptr(sd), ptr(vp.detach()), ptr(sp), ptr(img), stream()), "ru_pack")
+
+    def _ru_flush(self) -> None:
+        """Issues what ``_ru_image`` gathered: the weight-norm scales of all units as one launch, then their images as one."""
+        batch, self._ru_batch = self._ru_batch, None
+        if batch is None:
+            return
+        ops.wn_scale_multi(batch["wn"])
+        if batch["packs"]:
+            from ._lib import EbenRuPackJob
+
+            table = (EbenRuPackJob * len(batch["packs"]))()
+            for it, (c, math, which, vd, sd, vp, sp, img) in zip(table, batch["packs"]):
+                it.channels, it.math, it.which = c, math, which
+                it.v_dil, it.scale_dil, it.v_pw, it.scale_pw, it.wimg = ptr(vd), ptr(sd), ptr(vp), ptr(sp), ptr(img)
+            check(load().eben_ru_pack_multi(table, len(table), stream()), "ru_pack_multi")
 
     def prepack(self) -> None:
         """Rebuilds the fused units' weight images on the side stream (called with ``ops.prepack`` after the optimiser step);
@@ -156,8 +183,12 @@ class GeneratorEngine:
             return tuple((t.data_ptr(), t._version, e.get(t.data_ptr(), 0)) for t in ts) + (e.get(-1, 0),)
 
         def body():
-            for ru in units:
-                self._ru_image(ru)
+            self._ru_batch = {"wn": [], "packs": []}
+            try:
+                for ru in units:
+                    self._ru_image(ru)
+            finally:
+                self._ru_flush()
 
         def entry(ru):
             hit = self._ru_images.get(id(ru))

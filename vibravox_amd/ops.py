@@ -15,7 +15,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import torch
 
 from . import _lib
-from ._lib import EbenConv1dDesc, EbenWnBwdItem, EbenWnScaleItem, check, load, ptr, stream
+from ._lib import EbenConv1dDesc, EbenPackJob, EbenWnBwdItem, EbenWnScaleItem, check, load, ptr, stream
 
 # Optimisers that write parameters behind autograd's back (FusedAdam) bump the epoch of exactly
 # the storages they touched, so that only those layers' packed-weight caches are rebuilt.
@@ -283,6 +283,38 @@ class PackedWeights:
         self.last = None   # (spec, descriptor) of the latest pack: what `prepack` rebuilds ahead of the next step
 
 
+_pack_batch: List[Optional[list]] = [None]
+
+
+def conv1d_pack(d: EbenConv1dDesc, v, scale, wp_fwd, wp_bwd) -> None:
+    """``eben_conv1d_pack`` on the current stream -- or, inside ``pack_batch()``, one job of the ``eben_conv1d_pack_multi`` call
+    issued when the context closes (the prepack sequences: ~150 images per step in ~15 launches)."""
+    if _pack_batch[0] is not None:
+        _pack_batch[0].append((d, v, scale, wp_fwd, wp_bwd))
+        return
+    check(load().eben_conv1d_pack(ctypes.byref(d), ptr(v), ptr(scale), ptr(wp_fwd), ptr(wp_bwd), stream()), "conv1d_pack")
+
+
+@contextlib.contextmanager
+def pack_batch():
+    """Collects the ``conv1d_pack`` calls made inside and issues them as one ``eben_conv1d_pack_multi`` on the current stream at
+    exit (everything the jobs read -- the weight-norm scales -- must have been launched on that stream before)."""
+    if _pack_batch[0] is not None:   # nested: the outer context flushes
+        yield
+        return
+    _pack_batch[0] = []
+    try:
+        yield
+        jobs = _pack_batch[0]
+    finally:
+        _pack_batch[0] = None
+    if jobs:
+        table = (EbenPackJob * len(jobs))()
+        for it, (d, v, scale, wp_fwd, wp_bwd) in zip(table, jobs):
+            it.desc, it.v, it.scale, it.wp_fwd, it.wp_bwd = d, ptr(v), ptr(scale), ptr(wp_fwd), ptr(wp_bwd)
+        check(load().eben_conv1d_pack_multi(table, len(jobs), stream()), "conv1d_pack_multi")
+
+
 def _pack_key(v, g, d, d_bwd):
     return (v.data_ptr(), v._version, _storage_epoch.get(v.data_ptr(), 0), _storage_epoch.get(-1, 0),
             None if g is None else (g.data_ptr(), g._version, _storage_epoch.get(g.data_ptr(), 0)), d.batch, d.l_in, d.math, d_bwd.math)
@@ -316,10 +348,10 @@ def pack_weights(spec: ConvSpec, d: EbenConv1dDesc, v: torch.Tensor, g: Optional
         torch.empty(lib.eben_conv1d_packed_floats(ctypes.byref(d_bwd), 1), dtype=torch.float32, device=v.device) if need_bwd else None
     )
     if d_bwd is d or not need_bwd:
-        check(lib.eben_conv1d_pack(ctypes.byref(d), ptr(v), ptr(pw.scale), ptr(pw.wp_fwd), ptr(pw.wp_bwd), st), "conv1d_pack")
+        conv1d_pack(d, v, pw.scale, pw.wp_fwd, pw.wp_bwd)
     else:
-        check(lib.eben_conv1d_pack(ctypes.byref(d), ptr(v), ptr(pw.scale), ptr(pw.wp_fwd), None, st), "conv1d_pack")
-        check(lib.eben_conv1d_pack(ctypes.byref(d_bwd), ptr(v), ptr(pw.scale), None, ptr(pw.wp_bwd), st), "conv1d_pack")
+        conv1d_pack(d, v, pw.scale, pw.wp_fwd, None)
+        conv1d_pack(d_bwd, v, pw.scale, None, pw.wp_bwd)
     pw.key = key
     pw.last = (spec, d, d_bwd)
     return pw
@@ -401,10 +433,11 @@ def prepack(layers) -> None:
                 scales[id(m)] = (sc, nm)
                 jobs.append((g, v, rows, v.numel() // rows, sc, nm))
         wn_scale_multi(jobs)
-        for m in todo:
-            spec, d, d_bwd = m._packed.last
-            v, g = params_of(m)
-            pack_weights(spec, d, v, g, m._packed, True, d_bwd, scales.get(id(m)))
+        with pack_batch():
+            for m in todo:
+                spec, d, d_bwd = m._packed.last
+                v, g = params_of(m)
+                pack_weights(spec, d, v, g, m._packed, True, d_bwd, scales.get(id(m)))
 
     # everything the launch sequence depends on besides the weights' values: the layers, their descriptors, the parameter storage,
     # and WHICH layers are stale (a layer skipped while capturing would never be rebuilt by the replays)
