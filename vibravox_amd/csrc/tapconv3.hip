@@ -317,35 +317,62 @@ __global__ __launch_bounds__(256, NPW >= 2 ? 1 : 2) void tap3_kernel(const Tap3A
   // compiler waits for each load in turn -- ~32 exposed round trips per lane, several times the whole reduction of a short layer.
   const int t = t0 + wn * 32 + (lane & 31);
   if (t >= nt) return;
-  const long long col = (long long)t * P.OS + oo;
-  if (EBEN_T3_DBG & 16) { /* phase-major (coalesced) stores: scratch ablation */ }
-  const long long ybase = ((long long)b * P.Cy + (long long)g * P.Mg) * P.Ly + ((EBEN_T3_DBG & 16) ? (long long)ph * nt + t : col);
-  const long long ebase = ((long long)eb * P.Cy + (long long)g * P.Mg) * P.Ly + col;
+  // addresses: a block-uniform 64-bit base per tensor (scalar registers) + a 32-bit per-lane element offset (one group's rows of one
+  // batch item span < 2^31 elements), so that every access is the scalar-base form and no 64-bit vector arithmetic is left
+  const unsigned col = (unsigned)t * (unsigned)P.OS + (unsigned)oo;
+  const unsigned ycol = (EBEN_T3_DBG & 16) ? (unsigned)ph * (unsigned)nt + (unsigned)t : col;   // 16: phase-major (coalesced) stores, scratch ablation
+  const long long ubase = ((long long)b * P.Cy + (long long)g * P.Mg) * P.Ly;
+  float* __restrict__ yb = P.y + ubase;
+  const float* __restrict__ rb = P.res + ubase;
+  const float* __restrict__ eb_ = P.emask + ((long long)eb * P.Cy + (long long)g * P.Mg) * P.Ly;
+  const float* __restrict__ bb = P.bias + (long long)g * P.Mg;
   const int mlane = m0 + 4 * (lane >> 5);
   const int mlast = P.Mg - 1;
+  const bool plain = !use_res && P.emask == nullptr && !P.accumulate;
+  if (plain) {
+    // the forward's form: bias + activation only
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      float bz[16];
+      unsigned off[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = mlane + i * 32 + (r & 3) + 8 * (r >> 2);
+        const int mc = m < mlast ? m : mlast;
+        off[r] = (unsigned)mc * (unsigned)P.Ly + ycol;
+        bz[r] = P.bias ? bb[mc] : 0.f;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = mlane + i * 32 + (r & 3) + 8 * (r >> 2);
+        if (m < P.Mg) yb[off[r]] = lrelu(acc[i][r] + bz[r], P.out_slope);
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int ih = 0; ih < 2 * FM; ++ih) {   // eight rows (half an accumulator tile) per batch of loads: registers stay below the main loop's
     const int i = ih >> 1, r0 = (ih & 1) * 8;
     float bz[8], rz[8], ez[8], az[8];
-    int off[8];
+    unsigned off[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
       const int m = mlane + i * 32 + (r & 3) + 8 * ((r0 + r) >> 2);
       const int mc = m < mlast ? m : mlast;   // rows beyond the group re-read its last row and are not stored
-      off[r] = mc * P.Ly;
-      bz[r] = P.bias ? P.bias[g * P.Mg + mc] : 0.f;
+      off[r] = (unsigned)mc * (unsigned)P.Ly;
+      bz[r] = P.bias ? bb[mc] : 0.f;
     }
     if (use_res) {
 #pragma unroll
-      for (int r = 0; r < 8; ++r) rz[r] = P.res[ybase + off[r]];
+      for (int r = 0; r < 8; ++r) rz[r] = rb[off[r] + ycol];
     }
     if (P.emask) {
 #pragma unroll
-      for (int r = 0; r < 8; ++r) ez[r] = P.emask[ebase + off[r]];
+      for (int r = 0; r < 8; ++r) ez[r] = eb_[off[r] + col];
     }
     if (P.accumulate) {
 #pragma unroll
-      for (int r = 0; r < 8; ++r) az[r] = P.y[ybase + off[r]];
+      for (int r = 0; r < 8; ++r) az[r] = yb[off[r] + ycol];
     }
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
@@ -355,7 +382,7 @@ __global__ __launch_bounds__(256, NPW >= 2 ? 1 : 2) void tap3_kernel(const Tap3A
       if (use_res) v += lrelu(rz[r], P.res_slope);
       if (P.emask) v *= dlrelu(ez[r], P.emask_slope);
       if (P.accumulate) v += az[r];
-      if (m < P.Mg) P.y[ybase + off[r]] = v;
+      if (m < P.Mg) yb[off[r] + ycol] = v;
     }
   }
 }
