@@ -498,19 +498,38 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && CT < 4) ? 2 : 1) void ru3_bwd_
     }
   }
 
-  // ---- epilogue ----
+  // ---- epilogue: the three operands of the join are read for all 16 rows of a tile in one batch each (value by value the
+  // compiler waits for every load in turn) ----
   if (wc >= BO || t >= L) return;
+  const float* __restrict__ gyb = P.gy + rowbase + t;
+  const float* __restrict__ xmb = P.xmask + rowbase + t;
+  const float* __restrict__ pob = P.post + rowbase + t;
+  float* __restrict__ gxb = P.gx + rowbase + t;
 #pragma unroll
-  for (int i = 0; i < CT; ++i)
+  for (int i = 0; i < CT; ++i) {
+    float gv[16], xv[16], pv[16];
+    unsigned off[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int m = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      const long long idx = rowbase + (long long)m * L + t;
-      float v = acc2[i][r] + P.gy[idx];
-      if (P.xmask) v *= dlrelu(P.xmask[idx], P.in_slope);
-      if (P.post) v += P.post[idx];
-      P.gx[idx] = v;
+      off[r] = (unsigned)(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * (unsigned)L;
+      gv[r] = gyb[off[r]];
     }
+    if (P.xmask) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) xv[r] = xmb[off[r]];
+    }
+    if (P.post) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) pv[r] = pob[off[r]];
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float v = acc2[i][r] + gv[r];
+      if (P.xmask) v *= dlrelu(xv[r], P.in_slope);
+      if (P.post) v += pv[r];
+      gxb[off[r]] = v;
+    }
+  }
 }
 
 // backward weight image: entry en = 32 reduction channels: unit (((en 2 + kk) NP + q) CT + i) 64 + lane.

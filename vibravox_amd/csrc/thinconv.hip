@@ -128,22 +128,51 @@ __global__ __launch_bounds__(BN) void thin_kernel(const ThinArgs P) {
   const bool use_res = P.res != nullptr && (P.res_rows == 0 || b < P.res_rows);
   const int eb = P.em_seg > 0 ? P.em_map[b / P.em_seg] * P.em_seg + b % P.em_seg : b;
   const long long eoff = (long long)(eb - b) * P.Cy * P.Ly;
+  // the operands of the fused stages are read for all MT rows of a position in one batch each (clamped rows, no per-value
+  // branch): value by value the compiler waits for every load in turn
+  const long long ubase = ((long long)b * P.Cy + (long long)g * P.Mg) * P.Ly;
+  float* __restrict__ yb = P.y + ubase;
+  const float* __restrict__ rb = P.res + ubase;
+  const float* __restrict__ eb_ = P.emask + ubase + eoff;
+  const int mlast = P.Mg - 1;
 #pragma unroll
   for (int n = 0; n < NP; ++n) {
-  const int t = t0 + tid + n * BN;
-  if (t >= nt) continue;
+    const int t = t0 + tid + n * BN;
+    if (t >= nt) continue;
+    const unsigned col = (unsigned)t * (unsigned)P.OS + (unsigned)oo;
+    constexpr int MB = MT < 8 ? MT : 8;   // rows per batch of loads (registers)
 #pragma unroll
-  for (int m = 0; m < MT; ++m) {
-    const int mm = m0 + m;
-    if (mm >= P.Mg) continue;
-    const long long idx = ((long long)b * P.Cy + (long long)g * P.Mg + mm) * P.Ly + (long long)t * P.OS + oo;
-    float v = acc[n][m] + (P.bias ? P.bias[g * P.Mg + mm] : 0.f);
-    v = lrelu(v, P.out_slope);
-    if (use_res) v += lrelu(P.res[idx], P.res_slope);
-    if (P.emask) v *= dlrelu(P.emask[idx + eoff], P.emask_slope);
-    if (P.accumulate) v += P.y[idx];
-    P.y[idx] = v;
-  }
+    for (int mb = 0; mb < MT; mb += MB) {
+      float bz[MB], rz[MB], ez[MB], az[MB];
+      unsigned off[MB];
+#pragma unroll
+      for (int m = 0; m < MB; ++m) {
+        const int mc = m0 + mb + m < mlast ? m0 + mb + m : mlast;
+        off[m] = (unsigned)mc * (unsigned)P.Ly + col;
+        bz[m] = P.bias ? P.bias[g * P.Mg + mc] : 0.f;
+      }
+      if (use_res) {
+#pragma unroll
+        for (int m = 0; m < MB; ++m) rz[m] = rb[off[m]];
+      }
+      if (P.emask) {
+#pragma unroll
+        for (int m = 0; m < MB; ++m) ez[m] = eb_[off[m]];
+      }
+      if (P.accumulate) {
+#pragma unroll
+        for (int m = 0; m < MB; ++m) az[m] = yb[off[m]];
+      }
+#pragma unroll
+      for (int m = 0; m < MB; ++m) {
+        float v = acc[n][mb + m] + bz[m];
+        v = lrelu(v, P.out_slope);
+        if (use_res) v += lrelu(rz[m], P.res_slope);
+        if (P.emask) v *= dlrelu(ez[m], P.emask_slope);
+        if (P.accumulate) v += az[m];
+        if (m0 + mb + m < P.Mg) yb[off[m]] = v;
+      }
+    }
   }
 }
 
