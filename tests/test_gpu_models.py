@@ -312,12 +312,12 @@ BF16_STEP_TOLERANCES = {
 }
 
 
-def _one_step(make, disc_math, gen_bwd="f32", seed_weights=None):
+def _one_step(make, disc_math, gen_bwd="f32", seed_weights=None, stft_math="folded"):
     from vibravox_amd.disc_engine import DiscriminatorEngine
     from vibravox_amd.lightning_modules.eben import DISC_MATH_PLANS
 
     mod, batch = make()
-    mod.disc_math, mod.gen_backward_math = disc_math, gen_bwd
+    mod.disc_math, mod.gen_backward_math, mod.stft_math = disc_math, gen_bwd, stft_math
     if seed_weights is not None:
         mod._disc_engine = DiscriminatorEngine(mod.discriminator, DISC_MATH_PLANS[disc_math])
         mod._disc_engine.seed_weights = seed_weights
@@ -343,7 +343,8 @@ def test_bf16_step_against_fp32_step_at_config2(hip):
         return bench.build_module(DEV, 1234), bench.synthetic_batch(32, 32000, 1234, DEV)
 
     tol = BF16_STEP_TOLERANCES
-    f32, bf = _one_step(make, "f32"), _one_step(make, "bf16", "bf16")
+    # the bf16 step exactly as bench.py runs it: bf16 plan, bf16 generator backward, MRSTFT contractions on hi + lo bf16 operands
+    f32, bf = _one_step(make, "f32"), _one_step(make, "bf16", "bf16", stft_math="folded_x3")
     assert torch.equal(f32[0], bf[0])   # the generator's forward is exact fp32 in every mode
     for k, v in f32[1].items():
         t = tol["feature_matching_loss"] if "feature_matching" in k else tol["backprop_loss"] if "backprop" in k else tol["loss"]

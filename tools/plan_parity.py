@@ -6,13 +6,15 @@ import torch
 import bench
 
 DEV = torch.device("cuda")
-plans = sys.argv[1:] or ["bf16", "bf16_x6fwd", "bf16_f32fwd", "bf16x6", "bf16_plain"]
+args = [a for a in sys.argv[1:] if not a.startswith("--stft=")]
+stft = ([a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--stft=")] or [None])[0]   # MRSTFT math of the plans (reference: exact fp32)
+plans = args or ["bf16", "bf16_x6fwd", "bf16_f32fwd", "bf16x6", "bf16_plain"]
 
 
-def one_step(plan, gen_bwd):
+def one_step(plan, gen_bwd, stft_math="folded"):
     mod = bench.build_module(DEV, 1234)
     batch = bench.synthetic_batch(32, 32000, 1234, DEV)
-    mod.disc_math, mod.gen_backward_math = plan, gen_bwd
+    mod.disc_math, mod.gen_backward_math, mod.stft_math = plan, gen_bwd, stft_math
     mod.training_step(batch)
     torch.cuda.synchronize()
     m = []
@@ -31,6 +33,6 @@ ref, t32 = one_step("f32", "f32")
 print(f"{'f32':12s} {t32:7.2f} ms/step")
 for plan in plans:
     gb = "f32" if plan in ("f32", "bf16x6") else "bf16"
-    m, t = one_step(plan, gb)
+    m, t = one_step(plan, gb, stft or ("folded" if plan == "f32" else "folded_x6"))
     rel = [float((a - b).norm() / a.norm()) for a, b in zip(ref, m)]
-    print(f"{plan:12s} {t:7.2f} ms/step   generator grad {rel[0]:.3e}   discriminator grad {rel[1]:.3e}   (generator backward {gb})")
+    print(f"{plan:12s} (MRSTFT {stft or 'folded_x6'}) {t:7.2f} ms/step   generator grad {rel[0]:.3e}   discriminator grad {rel[1]:.3e}   (generator backward {gb})")
