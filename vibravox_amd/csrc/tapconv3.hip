@@ -140,8 +140,18 @@ __global__ __launch_bounds__(256, NPW >= 2 ? 1 : 2) void tap3_kernel(const Tap3A
     if (P.S != 1) { d = (int)__umulhi((unsigned)r, P.s_magic); p = r - d * P.S; }
     return bb * P.CSTRIDE + p * P.PLEN + d;
   };
+  // block-uniform shortcuts of the staging arithmetic (the short layers spend most of their instructions here): whole bundles
+  // (no channel of a bundle lies beyond the group) and no activation on load (the engine's launches: the producer applied it)
+  const bool full_c = (P.Cg & 7) == 0;
+  const bool plain_in = !IM && P.in_slope == 1.f;
   auto load8 = [&](const float* base, int c0, int qq, float (&v)[8]) {
     // channels c0 .. c0+7 of this group at position qq; rows past the group's last channel re-read row c0 (zeroed later)
+    if (full_c) {
+      const float* p = base + (long long)(c0 < P.Cg ? c0 : 0) * P.Lx + qq;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = p[(long long)e * P.Lx];
+      return;
+    }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int c = c0 + e < P.Cg ? c0 + e : (c0 < P.Cg ? c0 : 0);
@@ -150,10 +160,16 @@ __global__ __launch_bounds__(256, NPW >= 2 ? 1 : 2) void tap3_kernel(const Tap3A
   };
   auto cvt8 = [&](const float (&v)[8], const float (&mk)[8], int c0, int ok, u32x4 (&pc)[NPX]) {
     float t[8];
+    if (plain_in && full_c) {
+      const bool live = ok && c0 < P.Cg;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const float w = IM ? v[e] * dlrelu(mk[e], P.in_slope) : lrelu(v[e], P.in_slope);
-      t[e] = (ok && c0 + e < P.Cg) ? w : 0.f;
+      for (int e = 0; e < 8; ++e) t[e] = live ? v[e] : 0.f;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float w = IM ? v[e] * dlrelu(mk[e], P.in_slope) : lrelu(v[e], P.in_slope);
+        t[e] = (ok && c0 + e < P.Cg) ? w : 0.f;
+      }
     }
 #pragma unroll
     for (int q = 0; q < NPX; ++q) {
