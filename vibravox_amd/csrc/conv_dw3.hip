@@ -198,6 +198,7 @@ __global__ __launch_bounds__(256, 2) void conv_dw3_kernel(const Dw3Args P) {
       }
     }
   };
+  const bool plain_x = P.x_slope == 1.f;   // the engine's launches: no activation on load (block-uniform)
   auto store_x = [&](int q, int buf) {
     const int bg = q / P.nct;
     u32x4* dst = Xs + buf * XT;
@@ -207,7 +208,7 @@ __global__ __launch_bounds__(256, 2) void conv_dw3_kernel(const Dw3Args P) {
       const int b0 = bg * 16 + ((xpk[u] >> 30) & 1) * 8;
       float t[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) t[e] = (ok && b0 + e < P.B) ? lrelu(xreg[u][e], P.x_slope) : 0.f;
+      for (int e = 0; e < 8; ++e) t[e] = (ok && b0 + e < P.B) ? (plain_x ? xreg[u][e] : lrelu(xreg[u][e], P.x_slope)) : 0.f;
       u32x4 o;
       o[0] = dw3_pack_bf16(t[0], t[1]); o[1] = dw3_pack_bf16(t[2], t[3]); o[2] = dw3_pack_bf16(t[4], t[5]); o[3] = dw3_pack_bf16(t[6], t[7]);
       // lanes without a unit rewrite the constant zero cell with zero
