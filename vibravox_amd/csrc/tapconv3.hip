@@ -56,6 +56,12 @@ struct Tap3Args {
   unsigned s_magic;
   int ntt, nmt, tab_phase;
   long long w_tile, w_phase;                     // in 16-byte units
+  // host-side arithmetic of the block prologue (integer divisions are ~40 instructions each on the device, the 64-bit one
+  // behind span_magic ~150): the block-id decomposition by multiply-high, and the per-phase tap geometry for up to 8 phases
+  unsigned xq, xr;                               // gridDim.x / 8, gridDim.x % 8 (xcd_remap)
+  unsigned m_nph, m_ntt, m_B, m_nmt;             // ceil(2^32 / d); valid when id_fast
+  int id_fast, pg_n;
+  struct PG { int J, off0, minoff, nt, oo, span; unsigned span_magic; int pad; } pg[8];
 };
 
 // NPX / NPW: pieces per operand.  The input operand is staged as NPX bf16 tiles, piece q = bf16(x - p0 - .. - p(q-1)) (every
@@ -81,38 +87,51 @@ __global__ __launch_bounds__(256, NPW >= 2 ? 1 : 2) void tap3_kernel(const Tap3A
   const int lane = tid & 63;
   const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-  unsigned id = xcd_remap(blockIdx.x, gridDim.x);
-#ifndef EBEN_T3_PH_FIRST
-#define EBEN_T3_PH_FIRST 1   // MelGAN L2 / L3 / L4 input gradients at 128 items: 0.44 / 0.57 / 0.56 -> 0.36 / 0.50 / 0.46 ms
-#endif
-#if EBEN_T3_PH_FIRST
+  unsigned id;
+  {
+    const unsigned bid = blockIdx.x, xcd = bid & 7u, idx = bid >> 3;
+    id = (xcd < P.xr ? xcd * (P.xq + 1) : P.xr * (P.xq + 1) + (xcd - P.xr) * P.xq) + idx;   // xcd_remap with the host's quotient
+  }
   // the OS phases of one output tile interleave in memory (element t*OS + phase): neighbouring block ids, i.e. the same XCD at
   // about the same time, so that their partial cache lines meet in that XCD's L2
-  const int ph = __builtin_amdgcn_readfirstlane(id % P.nph); id /= P.nph;
-  const int tt = __builtin_amdgcn_readfirstlane(id % P.ntt); id /= P.ntt;
-  const int b = __builtin_amdgcn_readfirstlane(id % P.B); id /= P.B;
-#else
-  const int tt = __builtin_amdgcn_readfirstlane(id % P.ntt); id /= P.ntt;
-  const int b = __builtin_amdgcn_readfirstlane(id % P.B); id /= P.B;
-  const int ph = __builtin_amdgcn_readfirstlane(id % P.nph); id /= P.nph;
-#endif
-  const int mt = __builtin_amdgcn_readfirstlane(id % P.nmt);
-  const int g = __builtin_amdgcn_readfirstlane(id / P.nmt);
+  // (MelGAN L2 / L3 / L4 input gradients at 128 items: 0.44 / 0.57 / 0.56 -> 0.36 / 0.50 / 0.46 ms against phase-slowest)
+  int ph, tt, b, mt, g;
+  if (P.id_fast) {
+    // magic 0 = divisor 1 (ceil(2^32 / 1) does not fit)
+    unsigned qd = P.m_nph ? __umulhi(id, P.m_nph) : id; ph = (int)(id - qd * (unsigned)P.nph); id = qd;
+    qd = P.m_ntt ? __umulhi(id, P.m_ntt) : id; tt = (int)(id - qd * (unsigned)P.ntt); id = qd;
+    qd = P.m_B ? __umulhi(id, P.m_B) : id; b = (int)(id - qd * (unsigned)P.B); id = qd;
+    qd = P.m_nmt ? __umulhi(id, P.m_nmt) : id; mt = (int)(id - qd * (unsigned)P.nmt); g = (int)qd;
+  } else {
+    ph = id % P.nph; id /= P.nph;
+    tt = id % P.ntt; id /= P.ntt;
+    b = id % P.B; id /= P.B;
+    mt = id % P.nmt;
+    g = id / P.nmt;
+  }
+  ph = __builtin_amdgcn_readfirstlane(ph); tt = __builtin_amdgcn_readfirstlane(tt); b = __builtin_amdgcn_readfirstlane(b);
+  mt = __builtin_amdgcn_readfirstlane(mt); g = __builtin_amdgcn_readfirstlane(g);
   const int t0 = tt * BN, m0 = mt * BM;
 
-  const PhaseGeom q = phase_geom(P.mode, ph, P.J0, P.off0, P.nt, P.dstep, P.OS, P.ps_pad, P.ps_k, P.ps_d, P.ps_kstep, P.Ly);
-  const int J = q.J, nt = q.nt, oo = q.oo;
+  int J, nt, oo, minoff, span;
+  unsigned span_magic;
+  if (ph < P.pg_n) {
+    J = P.pg[ph].J; nt = P.pg[ph].nt; oo = P.pg[ph].oo; minoff = P.pg[ph].minoff; span = P.pg[ph].span; span_magic = P.pg[ph].span_magic;
+  } else {
+    const PhaseGeom q = phase_geom(P.mode, ph, P.J0, P.off0, P.nt, P.dstep, P.OS, P.ps_pad, P.ps_k, P.ps_d, P.ps_kstep, P.Ly);
+    J = q.J; nt = q.nt; oo = q.oo; minoff = q.minoff;
+    const int ad = P.dstep >= 0 ? P.dstep : -P.dstep;
+    span = J > 0 ? (BN - 1) * P.S + (J - 1) * ad + 1 : 0;
+    span_magic = span > 0 ? (unsigned)((0x100000000ull + (unsigned)span - 1) / (unsigned)span) : 0u;
+  }
   if (t0 >= nt) return;
-  const int adstep = P.dstep >= 0 ? P.dstep : -P.dstep;
-  const int span = J > 0 ? (BN - 1) * P.S + (J - 1) * adstep + 1 : 0;
   const int KS_CC = J * P.CP;
   const int KS = P.ncc * KS_CC;
   const int nch = (KS + KSC - 1) / KSC;
-  const int q0 = t0 * P.S + q.minoff;
+  const int q0 = t0 * P.S + minoff;
   const int xtot = P.CI_B * span;          // bundle-positions per input tile
   const int XBUF = P.CI_B * P.CSTRIDE;
   const int LO = SP ? P.nxb * XBUF + 1 : 0;   // split input: unit offset from piece q to piece q + 1 of every tile slot
-  const unsigned span_magic = span > 0 ? (unsigned)((0x100000000ull + (unsigned)span - 1) / (unsigned)span) : 0u;
 
   const u32x4* wsrc = P.wp + (long long)ph * P.w_phase + ((long long)g * P.nmt + mt) * P.w_tile;
   typedef const __attribute__((address_space(4))) int* ctab_t;
@@ -768,6 +787,29 @@ int tap3_launch(const Canon& c, int dir, const TapIO& io, int reflect, hipStream
   a.w_tile = p.w_tile; a.w_phase = p.w_phase;
   const long long nb = (long long)p.ntt * c.B * p.nph * p.nmt * p.G;
   if (nb <= 0 || nb > 0x7fffffffLL) return fail(EBEN_EINVAL, "tap3 grid of %lld blocks", nb);
+  a.xq = (unsigned)(nb / 8); a.xr = (unsigned)(nb % 8);
+  {
+    auto magic = [](int d) { return (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); };
+    int dmax = p.nph > p.ntt ? p.nph : p.ntt;
+    if (c.B > dmax) dmax = c.B;
+    if (p.nmt > dmax) dmax = p.nmt;
+    // q = mulhi(n, ceil(2^32 / d)) is exact while n * d < 2^32 (error term (magic * d - 2^32) * n < 2^32 since magic * d - 2^32 < d)
+    a.id_fast = nb * dmax < 0x100000000LL ? 1 : 0;
+    a.m_nph = magic(p.nph); a.m_ntt = magic(p.ntt); a.m_B = magic(c.B); a.m_nmt = magic(p.nmt);
+    if (p.nph == 1) a.m_nph = 0;   // d = 1: ceil(2^32 / 1) does not fit; handled below
+    if (p.ntt == 1) a.m_ntt = 0;
+    if (c.B == 1) a.m_B = 0;
+    if (p.nmt == 1) a.m_nmt = 0;
+    a.pg_n = p.nph <= 8 ? p.nph : 0;
+    const int ad = p.dstep >= 0 ? p.dstep : -p.dstep;
+    for (int ph = 0; ph < a.pg_n; ++ph) {
+      const PhaseGeom q = phase_geom(p.mode, ph, p.J, p.off0, p.nt, p.dstep, p.OS, p.ps_pad, c.k, c.d, p.kstep, p.Ly);
+      a.pg[ph].J = q.J; a.pg[ph].off0 = q.off0; a.pg[ph].minoff = q.minoff; a.pg[ph].nt = q.nt; a.pg[ph].oo = q.oo;
+      a.pg[ph].span = q.J > 0 ? (p.BN - 1) * p.S + (q.J - 1) * ad + 1 : 0;
+      a.pg[ph].span_magic = a.pg[ph].span > 0 ? magic(a.pg[ph].span) : 0u;
+      a.pg[ph].pad = 0;
+    }
+  }
 #define EBEN_T3_CASE(FMV)                                                          \
   switch (p.XRB) {                                                                 \
     case 2: return launch3_cfg<FMV, 2>(a, (int)nb, p.lds_bytes, p.npw, p.npx, st);               \
