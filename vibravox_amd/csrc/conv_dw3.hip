@@ -191,10 +191,17 @@ __global__ __launch_bounds__(256, 2) void conv_dw3_kernel(const Dw3Args P) {
       const int o = ok ? ((xpk[u] >> 16) & 0x3fff) * P.Lx + p : 0;
       okmask |= (unsigned)ok << u;
       const int b0 = bg * 16 + ((xpk[u] >> 30) & 1) * 8;
+      if (bg * 16 + 16 <= P.B) {
+        // whole group of 16 batch items (block-uniform): one 64-bit base per unit, then strides -- no clamps
+        const float* p8 = px + (long long)b0 * bstride + o;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int bb = b0 + e < P.B ? b0 + e : P.B - 1;
-        xreg[u][e] = px[(long long)bb * bstride + o];
+        for (int e = 0; e < 8; ++e) xreg[u][e] = p8[(long long)e * bstride];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int bb = b0 + e < P.B ? b0 + e : P.B - 1;
+          xreg[u][e] = px[(long long)bb * bstride + o];
+        }
       }
     }
   };
@@ -207,8 +214,13 @@ __global__ __launch_bounds__(256, 2) void conv_dw3_kernel(const Dw3Args P) {
       const int ok = (int)((okmask >> u) & 1u);
       const int b0 = bg * 16 + ((xpk[u] >> 30) & 1) * 8;
       float t[8];
+      if (plain_x && bg * 16 + 16 <= P.B) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) t[e] = (ok && b0 + e < P.B) ? (plain_x ? xreg[u][e] : lrelu(xreg[u][e], P.x_slope)) : 0.f;
+        for (int e = 0; e < 8; ++e) t[e] = ok ? xreg[u][e] : 0.f;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) t[e] = (ok && b0 + e < P.B) ? (plain_x ? xreg[u][e] : lrelu(xreg[u][e], P.x_slope)) : 0.f;
+      }
       u32x4 o;
       o[0] = dw3_pack_bf16(t[0], t[1]); o[1] = dw3_pack_bf16(t[2], t[3]); o[2] = dw3_pack_bf16(t[4], t[5]); o[3] = dw3_pack_bf16(t[6], t[7]);
       // lanes without a unit rewrite the constant zero cell with zero
