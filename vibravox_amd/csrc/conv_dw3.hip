@@ -58,25 +58,30 @@ __global__ __launch_bounds__(256) void dw3_pack_a_kernel(const Dw3Args P) {
   const int t0 = tg * 32;
   // eight independent loads in flight per thread (a load inside the bounds check is issued, waited for and stored one at a
   // time: 32 exposed memory round trips per block, 6-13x the time the 48 KB a block moves should take)
+  // element k of this thread: i = tid + 256 k  ->  time t = tid & 31, row m = (tid >> 5) + 8 (k & 3), batch item k >> 2: one 64-bit
+  // index per thread, the rest are block-uniform strides (the general form cost ~12 VALU instructions per element)
+  const int tl = threadIdx.x & 31, ml = threadIdx.x >> 5;
+  const int bb0 = bg * 16 + half * 8, mm0 = m32 * 32 + ml;
+  const long long rowstride = P.La, bstride = (long long)P.Ca * P.La;
+  const long long idx0 = ((long long)bb0 * P.Ca + (long long)g * P.Mg + mm0) * P.La + t0 + tl;
+  const bool t_ok = t0 + tl < P.La;
   for (int base = 0; base < 32; base += 8) {
     float v[8], mk[8];
     int ok[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      const int i = threadIdx.x + (base + u) * 256;
-      const int t = i & 31, m = (i >> 5) & 31, b = i >> 10;
-      const int bb = bg * 16 + half * 8 + b, mm = m32 * 32 + m;
-      ok[u] = (int)(bb < P.B) & (int)(mm < P.Mg) & (int)(t0 + t < P.La);
-      const long long idx = ok[u] ? ((long long)bb * P.Ca + (long long)g * P.Mg + mm) * P.La + t0 + t : 0;
+      const int k = base + u;
+      const int b = k >> 2, m = 8 * (k & 3);
+      ok[u] = (int)(bb0 + b < P.B) & (int)(mm0 + m < P.Mg) & (int)t_ok;
+      const long long idx = ok[u] ? idx0 + b * bstride + m * rowstride : 0;
       v[u] = P.a[idx];
       mk[u] = P.a_mode ? P.amask[idx] : 0.f;
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      const int i = threadIdx.x + (base + u) * 256;
-      const int t = i & 31, m = (i >> 5) & 31, b = i >> 10;
-      const float w = P.a_mode == 0 ? lrelu(v[u], P.a_slope) : v[u] * dlrelu(mk[u], P.a_slope);
-      tile[b][m][t] = ok[u] ? w : 0.f;
+      const int k = base + u;
+      const float w = P.a_mode == 0 ? (P.a_slope == 1.f ? v[u] : lrelu(v[u], P.a_slope)) : v[u] * dlrelu(mk[u], P.a_slope);
+      tile[k >> 2][ml + 8 * (k & 3)][tl] = ok[u] ? w : 0.f;
     }
   }
   __syncthreads();

@@ -364,6 +364,7 @@ __global__ __launch_bounds__(256, NPW >= 2 ? 1 : 2) void tap3_kernel(const Tap3A
   const int mlane = m0 + 4 * (lane >> 5);
   const int mlast = P.Mg - 1;
   const bool plain = !use_res && P.emask == nullptr && !P.accumulate;
+  const bool lin = P.out_slope == 1.f && P.res_slope == 1.f;   // the engine's input-gradient launches: no activation arithmetic
   if (plain) {
     // the forward's form: bias + activation only
 #pragma unroll
@@ -413,8 +414,12 @@ __global__ __launch_bounds__(256, NPW >= 2 ? 1 : 2) void tap3_kernel(const Tap3A
     for (int r = 0; r < 8; ++r) {
       const int m = mlane + i * 32 + (r & 3) + 8 * ((r0 + r) >> 2);
       float v = acc[i][r0 + r] + bz[r];
-      v = lrelu(v, P.out_slope);
-      if (use_res) v += lrelu(rz[r], P.res_slope);
+      if (!lin) {
+        v = lrelu(v, P.out_slope);
+        if (use_res) v += lrelu(rz[r], P.res_slope);
+      } else if (use_res) {
+        v += rz[r];
+      }
       if (P.emask) v *= dlrelu(ez[r], P.emask_slope);
       if (P.accumulate) v += az[r];
       if (m < P.Mg) yb[off[r] + ycol] = v;
