@@ -202,13 +202,16 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && CT < 4) ? 2 : 1) void ru3_fwd_
 
   const int t = t0 + col;
   const bool live = t < L;
+  // stores: one 64-bit base per lane (item, column), 32-bit row offsets
+  const long long lbase = (long long)b * C * L + t;
   if (P.h != nullptr && live) {
+    float* __restrict__ hb = P.h + lbase;
 #pragma unroll
     for (int i = 0; i < CT; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int m = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        P.h[((long long)b * C + m) * L + t] = acc1[i][r];
+        const unsigned m = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        hb[m * (unsigned)L] = acc1[i][r];
       }
   }
 
@@ -239,15 +242,18 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && CT < 4) ? 2 : 1) void ru3_fwd_
   // ---- epilogue: y = xin + lrelu(z) (xin from the staged tile) ----
   if (!live) return;
   const float* xc = Xs + xshift + d + col;
+  float* __restrict__ yb = P.y + lbase;
+  float* __restrict__ ub = P.u + lbase;
+  const bool keep_u = P.u != nullptr;
 #pragma unroll
   for (int i = 0; i < CT; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int m = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      const long long idx = ((long long)b * C + m) * L + t;
+      const unsigned m = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      const unsigned off = m * (unsigned)L;
       const float uu = lrelu(acc2[i][r], P.out_slope);
-      if (P.u != nullptr) P.u[idx] = uu;
-      P.y[idx] = xc[m * XS] + uu;
+      if (keep_u) ub[off] = uu;
+      yb[off] = xc[m * XS] + uu;
     }
 }
 
@@ -449,6 +455,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && CT < 4) ? 2 : 1) void ru3_bwd_
       // in place: a wave reads and writes only its own 32 columns (every row), so no barrier separates the two
       const int q = w0 + wc;
       const bool own = wc >= d && wc < d + BO && q < L;
+      float* __restrict__ ghb = P.gh + rowbase + (own ? q : 0);
 #pragma unroll
       for (int i = 0; i < CT; ++i)
 #pragma unroll
@@ -456,7 +463,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && CT < 4) ? 2 : 1) void ru3_bwd_
           const int m = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
           const float v = (q >= 0 && q < L) ? acc1[i][r] : 0.f;   // nothing of g_h exists beyond the signal
           Gs[m * GS + xshift + wc] = v;
-          if (own) P.gh[rowbase + (long long)m * L + q] = v;
+          if (own) ghb[(unsigned)m * (unsigned)L] = v;
         }
     }
     __syncthreads();
