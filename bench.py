@@ -282,6 +282,15 @@ def main():
         mod.training_step(next_batch())
         dt32, per32 = timed_steps(args.steps)
 
+    # ... and in the fp32-grade plan on the bf16 matrix pipe ("bf16x6": discriminator forward / input gradients and the MRSTFT
+    # contractions with three bf16 pieces per operand, weight gradients and the generator backward in fp32 arithmetic): the plan whose
+    # tests run at the fp32 tolerances, reported as value_fp32_grade
+    dt6 = per6 = None
+    if bf16 and not args.no_f32_leg:
+        mod.disc_math, mod.gen_backward_math, mod.stft_math = "bf16x6", "f32", "folded_x6"
+        mod.training_step(next_batch())
+        dt6, per6 = timed_steps(args.steps)
+
     # the roofline kernel once more, ALONE on the device (inside the step it shares the GPU with the three other
     # discriminator chains and the MRSTFT GEMMs, which stretches its launch-to-finish time): reported as `isolated`
     iso_ms = None
@@ -380,6 +389,12 @@ def main():
             line["ms_per_step_f32"] = round(ms32, 3)
             line["step_ms_f32"] = {"median": round(percentile(per32, 0.5), 3), "p10": round(percentile(per32, 0.1), 3), "p90": round(percentile(per32, 0.9), 3)}
             line["step_roofline_f32"] = {"ideal_ms": round(step_roofline_ms("f32", scale), 3), "frac": round(step_roofline_ms("f32", scale) / ms32, 4)}
+        if dt6 is not None:
+            ms6 = dt6 / args.steps * 1e3
+            line["value_fp32_grade"] = round(audio_s / (dt6 / args.steps), 2)
+            line["ms_per_step_fp32_grade"] = round(ms6, 3)
+            line["fp32_grade_plan"] = ("disc_math bf16x6 + stft folded_x6 + fp32 generator backward: every contraction either exact fp32 or six bf16 piece "
+                                       "products per fp32 product (dropped terms <= 2^-26); tests/test_gpu_models.py runs the golden replay in it")
         if use_ddp:
             line["comm"] = {"backend": dist.get_backend(), "ranks": world,
                             "exposed_ms_per_step": {k: (round(v, 4) if v is not None else None) for k, v in exposed.items()},
