@@ -32,6 +32,11 @@ struct ThinArgs {
   unsigned s_magic;
   int ntt, nmt;
   long long w_tile;   // floats per (phase, group, m-tile) weight panel: J0 * Cg * MT
+  // block prologue arithmetic done on the host (as tapconv3.hip): block-id decomposition by multiply-high (magic 0 = divisor 1),
+  // per-phase tap geometry and span magic for up to 8 phases
+  unsigned m_ntt, m_B, m_nph, m_nmt;
+  int id_fast, pg_n, tile;
+  struct PG { int J, off0, minoff, nt, oo, span; unsigned span_magic; int pad; } pg[8];
 };
 
 // NP: output positions per thread (block = BN * NP positions, position tid + n * BN: every store stays coalesced).  A block of
@@ -44,21 +49,39 @@ __global__ __launch_bounds__(BN) void thin_kernel(const ThinArgs P) {
   const int tid = threadIdx.x;
 
   unsigned id = blockIdx.x;
-  const int tt = __builtin_amdgcn_readfirstlane(id % P.ntt); id /= P.ntt;
-  const int b = __builtin_amdgcn_readfirstlane(id % P.B); id /= P.B;
-  const int ph = __builtin_amdgcn_readfirstlane(id % P.nph); id /= P.nph;
-  const int mt = __builtin_amdgcn_readfirstlane(id % P.nmt);
-  const int g = __builtin_amdgcn_readfirstlane(id / P.nmt);
+  int tt, b, ph, mt, g;
+  if (P.id_fast) {
+    unsigned qd = P.m_ntt ? __umulhi(id, P.m_ntt) : id; tt = (int)(id - qd * (unsigned)P.ntt); id = qd;
+    qd = P.m_B ? __umulhi(id, P.m_B) : id; b = (int)(id - qd * (unsigned)P.B); id = qd;
+    qd = P.m_nph ? __umulhi(id, P.m_nph) : id; ph = (int)(id - qd * (unsigned)P.nph); id = qd;
+    qd = P.m_nmt ? __umulhi(id, P.m_nmt) : id; mt = (int)(id - qd * (unsigned)P.nmt); g = (int)qd;
+  } else {
+    tt = id % P.ntt; id /= P.ntt;
+    b = id % P.B; id /= P.B;
+    ph = id % P.nph; id /= P.nph;
+    mt = id % P.nmt;
+    g = id / P.nmt;
+  }
+  tt = __builtin_amdgcn_readfirstlane(tt); b = __builtin_amdgcn_readfirstlane(b); ph = __builtin_amdgcn_readfirstlane(ph);
+  mt = __builtin_amdgcn_readfirstlane(mt); g = __builtin_amdgcn_readfirstlane(g);
   const int t0 = tt * TILE, m0 = mt * MT;
 
-  const PhaseGeom q = phase_geom(P.mode, ph, P.J0, P.off0, P.nt, P.dstep, P.OS, P.ps_pad, P.ps_k, P.ps_d, P.ps_kstep, P.Ly);
+  PhaseGeom q;
+  int span;
+  unsigned span_magic;
+  if (ph < P.pg_n) {
+    q.J = P.pg[ph].J; q.off0 = P.pg[ph].off0; q.minoff = P.pg[ph].minoff; q.nt = P.pg[ph].nt; q.oo = P.pg[ph].oo; q.k0 = 0;
+    span = P.pg[ph].span; span_magic = P.pg[ph].span_magic;
+  } else {
+    q = phase_geom(P.mode, ph, P.J0, P.off0, P.nt, P.dstep, P.OS, P.ps_pad, P.ps_k, P.ps_d, P.ps_kstep, P.Ly);
+    const int adstep = P.dstep >= 0 ? P.dstep : -P.dstep;
+    span = q.J > 0 ? (TILE - 1) * P.S + (q.J - 1) * adstep + 1 : 0;
+    span_magic = span > 0 ? (unsigned)((0x100000000ull + (unsigned)span - 1) / (unsigned)span) : 0u;
+  }
   const int J = q.J, nt = q.nt, oo = q.oo;
   if (t0 >= nt) return;
-  const int adstep = P.dstep >= 0 ? P.dstep : -P.dstep;
-  const int span = J > 0 ? (TILE - 1) * P.S + (J - 1) * adstep + 1 : 0;
   const int q0 = t0 * P.S + q.minoff;
   const int xtot = P.Cg * span;
-  const unsigned span_magic = span > 0 ? (unsigned)((0x100000000ull + (unsigned)span - 1) / (unsigned)span) : 0u;
 
   // ---- stage the input tile: 8 loads in flight per thread, branch-free ----
   {
@@ -81,14 +104,14 @@ __global__ __launch_bounds__(BN) void thin_kernel(const ThinArgs P) {
         ok[u] = live & (int)(qq >= 0) & (int)(qq < P.Lx);
         const int o = ok[u] ? c * P.Lx + qq : 0;
         v[u] = xp[o];
-        mk[u] = mp[o];
+        mk[u] = P.in_mode ? mp[o] : 0.f;
         int p = 0, d = r;
         if (P.S != 1) { d = (int)__umulhi((unsigned)r, P.s_magic); p = r - d * P.S; }
         sl[u] = live ? c * P.CSTRIDE + p * P.PLEN + d : -1;
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        const float t = P.in_mode == 0 ? lrelu(v[u], P.in_slope) : v[u] * dlrelu(mk[u], P.in_slope);
+        const float t = P.in_mode == 0 ? (P.in_slope == 1.f ? v[u] : lrelu(v[u], P.in_slope)) : v[u] * dlrelu(mk[u], P.in_slope);
         if (sl[u] >= 0) Xs[sl[u]] = ok[u] ? t : 0.f;
       }
     }
@@ -344,6 +367,24 @@ int thin_launch(const Canon& c, int dir, const TapIO& io, int reflect, hipStream
   a.ntt = p.ntt; a.nmt = p.nmt; a.w_tile = p.w_tile;
   const long long nb = (long long)p.ntt * c.B * p.nph * p.nmt * p.G;
   if (nb <= 0 || nb > 0x7fffffffLL) return fail(EBEN_EINVAL, "thin grid of %lld blocks", nb);
+  {
+    auto magic = [](int d) { return d == 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); };
+    int dmax = p.nph > p.ntt ? p.nph : p.ntt;
+    if (c.B > dmax) dmax = c.B;
+    if (p.nmt > dmax) dmax = p.nmt;
+    a.id_fast = nb * dmax < 0x100000000LL ? 1 : 0;   // mulhi(n, ceil(2^32 / d)) is exact while n * d < 2^32
+    a.m_ntt = magic(p.ntt); a.m_B = magic(c.B); a.m_nph = magic(p.nph); a.m_nmt = magic(p.nmt);
+    a.pg_n = p.nph <= 8 ? p.nph : 0;
+    a.tile = p.BN * p.NP;
+    const int ad = p.dstep >= 0 ? p.dstep : -p.dstep;
+    for (int ph = 0; ph < a.pg_n; ++ph) {
+      const PhaseGeom q = phase_geom(p.mode, ph, p.J, p.off0, p.nt, p.dstep, p.OS, p.ps_pad, c.k, c.d, p.kstep, p.Ly);
+      a.pg[ph].J = q.J; a.pg[ph].off0 = q.off0; a.pg[ph].minoff = q.minoff; a.pg[ph].nt = q.nt; a.pg[ph].oo = q.oo;
+      a.pg[ph].span = q.J > 0 ? (a.tile - 1) * p.S + (q.J - 1) * ad + 1 : 0;
+      a.pg[ph].span_magic = a.pg[ph].span > 0 ? (unsigned)((0x100000000ull + (unsigned)a.pg[ph].span - 1) / (unsigned)a.pg[ph].span) : 0u;
+      a.pg[ph].pad = 0;
+    }
+  }
   if (p.BN == 256 && p.NP == 4) {
     switch (p.MT) {
       case 1: return launch_thin_cfg<1, 256, 4>(a, (int)nb, p.lds_bytes, st);
