@@ -370,10 +370,17 @@ class ReplayedPrepack:
     def __init__(self):
         self.graph, self.sig, self.rounds = None, None, 0
 
+    @staticmethod
+    def _multi_rank() -> bool:
+        """Eager launches in data-parallel runs: the capture (device-wide synchronisation, cache flush) would run next to RCCL's
+        in-flight exchanges on the communication stream; the replay only saves host time, of which a multi-rank step has spare."""
+        d = torch.distributed
+        return d.is_available() and d.is_initialized() and d.get_world_size() > 1
+
     def run(self, sig, body, stream_) -> bool:
         """Runs (or replays) ``body`` on ``stream_`` (a torch side stream, current on entry); True when it was a replay, in which
         case the caller refreshes its own cache keys (the body's bookkeeping did not run)."""
-        if not self.enabled:
+        if not self.enabled or self._multi_rank():
             body()
             return False
         if sig != self.sig:
