@@ -146,8 +146,11 @@ __global__ __launch_bounds__(256, NPW >= 2 ? 1 : 2) void tap3_kernel(const Tap3A
   // ---- input tile staging: one element = one bundle (8 channels) at one position -------------------
   const long long xrow0 = ((long long)b * P.Cx + (long long)g * P.Cg) * P.Lx;
   const int refl = P.reflect;
+  // tiles that lie inside the signal (block-uniform: every tile but the first / last few of a row) need no bounds arithmetic
+  const bool inside = q0 >= 0 && q0 + span <= P.Lx;
   auto x_pos = [&](int r, int& ok) -> int {
     int qq = q0 + r;
+    if (inside) { ok = 1; return qq; }
     const int m1 = qq < 0 ? -qq : qq;
     const int m2 = m1 >= P.Lx ? 2 * (P.Lx - 1) - m1 : m1;
     qq = refl ? m2 : qq;
@@ -222,7 +225,7 @@ __global__ __launch_bounds__(256, NPW >= 2 ? 1 : 2) void tap3_kernel(const Tap3A
 #pragma unroll
     for (int u = 0; u < XRB; ++u) {
       int ok;
-      const int qq = x_pos(xg[u] & 0xffff, ok);
+      const int qq = x_pos(xg[u] >= 0 ? (xg[u] & 0xffff) : 0, ok);   // lanes without a unit re-read the tile's first position
       ok &= (int)(xg[u] >= 0);
       okmask |= (unsigned)ok << u;
       load8(xp, cc * P.CI_T + (xg[u] >= 0 ? (xg[u] >> 16) * 8 : 0), qq, xreg[u]);
