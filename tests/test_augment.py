@@ -148,7 +148,8 @@ def test_oracle_pitch_shift_on_a_sine(steps):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("steps,shape", [(-2, (3, 1, 4000)), (1, (2, 1, 7777)), (4, (2, 2, 3001)), (-4, (1, 16000))])
+@pytest.mark.parametrize("steps,shape", [(-2, (3, 1, 4000)), (1, (2, 1, 7777)), (4, (2, 2, 3001)), (-4, (1, 16000)), (6, (4, 32000)),
+                                         (-3, (4, 32000))])
 def test_device_pitch_shift_matches_oracle(steps, shape):
     from vibravox_amd.augment import pitch_shift
 
@@ -158,8 +159,9 @@ def test_device_pitch_shift_matches_oracle(steps, shape):
     assert tuple(got.shape) == ref.shape == tuple(shape)
     err = np.abs(got.double().numpy() - ref)
     scale = float(np.abs(ref).max())
-    # fp32 phase accumulation over a few hundred frames against float64: compare in RMS and bound the peak
-    assert float(np.sqrt((err ** 2).mean())) < 1e-3 * scale and float(err.max()) < 2e-2 * scale
+    # fp32 STFT / inverse STFT / resampling around a float64 phase walk (angles, wrap and running sum) against the float64 oracle:
+    # measured 2e-7 .. 1.2e-6 RMS and <= 8e-6 peak of the signal's scale (the fp32 walk of round 1 sat at 1e-3 / 2e-2)
+    assert float(np.sqrt((err ** 2).mean())) < 5e-6 * scale and float(err.max()) < 4e-5 * scale
 
 
 @pytest.mark.gpu

@@ -212,11 +212,32 @@ __global__ __launch_bounds__(256) void fm_bwd_kernel(const FmTable T, const floa
   const float s1 = sums[2 * p], s2 = sums[2 * p + 1];
   const float gs = gout[0] * inv_count;
   const float c1 = gs / s2, c2 = gs * s1 / (s2 * s2);
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-    const float av = a[i], dv = av - b[i];
+  auto grad = [&](float av, float bv) {
+    const float dv = av - bv;
     const float sg1 = (dv > 0.f) - (dv < 0.f), sg2 = (av > 0.f) - (av < 0.f);
-    da[i] = c1 * sg1 - c2 * sg2;
+    return c1 * sg1 - c2 * sg2;
+  };
+  // 16-byte accesses, two per tensor in flight per thread (the dword-per-thread loop wrote at ~1.5 TB/s)
+  const bool vec = (((unsigned long long)a | (unsigned long long)b | (unsigned long long)da) & 15ull) == 0;
+  const long long n4 = vec ? (n >> 2) : 0, stride = (long long)gridDim.x * 256;
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  for (; i + stride < n4; i += 2 * stride) {
+    const f32x4 a0 = reinterpret_cast<const f32x4*>(a)[i], a1 = reinterpret_cast<const f32x4*>(a)[i + stride];
+    const f32x4 b0 = reinterpret_cast<const f32x4*>(b)[i], b1 = reinterpret_cast<const f32x4*>(b)[i + stride];
+    f32x4 g0, g1;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { g0[e] = grad(a0[e], b0[e]); g1[e] = grad(a1[e], b1[e]); }
+    reinterpret_cast<f32x4*>(da)[i] = g0;
+    reinterpret_cast<f32x4*>(da)[i + stride] = g1;
   }
+  for (; i < n4; i += stride) {
+    const f32x4 a0 = reinterpret_cast<const f32x4*>(a)[i], b0 = reinterpret_cast<const f32x4*>(b)[i];
+    f32x4 g0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) g0[e] = grad(a0[e], b0[e]);
+    reinterpret_cast<f32x4*>(da)[i] = g0;
+  }
+  for (long long j = 4 * n4 + (long long)blockIdx.x * 256 + threadIdx.x; j < n; j += stride) da[j] = grad(a[j], b[j]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -564,7 +585,7 @@ extern "C" int eben_fm_bwd(const void* const* ptrs, void* const* da_ptrs, const 
     if (rc) return rc;
     long long mx = 0;
     for (int i = 0; i < cnt; ++i) { if (T.n[i] > mx) mx = T.n[i]; if (!T.da[i]) return fail(EBEN_EINVAL, "null gradient buffer"); }
-    hipLaunchKernelGGL(fm_bwd_kernel, dim3(grid_for((size_t)mx, 1024), cnt), dim3(256), 0, as_stream(stream), T, sums + 2 * p0, gout, inv_count);
+    hipLaunchKernelGGL(fm_bwd_kernel, dim3(grid_for((size_t)(mx + 7) / 8, 1024), cnt), dim3(256), 0, as_stream(stream), T, sums + 2 * p0, gout, inv_count);
     EBEN_CHECK_LAUNCH("fm_bwd_kernel");
   }
   return EBEN_OK;
@@ -811,6 +832,8 @@ extern "C" int eben_resample(const float* x, const float* kernels, float* out, i
 //   ts = i*rate, i0 = floor(ts), alpha = ts - i0, s0 = spec[i0], s1 = spec[i0+1] (zero past the end)
 //   dphi = wrap(angle(s1) - angle(s0) - adv[k]) + adv[k];  phase_i = angle(spec[0]) + sum_{i' < i} dphi_i'
 //   out_i = (alpha*|s1| + (1-alpha)*|s0|) * exp(j*phase_i),   adv[k] = pi*hop*k/(bins-1)
+// (torchaudio runs this in the input's precision, complex64 here; float64 inside the walk costs nothing measurable and is the
+// side of the reference's own rounding noise the float64 oracle sits on.)
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void phase_vocoder_kernel(const float* __restrict__ spec, float* __restrict__ out, int rows, int bins,
                                                             int frames, int frames_out, double rate, float hop) {
@@ -822,21 +845,29 @@ __global__ __launch_bounds__(256) void phase_vocoder_kernel(const float* __restr
   const float* im = re + (long long)bins * in_cols;
   float* ore = out + (long long)k * out_cols + (long long)r * frames_out;
   float* oim = ore + (long long)bins * out_cols;
-  const float two_pi = 6.283185307179586f;
-  const float adv = 3.14159265358979323846f * hop * (float)k / (float)(bins - 1);
-  float phase = atan2f(im[0], re[0]);
+  // The phase is a running sum over a few hundred frames and each term is a difference of angles: angles, wrap and the
+  // running sum are kept in float64 (2 atan2 + 1 sincos per output value — this is the collator's augmentation, a few
+  // million values per batch), which holds the result at the fp32 STFT's own 1e-6 instead of 1e-3 of the signal.
+  const double two_pi = 6.283185307179586476925286766559;
+  const double adv = 3.14159265358979323846264338327950288 * (double)hop * (double)k / (double)(bins - 1);
+  double phase = atan2((double)im[0], (double)re[0]);
+  double a0 = phase;   // angle(spec[i0]) of the current frame pair, reused while i0 stands still
+  int i0_prev = 0;
   for (int f = 0; f < frames_out; ++f) {
     const double ts = (double)f * rate;   // as torch.arange(0, frames, rate) in float64: the frame index must not flip
     const int i0 = (int)ts;
-    const float alpha = (float)(ts - (double)i0);
+    const double alpha = ts - (double)i0;
     const float r0 = i0 < frames ? re[i0] : 0.f, m0 = i0 < frames ? im[i0] : 0.f;
     const float r1 = i0 + 1 < frames ? re[i0 + 1] : 0.f, m1 = i0 + 1 < frames ? im[i0 + 1] : 0.f;
-    const float n0 = sqrtf(r0 * r0 + m0 * m0), n1 = sqrtf(r1 * r1 + m1 * m1);
-    const float mag = alpha * n1 + (1.f - alpha) * n0;
-    ore[f] = mag * cosf(phase);
-    oim[f] = mag * sinf(phase);
-    float d = atan2f(m1, r1) - atan2f(m0, r0) - adv;
-    d = d - two_pi * rintf(d / two_pi);
+    const double n0 = sqrt((double)r0 * r0 + (double)m0 * m0), n1 = sqrt((double)r1 * r1 + (double)m1 * m1);
+    const double mag = alpha * n1 + (1.0 - alpha) * n0;
+    double sn, cs;
+    sincos(phase, &sn, &cs);
+    ore[f] = (float)(mag * cs);
+    oim[f] = (float)(mag * sn);
+    if (i0 != i0_prev) { a0 = atan2((double)m0, (double)r0); i0_prev = i0; }
+    double d = atan2((double)m1, (double)r1) - a0 - adv;
+    d = d - two_pi * rint(d / two_pi);
     phase += d + adv;
   }
 }
