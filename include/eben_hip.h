@@ -150,6 +150,15 @@ EBEN_API int eben_conv1d_bwd_dx_res(const EbenConv1dDesc* d, const float* dy, co
  * through the reference branch) with one pass over stacked gradients. */
 EBEN_API int eben_conv1d_bwd_dx_ex(const EbenConv1dDesc* d, const float* g, const float* wp_bwd, const float* res, int res_rows,
                           const float* mask, float mask_slope, int seg, const int* seg_map, float* dx, void* stream);
+/* The same launch with the feature-matching gradient of the embedding formed in the epilogue (feature_loss.py:40-47, the term
+ * |a - b|.sum() / |a|.sum() of one (enhanced, reference) embedding pair) instead of read from a buffer eben_fm_bwd wrote:
+ *   dx[b] = ( conv^T(g[b]) + (b < fm_rows ? fm_gs * (sgn(mask[b] - ref[b]) / s2 - s1 * sgn(mask[b]) / s2^2) : 0) )
+ *           * lrelu'(mask[map(b)], mask_slope),      (s1, s2) = fm_sums[0..1] (device memory, written by eben_fm_sums)
+ * ref = the reference rows of the embedding whose enhanced rows are mask rows 0 .. fm_rows-1.  Only the thin and the bf16 tap-conv
+ * kernels (eben_conv1d_kernel_generation(d, 1) == 3 or 4) carry this epilogue; EBEN_EUNSUPPORTED otherwise. */
+EBEN_API int eben_conv1d_bwd_dx_fm(const EbenConv1dDesc* d, const float* g, const float* wp_bwd, const float* ref, int fm_rows,
+                          const float* fm_sums, float fm_gs, const float* mask, float mask_slope, int seg, const int* seg_map,
+                          float* dx, void* stream);
 /* partial weight (+bias) gradients into `slabs` (layout reported by bwd_dw_workspace);
  * finish with eben_wn_bwd. */
 EBEN_API int eben_conv1d_bwd_dw(const EbenConv1dDesc* d, const float* dy, const float* y, const float* x, int has_bias,

@@ -662,6 +662,67 @@ def test_batched_input_gradient_ex(hip, name):
     assert rel_err(dx, ref) < 3e-5
 
 
+@pytest.mark.parametrize("name,mathmode", [("thin_pqmf_l1", 0), ("pqmf_disc_wide", 1), ("melgan_l2_like", 1), ("dense_k5_chunks", 1),
+                                           ("pqmf_disc_wide", 0)])
+def test_batched_input_gradient_with_feature_matching_epilogue(hip, name, mathmode):
+    """eben_conv1d_bwd_dx_fm: the feature-matching gradient of the embedding pair (feature_loss.py:40-47) formed in the
+    input-gradient epilogue == eben_fm_bwd into a buffer + eben_conv1d_bwd_dx_ex reading it, bit for bit, and == fp64; kernel
+    generations without that epilogue refuse."""
+    import ctypes
+    import dataclasses
+
+    from vibravox_amd import ops
+    from vibravox_amd._lib import check, load, ptr, stream
+
+    lib = load()
+    kw, _, length, _, _ = CONV_CASES[name]
+    spec = dataclasses.replace(ops.ConvSpec(**kw), in_slope=1.0, out_slope=1.0)
+    S = 2
+    wshape = spec.weight_shape()
+    w = formula_tensor(f"fmx/{name}/w", wshape, 1 / math.sqrt(wshape[1] * wshape[2]))
+    l_out = spec.out_len(length)
+    g = formula_tensor(f"fmx/{name}/g", (4 * S, spec.c_out, l_out))
+    act = formula_tensor(f"fmx/{name}/act", (2 * S, spec.c_in, length))
+    dev = torch.device("cuda")
+    d = ops.conv_desc(spec, 4 * S, length, mathmode)
+    gen = lib.eben_conv1d_kernel_generation(ctypes.byref(d), 1)
+    wd, gd, ad = w.to(dev), g.to(dev), act.to(dev)
+    wp = torch.empty(lib.eben_conv1d_packed_floats(ctypes.byref(d), 1), dtype=torch.float32, device=dev)
+    check(lib.eben_conv1d_pack(ctypes.byref(d), ptr(wd), None, None, ptr(wp), stream()), "pack")
+    seg_map = (ctypes.c_int * 4)(0, 0, 0, 1)
+    # sums of the pair (s1 = sum|a - b|, s2 = sum|a|) as eben_fm_sums leaves them, and the gradient buffer of the two-kernel form
+    a, b = ad[:S], ad[S:]
+    sums = torch.stack(((a - b).abs().sum(), a.abs().sum())).to(torch.float32).contiguous()
+    gs = 1.0 / 7.0
+    one = torch.ones(1, dtype=torch.float32, device=dev)
+    da = torch.empty_like(a)
+    pairs = (ctypes.c_void_p * 2)(ptr(a), ptr(b))
+    outs = (ctypes.c_void_p * 1)(ptr(da))
+    numel = (ctypes.c_int64 * 1)(a.numel())
+    check(lib.eben_fm_bwd(pairs, outs, numel, 1, ptr(sums), ptr(one), gs, stream()), "fm_bwd")
+    two = torch.empty(4 * S, spec.c_in, length, dtype=torch.float32, device=dev)
+    check(lib.eben_conv1d_bwd_dx_ex(ctypes.byref(d), ptr(gd), ptr(wp), ptr(da), S, ptr(ad), 0.2, S, seg_map, ptr(two), stream()), "bwd_dx_ex")
+    one_pass = torch.empty_like(two)
+    rc = lib.eben_conv1d_bwd_dx_fm(ctypes.byref(d), ptr(gd), ptr(wp), ptr(b), S, ptr(sums), gs, ptr(ad), 0.2, S, seg_map, ptr(one_pass), stream())
+    if gen not in (3, 4):
+        assert rc == -3   # EBEN_EUNSUPPORTED
+        return
+    check(rc, "bwd_dx_fm")
+    torch.cuda.synchronize()
+    assert torch.equal(one_pass, two)
+    # fp64 of the same expression
+    xr = torch.zeros(4 * S, spec.c_in, length, dtype=torch.float64, requires_grad=True)
+    okw = {k: v for k, v in kw.items() if k not in ("c_in", "c_out", "ksize", "in_slope", "out_slope")}
+    (O.conv_layer(xr, w.double(), None, None, **okw) * g.double()).sum().backward()
+    ref = xr.grad.clone()
+    a64, b64 = act.double()[:S], act.double()[S:]
+    s1, s2 = (a64 - b64).abs().sum(), a64.abs().sum()
+    ref[:S] += gs * (torch.sign(a64 - b64) / s2 - s1 * torch.sign(a64) / s2 ** 2)
+    rows = torch.tensor([0, 1, 0, 1, 0, 1, 2, 3])
+    ref = ref * torch.where(act.double()[rows] > 0, 1.0, 0.2)
+    assert rel_err(one_pass, ref) < (3e-5 if mathmode == 0 else 2e-2)
+
+
 def test_conv_bad_descriptor_raises(hip):
     from vibravox_amd import _lib, ops
 

@@ -99,6 +99,7 @@ SIGNATURES = {
     "eben_conv1d_bwd_dw_workspace": (c_size_t, [_D, POINTER(c_int), POINTER(c_int)]),
     "eben_conv1d_bwd_dx": (c_int, [_D, _P, _P, _P, _P, _P, c_int, _P, c_size_t, _P]),
     "eben_conv1d_bwd_dx_ex": (c_int, [_D, _P, _P, _P, c_int, _P, c_float, c_int, POINTER(c_int), _P, _P]),
+    "eben_conv1d_bwd_dx_fm": (c_int, [_D, _P, _P, _P, c_int, _P, c_float, _P, c_float, c_int, POINTER(c_int), _P, _P]),
     "eben_conv1d_bwd_dw": (c_int, [_D, _P, _P, _P, c_int, _P, c_size_t, _P]),
     "eben_ru_packed_floats": (c_size_t, [c_int]),
     "eben_ru_pack": (c_int, [c_int, _P, _P, _P, _P, _P, _P]),

@@ -93,6 +93,10 @@ struct TapIO {
   // b < res_rows (0 = all rows); the epilogue mask is read from batch row
   // em_map[b / em_seg] * em_seg + b % em_seg (em_seg = 0: row b)
   int res_rows; int em_seg; int em_map[4];
+  // feature-matching gradient formed in the epilogue (eben_conv1d_bwd_dx_fm): `res` then points at the REFERENCE rows of the
+  // embedding the mask is read from, and rows b < res_rows receive c1 sgn(mask - res) - c2 sgn(mask) with c1 = fm_gs / s2,
+  // c2 = fm_gs s1 / s2^2, (s1, s2) = fm_sums[0..1] on the device (feature_loss.py:40-47); nullptr = plain residual
+  const float* fm_sums; float fm_gs;
 };
 
 // Tap geometry of one output phase.  mode 0 (gather-strided): every block uses (J0, off0_gs, nt_gs).

@@ -854,8 +854,25 @@ extern "C" int eben_conv1d_bwd_dx_res(const EbenConv1dDesc* d, const float* dy, 
 //   dx[b] = ( conv^T(g[b]) + (b < res_rows ? res[b] : 0) ) * lrelu'(mask[map(b)], mask_slope)
 // g is consumed as is: the producer already applied its activation derivative in ITS epilogue, so no
 // kernel on this path reads a mask on load.
+static int bwd_dx_batched(const EbenConv1dDesc* d, const float* g, const float* wp_bwd, const float* res, int res_rows, const float* fm_sums,
+                          float fm_gs, const float* mask, float mask_slope, int seg, const int* seg_map, float* dx, void* stream);
 extern "C" int eben_conv1d_bwd_dx_ex(const EbenConv1dDesc* d, const float* g, const float* wp_bwd, const float* res, int res_rows,
                                      const float* mask, float mask_slope, int seg, const int* seg_map, float* dx, void* stream) {
+  return bwd_dx_batched(d, g, wp_bwd, res, res_rows, nullptr, 0.f, mask, mask_slope, seg, seg_map, dx, stream);
+}
+// The same launch with the feature-matching gradient of the embedding formed in the epilogue instead of read from a buffer a separate
+// kernel wrote (feature_loss.py:40-47: d/da [ sum|a - b| / sum|a| ] = sgn(a - b) / s2 - s1 sgn(a) / s2^2):
+//   dx[b] = ( conv^T(g[b]) + (b < fm_rows ? fm_gs (sgn(mask[b] - ref[b]) / s2 - s1 sgn(mask[b]) / s2^2) : 0) ) * lrelu'(mask[map(b)])
+// with (s1, s2) = fm_sums[0..1] read on the device.  Only the thin and the bf16 tap-conv kernels (generations 3 / 4, the ones the
+// discriminators' input gradients run on) carry this epilogue: EBEN_EUNSUPPORTED otherwise (use eben_fm_bwd + bwd_dx_ex).
+extern "C" int eben_conv1d_bwd_dx_fm(const EbenConv1dDesc* d, const float* g, const float* wp_bwd, const float* ref, int fm_rows,
+                                     const float* fm_sums, float fm_gs, const float* mask, float mask_slope, int seg, const int* seg_map,
+                                     float* dx, void* stream) {
+  EBEN_REQUIRE(ref && fm_sums && mask && fm_rows > 0, "bad feature-matching arguments in conv1d_bwd_dx_fm");
+  return bwd_dx_batched(d, g, wp_bwd, ref, fm_rows, fm_sums, fm_gs, mask, mask_slope, seg, seg_map, dx, stream);
+}
+static int bwd_dx_batched(const EbenConv1dDesc* d, const float* g, const float* wp_bwd, const float* res, int res_rows, const float* fm_sums,
+                          float fm_gs, const float* mask, float mask_slope, int seg, const int* seg_map, float* dx, void* stream) {
   Canon c;
   int rc = canon_from_desc(d, &c);
   if (rc) return rc;
@@ -870,6 +887,8 @@ extern "C" int eben_conv1d_bwd_dx_ex(const EbenConv1dDesc* d, const float* g, co
   for (int i = 0; i < 4; ++i) io.em_map[i] = (seg > 0 && seg_map) ? seg_map[i] : i;
   io.y = dx; io.accumulate = 0;
   const int gen = tap_generation(c, dir);
+  io.fm_sums = fm_sums; io.fm_gs = fm_gs;
+  if (fm_sums && gen != 3 && gen != 4) return fail(EBEN_EUNSUPPORTED, "conv1d_bwd_dx_fm: kernel generation %d has no feature-matching epilogue", gen);
   hipStream_t st = as_stream(stream);
   if (gen == 2) return tap2_launch(c, dir, io, 0, st);
   if (gen == 3) return thin_launch(c, dir, io, 0, st);

@@ -51,6 +51,7 @@ struct Tap3Args {
   int ps_pad, ps_k, ps_d, ps_kstep;
   int reflect, accumulate, in_mode;   // in_mode 1: the input is multiplied by lrelu'(xmask) as it is staged (autograd's mask-on-load)
   int res_rows, em_seg, em_map[4];
+  const float* fm_sums; float fm_gs;
   float in_slope, out_slope, res_slope, emask_slope;
   int CI_T, CI_B, CP, ncc, PLEN, CSTRIDE, nxb;   // CI_T channels = CI_B bundles per input tile; CP = CI_B / 2 k-steps per tap
   unsigned s_magic;
@@ -368,6 +369,10 @@ __global__ __launch_bounds__(256, NPW >= 2 ? 1 : 2) void tap3_kernel(const Tap3A
   const int mlast = P.Mg - 1;
   const bool plain = !use_res && P.emask == nullptr && !P.accumulate;
   const bool lin = P.out_slope == 1.f && P.res_slope == 1.f;   // the engine's input-gradient launches: no activation arithmetic
+  // feature-matching rows: the addend is formed from the two embeddings (mask = enhanced rows, res = reference rows) instead of read
+  const bool fm = use_res && P.fm_sums != nullptr;
+  float fc1 = 0.f, fc2 = 0.f;
+  if (fm) { const float s1 = P.fm_sums[0], s2 = P.fm_sums[1]; fc1 = P.fm_gs / s2; fc2 = P.fm_gs * s1 / (s2 * s2); }
   if (plain) {
     // the forward's form: bias + activation only
 #pragma unroll
@@ -417,7 +422,10 @@ __global__ __launch_bounds__(256, NPW >= 2 ? 1 : 2) void tap3_kernel(const Tap3A
     for (int r = 0; r < 8; ++r) {
       const int m = mlane + i * 32 + (r & 3) + 8 * ((r0 + r) >> 2);
       float v = acc[i][r0 + r] + bz[r];
-      if (!lin) {
+      if (fm) {
+        const float av = ez[r], dv = av - rz[r];
+        v += fc1 * (float)((dv > 0.f) - (dv < 0.f)) - fc2 * (float)((av > 0.f) - (av < 0.f));
+      } else if (!lin) {
         v = lrelu(v, P.out_slope);
         if (use_res) v += lrelu(rz[r], P.res_slope);
       } else if (use_res) {
@@ -786,7 +794,7 @@ int tap3_launch(const Canon& c, int dir, const TapIO& io, int reflect, hipStream
   a.S = p.S; a.OS = p.OS; a.dstep = p.dstep; a.J0 = p.J; a.mode = p.mode; a.off0 = p.off0; a.nt = p.nt; a.nph = p.nph;
   a.ps_pad = p.ps_pad; a.ps_k = c.k; a.ps_d = c.d; a.ps_kstep = p.kstep;
   a.reflect = reflect; a.accumulate = io.accumulate;
-  a.res_rows = io.res_rows; a.em_seg = io.em_seg;
+  a.res_rows = io.res_rows; a.em_seg = io.em_seg; a.fm_sums = io.fm_sums; a.fm_gs = io.fm_gs;
   for (int i = 0; i < 4; ++i) a.em_map[i] = io.em_map[i];
   a.in_slope = io.in_slope; a.out_slope = io.out_slope; a.res_slope = io.res_slope; a.emask_slope = io.emask_slope;
   a.CI_T = p.CI_T; a.CI_B = p.CI_B; a.CP = p.CP; a.ncc = p.ncc; a.PLEN = p.PLEN; a.CSTRIDE = p.CSTRIDE; a.nxb = p.nxbuf;

@@ -27,6 +27,7 @@ struct ThinArgs {
   int ps_pad, ps_k, ps_d, ps_kstep;
   int reflect, in_mode, accumulate;
   int res_rows, em_seg, em_map[4];
+  const float* fm_sums; float fm_gs;
   float in_slope, out_slope, res_slope, emask_slope;
   int PLEN, CSTRIDE;
   unsigned s_magic;
@@ -158,6 +159,10 @@ __global__ __launch_bounds__(BN) void thin_kernel(const ThinArgs P) {
   const float* __restrict__ rb = P.res + ubase;
   const float* __restrict__ eb_ = P.emask + ubase + eoff;
   const int mlast = P.Mg - 1;
+  // feature-matching rows: the addend is formed from the two embeddings (mask = enhanced rows, res = reference rows) instead of read
+  const bool fm = use_res && P.fm_sums != nullptr;
+  float fc1 = 0.f, fc2 = 0.f;
+  if (fm) { const float s1 = P.fm_sums[0], s2 = P.fm_sums[1]; fc1 = P.fm_gs / s2; fc2 = P.fm_gs * s1 / (s2 * s2); }
 #pragma unroll
   for (int n = 0; n < NP; ++n) {
     const int t = t0 + tid + n * BN;
@@ -190,7 +195,12 @@ __global__ __launch_bounds__(BN) void thin_kernel(const ThinArgs P) {
       for (int m = 0; m < MB; ++m) {
         float v = acc[n][mb + m] + bz[m];
         v = lrelu(v, P.out_slope);
-        if (use_res) v += lrelu(rz[m], P.res_slope);
+        if (fm) {
+          const float av = ez[m], dv = av - rz[m];
+          v += fc1 * (float)((dv > 0.f) - (dv < 0.f)) - fc2 * (float)((av > 0.f) - (av < 0.f));
+        } else if (use_res) {
+          v += lrelu(rz[m], P.res_slope);
+        }
         if (P.emask) v *= dlrelu(ez[m], P.emask_slope);
         if (P.accumulate) v += az[m];
         if (m0 + mb + m < P.Mg) yb[off[m]] = v;
@@ -359,7 +369,7 @@ int thin_launch(const Canon& c, int dir, const TapIO& io, int reflect, hipStream
   a.S = p.S; a.OS = p.OS; a.dstep = p.dstep; a.J0 = p.J; a.mode = p.mode; a.off0 = p.off0; a.nt = p.nt; a.nph = p.nph;
   a.ps_pad = p.ps_pad; a.ps_k = c.k; a.ps_d = c.d; a.ps_kstep = p.kstep;
   a.reflect = reflect; a.in_mode = io.in_mode; a.accumulate = io.accumulate;
-  a.res_rows = io.res_rows; a.em_seg = io.em_seg;
+  a.res_rows = io.res_rows; a.em_seg = io.em_seg; a.fm_sums = io.fm_sums; a.fm_gs = io.fm_gs;
   for (int i = 0; i < 4; ++i) a.em_map[i] = io.em_map[i];
   a.in_slope = io.in_slope; a.out_slope = io.out_slope; a.res_slope = io.res_slope; a.emask_slope = io.emask_slope;
   a.PLEN = p.PLEN; a.CSTRIDE = p.CSTRIDE;

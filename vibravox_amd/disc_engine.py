@@ -103,6 +103,7 @@ class _Chain:
         """math: EBEN_MATH_* or (forward, input gradient, weight gradient), or a callable layer index -> one of those."""
         self.layers: List[_Layer] = []
         self.pad = 0
+        self._fm_ok: Dict[tuple, bool] = {}
         convs = []
         for m in modules:
             if isinstance(m, torch.nn.Sequential):
@@ -152,9 +153,30 @@ class _Chain:
         return bufs
 
     # ---- backward of the four stacked right-hand sides
-    def backward(self, emb: List[torch.Tensor], xp: torch.Tensor, fm_grads: List[Optional[torch.Tensor]], seeds: torch.Tensor,
-                 half: int, want_param_grads: bool):
-        """emb = [input, out_0..out_{L-1}] with 2*half rows; fm_grads[i] = d(fm)/d(out_i) (half rows) or None;
+    def fm_epilogue_ok(self, emb: List[torch.Tensor], xp: torch.Tensor, half: int) -> bool:
+        """Whether every input-gradient launch of this chain runs on a kernel that can form the feature-matching gradient of the
+        embedding it produces the gradient for in its epilogue (eben_conv1d_bwd_dx_fm: the thin and the bf16 tap-conv kernels)."""
+        outs = emb[1:]
+        key = (half,) + tuple(int(o.shape[2]) for o in outs[:-1])
+        hit = self._fm_ok.get(key)
+        if hit is None:
+            lib = load()
+            hit = True
+            for i in range(1, len(self.layers)):
+                lay = self.layers[i]
+                d = ops.conv_desc(lay.spec_lin, 4 * half, outs[i - 1].shape[2], lay.math_dx)
+                if self.layers[i - 1].spec.out_slope == 1.0 or lib.eben_conv1d_kernel_generation(ctypes.byref(d), 1) not in (3, 4):
+                    hit = False
+            if len(self._fm_ok) > 64:
+                self._fm_ok.clear()
+            self._fm_ok[key] = hit
+        return hit
+
+    def backward(self, emb: List[torch.Tensor], xp: torch.Tensor, fm_grads: Optional[List[Optional[torch.Tensor]]], seeds: torch.Tensor,
+                 half: int, want_param_grads: bool, fm_fused: Optional[Tuple[int, float]] = None):
+        """emb = [input, out_0..out_{L-1}] with 2*half rows; fm_grads[i] = d(fm)/d(out_i) (half rows) or None -- or, with
+        ``fm_fused`` = (device address of this chain's (s1, s2) sums, d loss / d term), no gradient buffers at all: the
+        input-gradient launches form the feature-matching gradient from the two halves of the embedding in their epilogue;
         seeds = (4*half, 1, L_logits) rows [fm | adv | fake | real].  Returns (d_input (2*half rows: fm | adv),
         [(dv, dg, dbias) per layer] or None)."""
         lib = load()
@@ -174,14 +196,19 @@ class _Chain:
                 rows = 4 * half
                 d = ops.conv_desc(lay.spec_lin, rows, l_in, lay.math_dx)
                 gp = torch.empty((rows, lay.spec.c_in, l_in), dtype=torch.float32, device=g.device)
-                res = fm_grads[i - 1]
                 prev_slope = self.layers[i - 1].spec.out_slope
                 wp = lay.packed(1, rows, l_in)
                 tm = ops.kernel_timer_for(lay.spec, "dx")
                 e0 = tm.start() if tm is not None else None
-                check(lib.eben_conv1d_bwd_dx_ex(ctypes.byref(d), ptr(g), ptr(wp), ptr(res), half if res is not None else 0,
-                                                ptr(outs[i - 1]) if prev_slope != 1.0 else None, prev_slope, half, seg_map, ptr(gp), st),
-                      "conv1d_bwd_dx_ex")
+                if fm_fused is not None:
+                    check(lib.eben_conv1d_bwd_dx_fm(ctypes.byref(d), ptr(g), ptr(wp), ptr(outs[i - 1][half:]), half,
+                                                    fm_fused[0] + 8 * (i - 1), fm_fused[1], ptr(outs[i - 1]), prev_slope, half, seg_map,
+                                                    ptr(gp), st), "conv1d_bwd_dx_fm")
+                else:
+                    res = fm_grads[i - 1]
+                    check(lib.eben_conv1d_bwd_dx_ex(ctypes.byref(d), ptr(g), ptr(wp), ptr(res), half if res is not None else 0,
+                                                    ptr(outs[i - 1]) if prev_slope != 1.0 else None, prev_slope, half, seg_map, ptr(gp), st),
+                          "conv1d_bwd_dx_ex")
                 if tm is not None:
                     tm.stop(e0, rows)
                 g = gp
@@ -320,6 +347,9 @@ class DiscriminatorEngine:
     #: weight gradients) instead of behind the other two -- the PQMF chains' exact-fp32 forward ("bf16" plan) is the longest
     #: stream of that phase otherwise
     spread_forward = os.environ.get("EBEN_D_FWD_SPREAD", "1") != "0"
+    #: feature-matching gradient inside the input-gradient epilogues (eben_conv1d_bwd_dx_fm) instead of a kernel per chain that
+    #: writes it into buffers the epilogues then read
+    fm_in_epilogue = os.environ.get("EBEN_FM_EPILOGUE", "1") != "0"
     spread_backward = os.environ.get("EBEN_D_BWD_SPREAD", "1") != "0"   # [MI355X] 19.6 -> 19.35 ms/step (the input-gradient phase shortens by 0.4 ms, the generator backward, which then shares the GPU with more weight-gradient work, lengthens by 0.15)
 
     def _launch_on_streams(self, fn, forward: bool = False):
@@ -500,7 +530,14 @@ class DiscriminatorEngine:
         dev = emb[0][0].device
         n = len(s["fm_a"])
         one = torch.ones(1, dtype=torch.float32, device=dev)
-        da = [torch.empty_like(t) for t in s["fm_a"]]
+        # feature-matching gradient: formed in the input-gradient epilogues where every launch of a chain can (no buffers, no extra
+        # pass over the embeddings), by one eben_fm_bwd launch per chain otherwise
+        fused = [self.fm_in_epilogue and ch.fm_epilogue_ok(emb[i], s["xp"][i], half) for i, ch in enumerate(self.chains)]
+        da, k = [], 0
+        for i, scale in enumerate(emb):
+            for t in s["fm_a"][k:k + len(scale) - 2]:
+                da.append(None if fused[i] else torch.empty_like(t))
+            k += len(scale) - 2
         # feature-matching gradients per chain, aligned with out_0 .. out_{L-2}; each chain forms its own on its own stream (one
         # launch over all 26 pairs in front of the chains was 0.4 ms during which nothing else could start)
         fm_per_chain, first, k = [], [], 0
@@ -514,7 +551,7 @@ class DiscriminatorEngine:
 
         def run(i):
             k0, cnt = first[i], len(fm_per_chain[i])
-            if cnt:
+            if cnt and not fused[i]:
                 pairs = (ctypes.c_void_p * (2 * cnt))(*fm_all[2 * k0:2 * (k0 + cnt)])
                 outs = (ctypes.c_void_p * cnt)(*[ptr(t) for t in fm_per_chain[i]])
                 numel = (ctypes.c_int64 * cnt)(*numel_all[k0:k0 + cnt])
@@ -527,7 +564,8 @@ class DiscriminatorEngine:
             for k2, (rows, target) in enumerate(((lg[:half], 1.0), (lg[:half], -1.0), (lg[half:], 1.0))):
                 check(lib.eben_hinge_bwd(ptr(rows), rows.numel(), target, ptr(one), inv_scales * self.seed_weights[k2],
                                          ptr(flat[(k2 + 1) * per:]), _stream()), "hinge_bwd")
-            return self.chains[i].backward(scale, s["xp"][i], fm_per_chain[i], seeds, half, want_param_grads)
+            return self.chains[i].backward(scale, s["xp"][i], fm_per_chain[i], seeds, half, want_param_grads,
+                                           (sums_ptr + 8 * k0, s["fm_inv"]) if fused[i] and cnt else None)
 
         # `da` / `one` live on the main stream's pool and are read by the chains: keep them referenced until the join
         self._bwd = (self._launch_on_streams(run), want_param_grads, (da, one, fm_per_chain))
