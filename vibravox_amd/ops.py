@@ -87,13 +87,16 @@ class weight_grads_on_side_stream:
             # launched, then drop everything instead of letting the next join() write through stale pointers
             st = _side["stream"]
             if st is not None:
-                torch.cuda.current_stream(st.device).wait_stream(st)
+                for k in SIDE_STREAMS:
+                    torch.cuda.current_stream(st.device).wait_stream(aux_stream(k, st.device))
             for key in ("wn_jobs", "keep", "sunk", "assign"):
                 _side[key] = []
 
     def join(self):
         st = _side["stream"]
         if st is not None:
+            for k in SIDE_STREAMS[1:]:
+                st.wait_stream(aux_stream(k, st.device))
             if _side["wn_jobs"]:
                 with torch.cuda.stream(st):
                     wn_bwd_multi(_side["wn_jobs"])   # slab sums + weight-norm chain rule of every layer: two launches
@@ -128,9 +131,19 @@ def aux_stream(i: int, device=None) -> "torch.cuda.Stream":
     return _aux["streams"][i]
 
 
-def _side_stream(device) -> "torch.cuda.Stream":
-    st = _side["stream"] = aux_stream(2, device)
-    return st
+#: auxiliary streams the deferred weight-gradient jobs are dealt over (round robin).  One stream is the measured best [MI355X]:
+#: "2" 15.35 / 15.39 ms/step, "2,1" 15.62, "2,1,0" 15.54, "2,0" 16.76 -- the other queues still carry the discriminators'
+#: weight gradients, and a generator job dealt behind them waits for work it does not depend on
+SIDE_STREAMS = tuple(int(t) for t in os.environ.get("EBEN_SIDE_STREAMS", "2").split(",") if t.strip() != "")
+
+
+def _side_stream(device, deal: bool = False) -> "torch.cuda.Stream":
+    """The side stream (weight pre-packing; joins); ``deal``: the next one of SIDE_STREAMS, for a weight-gradient job."""
+    st = _side["stream"] = aux_stream(SIDE_STREAMS[0], device)
+    if not deal or len(SIDE_STREAMS) == 1:
+        return st
+    k = _side["rr"] = (_side.get("rr", -1) + 1) % len(SIDE_STREAMS)
+    return aux_stream(SIDE_STREAMS[k], device)
 
 
 def wn_bwd_multi(jobs) -> None:
@@ -492,7 +505,7 @@ def weight_grads(d: EbenConv1dDesc, dy: torch.Tensor, y: Optional[torch.Tensor],
     slabs = _empty(ws_bytes, x)
     job, outs = _wg_job(slabs, nslab, row_stride, v, g, bias, norm, sunk, x.device)
     if use_side:
-        side = _side_stream(x.device)
+        side = _side_stream(x.device, deal=True)
         side.wait_stream(torch.cuda.current_stream(x.device))   # dy (and everything saved by the forward) is complete on the main stream
         check(lib.eben_conv1d_bwd_dw(ctypes.byref(d), ptr(dy), ptr(y), ptr(x), 1 if has_bias else 0, ptr(slabs), ws_bytes, side.cuda_stream), "conv1d_bwd_dw")
         _side["keep"].append((dy, x, y, norm, slabs))
@@ -563,7 +576,7 @@ def weight_grads_ru(math: int, dilation: int, gy: torch.Tensor, u: torch.Tensor,
     job_p, outs_p = _wg_job(slabs_p, nslab, c, vp, gp, None, np_, route_p[1], gy.device)
     job_d, outs_d = _wg_job(slabs_d, nslab, 3 * c, vd, gd, None, nd, route_d[1], gy.device)
     if use_side:
-        side = _side_stream(gy.device)
+        side = _side_stream(gy.device, deal=True)
         side.wait_stream(torch.cuda.current_stream(gy.device))
         st = side.cuda_stream
     else:
