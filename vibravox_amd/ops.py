@@ -488,6 +488,11 @@ def join_prepack() -> None:
         torch.cuda.current_stream().wait_event(ev)
 
 
+#: transposed convs with a fused output activation: mask the gradient by one element-wise launch so that the bf16 weight-gradient
+#: kernel applies (see weight_grads)
+PREMASK_TRANSPOSED_DW = os.environ.get("EBEN_PREMASK_DW", "1") != "0"
+
+
 def weight_grads(d: EbenConv1dDesc, dy: torch.Tensor, y: Optional[torch.Tensor], x: torch.Tensor, v: torch.Tensor,
                  g: Optional[torch.Tensor], bias: Optional[torch.Tensor], norm: Optional[torch.Tensor]):
     """Weight (+ bias) gradient of one conv layer: ``eben_conv1d_bwd_dw`` into split-K slabs, then the slab sum and the
@@ -500,6 +505,16 @@ def weight_grads(d: EbenConv1dDesc, dy: torch.Tensor, y: Optional[torch.Tensor],
     lib = load()
     has_g, has_bias = g is not None, bias is not None
     use_side, sunk = _wg_route(v, g, bias)
+    premask = None
+    if PREMASK_TRANSPOSED_DW and d.transposed and d.out_slope != 1.0 and y is not None and d.math in (MATH_BF16, MATH_BF16X2):
+        # ConvTranspose1d with a fused output activation: the bf16 weight-gradient kernel takes no mask on that operand (the layer
+        # would fall to the exact-fp32 kernel, 3-4x the time for the decoder's transposed convs) -- the masked gradient is formed by
+        # one element-wise launch on the stream the weight gradient runs on, and the layer handed over as one without activation
+        plain = getattr(d, "_dw_plain", None)
+        if plain is None:
+            plain = d._dw_plain = type(d).from_buffer_copy(d)
+            plain.out_slope = 1.0
+        premask, d = (dy, y, d.out_slope), plain
     ws = getattr(d, "_dw_ws", None)   # (bytes, slabs, row stride) of this descriptor: asked once
     if ws is None:
         nslab, row_stride = ctypes.c_int(0), ctypes.c_int(0)
@@ -510,11 +525,18 @@ def weight_grads(d: EbenConv1dDesc, dy: torch.Tensor, y: Optional[torch.Tensor],
     # stream -- which waits for the side stream there -- may reuse it.
     slabs = _empty(ws_bytes, x)
     job, outs = _wg_job(slabs, nslab, row_stride, v, g, bias, norm, sunk, x.device)
+    raw = None
     if use_side:
         side = _side_stream(x.device, deal=True)
         side.wait_stream(torch.cuda.current_stream(x.device))   # dy (and everything saved by the forward) is complete on the main stream
-        check(lib.eben_conv1d_bwd_dw(ctypes.byref(d), ptr(dy), ptr(y), ptr(x), 1 if has_bias else 0, ptr(slabs), ws_bytes, side.cuda_stream), "conv1d_bwd_dw")
-        _side["keep"].append((dy, x, y, norm, slabs))
+        raw = side.cuda_stream
+    if premask is not None:
+        gm = torch.empty_like(dy)
+        check(lib.eben_lrelu_bwd(ptr(dy), ptr(y), ptr(gm), dy.numel(), premask[2], raw if use_side else stream()), "lrelu_bwd")
+        dy, y = gm, None
+    if use_side:
+        check(lib.eben_conv1d_bwd_dw(ctypes.byref(d), ptr(dy), ptr(y), ptr(x), 1 if has_bias else 0, ptr(slabs), ws_bytes, raw), "conv1d_bwd_dw")
+        _side["keep"].append((dy, x, y, norm, slabs) + (premask[:2] if premask is not None else ()))
         _wg_defer(job, outs, v, g, bias, sunk)
         return None, None, None
     check(lib.eben_conv1d_bwd_dw(ctypes.byref(d), ptr(dy), ptr(y), ptr(x), 1 if has_bias else 0, ptr(slabs), ws_bytes, stream()), "conv1d_bwd_dw")
