@@ -228,6 +228,13 @@ EBEN_API int eben_fir_interp_sum(const float* y, const float* w, float* x, int b
 /* ---- elementwise ------------------------------------------------------------------------ */
 EBEN_API int eben_lrelu_fwd(const float* x, float* y, size_t n, float slope, void* stream);
 EBEN_API int eben_lrelu_bwd(const float* dy, const float* x_or_y, float* dx, size_t n, float slope, void* stream);
+/* Space to depth along time: out[row][r][q] = xp[row][S*q + r + off] (r < S, q < Lq; xp = x continued by reflection or by zeros
+ * beyond [0, L)), optionally times lrelu'(mask[row][.], mask_slope).  out: (rows, S, Lq).  Turns a stride-S Conv1d with
+ * ksize = kq*S (EncBlock.conv, eben_generator.py:251-254) -- or the input gradient of the matching ConvTranspose1d (DecBlock,
+ * eben_generator.py:282-284) -- into a stride-1 conv with kq taps over C*S channels, with the weights viewed as
+ * (M, C, kq, S) -> (M, C, S, kq). */
+EBEN_API int eben_space_to_depth(const float* x, const float* mask, float mask_slope, float* out, int rows, int L, int S, int off, int Lq,
+                        int reflect, void* stream);
 EBEN_API int eben_add(const float* a, const float* b, float* out, size_t n, void* stream);
 EBEN_API int eben_axpby(const float* a, float alpha, const float* b, float beta, float* out, size_t n, void* stream);
 /* bands = tanh(x + lift) where lift has `c_lift` leading channels (eben_generator.py:203-208) */

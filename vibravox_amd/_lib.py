@@ -118,6 +118,7 @@ SIGNATURES = {
     "eben_fir_interp_sum": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "eben_lrelu_fwd": (c_int, [_P, _P, c_size_t, c_float, _P]),
     "eben_lrelu_bwd": (c_int, [_P, _P, _P, c_size_t, c_float, _P]),
+    "eben_space_to_depth": (c_int, [_P, _P, c_float, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "eben_add": (c_int, [_P, _P, _P, c_size_t, _P]),
     "eben_axpby": (c_int, [_P, c_float, _P, c_float, _P, c_size_t, _P]),
     "eben_tanh_lift_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),

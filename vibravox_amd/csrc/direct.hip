@@ -500,6 +500,46 @@ extern "C" int eben_lrelu_bwd(const float* dy, const float* ref, float* dx, size
   EBEN_CHECK_LAUNCH("lrelu_bwd_kernel");
   return EBEN_OK;
 }
+// ---------------------------------------------------------------------------------------------
+// Space to depth along time: out[row][r][q] = xp[row][S q + r + off], r in [0, S), q in [0, Lq), where xp is x continued by
+// reflection (reflect) or zeros beyond [0, L), optionally times lrelu'(mask[row][.], slope) (the gradient of a fused output
+// activation).  A stride-S conv with k = kq S taps over C channels is then a stride-1 conv with kq taps over the C S channels
+// (c, r) of `out` -- the form the split-operand tap-conv covers (a stride-8 layer's input tile of 128 outputs is 1032 positions
+// wide, beyond its per-thread prefetch; as 8 channels x 129 positions it is an ordinary tile).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void space_to_depth_kernel(const float* __restrict__ x, const float* __restrict__ mask, float* __restrict__ out,
+                                                             int L, int S, int off, int Lq, int reflect, float slope) {
+  const long long row = blockIdx.y;
+  const float* xr = x + row * L;
+  const float* mr = mask ? mask + row * L : nullptr;
+  float* o = out + row * (long long)S * Lq;
+  const int n = S * Lq;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const int r = i / Lq, q = i - r * Lq;
+    int p = S * q + r + off;
+    bool ok = true;
+    if (reflect) {
+      if (p < 0) p = -p;
+      if (p >= L) p = 2 * (L - 1) - p;
+      ok = p >= 0 && p < L;
+    } else {
+      ok = p >= 0 && p < L;
+    }
+    float v = ok ? xr[p] : 0.f;
+    if (mr && ok) v *= dlrelu(mr[p], slope);
+    o[i] = v;
+  }
+}
+extern "C" int eben_space_to_depth(const float* x, const float* mask, float mask_slope, float* out, int rows, int L, int S, int off, int Lq,
+                                   int reflect, void* stream) {
+  EBEN_REQUIRE(x && out && rows > 0 && L > 0 && S > 0 && Lq > 0, "bad space_to_depth arguments");
+  EBEN_REQUIRE(!reflect || (-off < L && S * (Lq - 1) + S - 1 + off < 2 * L - 1), "space_to_depth: reflection wider than the signal");
+  EBEN_REQUIRE(rows <= 65535, "space_to_depth: too many rows for one launch");
+  hipLaunchKernelGGL(space_to_depth_kernel, dim3(grid_for((size_t)S * Lq, 64), rows), dim3(256), 0, as_stream(stream), x, mask, out, L, S, off,
+                     Lq, reflect, mask_slope);
+  EBEN_CHECK_LAUNCH("space_to_depth_kernel");
+  return EBEN_OK;
+}
 extern "C" int eben_add(const float* a, const float* b, float* out, size_t n, void* stream) {
   EBEN_REQUIRE(a && b && out, "null pointer");
   if (n == 0) return EBEN_OK;

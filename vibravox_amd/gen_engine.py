@@ -41,6 +41,8 @@ RU_FWD_MATH = _RU_MATH[os.environ.get("EBEN_RU_FWD_MATH", "bf16x6")]
 RU_BWD_F32_MATH = _RU_MATH[os.environ.get("EBEN_RU_BWD_F32_MATH", "bf16x6")]
 # forward of the other conv layers of the core (first / strided / latent / transposed convs): the same fp32-grade split form
 CONV_FWD_MATH = _RU_MATH[os.environ.get("EBEN_GEN_CONV_FWD_MATH", "bf16x6")]
+#: strided convs from this stride up run as space-to-depth + stride-1 tap-conv where the tap-conv does not cover them directly (0: never)
+S2D_MIN_STRIDE = int(os.environ.get("EBEN_GEN_S2D_MIN_STRIDE", "8"))
 
 
 def _params(m):
@@ -53,10 +55,10 @@ def _params(m):
 class _ConvRec:
     """What the backward of one conv launch needs."""
 
-    __slots__ = ("m", "spec", "d", "x", "y", "wp_bwd", "norm")
+    __slots__ = ("m", "spec", "d", "x", "y", "wp_bwd", "norm", "scale")
 
-    def __init__(self, m, spec, d, x, y, wp_bwd, norm):
-        self.m, self.spec, self.d, self.x, self.y, self.wp_bwd, self.norm = m, spec, d, x, y, wp_bwd, norm
+    def __init__(self, m, spec, d, x, y, wp_bwd, norm, scale=None):
+        self.m, self.spec, self.d, self.x, self.y, self.wp_bwd, self.norm, self.scale = m, spec, d, x, y, wp_bwd, norm, scale
 
 
 class GeneratorEngine:
@@ -64,6 +66,7 @@ class GeneratorEngine:
         self.gen = gen
         self._spec_cache: Dict[tuple, ops.ConvSpec] = {}
         self._ru_images: Dict[int, dict] = {}   # id(ResidualUnit) -> {key, fwd image, bwd images per math, scales}
+        self._s2d_images: Dict[int, tuple] = {}  # id(conv) -> (key, image of the space-to-depth form, permuted weights)
         self._prepack_graph = ops.ReplayedPrepack()
         self._ru_batch = None
 
@@ -89,15 +92,58 @@ class GeneratorEngine:
         pw = ops.pack_weights(m.spec, d, v.detach(), None if g is None else g.detach(), m._packed, train, d_bwd)
         return d, d_bwd, pw
 
+    # ---- stride >= 8 as space-to-depth ---------------------------------------------------------------------------------------
+    # The split-operand tap-conv stages the input tile of 128 outputs through a per-thread prefetch that a stride-8 layer's 1032
+    # positions exceed: EncBlock's last strided conv and the input gradient of DecBlock's first transposed conv fell to the exact-fp32
+    # kernel (0.15 ms each, the longest launches of the generator).  With the time axis folded into channels (`eben_space_to_depth`:
+    # channel (c, r) = samples S q + r) the same contraction is a stride-1 conv with k / S taps over C S channels, which it covers.
+    def _s2d_route(self, m, spec, batch: int, l_q: int, kq: int, math: int, c: int, rows_out: int, in_slope: float, out_slope: float, scale):
+        """(descriptor, packed image) of the stride-1 form, or None when the tap-conv does not cover it either."""
+        lib = load()
+        alt = self._spec_cache.get((id(m), "s2d", in_slope, out_slope))
+        if alt is None:
+            alt = self._spec_cache[(id(m), "s2d", in_slope, out_slope)] = ops.ConvSpec(
+                c_in=c * spec.stride, c_out=rows_out, ksize=kq, in_slope=float(in_slope), out_slope=float(out_slope))
+        d = ops.conv_desc(alt, batch, l_q, math)
+        if lib.eben_conv1d_kernel_generation(ctypes.byref(d), 0) != 4:
+            return None
+        v, g = _params(m)
+        e = ops._storage_epoch
+        key = (v.data_ptr(), v._version, e.get(v.data_ptr(), 0), None if g is None else (g.data_ptr(), g._version), e.get(-1, 0), batch, l_q, math)
+        hit = self._s2d_images.get(id(m))
+        if hit is None or hit[0] != key:
+            vv = v.detach().view(rows_out, c, kq, spec.stride).permute(0, 1, 3, 2).reshape(rows_out, c * spec.stride, kq).contiguous()
+            wp = torch.empty(lib.eben_conv1d_packed_floats(ctypes.byref(d), 0), dtype=torch.float32, device=v.device)
+            ops.conv1d_pack(d, vv, scale, wp, None)
+            hit = self._s2d_images[id(m)] = (key, wp, vv)
+        return d, hit[1]
+
+    @staticmethod
+    def _s2d_wanted(spec, math: int) -> bool:
+        return (S2D_MIN_STRIDE > 0 and spec.stride >= S2D_MIN_STRIDE and spec.ksize % spec.stride == 0 and spec.groups == 1
+                and spec.dilation == 1 and math != ops.MATH_F32)
+
     def _conv(self, m, x, train, in_slope=None, recs=None):
         """y = conv layer ``m`` on x (its own fused output activation; ``in_slope``: LeakyReLU on load)."""
+        lib = load()
         spec = self._spec(m, in_slope=in_slope)
         b, _, l_in = x.shape
         d, d_bwd, pw = self._pack(m, spec, b, l_in, train)
         y = torch.empty((b, spec.c_out, d.l_out), dtype=torch.float32, device=x.device)
-        check(load().eben_conv1d_fwd(ctypes.byref(d), ptr(x), ptr(pw.wp_fwd), ptr(m.bias), None, ptr(y), stream()), "conv1d_fwd")
+        route = None
+        if not spec.transposed and self._s2d_wanted(spec, CONV_FWD_MATH) and lib.eben_conv1d_kernel_generation(ctypes.byref(d), 0) != 4:
+            kq = spec.ksize // spec.stride
+            l_q = d.l_out + kq - 1
+            route = self._s2d_route(m, spec, b, l_q, kq, CONV_FWD_MATH, spec.c_in, spec.c_out, spec.in_slope, spec.out_slope, pw.scale)
+        if route is not None:
+            xq = torch.empty((b, spec.c_in * spec.stride, l_q), dtype=torch.float32, device=x.device)
+            check(lib.eben_space_to_depth(ptr(x), None, 1.0, ptr(xq), b * spec.c_in, l_in, spec.stride, -spec.pad_l, l_q,
+                                          1 if spec.reflect else 0, stream()), "space_to_depth")
+            check(lib.eben_conv1d_fwd(ctypes.byref(route[0]), ptr(xq), ptr(route[1]), ptr(m.bias), None, ptr(y), stream()), "conv1d_fwd")
+        else:
+            check(lib.eben_conv1d_fwd(ctypes.byref(d), ptr(x), ptr(pw.wp_fwd), ptr(m.bias), None, ptr(y), stream()), "conv1d_fwd")
         if recs is not None:
-            recs.append(_ConvRec(m, spec, d_bwd, x, y if spec.out_slope != 1.0 else None, pw.wp_bwd, pw.norm))
+            recs.append(_ConvRec(m, spec, d_bwd, x, y if spec.out_slope != 1.0 else None, pw.wp_bwd, pw.norm, pw.scale))
         return y
 
     @staticmethod
@@ -277,10 +323,24 @@ class GeneratorEngine:
         return cur, first_bands, saved
 
     # ---- backward ------------------------------------------------------------------------------------
-    @staticmethod
-    def _dx(rec: _ConvRec, dy, res_pre=None, res_post=None):
+    def _dx(self, rec: _ConvRec, dy, res_pre=None, res_post=None):
         lib = load()
         d = rec.d
+        spec = rec.spec
+        if (spec.transposed and res_pre is None and res_post is None and spec.in_slope == 1.0 and spec.output_padding == 0
+                and self._s2d_wanted(spec, d.math) and lib.eben_conv1d_kernel_generation(ctypes.byref(d), 1) != 4):
+            # input gradient of ConvTranspose1d = stride-S conv of the (masked) output gradient with the same (in, out, k) weights
+            b, c_dy, l_dy = dy.shape
+            kq = spec.ksize // spec.stride
+            l_q = rec.x.shape[2] + kq - 1
+            route = self._s2d_route(rec.m, spec, b, l_q, kq, d.math, c_dy, spec.c_in, 1.0, 1.0, rec.scale)
+            if route is not None:
+                gq = torch.empty((b, c_dy * spec.stride, l_q), dtype=torch.float32, device=dy.device)
+                check(lib.eben_space_to_depth(ptr(dy), ptr(rec.y) if spec.out_slope != 1.0 else None, spec.out_slope, ptr(gq), b * c_dy, l_dy,
+                                              spec.stride, -spec.pad_l, l_q, 0, stream()), "space_to_depth")
+                dx = torch.empty_like(rec.x)
+                check(lib.eben_conv1d_fwd(ctypes.byref(route[0]), ptr(gq), ptr(route[1]), None, None, ptr(dx), stream()), "conv1d_fwd")
+                return dx
         ws_bytes = getattr(d, "_dx_ws", None)
         if ws_bytes is None:
             ws_bytes = d._dx_ws = lib.eben_conv1d_bwd_dx_workspace(ctypes.byref(d))
