@@ -723,6 +723,43 @@ def test_batched_input_gradient_with_feature_matching_epilogue(hip, name, mathmo
     assert rel_err(one_pass, ref) < (3e-5 if mathmode == 0 else 2e-2)
 
 
+@pytest.mark.parametrize("reflect,masked", [(True, False), (False, True), (False, False)])
+def test_space_to_depth_turns_a_strided_conv_into_a_stride_one_conv(hip, reflect, masked):
+    """eben_space_to_depth: out[row][r][q] = xp[row][S q + r + off] (bit-exact gather, reflection / zeros beyond the signal, optional
+    lrelu' mask), and the stride-8 k-16 conv of EncBlock (eben_generator.py:251-254) == the two-tap stride-1 conv over the C*S
+    channels of `out` with the weights viewed (M, C, 2, 8) -> (M, C, 8, 2)."""
+    from vibravox_amd._lib import check, load, ptr, stream
+
+    lib = load()
+    b, c, m, length, s_, k, pad = 2, 6, 5, 203, 8, 16, 7 if reflect else 4
+    x = formula_tensor(f"s2d/x/{reflect}", (b, c, length))
+    mk = formula_tensor(f"s2d/m/{reflect}", (b, c, length))
+    w = formula_tensor(f"s2d/w/{reflect}", (m, c, k), 0.1)
+    l_out = (length + 2 * pad - k) // s_ + 1
+    l_q = l_out + k // s_ - 1
+    dev = torch.device("cuda")
+    xd, md = x.to(dev), mk.to(dev)
+    out = torch.empty((b, c * s_, l_q), dtype=torch.float32, device=dev)
+    check(lib.eben_space_to_depth(ptr(xd), ptr(md) if masked else None, 0.2, ptr(out), b * c, length, s_, -pad, l_q, 1 if reflect else 0,
+                                  stream()), "space_to_depth")
+    torch.cuda.synchronize()
+    src = x * torch.where(mk > 0, 1.0, 0.2) if masked else x
+    if reflect:
+        xp = torch.nn.functional.pad(src, (pad, pad), mode="reflect")
+        xp = torch.nn.functional.pad(xp, (0, max(0, s_ * l_q - xp.shape[-1])))
+    else:
+        xp = torch.nn.functional.pad(src, (pad, max(0, s_ * l_q - length - pad)))
+    ref = xp[..., :s_ * l_q].reshape(b, c, l_q, s_).permute(0, 1, 3, 2).reshape(b, c * s_, l_q)
+    got = out.cpu()
+    n_ok = (length + 2 * pad) // s_ if reflect else l_q   # reflect side: the positions inside the padded signal (all the conv reads)
+    assert torch.equal(got[..., :n_ok], ref[..., :n_ok])
+    # the conv identity (fp64 on the CPU)
+    y_ref = torch.nn.functional.conv1d(torch.nn.functional.pad(src.double(), (pad, pad), mode="reflect" if reflect else "constant"), w.double(), stride=s_)
+    w2 = w.double().view(m, c, k // s_, s_).permute(0, 1, 3, 2).reshape(m, c * s_, k // s_)
+    y_alt = torch.nn.functional.conv1d(got.double(), w2)
+    assert y_alt.shape == y_ref.shape and rel_err(y_alt, y_ref) < 1e-12
+
+
 def test_conv_bad_descriptor_raises(hip):
     from vibravox_amd import _lib, ops
 

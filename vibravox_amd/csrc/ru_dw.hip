@@ -84,9 +84,11 @@ __device__ __forceinline__ void rd_load8(const float* __restrict__ row, int p0, 
   }
 }
 
-template <int CT, int NP>
+template <int CT, int NP, int UN>
 __global__ __launch_bounds__(256) void ru_dw_kernel(const RuDwArgs P) {
   constexpr int C = 32 * CT;
+  // UN k-steps (16 UN positions) per iteration: every operand load of an iteration is in flight before its first MFMA, and the two
+  // 64-byte halves of each row's cache line are asked for together
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);     // 0: pointwise, 1..3: tap wv - 1
   const int i = __builtin_amdgcn_readfirstlane(blockIdx.x % CT);   // row tile
@@ -111,42 +113,49 @@ __global__ __launch_bounds__(256) void ru_dw_kernel(const RuDwArgs P) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
 
-  float av[8], uv[8], bv[CT][8];
+  float av[UN][8], uv[UN][8], bv[UN][CT][8];
   auto load = [&](int t) {
-    const int p = t + 8 * kh;
-    rd_load8<false>(arow, p, L, t_hi, av);
-    if (wv == 0) rd_load8<false>(urow, p, L, t_hi, uv);
 #pragma unroll
-    for (int c = 0; c < CT; ++c) {
-      if (wv == 0) rd_load8<false>(brow + (long long)c * 32 * L, p, L, L, bv[c]);
-      else rd_load8<true>(brow + (long long)c * 32 * L, p + shift, L, 0x7fffffff, bv[c]);
+    for (int un = 0; un < UN; ++un) {
+      const int p = t + 16 * un + 8 * kh;
+      rd_load8<false>(arow, p, L, t_hi, av[un]);
+      if (wv == 0) rd_load8<false>(urow, p, L, t_hi, uv[un]);
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        if (wv == 0) rd_load8<false>(brow + (long long)c * 32 * L, p, L, L, bv[un][c]);
+        else rd_load8<true>(brow + (long long)c * 32 * L, p + shift, L, 0x7fffffff, bv[un][c]);
+      }
     }
   };
 
   if (t_lo < t_hi) load(t_lo);
-  for (int t = t_lo; t < t_hi; t += 16) {
-    u32x4 ap[NP], bp[CT][NP];
-    {
+  for (int t = t_lo; t < t_hi; t += 16 * UN) {
+    u32x4 ap[UN][NP], bp[UN][CT][NP];
+#pragma unroll
+    for (int un = 0; un < UN; ++un) {
       float a[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) a[e] = wv == 0 ? av[e] * dlrelu(uv[e], P.out_slope) : av[e];
-      rd_split8<NP>(a, ap);
+      for (int e = 0; e < 8; ++e) a[e] = wv == 0 ? av[un][e] * dlrelu(uv[un][e], P.out_slope) : av[un][e];
+      rd_split8<NP>(a, ap[un]);
 #pragma unroll
       for (int c = 0; c < CT; ++c) {
         float bb[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) bb[e] = act_b ? lrelu(bv[c][e], P.in_slope) : bv[c][e];
-        rd_split8<NP>(bb, bp[c]);
+        for (int e = 0; e < 8; ++e) bb[e] = act_b ? lrelu(bv[un][c][e], P.in_slope) : bv[un][c][e];
+        rd_split8<NP>(bb, bp[un][c]);
       }
     }
-    if (t + 16 < t_hi) load(t + 16);   // the next k-step's loads fly under this one's MFMAs
+    if (t + 16 * UN < t_hi) load(t + 16 * UN);   // the next iteration's loads fly under this one's MFMAs
 #pragma unroll
-    for (int lvl = NP - 1; lvl >= 0; --lvl)
+    for (int un = 0; un < UN; ++un)
 #pragma unroll
-      for (int q = 0; q <= lvl; ++q)
+      for (int lvl = NP - 1; lvl >= 0; --lvl)
 #pragma unroll
-        for (int c = 0; c < CT; ++c)
-          acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ap[q]), __builtin_bit_cast(bf16x8, bp[c][lvl - q]), acc[c], 0, 0, 0);
+        for (int q = 0; q <= lvl; ++q)
+#pragma unroll
+          for (int c = 0; c < CT; ++c)
+            acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ap[un][q]), __builtin_bit_cast(bf16x8, bp[un][c][lvl - q]),
+                                                             acc[c], 0, 0, 0);
   }
 
   // ---- this block's rows of slab ks: D tile column = lane & 31 (input channel), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) ----
@@ -202,11 +211,14 @@ extern "C" int eben_ru_dw(int math, int batch, int channels, int length, int dil
   const long long nb = (long long)batch * a.nseg * CT;
   if (nb > 0x7fffffffLL) return fail(EBEN_EINVAL, "ru_dw grid too large");
   hipStream_t st = as_stream(stream);
-#define EBEN_RUDW(CTV, NPV) hipLaunchKernelGGL((ru_dw_kernel<CTV, NPV>), dim3((unsigned)nb), dim3(256), 0, st, a)
-  if (math == EBEN_MATH_BF16) {
-    switch (CT) { case 1: EBEN_RUDW(1, 1); break; case 2: EBEN_RUDW(2, 1); break; default: EBEN_RUDW(4, 1); }
+#define EBEN_RUDW(CTV, NPV, UNV) hipLaunchKernelGGL((ru_dw_kernel<CTV, NPV, UNV>), dim3((unsigned)nb), dim3(256), 0, st, a)
+  static const int un = getenv("EBEN_RUDW_UNROLL") ? atoi(getenv("EBEN_RUDW_UNROLL")) : 2;
+  if (math == EBEN_MATH_BF16 && un >= 2) {
+    switch (CT) { case 1: EBEN_RUDW(1, 1, 2); break; case 2: EBEN_RUDW(2, 1, 2); break; default: EBEN_RUDW(4, 1, 2); }
+  } else if (math == EBEN_MATH_BF16) {
+    switch (CT) { case 1: EBEN_RUDW(1, 1, 1); break; case 2: EBEN_RUDW(2, 1, 1); break; default: EBEN_RUDW(4, 1, 1); }
   } else {
-    switch (CT) { case 1: EBEN_RUDW(1, 3); break; case 2: EBEN_RUDW(2, 3); break; default: EBEN_RUDW(4, 3); }
+    switch (CT) { case 1: EBEN_RUDW(1, 3, 1); break; case 2: EBEN_RUDW(2, 3, 1); break; default: EBEN_RUDW(4, 3, 1); }
   }
 #undef EBEN_RUDW
   EBEN_CHECK_LAUNCH("ru_dw_kernel");
