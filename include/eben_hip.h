@@ -228,6 +228,14 @@ EBEN_API int eben_fir_interp_sum(const float* y, const float* w, float* x, int b
 /* ---- elementwise ------------------------------------------------------------------------ */
 EBEN_API int eben_lrelu_fwd(const float* x, float* y, size_t n, float slope, void* stream);
 EBEN_API int eben_lrelu_bwd(const float* dy, const float* x_or_y, float* dx, size_t n, float slope, void* stream);
+/* Grouped GEMM y[g] = W[g] (m x k) * x[g] (k x n), row-major with the n columns contiguous, fp32 in / out, products of split bf16
+ * operands on the bf16 MFMA (math: EBEN_MATH_BF16, EBEN_MATH_BF16X3 = hi + lo operands / three products, EBEN_MATH_BF16X6 = three
+ * pieces / six products, fp32-grade).  The windowed-DFT contractions of auraloss' STFT (torch.stft inside
+ * auraloss.freq.STFTLoss.stft, configs/lightning_module/loss_module/multi_stft.yaml:1-18) and their transposes in the backward:
+ * groups = 2 is the folded even / odd form.  w is packed once per basis (eben_gemm_pack -> eben_gemm_packed_floats floats). */
+EBEN_API size_t eben_gemm_packed_floats(int math, int groups, int m, int k);
+EBEN_API int eben_gemm_pack(int math, int groups, int m, int k, const float* w, float* wp, void* stream);
+EBEN_API int eben_gemm_fwd(int math, int groups, int m, int k, long long n, const float* x, const float* wp, float* y, void* stream);
 /* Space to depth along time: out[row][r][q] = xp[row][S*q + r + off] (r < S, q < Lq; xp = x continued by reflection or by zeros
  * beyond [0, L)), optionally times lrelu'(mask[row][.], mask_slope).  out: (rows, S, Lq).  Turns a stride-S Conv1d with
  * ksize = kq*S (EncBlock.conv, eben_generator.py:251-254) -- or the input gradient of the matching ConvTranspose1d (DecBlock,

@@ -760,6 +760,28 @@ def test_space_to_depth_turns_a_strided_conv_into_a_stride_one_conv(hip, reflect
     assert y_alt.shape == y_ref.shape and rel_err(y_alt, y_ref) < 1e-12
 
 
+@pytest.mark.parametrize("mathmode,tol", [(1, 2e-2), (3, 1e-4), (4, 3e-5)])
+@pytest.mark.parametrize("g,m,k,n", [(2, 257, 120, 1000), (2, 120, 257, 333), (1, 33, 16, 129), (2, 513, 300, 4100), (3, 31, 50, 64)])
+def test_grouped_gemm_on_split_bf16_operands(hip, g, m, k, n, mathmode, tol):
+    """eben_gemm_fwd (the folded windowed-DFT contraction of the MRSTFT loss and its transpose): y[g] = W[g] x[g] against fp64, in
+    the three operand splits; ragged M / K / N (tiles of 64 rows, 16 reduction rows, 128 columns)."""
+    from vibravox_amd._lib import check, load, ptr, stream
+
+    lib = load()
+    w = formula_tensor(f"gemm/w/{g}/{m}/{k}", (g * m, k), 1 / math.sqrt(k))
+    x = formula_tensor(f"gemm/x/{g}/{k}/{n}", (g * k, n))
+    dev = torch.device("cuda")
+    wd, xd = w.to(dev), x.to(dev)
+    wp = torch.empty(lib.eben_gemm_packed_floats(mathmode, g, m, k), dtype=torch.float32, device=dev)
+    check(lib.eben_gemm_pack(mathmode, g, m, k, ptr(wd), ptr(wp), stream()), "gemm_pack")
+    y = torch.full((g * m, n), float("nan"), dtype=torch.float32, device=dev)
+    check(lib.eben_gemm_fwd(mathmode, g, m, k, n, ptr(xd), ptr(wp), ptr(y), stream()), "gemm_fwd")
+    torch.cuda.synchronize()
+    ref = torch.bmm(w.double().view(g, m, k), x.double().view(g, k, n)).reshape(g * m, n)
+    assert rel_err(y, ref) < tol
+    assert lib.eben_gemm_fwd(0, g, m, k, n, ptr(xd), ptr(wp), ptr(y), stream()) != 0   # exact fp32 is not a mode of this kernel
+
+
 def test_conv_bad_descriptor_raises(hip):
     from vibravox_amd import _lib, ops
 

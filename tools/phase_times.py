@@ -6,6 +6,9 @@ import bench
 dev = torch.device("cuda", 0)
 mod = bench.build_module(dev, 1234)
 mod.disc_math = os.environ.get("EBEN_DISC_MATH", "bf16"); mod.gen_backward_math = os.environ.get("EBEN_GEN_BWD_MATH", mod.disc_math)
+if os.environ.get("NO_RECON", "0") == "1":   # the discriminator phases alone: how long the chains take with nothing beside them
+    mod.reconstructive_loss_freq_fn = None
+    mod.reconstructive_loss_temp_fn = None
 batch = bench.synthetic_batch(32, 32000, 1234, dev)
 for _ in range(3):
     mod.training_step(batch)

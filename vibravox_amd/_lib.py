@@ -119,6 +119,9 @@ SIGNATURES = {
     "eben_lrelu_fwd": (c_int, [_P, _P, c_size_t, c_float, _P]),
     "eben_lrelu_bwd": (c_int, [_P, _P, _P, c_size_t, c_float, _P]),
     "eben_space_to_depth": (c_int, [_P, _P, c_float, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "eben_gemm_packed_floats": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "eben_gemm_pack": (c_int, [c_int, c_int, c_int, c_int, _P, _P, _P]),
+    "eben_gemm_fwd": (c_int, [c_int, c_int, c_int, c_int, ctypes.c_longlong, _P, _P, _P, _P]),
     "eben_add": (c_int, [_P, _P, _P, c_size_t, _P]),
     "eben_axpby": (c_int, [_P, c_float, _P, c_float, _P, c_size_t, _P]),
     "eben_tanh_lift_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),

@@ -268,29 +268,44 @@ __global__ __launch_bounds__(256, NPW >= 2 ? 1 : 2) void tap3_kernel(const Tap3A
     if ((EBEN_T3_DBG & 1) == 0 && nch > 1) issue_w(1);
     const float* xp = P.x + xrow0;
     const float* mp = P.xmask + xrow0;
-    for (int base = 0; base < xtot; base += 2 * NT) {
-      float v[2][8], mk[IM ? 2 : 1][8];
-      int sl[2], ok[2], c0[2];
+    // two rounds of (2 units = 16 loads per thread) in flight: round r + 1 is asked for before round r is converted and written --
+    // a single-tile layer (every PQMF-band layer, the k = 1 STFT contractions) runs 3-5 such rounds back to back with nothing else
+    // of the block to hide them behind
+    struct Round { float v[2][8]; float mk[IM ? 2 : 1][8]; int sl[2], ok[2], c0[2]; };
+    auto pro_load = [&](int base, Round& R) {
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int i = base + tid + u * NT;
         const int bb = (int)__umulhi((unsigned)i, span_magic);
         const int r = i - bb * span;
-        const int qq = x_pos(i < xtot ? r : 0, ok[u]);
-        ok[u] &= (int)(i < xtot);
-        c0[u] = i < xtot ? bb * 8 : 0;
-        load8(xp, c0[u], qq, v[u]);
-        if constexpr (IM) load8(mp, c0[u], qq, mk[u]);
-        sl[u] = i < xtot ? x_slot(bb, r) : -1;
+        const int qq = x_pos(i < xtot ? r : 0, R.ok[u]);
+        R.ok[u] &= (int)(i < xtot);
+        R.c0[u] = i < xtot ? bb * 8 : 0;
+        load8(xp, R.c0[u], qq, R.v[u]);
+        if constexpr (IM) load8(mp, R.c0[u], qq, R.mk[u]);
+        R.sl[u] = i < xtot ? x_slot(bb, r) : -1;
       }
+    };
+    auto pro_store = [&](Round& R) {
 #pragma unroll
       for (int u = 0; u < 2; ++u)
-        if (sl[u] >= 0) {
+        if (R.sl[u] >= 0) {
           u32x4 pc[NPX];
-          cvt8(v[u], mk[IM ? u : 0], c0[u], ok[u], pc);
+          cvt8(R.v[u], R.mk[IM ? u : 0], R.c0[u], R.ok[u], pc);
 #pragma unroll
-          for (int q = 0; q < NPX; ++q) Xs[sl[u] + q * LO] = pc[q];
+          for (int q = 0; q < NPX; ++q) Xs[R.sl[u] + q * LO] = pc[q];
         }
+    };
+    Round ra, rb;
+    if (xtot > 0) pro_load(0, ra);
+    for (int base = 0; base < xtot; base += 4 * NT) {
+      const bool second = base + 2 * NT < xtot;
+      if (second) pro_load(base + 2 * NT, rb);
+      pro_store(ra);
+      if (second) {
+        if (base + 4 * NT < xtot) pro_load(base + 4 * NT, ra);
+        pro_store(rb);
+      }
     }
     if (P.ncc > 1) fetch_x(1);
   }

@@ -929,6 +929,23 @@ class StftPlan:
     #: channels (half the products, exact fp32); "bf16x3": the folded form with hi / lo bf16 operand splits on the bf16 MFMA
     math: str = "folded"
     folded: Optional[dict] = None   # math -> (spec_f, basis_f, spec_t, basis_t, cache_fwd, cache_bwd), built on first use
+    gemm: Optional[dict] = None     # (math, which) -> (basis address, packed image, basis) for the grouped GEMM kernel
+
+    def gemm_image(self, math: str, which: int, basis: torch.Tensor) -> torch.Tensor:
+        """Packed basis of the folded contraction for ``eben_gemm_fwd``: which = 0 the forward's (2 groups x bins x win/2), 1 its
+        transpose's (2 groups x win/2 x bins); built once per (math, basis storage) -- the bases are constants."""
+        if self.gemm is None:
+            self.gemm = {}
+        key = (math, which)
+        hit = self.gemm.get(key)
+        if hit is None or hit[0] != basis.data_ptr():
+            lib = load()
+            h, cmath = self.win // 2, _STFT_CONV_MATH[math]
+            m, k = (self.bins, h) if which == 0 else (h, self.bins)
+            wp = torch.empty(lib.eben_gemm_packed_floats(cmath, 2, m, k), dtype=torch.float32, device=basis.device)
+            check(lib.eben_gemm_pack(cmath, 2, m, k, ptr(basis), ptr(wp), stream()), "gemm_pack")
+            hit = self.gemm[key] = (basis.data_ptr(), wp, basis)
+        return hit[1]
 
     def folded_parts(self, math: str):
         """Weights of the folded pointwise convs (eben_stft_frames_folded): forward, 2 groups x (nsub*h -> bins) with
@@ -958,6 +975,10 @@ class StftPlan:
 #: StftPlan.math -> EBEN_MATH_* of the folded windowed-DFT contractions ("bf16x3": single bf16 operands over the concatenated
 #: [hi ; lo ; hi] x [W_hi ; W_hi ; W_lo] reduction; "folded_x3" / "folded_x6": the tap-conv's own split operands, tapconv3.hip)
 _STFT_CONV_MATH = {"bf16x3": MATH_BF16, "folded_x3": MATH_BF16X3, "folded_x6": MATH_BF16X6}
+
+
+#: the folded windowed-DFT contractions on the grouped GEMM kernel (pw_gemm.hip) instead of the pointwise tap-conv
+STFT_GEMM = os.environ.get("EBEN_STFT_GEMM", "1") != "0"
 
 
 class _MRSTFTFn(torch.autograd.Function):
@@ -998,10 +1019,14 @@ class _MRSTFTFn(torch.autograd.Function):
                 fr = torch.empty((1, spec_f.c_in, cols), dtype=torch.float32, device=x.device)
                 check(lib.eben_stft_frames_folded(ptr(sig), ptr(fr), 2 * rows, t, p.win, p.hop, p.pad, frames, 1 if math == "bf16x3" else 0, st),
                       "stft_frames_folded")
-            d2 = conv_desc(spec_f, 1, cols, cmath)
-            pw = pack_weights(spec_f, d2, basis_f, None, cache, False)
             spec = torch.empty((1, 2 * p.bins, cols), dtype=torch.float32, device=x.device)
-            check(lib.eben_conv1d_fwd(ctypes.byref(d2), ptr(fr), ptr(pw.wp_fwd), None, None, ptr(spec), st), "stft_fwd")
+            if STFT_GEMM and math in ("folded_x3", "folded_x6"):
+                # the folded contraction as what it is, a 2-group GEMM (pw_gemm.hip): no input tile, no staging pass per row tile
+                check(lib.eben_gemm_fwd(cmath, 2, p.bins, p.win // 2, cols, ptr(fr), ptr(p.gemm_image(math, 0, basis_f)), ptr(spec), st), "stft_fwd")
+            else:
+                d2 = conv_desc(spec_f, 1, cols, cmath)
+                pw = pack_weights(spec_f, d2, basis_f, None, cache, False)
+                check(lib.eben_conv1d_fwd(ctypes.byref(d2), ptr(fr), ptr(pw.wp_fwd), None, None, ptr(spec), st), "stft_fwd")
             sums = torch.empty((rows, 3), dtype=torch.float32, device=x.device)
             # y rows: same strides, column offset rows*frames
             ws_bytes = lib.eben_stft_loss_sums_workspace(rows)
@@ -1036,10 +1061,13 @@ class _MRSTFTFn(torch.autograd.Function):
                     dsplit = torch.empty((1, spec_t.c_in, xcols), dtype=torch.float32, device=gout.device)
                     check(lib.eben_split3(ptr(dspec), ptr(dsplit), 2, p.bins, xcols, st), "split3")
                     dspec = dsplit
-            d1 = conv_desc(spec_t, 1, xcols, cmath)
-            pw = pack_weights(spec_t, d1, basis_t, None, cache, False)
             dfr = torch.empty((1, spec_t.c_out, xcols), dtype=torch.float32, device=gout.device)
-            check(lib.eben_conv1d_fwd(ctypes.byref(d1), ptr(dspec), ptr(pw.wp_fwd), None, None, ptr(dfr), st), "stft_bwd_gemm")
+            if STFT_GEMM and math in ("folded_x3", "folded_x6"):
+                check(lib.eben_gemm_fwd(cmath, 2, p.win // 2, p.bins, xcols, ptr(dspec), ptr(p.gemm_image(math, 1, basis_t)), ptr(dfr), st), "stft_bwd_gemm")
+            else:
+                d1 = conv_desc(spec_t, 1, xcols, cmath)
+                pw = pack_weights(spec_t, d1, basis_t, None, cache, False)
+                check(lib.eben_conv1d_fwd(ctypes.byref(d1), ptr(dspec), ptr(pw.wp_fwd), None, None, ptr(dfr), st), "stft_bwd_gemm")
             if math == "dense":
                 check(lib.eben_overlap_add_ex(ptr(dfr), ptr(dsig), rows, t, p.win, frames, p.hop, p.pad, 1, 1 if i else 0, frames, xcols, st),
                       "overlap_add")
