@@ -265,6 +265,9 @@ EBEN_API int eben_fm_bwd(const void* const* ptrs, void* const* da_ptrs, const in
                 const float* gout, float inv_count, void* stream);
 /* hinge (losses/hinge_loss.py:35-43): out[i] = mean(relu(1 - target*x_i)) ; bwd adds nothing else */
 EBEN_API int eben_hinge_fwd(const float* x, size_t n, float target, float* out, void* stream);
+/* n <= 32 hinge terms in one launch: out[i] = mean(max(0, 1 - targets[i] * xs[i][.])) (the 3 targets x 4 sub-discriminators of one
+ * step, eben.py:99-128 through hinge_loss.py:35-43); the single-term kernel's summation order. */
+EBEN_API int eben_hinge_fwd_multi(const void* const* xs, const int64_t* numel, const float* targets, int n, float* out, void* stream);
 EBEN_API int eben_hinge_bwd(const float* x, size_t n, float target, const float* gout, float scale, float* dx, void* stream);
 /* STFT magnitude losses (auraloss.freq.STFTLoss as configured by multi_stft.yaml; call site
  * vibravox/lightning_modules/eben.py:195-198).  spec_* hold (rows, 2*bins_pad, frames) with re in

@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void reflect_pad_bwd_kernel(const float* __res
 // feature matching (feature_loss.py:37-50)
 // ---------------------------------------------------------------------------------------------
 constexpr int FM_MAX_PAIRS = 32;
-constexpr int FM_BLOCKS = 256;
+constexpr int FM_BLOCKS = 1024;
 struct FmTable {
   const float* a[FM_MAX_PAIRS];
   const float* b[FM_MAX_PAIRS];
@@ -249,6 +249,21 @@ __global__ __launch_bounds__(256) void hinge_fwd_kernel(const float* __restrict_
   for (size_t i = threadIdx.x; i < n; i += 256) s += fmaxf(1.f - target * x[i], 0.f);
   s = block_sum_256(s, red);
   if (threadIdx.x == 0) out[0] = s / (float)n;
+}
+// several hinge terms in one launch (the engine's 12 per step: 3 targets x 4 sub-discriminators): block i = term i, the
+// single-term kernel's summation order (same bits)
+constexpr int HINGE_MULTI = 32;
+struct HingeTable { const float* x[HINGE_MULTI]; long long n[HINGE_MULTI]; float target[HINGE_MULTI]; };
+__global__ __launch_bounds__(256) void hinge_fwd_multi_kernel(const HingeTable T, float* __restrict__ out) {
+  __shared__ float red[4];
+  const int k = blockIdx.x;
+  const float* __restrict__ x = T.x[k];
+  const size_t n = (size_t)T.n[k];
+  const float target = T.target[k];
+  float s = 0.f;
+  for (size_t i = threadIdx.x; i < n; i += 256) s += fmaxf(1.f - target * x[i], 0.f);
+  s = block_sum_256(s, red);
+  if (threadIdx.x == 0) out[k] = s / (float)n;
 }
 __global__ __launch_bounds__(256) void hinge_bwd_kernel(const float* __restrict__ x, size_t n, float target,
                                                         const float* __restrict__ gout, float scale, float* __restrict__ dx) {
@@ -635,6 +650,17 @@ extern "C" int eben_hinge_fwd(const float* x, size_t n, float target, float* out
   EBEN_REQUIRE(x && out && n > 0, "bad hinge arguments");
   hipLaunchKernelGGL(hinge_fwd_kernel, dim3(1), dim3(256), 0, as_stream(stream), x, n, target, out);
   EBEN_CHECK_LAUNCH("hinge_fwd_kernel");
+  return EBEN_OK;
+}
+extern "C" int eben_hinge_fwd_multi(const void* const* xs, const int64_t* numel, const float* targets, int n, float* out, void* stream) {
+  EBEN_REQUIRE(xs && numel && targets && out && n > 0 && n <= HINGE_MULTI, "hinge_fwd_multi: 1..%d terms", HINGE_MULTI);
+  HingeTable T;
+  for (int i = 0; i < n; ++i) {
+    EBEN_REQUIRE(xs[i] && numel[i] > 0, "hinge_fwd_multi: empty term %d", i);
+    T.x[i] = static_cast<const float*>(xs[i]); T.n[i] = numel[i]; T.target[i] = targets[i];
+  }
+  hipLaunchKernelGGL(hinge_fwd_multi_kernel, dim3(n), dim3(256), 0, as_stream(stream), T, out);
+  EBEN_CHECK_LAUNCH("hinge_fwd_multi_kernel");
   return EBEN_OK;
 }
 extern "C" int eben_hinge_bwd(const float* x, size_t n, float target, const float* gout, float scale, float* dx, void* stream) {

@@ -505,10 +505,14 @@ class DiscriminatorEngine:
         s.update(fm_a=a, fm_b=b, fm_sums=sums, fm_inv=inv, fm_numel=numel, fm_ptrs=ptrs)
         out = {"feature_matching_loss": (sums[0::2] / sums[1::2]).sum() * inv}
         hinge = torch.empty(3 * len(emb), dtype=torch.float32, device=dev)
-        for i, scale in enumerate(emb):
-            lg = scale[-1]
-            for k, (rows, target) in enumerate(((lg[:half], 1.0), (lg[:half], -1.0), (lg[half:], 1.0))):
-                check(lib.eben_hinge_fwd(ptr(rows), rows.numel(), target, ptr(hinge[3 * i + k:]), _stream()), "hinge_fwd")
+        terms = [(rows, target) for scale in emb for rows, target in ((scale[-1][:half], 1.0), (scale[-1][:half], -1.0), (scale[-1][half:], 1.0))]
+        nt = len(terms)
+        if nt <= 32:   # one launch for all of them (this phase runs alone on the GPU: every launch is on the step's critical path)
+            check(lib.eben_hinge_fwd_multi((ctypes.c_void_p * nt)(*[ptr(r) for r, _ in terms]), (ctypes.c_int64 * nt)(*[r.numel() for r, _ in terms]),
+                                           (ctypes.c_float * nt)(*[t for _, t in terms]), nt, ptr(hinge), _stream()), "hinge_fwd_multi")
+        else:
+            for k, (rows, target) in enumerate(terms):
+                check(lib.eben_hinge_fwd(ptr(rows), rows.numel(), target, ptr(hinge[k:]), _stream()), "hinge_fwd")
         hv = hinge.reshape(len(emb), 3).sum(dim=0) / len(emb)
         out["adv_loss_gen"], out["fake_loss"], out["real_loss"] = hv[0], hv[1], hv[2]
         return out
