@@ -265,6 +265,14 @@ EBEN_API int eben_fm_bwd(const void* const* ptrs, void* const* da_ptrs, const in
                 const float* gout, float inv_count, void* stream);
 /* hinge (losses/hinge_loss.py:35-43): out[i] = mean(relu(1 - target*x_i)) ; bwd adds nothing else */
 EBEN_API int eben_hinge_fwd(const float* x, size_t n, float target, float* out, void* stream);
+/* Dynamic loss balancing of the generator step (vibravox/lightning_modules/eben.py:222-240), the scalar part in one launch:
+ * old[i] = init ? *norms[i] : old[i];  if (ema) old[i] = beta * old[i] + one_minus_beta * *norms[i];
+ * lambdas[i] = clamp(1 / (old[i] + 1e-4), 0, 1e4);  backprop[0] = sum_i *losses[i] * lambdas[i]   (torch's operation order and
+ * roundings; norms / losses: n <= 8 device scalars), and the lambda-weighted sum of n tensors out = sum_i weights[i] * tensors[i]
+ * (weights on the device) that seeds the generator backward. */
+EBEN_API int eben_balance(const void* const* norms, const void* const* losses, int n, float* old, int init, int ema, float beta,
+                 float one_minus_beta, float* lambdas, float* backprop, void* stream);
+EBEN_API int eben_weighted_sum(const void* const* tensors, const float* weights, int n, size_t numel, float* out, void* stream);
 /* n <= 32 hinge terms in one launch: out[i] = mean(max(0, 1 - targets[i] * xs[i][.])) (the 3 targets x 4 sub-discriminators of one
  * step, eben.py:99-128 through hinge_loss.py:35-43); the single-term kernel's summation order. */
 EBEN_API int eben_hinge_fwd_multi(const void* const* xs, const int64_t* numel, const float* targets, int n, float* out, void* stream);

@@ -782,6 +782,46 @@ def test_grouped_gemm_on_split_bf16_operands(hip, g, m, k, n, mathmode, tol):
     assert lib.eben_gemm_fwd(0, g, m, k, n, ptr(xd), ptr(wp), ptr(y), stream()) != 0   # exact fp32 is not a mode of this kernel
 
 
+@pytest.mark.parametrize("mode,first", [("ema", True), ("ema", False), ("simple", False)])
+def test_fused_balancing_matches_the_torch_arithmetic_bit_for_bit(hip, mode, first):
+    """eben_balance + eben_weighted_sum == the one-element torch kernels of EBENLightningModule._update_lambdas and the weighted seed
+    (eben.py:229-240): EMA with the first-call quirk, clamp(1 / (ema + 1e-4), 0, 1e4), sum loss_i lambda_i, sum s_i lambda_i."""
+    import ctypes
+
+    from vibravox_amd import ops
+    from vibravox_amd._lib import check, load, ptr, stream
+
+    lib = load()
+    dev = torch.device("cuda")
+    n, beta = 3, 0.9
+    norms = [formula_tensor(f"bal/n/{mode}/{i}", (1,), 1.0).abs().reshape(()).to(dev) * (10.0 ** (i - 1)) + 1e-3 for i in range(n)]
+    norms[2] = norms[2] * 0 + 3e-5   # lambda = 1 / 1.3e-4 = 7692: below the clamp; and one above it
+    losses = [formula_tensor(f"bal/l/{mode}/{i}", (1,), 1.0).reshape(()).to(dev) for i in range(n)]
+    old0 = [formula_tensor(f"bal/o/{mode}/{i}", (1,), 1.0).abs().reshape(()).to(dev) + 0.5 for i in range(n)]
+    seeds = [formula_tensor(f"bal/s/{mode}/{i}", (2, 4, 1003)).to(dev) for i in range(n)]
+    # torch, as _update_lambdas writes it
+    old = list(norms) if (first or mode == "simple") else list(old0)
+    if mode == "ema":
+        old = [beta * o + (1 - beta) * nv for o, nv in zip(old, norms)]
+    lam = [torch.clamp(1 / (o + 1e-4), min=0.0, max=1e4) for o in old]
+    bp = sum(l * w for l, w in zip(losses, lam))
+    seed = None
+    for s_, w in zip(seeds, lam):
+        seed = s_ * w if seed is None else seed + s_ * w
+    # fused
+    state = torch.stack(old0).contiguous()
+    out = torch.empty(n + 1, dtype=torch.float32, device=dev)
+    check(lib.eben_balance((ctypes.c_void_p * n)(*[ptr(t) for t in norms]), (ctypes.c_void_p * n)(*[ptr(t) for t in losses]), n, ptr(state),
+                           1 if (first or mode == "simple") else 0, 1 if mode == "ema" else 0, beta, 1 - beta, ptr(out), ptr(out[n:]), stream()),
+          "balance")
+    got_seed = ops.weighted_sum(seeds, out[:n])
+    torch.cuda.synchronize()
+    assert torch.equal(state, torch.stack(old))
+    assert torch.equal(out[:n], torch.stack(lam))
+    assert torch.equal(out[n], bp)
+    assert torch.equal(got_seed, seed)
+
+
 def test_conv_bad_descriptor_raises(hip):
     from vibravox_amd import _lib, ops
 

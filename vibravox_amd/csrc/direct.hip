@@ -652,6 +652,66 @@ extern "C" int eben_hinge_fwd(const float* x, size_t n, float target, float* out
   EBEN_CHECK_LAUNCH("hinge_fwd_kernel");
   return EBEN_OK;
 }
+// ---------------------------------------------------------------------------------------------
+// Dynamic loss balancing (eben.py:222-240 as restated by EBENLightningModule._update_lambdas): the scalar arithmetic of a step --
+// EMA of the gradient norms (initialised with the first norms, the update applied on that same call), lambda = clamp(1 / (ema +
+// 1e-4), 0, 1e4), backprop loss = sum loss_i lambda_i -- and the lambda-weighted sum of the seeds, as two launches instead of ~35
+// one-element torch kernels on the main stream in front of the generator backward.  Operation by operation torch's order and
+// roundings (no contraction).
+// ---------------------------------------------------------------------------------------------
+// one rounding per product / sum, whatever -ffp-contract says (the pragma does not reach through the grid-stride macro's loop body)
+__device__ __forceinline__ float bal_mul(float a, float b) { float r; asm volatile("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float bal_add(float a, float b) { float r; asm volatile("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+constexpr int BAL_MAX = 8;
+struct BalTable { const float* norm[BAL_MAX]; const float* loss[BAL_MAX]; };
+__global__ void balance_kernel(const BalTable T, float* __restrict__ old, int n, int init, int ema, float beta, float one_minus_beta,
+                               float* __restrict__ lambdas, float* __restrict__ backprop) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float bp = 0.f;
+  for (int i = 0; i < n; ++i) {
+    const float nv = *T.norm[i];
+    float o = init ? nv : old[i];
+    if (ema) o = bal_add(bal_mul(beta, o), bal_mul(one_minus_beta, nv));
+    old[i] = o;
+    const float r = __fdiv_rn(1.f, bal_add(o, 1e-4f));
+    const float lam = r != r ? r : fminf(fmaxf(r, 0.f), 1e4f);   // torch.clamp keeps a NaN
+    lambdas[i] = lam;
+    const float term = bal_mul(*T.loss[i], lam);
+    bp = i == 0 ? term : bal_add(bp, term);
+  }
+  backprop[0] = bp;
+}
+struct WsumTable { const float* t[BAL_MAX]; };
+__global__ __launch_bounds__(256) void weighted_sum_kernel(const WsumTable T, const float* __restrict__ w, int n, size_t numel, float* __restrict__ out) {
+  float wv[BAL_MAX];
+#pragma unroll
+  for (int i = 0; i < BAL_MAX; ++i) wv[i] = i < n ? w[i] : 0.f;
+  EBEN_GRID_STRIDE(j, numel) {
+    float acc = bal_mul(T.t[0][j], wv[0]);
+    for (int i = 1; i < n; ++i) acc = bal_add(acc, bal_mul(T.t[i][j], wv[i]));
+    out[j] = acc;
+  }
+}
+extern "C" int eben_balance(const void* const* norms, const void* const* losses, int n, float* old, int init, int ema, float beta,
+                            float one_minus_beta, float* lambdas, float* backprop, void* stream) {
+  EBEN_REQUIRE(norms && losses && old && lambdas && backprop && n > 0 && n <= BAL_MAX, "balance: 1..%d losses", BAL_MAX);
+  BalTable T;
+  for (int i = 0; i < n; ++i) {
+    EBEN_REQUIRE(norms[i] && losses[i], "balance: null term %d", i);
+    T.norm[i] = static_cast<const float*>(norms[i]); T.loss[i] = static_cast<const float*>(losses[i]);
+  }
+  hipLaunchKernelGGL(balance_kernel, dim3(1), dim3(64), 0, as_stream(stream), T, old, n, init, ema, beta, one_minus_beta, lambdas, backprop);
+  EBEN_CHECK_LAUNCH("balance_kernel");
+  return EBEN_OK;
+}
+extern "C" int eben_weighted_sum(const void* const* tensors, const float* weights, int n, size_t numel, float* out, void* stream) {
+  EBEN_REQUIRE(tensors && weights && out && n > 0 && n <= BAL_MAX && numel > 0, "weighted_sum: 1..%d tensors", BAL_MAX);
+  WsumTable T;
+  for (int i = 0; i < n; ++i) { EBEN_REQUIRE(tensors[i], "weighted_sum: null tensor %d", i); T.t[i] = static_cast<const float*>(tensors[i]); }
+  hipLaunchKernelGGL(weighted_sum_kernel, dim3(grid_for(numel)), dim3(256), 0, as_stream(stream), T, weights, n, numel, out);
+  EBEN_CHECK_LAUNCH("weighted_sum_kernel");
+  return EBEN_OK;
+}
 extern "C" int eben_hinge_fwd_multi(const void* const* xs, const int64_t* numel, const float* targets, int n, float* out, void* stream) {
   EBEN_REQUIRE(xs && numel && targets && out && n > 0 && n <= HINGE_MULTI, "hinge_fwd_multi: 1..%d terms", HINGE_MULTI);
   HingeTable T;

@@ -507,7 +507,7 @@ class DiscriminatorEngine:
         hinge = torch.empty(3 * len(emb), dtype=torch.float32, device=dev)
         terms = [(rows, target) for scale in emb for rows, target in ((scale[-1][:half], 1.0), (scale[-1][:half], -1.0), (scale[-1][half:], 1.0))]
         nt = len(terms)
-        if nt <= 32:   # one launch for all of them (this phase runs alone on the GPU: every launch is on the step's critical path)
+        if nt <= 32 and os.environ.get("EBEN_HINGE_MULTI", "1") != "0":   # one launch for all of them (this phase runs alone on the GPU: every launch is on the step's critical path)
             check(lib.eben_hinge_fwd_multi((ctypes.c_void_p * nt)(*[ptr(r) for r, _ in terms]), (ctypes.c_int64 * nt)(*[r.numel() for r, _ in terms]),
                                            (ctypes.c_float * nt)(*[t for _, t in terms]), nt, ptr(hinge), _stream()), "hinge_fwd_multi")
         else:

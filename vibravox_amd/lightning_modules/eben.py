@@ -254,13 +254,18 @@ class EBENLightningModule(BaseSELightningModule):
                 seeds.append(adv_b + torch.autograd.grad(enhanced_speech, bands, grad_outputs=adv_a, retain_graph=True)[0])
             else:
                 seeds.append(own[key])
-        atomic_norms = [torch.norm(torch.autograd.grad(bands, leaf, grad_outputs=s, retain_graph=True)[0]).detach() for s in seeds]
-        lambdas = self._update_lambdas(atomic_norms)
-        backprop_loss_generator = sum(loss.detach() * lam for loss, lam in zip(losses.values(), lambdas))
+        with ops.input_grads_disabled():   # only last_conv's weight gradient is wanted: its input gradient would be computed and dropped
+            atomic_norms = [torch.norm(torch.autograd.grad(bands, leaf, grad_outputs=s, retain_graph=True)[0]).detach() for s in seeds]
+        if self.fused_balancing and len(seeds) <= 8 and atomic_norms[0].is_cuda:
+            lambdas, backprop_loss_generator = self._update_lambdas_fused(atomic_norms, [loss.detach() for loss in losses.values()])
+            seed = ops.weighted_sum(seeds, self._bal["lam"])
+        else:
+            lambdas = self._update_lambdas(atomic_norms)
+            backprop_loss_generator = sum(loss.detach() * lam for loss, lam in zip(losses.values(), lambdas))
+            seed = None
+            for s, lam in zip(seeds, lambdas):
+                seed = s * lam if seed is None else seed + s * lam
         self.log("train/generator/backprop_loss", backprop_loss_generator, sync_dist=True)
-        seed = None
-        for s, lam in zip(seeds, lambdas):
-            seed = s * lam if seed is None else seed + s * lam
         self._mark("balancing (3 seeds + norms)")
         with ops.weight_grads_on_side_stream(sink=g_sink) as side:   # dX chain on this stream, dW work beside it
             torch.autograd.backward(bands, seed, inputs=g_params)
@@ -466,6 +471,36 @@ class EBENLightningModule(BaseSELightningModule):
         lambdas = [torch.clamp(1 / (norm + 1e-4), min=0.0, max=1e4) for norm in self.atomic_norms_old]
         self.last_norms, self.last_lambdas = atomic_norms, lambdas
         return lambdas
+
+    #: the engine step's balancing arithmetic (EMA, lambdas, backprop loss, weighted seed) as two launches (`eben_balance`,
+    #: `eben_weighted_sum`) instead of ~35 one-element torch kernels in front of the generator backward; same values bit for bit
+    fused_balancing: bool = os.environ.get("EBEN_FUSED_BALANCING", "1") != "0"
+
+    def _update_lambdas_fused(self, atomic_norms, losses):
+        """``_update_lambdas`` + the backprop loss on the device in one launch; the state stays readable as ``atomic_norms_old``."""
+        import ctypes
+
+        from .._lib import check, load, ptr, stream
+
+        n = len(atomic_norms)
+        dev = atomic_norms[0].device
+        bal = getattr(self, "_bal", None)
+        if bal is None or bal["n"] != n or bal["old"].device != dev:
+            bal = self._bal = {"n": n, "old": torch.zeros(n, dtype=torch.float32, device=dev), "lam": None}
+            if self.atomic_norms_old is not None:   # state built by another step path: carry it over
+                bal["old"].copy_(torch.stack([t.to(dev).reshape(()) for t in self.atomic_norms_old]))
+        init = self.atomic_norms_old is None or self.dynamic_loss_balancing == "simple"
+        out = torch.empty(n + 1, dtype=torch.float32, device=dev)   # fresh per step: last_lambdas of earlier steps stay what they were
+        norms = [t.contiguous() for t in atomic_norms]
+        ls = [t.to(torch.float32).contiguous() for t in losses]
+        check(load().eben_balance((ctypes.c_void_p * n)(*[ptr(t) for t in norms]), (ctypes.c_void_p * n)(*[ptr(t) for t in ls]), n,
+                                  ptr(bal["old"]), 1 if init else 0, 1 if self.dynamic_loss_balancing == "ema" else 0, float(self.beta_ema),
+                                  float(1 - self.beta_ema), ptr(out), ptr(out[n:]), stream()), "balance")
+        bal["lam"] = out[:n]
+        self.atomic_norms_old = [bal["old"][i] for i in range(n)]
+        lambdas = [out[i] for i in range(n)]
+        self.last_norms, self.last_lambdas = atomic_norms, lambdas
+        return lambdas, out[n]
 
     def dynamically_balance_losses(self, atomic_losses: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
         """eben.py:222-240: one partial backward per loss down to the last generator layer, then ``_update_lambdas``."""

@@ -39,6 +39,20 @@ def bump_weights_epoch(params=None) -> None:
 _skip_weight_grads = [False]
 
 
+# Set while a backward pass only needs WEIGHT gradients (the balancing norms: torch.autograd.grad(bands, last_conv.weight)): the
+# Function cannot know that its input gradient is discarded either.
+_skip_input_grads = [False]
+
+
+class input_grads_disabled:
+    def __enter__(self):
+        self.prev = _skip_input_grads[0]
+        _skip_input_grads[0] = True
+
+    def __exit__(self, *exc):
+        _skip_input_grads[0] = self.prev
+
+
 class weight_grads_disabled:
     def __enter__(self):
         self.prev = _skip_weight_grads[0]
@@ -656,7 +670,7 @@ class _ConvLayerFn(torch.autograd.Function):
         dy = dy.contiguous()
         st = stream()
         dx = dv = dg = dbias = None
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] and not _skip_input_grads[0]:
             ws_bytes = lib.eben_conv1d_bwd_dx_workspace(ctypes.byref(d))
             ws = _empty(ws_bytes, x) if ws_bytes else None
             dx = torch.empty_like(x)
@@ -879,6 +893,14 @@ class _FeatureLossFn(torch.autograd.Function):
         check(lib.eben_fm_bwd(_ptr_array(inter), _ptr_array(da), (ctypes.c_int64 * n)(*[t.numel() for t in a]), n, ptr(sums),
                               ptr(gout), ctx.inv_count, stream()), "fm_bwd")
         return (None, None, *da, *([None] * n))
+
+
+def weighted_sum(tensors: Sequence[torch.Tensor], weights: torch.Tensor) -> torch.Tensor:
+    """sum_i weights[i] * tensors[i] (weights: device vector), torch's order and roundings, one launch (``eben_weighted_sum``)."""
+    ts = [t.contiguous() for t in tensors]
+    out = torch.empty_like(ts[0])
+    check(load().eben_weighted_sum(_ptr_array(ts), ptr(weights), len(ts), out.numel(), ptr(out), stream()), "weighted_sum")
+    return out
 
 
 def feature_loss(emb_a: List[List[torch.Tensor]], emb_b: List[List[torch.Tensor]]) -> torch.Tensor:
