@@ -273,6 +273,13 @@ EBEN_API int eben_hinge_fwd(const float* x, size_t n, float target, float* out, 
 EBEN_API int eben_balance(const void* const* norms, const void* const* losses, int n, float* old, int init, int ema, float beta,
                  float one_minus_beta, float* lambdas, float* backprop, void* stream);
 EBEN_API int eben_weighted_sum(const void* const* tensors, const float* weights, int n, size_t numel, float* out, void* stream);
+/* The four discriminator-side loss values of a step from their partial results, one launch: out[0] = inv_count * sum_p s1_p / s2_p
+ * (feature_loss.py:37-50, (s1, s2) pairs of eben_fm_sums), out[1 + k] = mean over the sub-discriminators of hinge[3 i + k]
+ * (eben.py:99-128: generator-side adversarial, fake, real). */
+EBEN_API int eben_disc_losses(const float* fm_sums, int npairs, float inv_count, const float* hinge, int nchains, float* out, void* stream);
+/* The MRSTFT loss value from the per-row sums of eben_stft_loss_sums_ex of n <= 8 resolutions (auraloss MultiResolutionSTFTLoss:
+ * mean over resolutions of  mean_r sqrt(s0 / s1) + sum_r s2 * inv_counts[i],  inv_counts[i] = 1 / (rows bins_i frames_i)). */
+EBEN_API int eben_stft_loss_total(const void* const* sums, const float* inv_counts, int n, int rows, float* out, void* stream);
 /* n <= 32 hinge terms in one launch: out[i] = mean(max(0, 1 - targets[i] * xs[i][.])) (the 3 targets x 4 sub-discriminators of one
  * step, eben.py:99-128 through hinge_loss.py:35-43); the single-term kernel's summation order. */
 EBEN_API int eben_hinge_fwd_multi(const void* const* xs, const int64_t* numel, const float* targets, int n, float* out, void* stream);

@@ -331,6 +331,27 @@ __global__ __launch_bounds__(64) void stft_sums_final_kernel(const float* __rest
   }
 }
 
+// The loss value from the per-row sums of all resolutions in one launch (auraloss: per resolution mean_r sqrt(s0 / s1) [spectral
+// convergence] + sum_r s2 / (rows bins frames) [log magnitude], then the mean over the resolutions): ~8 one-element torch kernels
+// per resolution otherwise, on the main stream.  One wave; fixed reduction order.
+constexpr int STFT_TOTAL_MAX = 8;
+struct StftTotalTable { const float* sums[STFT_TOTAL_MAX]; float inv_count[STFT_TOTAL_MAX]; };
+__global__ __launch_bounds__(64) void stft_total_kernel(const StftTotalTable T, int n, int rows, float* __restrict__ out) {
+  const int lane = threadIdx.x;
+  float total = 0.f;
+  for (int p = 0; p < n; ++p) {
+    float sc = 0.f, lg = 0.f;
+    for (int r = lane; r < rows; r += 64) {
+      sc += sqrtf(T.sums[p][3 * r] / T.sums[p][3 * r + 1]);
+      lg += T.sums[p][3 * r + 2];
+    }
+    sc = wave_sum(sc);
+    lg = wave_sum(lg);
+    total += sc / (float)rows + lg * T.inv_count[p];
+  }
+  if (lane == 0) out[0] = total / (float)n;
+}
+
 __global__ __launch_bounds__(256) void stft_bwd_kernel(const float* __restrict__ sx, const float* __restrict__ sy, int rows, int bins,
                                                        StftLayout L, StftLayout LO, int frames, float eps, const float* __restrict__ sums,
                                                        const float* __restrict__ gout, float scale, float* __restrict__ dsx) {
@@ -712,6 +733,27 @@ extern "C" int eben_weighted_sum(const void* const* tensors, const float* weight
   EBEN_CHECK_LAUNCH("weighted_sum_kernel");
   return EBEN_OK;
 }
+// feature-matching value and the three hinge means of a step from the per-pair sums / per-term hinges, one launch:
+//   out[0] = inv_count * sum_p s1_p / s2_p;   out[1 + k] = (1 / nchains) sum_i hinge[3 i + k]
+__global__ __launch_bounds__(64) void disc_losses_kernel(const float* __restrict__ fm_sums, int npairs, float inv_count, const float* __restrict__ hinge,
+                                                         int nchains, float* __restrict__ out) {
+  const int lane = threadIdx.x;
+  float f = 0.f;
+  for (int p = lane; p < npairs; p += 64) f += fm_sums[2 * p] / fm_sums[2 * p + 1];
+  f = wave_sum(f);
+  if (lane == 0) out[0] = f * inv_count;
+  if (lane < 3) {
+    float h = 0.f;
+    for (int i = 0; i < nchains; ++i) h += hinge[3 * i + lane];
+    out[1 + lane] = h / (float)nchains;
+  }
+}
+extern "C" int eben_disc_losses(const float* fm_sums, int npairs, float inv_count, const float* hinge, int nchains, float* out, void* stream) {
+  EBEN_REQUIRE(fm_sums && hinge && out && npairs > 0 && nchains > 0, "bad disc_losses arguments");
+  hipLaunchKernelGGL(disc_losses_kernel, dim3(1), dim3(64), 0, as_stream(stream), fm_sums, npairs, inv_count, hinge, nchains, out);
+  EBEN_CHECK_LAUNCH("disc_losses_kernel");
+  return EBEN_OK;
+}
 extern "C" int eben_hinge_fwd_multi(const void* const* xs, const int64_t* numel, const float* targets, int n, float* out, void* stream) {
   EBEN_REQUIRE(xs && numel && targets && out && n > 0 && n <= HINGE_MULTI, "hinge_fwd_multi: 1..%d terms", HINGE_MULTI);
   HingeTable T;
@@ -753,6 +795,17 @@ extern "C" int eben_stft_loss_sums_ex(const float* spec_x, const float* spec_y, 
   EBEN_CHECK_LAUNCH("stft_sums_kernel");
   hipLaunchKernelGGL(stft_sums_final_kernel, dim3(rows), dim3(64), 0, as_stream(stream), partial_ws, out);
   EBEN_CHECK_LAUNCH("stft_sums_final_kernel");
+  return EBEN_OK;
+}
+extern "C" int eben_stft_loss_total(const void* const* sums, const float* inv_counts, int n, int rows, float* out, void* stream) {
+  EBEN_REQUIRE(sums && inv_counts && out && n > 0 && n <= STFT_TOTAL_MAX && rows > 0, "stft_loss_total: 1..%d resolutions", STFT_TOTAL_MAX);
+  StftTotalTable T;
+  for (int i = 0; i < n; ++i) {
+    EBEN_REQUIRE(sums[i], "stft_loss_total: null sums %d", i);
+    T.sums[i] = static_cast<const float*>(sums[i]); T.inv_count[i] = inv_counts[i];
+  }
+  hipLaunchKernelGGL(stft_total_kernel, dim3(1), dim3(64), 0, as_stream(stream), T, n, rows, out);
+  EBEN_CHECK_LAUNCH("stft_total_kernel");
   return EBEN_OK;
 }
 extern "C" int eben_stft_loss_sums(const float* spec_x, const float* spec_y, int rows, int bins, int bins_pad, int frames,

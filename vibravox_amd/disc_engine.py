@@ -503,7 +503,6 @@ class DiscriminatorEngine:
         check(lib.eben_fm_sums(ptrs, numel, n, ptr(ws), ws_bytes, ptr(sums), _stream()), "fm_sums")
         inv = 1.0 / (len(emb) * len(emb[-1][1:-1]))
         s.update(fm_a=a, fm_b=b, fm_sums=sums, fm_inv=inv, fm_numel=numel, fm_ptrs=ptrs)
-        out = {"feature_matching_loss": (sums[0::2] / sums[1::2]).sum() * inv}
         hinge = torch.empty(3 * len(emb), dtype=torch.float32, device=dev)
         terms = [(rows, target) for scale in emb for rows, target in ((scale[-1][:half], 1.0), (scale[-1][:half], -1.0), (scale[-1][half:], 1.0))]
         nt = len(terms)
@@ -513,9 +512,12 @@ class DiscriminatorEngine:
         else:
             for k, (rows, target) in enumerate(terms):
                 check(lib.eben_hinge_fwd(ptr(rows), rows.numel(), target, ptr(hinge[k:]), _stream()), "hinge_fwd")
-        hv = hinge.reshape(len(emb), 3).sum(dim=0) / len(emb)
-        out["adv_loss_gen"], out["fake_loss"], out["real_loss"] = hv[0], hv[1], hv[2]
-        return out
+        if not ops.FUSED_LOSS_GLUE:
+            hv = hinge.reshape(len(emb), 3).sum(dim=0) / len(emb)
+            return {"feature_matching_loss": (sums[0::2] / sums[1::2]).sum() * inv, "adv_loss_gen": hv[0], "fake_loss": hv[1], "real_loss": hv[2]}
+        vals = torch.empty(4, dtype=torch.float32, device=dev)
+        check(lib.eben_disc_losses(ptr(sums), n, inv, ptr(hinge), len(emb), ptr(vals), _stream()), "disc_losses")
+        return {"feature_matching_loss": vals[0], "adv_loss_gen": vals[1], "fake_loss": vals[2], "real_loss": vals[3]}
 
     # ---- the four backwards as one stacked pass ------------------------------------------------------
     def backward(self, want_param_grads: bool = True, sink=None):

@@ -999,6 +999,8 @@ class StftPlan:
 _STFT_CONV_MATH = {"bf16x3": MATH_BF16, "folded_x3": MATH_BF16X3, "folded_x6": MATH_BF16X6}
 
 
+#: loss values from their partial sums by one launch each (eben_stft_loss_total, eben_disc_losses) instead of one-element torch kernels
+FUSED_LOSS_GLUE = os.environ.get("EBEN_FUSED_LOSS_GLUE", "1") != "0"
 #: the folded windowed-DFT contractions on the grouped GEMM kernel (pw_gemm.hip) instead of the pointwise tap-conv
 STFT_GEMM = os.environ.get("EBEN_STFT_GEMM", "1") != "0"
 
@@ -1054,11 +1056,19 @@ class _MRSTFTFn(torch.autograd.Function):
             ws_bytes = lib.eben_stft_loss_sums_workspace(rows)
             check(lib.eben_stft_loss_sums_ex(ptr(spec), ptr(spec) + 4 * rows * frames, rows, p.bins, frames, frames, cols, p.bins * cols, eps,
                                              ptr(_empty(ws_bytes, x)), ws_bytes, ptr(sums), st), "stft_loss_sums")
-            term = torch.sqrt(sums[:, 0] / sums[:, 1]).mean() + sums[:, 2].sum() / float(rows * p.bins * frames)
-            total = term if total is None else total + term
             saved.append((spec, sums, frames, math))
         ctx.plans, ctx.eps, ctx.geom, ctx.saved, ctx.fir = plans, eps, (b, c, t, rows), saved, fir
-        return total / len(plans)
+        n = len(plans)
+        if n <= 8 and FUSED_LOSS_GLUE:   # the value from the per-row sums of all resolutions: one launch instead of ~8 one-element torch kernels per resolution
+            total = torch.empty((), dtype=torch.float32, device=x.device)
+            check(lib.eben_stft_loss_total((ctypes.c_void_p * n)(*[ptr(sv[1]) for sv in saved]),
+                                           (ctypes.c_float * n)(*[1.0 / float(rows * p.bins * sv[2]) for p, sv in zip(plans, saved)]), n, rows,
+                                           ptr(total), st), "stft_loss_total")
+            return total
+        for p, (_, sums, frames, _) in zip(plans, saved):
+            term = torch.sqrt(sums[:, 0] / sums[:, 1]).mean() + sums[:, 2].sum() / float(rows * p.bins * frames)
+            total = term if total is None else total + term
+        return total / n
 
     @staticmethod
     def backward(ctx, gout):
