@@ -183,7 +183,8 @@ __global__ __launch_bounds__(256) void ru_dw_kernel(const RuDwArgs P) {
 
 static int rdw_seg(int length) {
   // ~500 positions per K slab (a multiple of 16): 512 / 256 / 64 slabs of 16 / 64 / 256 KB at the generator's three widths
-  const int nseg = ceil_div(length, 512);
+  static const int target = getenv("EBEN_RUDW_SEG") ? atoi(getenv("EBEN_RUDW_SEG")) : 512;
+  const int nseg = ceil_div(length, target > 32 ? target : 32);
   return round_up(ceil_div(length, nseg), 16);
 }
 
