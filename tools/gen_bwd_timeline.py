@@ -10,28 +10,28 @@ batch = bench.synthetic_batch(32, 32000, 1234, dev)
 gen = mod.generator
 x = gen.cut_to_valid_length(batch["audio_body_conducted"])
 gp = [p for p in gen.parameters() if p.requires_grad]
-def once():
+def once(prof_ctx=None):
     with ops.backward_math(ops.MATH_BF16):
         y, bands = gen(x)
         seed = torch.ones_like(bands)
         torch.cuda.synchronize()
+        if prof_ctx is not None:
+            prof_ctx.__enter__()
         with ops.weight_grads_on_side_stream() as side:
             torch.autograd.backward(bands, seed, inputs=gp)
             side.join()
         torch.cuda.synchronize()
+        if prof_ctx is not None:
+            prof_ctx.__exit__(None, None, None)
         for p in gp:
             p.grad = None
 for _ in range(3):
     once()
 from torch.profiler import profile, ProfilerActivity
-with profile(activities=[ProfilerActivity.CUDA]) as prof:
-    once()
+prof = profile(activities=[ProfilerActivity.CUDA])
+once(prof)
 evs = [e for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA]
 evs.sort(key=lambda e: e.time_range.start)
-# the backward starts after the forward's last kernel: find the largest gap (the synchronize between them)
-gaps = [(evs[i + 1].time_range.start - evs[i].time_range.end, i) for i in range(len(evs) - 1)]
-cut = max(gaps)[1] + 1
-evs = evs[cut:]
 t0 = evs[0].time_range.start
 for e in evs:
     print(f"{(e.time_range.start - t0):8.1f} us  {e.time_range.end - e.time_range.start:7.1f} us  {e.name[:100]}")
