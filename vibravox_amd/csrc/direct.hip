@@ -544,12 +544,12 @@ extern "C" int eben_lrelu_bwd(const float* dy, const float* ref, float* dx, size
 // wide, beyond its per-thread prefetch; as 8 channels x 129 positions it is an ordinary tile).
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void space_to_depth_kernel(const float* __restrict__ x, const float* __restrict__ mask, float* __restrict__ out,
-                                                             int L, int S, int off, int Lq, int reflect, float slope) {
-  const long long row = blockIdx.y;
+                                                             int rows, int L, int S, int off, int Lq, int reflect, float slope) {
+  const int n = S * Lq;
+  for (long long row = blockIdx.y; row < rows; row += gridDim.y) {
   const float* xr = x + row * L;
   const float* mr = mask ? mask + row * L : nullptr;
   float* o = out + row * (long long)S * Lq;
-  const int n = S * Lq;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
     const int r = i / Lq, q = i - r * Lq;
     int p = S * q + r + off;
@@ -565,14 +565,14 @@ __global__ __launch_bounds__(256) void space_to_depth_kernel(const float* __rest
     if (mr && ok) v *= dlrelu(mr[p], slope);
     o[i] = v;
   }
+  }
 }
 extern "C" int eben_space_to_depth(const float* x, const float* mask, float mask_slope, float* out, int rows, int L, int S, int off, int Lq,
                                    int reflect, void* stream) {
   EBEN_REQUIRE(x && out && rows > 0 && L > 0 && S > 0 && Lq > 0, "bad space_to_depth arguments");
   EBEN_REQUIRE(!reflect || (-off < L && S * (Lq - 1) + S - 1 + off < 2 * L - 1), "space_to_depth: reflection wider than the signal");
-  EBEN_REQUIRE(rows <= 65535, "space_to_depth: too many rows for one launch");
-  hipLaunchKernelGGL(space_to_depth_kernel, dim3(grid_for((size_t)S * Lq, 64), rows), dim3(256), 0, as_stream(stream), x, mask, out, L, S, off,
-                     Lq, reflect, mask_slope);
+  hipLaunchKernelGGL(space_to_depth_kernel, dim3(grid_for((size_t)S * Lq, 64), rows < 65535 ? rows : 65535), dim3(256), 0, as_stream(stream), x, mask,
+                     out, rows, L, S, off, Lq, reflect, mask_slope);
   EBEN_CHECK_LAUNCH("space_to_depth_kernel");
   return EBEN_OK;
 }
