@@ -583,3 +583,148 @@ def test_noisy_bwe_chain_at_config4_size(hip, golden):
         assert np.isfinite(float(v)), k
     steps = [float((p.detach() - b).abs().max()) for p, b in zip(params, before)]
     assert max(steps) <= 3e-4 * 1.001 + 1e-7 and sum(st > 0.0 for st in steps) >= len(steps) - 2, sorted(steps)[:4]
+
+
+def _adam_moments(optimizers):
+    """Adam's first moment after ONE step from zero state = (1 - beta1) * gradient: the step's gradients, read back per network."""
+    out = []
+    for opt in optimizers:
+        out.append(torch.cat([opt.state[p]["exp_avg"].detach().double().flatten().cpu() for grp in opt.param_groups for p in grp["params"]
+                              if "exp_avg" in opt.state.get(p, {})]))
+    return out
+
+
+def test_full_size_step_against_oracle(hip, golden):
+    """BASELINE config 2 at its FULL size (batch 32 x 32000 -> 31968 noise clips, default initialisation: bench.py's workload): one
+    train step of eben.py:82-130 through the CPU oracle (pinned to the reference by the golden fixtures; ~5-20 s on the host) against
+    the HIP step in three arithmetic plans -- "f32" (exact fp32 products), "bf16x6" (fp32-grade split products) at the fp32 tolerances,
+    and the plan bench.py times ("bf16" discriminator plan + bf16 generator backward + "folded_x3" MRSTFT) at BF16_STEP_TOLERANCES.
+    Gradients are compared through Adam's first moment after the step (whole-vector relative L2 per network)."""
+    import bench
+
+    floor = float(golden["check:disc_grad_fp64_floor"])
+    probe = bench.build_module(DEV, 1234)
+    g_sd = {k: v.detach().cpu().clone() for k, v in probe.generator.state_dict().items()}
+    d_sd = {k: v.detach().cpu().clone() for k, v in probe.discriminator.state_dict().items()}
+    del probe
+    data = bench.synthetic_batch(32, 32000, 1234, "cpu")
+    trainer = O.OracleTrainer(g_sd, d_sd, p=2, q=4, use_mrstft=True)
+    logs = trainer.step(data["audio_body_conducted"], data["audio_airborne"])
+    want = _adam_moments([trainer.g_opt, trainer.d_opt])
+    keys = ("train/generator/reconstructive_loss_freq", "train/generator/feature_matching_loss", "train/generator/adv_loss_gen",
+            "train/generator/backprop_loss", "train/discriminator/real_loss", "train/discriminator/fake_loss")
+    tol = BF16_STEP_TOLERANCES
+    report = {}
+    for plan, gen_bwd, stft in (("f32", "f32", "folded"), ("bf16x6", "f32", "folded_x6"), ("bf16", "bf16", "folded_x3")):
+        mod = bench.build_module(DEV, 1234)
+        mod.disc_math, mod.gen_backward_math, mod.stft_math = plan, gen_bwd, stft
+        out = mod.training_step({k: v.to(DEV) for k, v in data.items()})
+        torch.cuda.synchronize()
+        enh = out["enhanced"].cpu().double()
+        mse = float(((enh - logs["enhanced"].double()) ** 2).mean())
+        assert enh.shape == (32, 1, 31968) and mse < 1e-10, (plan, mse)   # north-star bar: 1e-5
+        got = _adam_moments(mod.optimizers())
+        g_rel, d_rel = _rel(want[0], got[0]), _rel(want[1], got[1])
+        norms = (torch.stack(mod.last_norms).cpu().double() - logs["balancing/norms"].double()).abs() / logs["balancing/norms"].double().abs()
+        worst = {k: abs(float(mod.logged[k]) - float(logs[k])) / abs(float(logs[k])) for k in keys}
+        report[plan] = (mse, g_rel, d_rel, float(norms.max()), max(worst.values()))
+        if plan == "bf16":
+            for k, w in worst.items():
+                t = tol["feature_matching_loss"] if "feature_matching" in k else tol["backprop_loss"] if "backprop" in k else tol["loss"]
+                assert w <= t, (plan, k, w)
+            assert float(norms.max()) < tol["balancing_norms"]
+            assert g_rel < tol["generator_grad"] and d_rel < tol["discriminator_grad"], (g_rel, d_rel)
+        else:
+            assert max(worst.values()) <= 1e-3, (plan, worst)
+            assert float(norms.max()) < 5e-3, (plan, norms)
+            # the generator's gradient passes through the discriminators' sign() / LeakyReLU discontinuities too: the reference's own
+            # fp32-vs-fp64 floor is the yardstick for both networks
+            assert g_rel <= 2 * floor + 1e-3 and d_rel <= 2 * floor + 1e-3, (plan, g_rel, d_rel, floor)
+        del mod
+    print("full-size step vs oracle (enhanced MSE, generator grad, discriminator grad, balancing norms, worst logged loss): "
+          + "; ".join(f"{k}: " + " ".join(f"{x:.2e}" for x in v) for k, v in report.items()))
+
+
+def test_benchmarked_plan_two_steps_with_mrstft_against_oracle(hip, golden):
+    """What bench.py times -- discriminator plan "bf16", bf16 generator backward, MRSTFT contractions "folded_x3" -- for two
+    consecutive steps on the formula clips against the CPU oracle (the reference-pinned restatement): logged values at the bf16
+    tolerances of `test_bf16_step_against_reference_replay_golden`, the generator output at the fp32 bound on the first step."""
+    table = {"train/generator/reconstructive_loss_freq": 2e-3, "train/generator/feature_matching_loss": 2e-2, "train/generator/adv_loss_gen": 2e-3,
+             "train/generator/backprop_loss": 5e-2, "train/discriminator/real_loss": 2e-3, "train/discriminator/fake_loss": 2e-3}
+    mod, g_sd, d_sd = make_module(golden, use_mrstft=True)
+    mod.disc_math, mod.gen_backward_math, mod.stft_math = "bf16", "bf16", "folded_x3"
+    trainer = O.OracleTrainer(g_sd, d_sd, p=2, q=4, use_mrstft=True)
+    for i in range(2):
+        bc, air = formula_audio(f"mstep{i}/bc", 2, 8200), formula_audio(f"mstep{i}/air", 2, 8200)
+        out = mod.training_step({"audio_body_conducted": bc.to(DEV), "audio_airborne": air.to(DEV)})
+        logs = trainer.step(bc, air)
+        if i == 0:
+            assert max_abs(out["enhanced"], logs["enhanced"]) < 2e-5
+        for k, rtol in table.items():
+            np.testing.assert_allclose(mod.logged[k].item(), logs[k].item(), rtol=rtol * (1 if i == 0 else 5), err_msg=f"step {i} {k}")
+        np.testing.assert_allclose(torch.stack(mod.last_norms).cpu().numpy(), logs["balancing/norms"].numpy(), rtol=5e-2)
+
+
+def test_prepack_graph_survives_a_forward_at_another_shape(hip, golden):
+    """train x4 (the prepack sequences settle and are captured into HIP graphs) -> validation forward at another batch / length (the
+    shared image caches miss and reallocate) -> train x2: bit-identical to the same sequence with the graphs disabled.  A replay that
+    kept writing the buffers it captured would leave the generator's convolutions on pre-update weights from here on."""
+    from vibravox_amd import ops
+
+    def run(graphs):
+        prev = ops.ReplayedPrepack.enabled
+        ops.ReplayedPrepack.enabled = graphs
+        try:
+            mod, _, _ = make_module(golden, use_mrstft=False)
+            captured = 0
+            for i in range(6):
+                if i == 4:
+                    mod.validation_step({"audio_body_conducted": formula_audio("pp/val/bc", 3, 5000).to(DEV),
+                                         "audio_airborne": formula_audio("pp/val/air", 3, 5000).to(DEV)}, 0)
+                batch = {"audio_body_conducted": formula_audio(f"pp/{i}/bc", 2, 8200).to(DEV), "audio_airborne": formula_audio(f"pp/{i}/air", 2, 8200).to(DEV)}
+                mod.training_step(batch)
+                if i == 3:
+                    captured = sum(g.graph is not None for g in (ops._conv_prepack_graph, mod.generator._engine._prepack_graph, mod._disc_engine._prepack_graph))
+            torch.cuda.synchronize()
+            out = {f"G.{k}": v.clone() for k, v in mod.generator.state_dict().items()}
+            out.update({f"D.{k}": v.clone() for k, v in mod.discriminator.state_dict().items()})
+            out["enhanced"] = mod.generator(mod.generator.cut_to_valid_length(formula_audio("pp/probe", 2, 8200).to(DEV)))[0].detach().clone()
+            return out, captured
+        finally:
+            ops.ReplayedPrepack.enabled = prev
+
+    ops._conv_prepack_graph.graph, ops._conv_prepack_graph.sig = None, None
+    (a, cap_a), (b, cap_b) = run(True), run(False)
+    assert cap_a == 3 and cap_b == 0, (cap_a, cap_b)   # the three sequences were graph replays before the validation forward
+    assert [k for k in a if not torch.equal(a[k], b[k])] == []
+
+
+def test_fused_adam_follows_a_restored_state(hip):
+    """optimizer.load_state_dict() after a step replaces the moment tensors: the kernel's cached table must follow (and a deep copy
+    of the optimiser must step at all)."""
+    import copy
+
+    from vibravox_amd.optim import FusedAdam
+
+    torch.manual_seed(0)
+    w = [torch.nn.Parameter(torch.randn(n, device=DEV)) for n in (1000, 17, 4096)]
+    ref = [torch.nn.Parameter(p.detach().clone()) for p in w]
+    ours, theirs = FusedAdam(w, lr=3e-4, betas=(0.5, 0.9)), torch.optim.Adam(ref, lr=3e-4, betas=(0.5, 0.9))
+    def step(k):
+        for p, q in zip(w, ref):
+            g = torch.randn(p.shape, device=DEV, generator=torch.Generator(DEV).manual_seed(100 + k))
+            p.grad, q.grad = g.clone(), g.clone()
+        ours.step(); theirs.step()
+    step(0); step(1)
+    saved_o, saved_t = copy.deepcopy(ours.state_dict()), copy.deepcopy(theirs.state_dict())
+    step(2)
+    ours.load_state_dict(saved_o); theirs.load_state_dict(saved_t)   # back to the state after two steps: new moment tensors
+    step(3)
+    for p, q in zip(w, ref):
+        assert torch.allclose(p, q, rtol=0, atol=2e-6)
+    for p, q in zip(w, ref):
+        assert torch.allclose(ours.state[p]["exp_avg"], theirs.state[q]["exp_avg"], rtol=1e-6, atol=1e-7)
+    clone = copy.deepcopy(ours)
+    for p in clone.param_groups[0]["params"]:
+        p.grad = torch.ones_like(p)
+    clone.step()

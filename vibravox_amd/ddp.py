@@ -37,6 +37,7 @@ class _Bucket:
         self.work = None
         self.events = []   # producer-stream events the exchange has to wait for (gradients written outside autograd)
         self.index = {id(p): i for i, p in enumerate(params)}
+        self.idx = -1      # position in GradSync.buckets
 
 
 class GradSync:
@@ -69,14 +70,15 @@ class GradSync:
         if cur:
             self.buckets.append(_Bucket(cur, dev, dtype))
         self._owner = {}
-        for b in self.buckets:
+        for i, b in enumerate(self.buckets):
+            b.idx = i
             for p, v in zip(b.params, b.views):
                 self._owner[id(p)] = b
                 p.grad = v  # gradient-as-bucket-view: autograd accumulates in place
                 p.register_post_accumulate_grad_hook(self._on_grad)
         self.launched = 0
-        self.order: List[int] = []   # bucket indices in the order their exchanges were issued (identical on every rank)
-        self.exposed_ms: List[float] = []   # per finish(): main-stream time spent waiting for the exchange (profile=True)
+        #: bucket indices in the order their exchanges were issued (identical on every rank); the last few steps' worth is kept
+        self.order: List[int] = []
         self.profile = False
         self._pending_timing = []
 
@@ -125,7 +127,9 @@ class GradSync:
         if self.world == 1 and not dist.is_initialized():
             b.events.clear()
             return
-        self.order.append(self.buckets.index(b))
+        self.order.append(b.idx)
+        if len(self.order) > 16 * len(self.buckets):   # a training run issues these for ever: keep the recent ones
+            del self.order[: len(self.order) - 8 * len(self.buckets)]
         if self.on_gpu:
             # the collective is ordered behind what produced the bucket: the current stream (autograd hooks, the last
             # mark_ready) and the recorded events of the other producer streams -- not behind unrelated work queued on the

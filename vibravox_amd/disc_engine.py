@@ -56,6 +56,7 @@ class _Layer:
         self.used = set()   # slots touched since the last prepack(): the only ones it rebuilds
         self.scale_key = None
         self.scale = self.norm = None
+        self.reuse = False   # inside prepack(): rebuild into the buffers already held (ops._buffer)
 
     def params(self):
         prm = self.conv.parametrizations["weight"]
@@ -75,8 +76,8 @@ class _Layer:
         wkey = self._weights_key()
         if self.scale_key != wkey:
             rows = v.shape[0]
-            self.scale = torch.empty(rows, dtype=torch.float32, device=v.device)
-            self.norm = torch.empty(rows, dtype=torch.float32, device=v.device)
+            self.scale = ops._buffer(self.scale, rows, v, self.reuse)
+            self.norm = ops._buffer(self.norm, rows, v, self.reuse)
             check(lib.eben_wn_scale(ptr(g), ptr(v), rows, v.numel() // rows, ptr(self.scale), ptr(self.norm), _stream()), "wn_scale")
             self.scale_key = wkey
         slot = (which, batch, l_in)
@@ -90,7 +91,7 @@ class _Layer:
             for old in [k for k in self.packs if k not in self.used] or list(self.packs)[:1]:
                 del self.packs[old]
         d = ops.conv_desc(self.spec, batch, l_in, self.math_fwd if which == 0 else self.math_dx)
-        wp = torch.empty(lib.eben_conv1d_packed_floats(ctypes.byref(d), which), dtype=torch.float32, device=v.device)
+        wp = ops._buffer(None if hit is None else hit[1], lib.eben_conv1d_packed_floats(ctypes.byref(d), which), v, self.reuse)
         ops.conv1d_pack(d, v, self.scale, wp if which == 0 else None, wp if which == 1 else None)
         self.packs[slot] = (wkey, wp)
         return wp
@@ -453,24 +454,31 @@ class DiscriminatorEngine:
                 if lay.packs and lay.scale_key != wkey:
                     v, g, _ = lay.params()
                     rows = v.shape[0]
-                    lay.scale = torch.empty(rows, dtype=torch.float32, device=dev)
-                    lay.norm = torch.empty(rows, dtype=torch.float32, device=dev)
+                    lay.scale = ops._buffer(lay.scale, rows, v, True)
+                    lay.norm = ops._buffer(lay.norm, rows, v, True)
                     lay.scale_key = wkey
                     jobs.append((g.detach(), v.detach(), rows, v.numel() // rows, lay.scale, lay.norm))
             ops.wn_scale_multi(jobs)
             with ops.pack_batch():
                 for lay in layers:
                     used, lay.used = lay.used, set()
-                    for slot in list(lay.packs):
-                        if slot in used:
-                            lay.packed(*slot)     # what the last step launched: the next step most likely launches it again
-                        else:
-                            del lay.packs[slot]   # a shape of an earlier step: rebuilt on demand if it comes back
+                    lay.reuse = True
+                    try:
+                        for slot in list(lay.packs):
+                            if slot in used:
+                                lay.packed(*slot)     # what the last step launched: the next step most likely launches it again
+                            else:
+                                del lay.packs[slot]   # a shape of an earlier step: rebuilt on demand if it comes back
+                    finally:
+                        lay.reuse = False
                     lay.used = set()              # re-packing is not a use: the next step decides what survives the next prepack
 
         # the launch sequence as a function of everything but the weights' values (ops.ReplayedPrepack): layers, the slots the last
-        # step used (= all the slots held, or the eager path prunes), parameter storage, and that every image is stale
+        # step used (= all the slots held, or the eager path prunes), parameter storage, the image / scale buffers written, and that
+        # every image is stale
         sig = tuple((id(lay), tuple(sorted(lay.packs)), tuple(sorted(lay.used)) == tuple(sorted(lay.packs)), lay.params()[0].data_ptr(),
+                     tuple(lay.packs[k][1].data_ptr() for k in sorted(lay.packs)), 0 if lay.scale is None else lay.scale.data_ptr(),
+                     0 if lay.norm is None else lay.norm.data_ptr(),
                      lay.scale_key != lay._weights_key()) for lay in layers) + (ops._storage_epoch.get(-1, 0),)
         with torch.cuda.stream(side), torch.no_grad():
             if self._prepack_graph.run(sig, body, side):

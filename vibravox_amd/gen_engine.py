@@ -15,8 +15,16 @@ encoder blocks, latent convs, decoder blocks: everything up to the input of ``la
   * ``last_conv`` (the leaf of the loss balancing, eben.py:223), the tanh recomposition and the PQMF synthesis stay in
     autograd: the step differentiates them three extra times with ``retain_graph`` and they are cheap.
 
-Same kernels' arithmetic as the layer-by-layer path (exact fp32 forward; the fused unit sums its products in a different
-order); the module tree, parameters and ``state_dict`` are untouched -- this is only how ``EBENGenerator.forward`` executes.
+Arithmetic: the forward (training, evaluation and the exported output alike) runs on the bf16 matrix pipe with every fp32 operand
+entering as three bf16 pieces (``RU_FWD_MATH`` / ``CONV_FWD_MATH`` = EBEN_MATH_BF16X6: six piece products, dropped terms <= 2^-26 of
+a product, fp32 accumulation) -- fp32-grade, held by ``tests/test_gpu_ops.py`` to the fp32 MFMA kernels' own bound against fp64;
+``EBEN_RU_FWD_MATH=f32 EBEN_GEN_CONV_FWD_MATH=f32`` selects the ``v_mfma_f32_*_f32`` kernels.  The module tree, parameters and
+``state_dict`` are untouched -- this is only how ``EBENGenerator.forward`` executes.
+
+The core's parameter gradients are produced by the engine as a side effect of ``backward`` (written to ``.grad`` / the data-parallel
+buckets, never returned to autograd): ``torch.autograd.grad(loss, core parameters)`` returns nothing useful for them -- differentiate
+with ``backward()`` and read ``.grad``, as the train step does (only ``last_conv``, outside the core, is reached through
+``torch.autograd.grad``: eben.py:223-227).
 """
 from __future__ import annotations
 
@@ -169,24 +177,27 @@ class GeneratorEngine:
         c = vd.shape[0]
         dev = vd.device
         batch = self._ru_batch   # inside prepack(): the launches of all units are gathered into one wn_scale / one pack call
+        reuse = batch is not None   # prepack(): rebuild into the buffers held (a graph replay writes the ones it captured)
         if hit is None or hit["key"] != key:
-            scales = torch.empty((4, c), dtype=torch.float32, device=dev)   # scale / norm of the dilated, then of the pointwise conv
+            # scale / norm of the dilated, then of the pointwise conv
+            scales = ops._buffer(None if hit is None else hit["scales"], 4 * c, vd, reuse).view(4, c)
             wn = [(gd.detach(), vd.detach(), c, vd.numel() // c, scales[0], scales[1]), (gp.detach(), vp.detach(), c, vp.numel() // c, scales[2], scales[3])]
             if batch is not None:
                 batch["wn"].extend(wn)
             else:
                 ops.wn_scale_multi(wn)
-            img = torch.empty(lib.eben_ru_packed_floats_ex(c, RU_FWD_MATH), dtype=torch.float32, device=dev)
+            img = ops._buffer(None if hit is None else hit["fwd"], lib.eben_ru_packed_floats_ex(c, RU_FWD_MATH), vd, reuse)
             self._ru_pack(c, RU_FWD_MATH, 0, vd, scales[0], vp, scales[2], img)
             maths = set(hit["bwd"]) if hit is not None else set()
+            old_bwd = hit["bwd"] if hit is not None else {}
             hit = self._ru_images[id(ru)] = {"key": key, "fwd": img, "bwd": {}, "scales": scales}
         else:
-            maths = set()
+            maths, old_bwd = set(), {}
         if bm is not None:
             maths.add(bm)
         scales = hit["scales"]
         for m in maths:
-            img_b = torch.empty(lib.eben_ru_packed_floats_ex(c, m), dtype=torch.float32, device=dev)
+            img_b = ops._buffer(old_bwd.get(m), lib.eben_ru_packed_floats_ex(c, m), vd, reuse)
             self._ru_pack(c, m, 1, vd, scales[0], vp, scales[2], img_b)
             hit["bwd"][m] = img_b
         return hit["fwd"] if which == 0 else hit["bwd"][bm]
@@ -237,8 +248,11 @@ class GeneratorEngine:
                 self._ru_flush()
 
         def entry(ru):
+            # what the launch sequence depends on besides the weights' values, the buffers it writes included (ops.ReplayedPrepack)
             hit = self._ru_images.get(id(ru))
-            return (id(ru), _params(ru.dilated_conv)[0].data_ptr(), None if hit is None else (tuple(sorted(hit["bwd"])), hit["key"] != key_of(ru)))
+            return (id(ru), _params(ru.dilated_conv)[0].data_ptr(),
+                    None if hit is None else (tuple((m, hit["bwd"][m].data_ptr()) for m in sorted(hit["bwd"])), hit["fwd"].data_ptr(),
+                                              hit["scales"].data_ptr(), hit["key"] != key_of(ru)))
 
         sig = tuple(entry(ru) for ru in units) + (ops._storage_epoch.get(-1, 0),)
         with torch.cuda.stream(side), torch.no_grad():
@@ -360,7 +374,7 @@ class GeneratorEngine:
             return
         grads = ops.weight_grads(rec.d, dy, rec.y, rec.x, v, g, rec.m.bias, rec.norm)
         for p, t in zip((v, g, rec.m.bias), grads):   # not deferred (no side-stream context): accumulate like autograd would
-            if p is not None and t is not None:
+            if p is not None and t is not None and p.requires_grad:
                 p.grad = t if p.grad is None else p.grad.add_(t)
                 for hook in list((getattr(p, "_post_accumulate_grad_hooks", None) or {}).values()):
                     hook(p)   # e.g. ddp.GradSync's bucket accounting
@@ -368,7 +382,7 @@ class GeneratorEngine:
     @staticmethod
     def _accumulate(params, grads) -> None:
         for p, t in zip(params, grads):   # not deferred (no side-stream context): accumulate like autograd would
-            if p is not None and t is not None:
+            if p is not None and t is not None and p.requires_grad:
                 p.grad = t if p.grad is None else p.grad.add_(t)
                 for hook in list((getattr(p, "_post_accumulate_grad_hooks", None) or {}).values()):
                     hook(p)   # e.g. ddp.GradSync's bucket accounting

@@ -153,10 +153,12 @@ class EBENLightningModule(BaseSELightningModule):
     use_disc_engine: bool = os.environ.get("EBEN_DISC_ENGINE", "1") != "0"
     #: arithmetic of the discriminator contractions inside the engine: a key of DISC_MATH_PLANS -- "f32" (bit-exact fp32
     #: products), "bf16" (bf16 MFMA operands, fp32 accumulate, activation operand split -- BASELINE config 2), "bf16_plain" --
-    #: or a plan the engine understands.  The generator's forward always computes in fp32.
+    #: or a plan the engine understands.  The generator's forward computes in fp32-grade split-bf16 products (gen_engine.RU_FWD_MATH /
+    #: CONV_FWD_MATH = EBEN_MATH_BF16X6: every mantissa bit of both fp32 operands, fp32 accumulation) in every plan.
     disc_math: str = os.environ.get("EBEN_DISC_MATH", "f32")
     #: arithmetic of the generator's BACKWARD contractions (input / weight gradients) in the engine step; its forward --
-    #: the product's output -- is exact fp32 either way
+    #: the product's output -- is fp32-grade either way (six-piece bf16 products, <= 2^-26 dropped per product: within 2x of the
+    #: fp32 MFMA kernels' own error against fp64, tests/test_gpu_ops.py; EBEN_RU_FWD_MATH=f32 selects those kernels)
     gen_backward_math: str = os.environ.get("EBEN_GEN_BWD_MATH", "f32")
 
     #: arithmetic of the MRSTFT loss's windowed-DFT contractions in the engine step (mrstft_loss.MultiResolutionSTFTLoss.stft_math):
@@ -487,8 +489,12 @@ class EBENLightningModule(BaseSELightningModule):
         bal = getattr(self, "_bal", None)
         if bal is None or bal["n"] != n or bal["old"].device != dev:
             bal = self._bal = {"n": n, "old": torch.zeros(n, dtype=torch.float32, device=dev), "lam": None}
-            if self.atomic_norms_old is not None:   # state built by another step path: carry it over
-                bal["old"].copy_(torch.stack([t.to(dev).reshape(()) for t in self.atomic_norms_old]))
+        old = self.atomic_norms_old
+        if old is not None and len(old) == n and any(
+                not torch.is_tensor(t) or t.device != dev or t.data_ptr() != bal["old"].data_ptr() + 4 * i for i, t in enumerate(old)):
+            # the state was written by someone else since the last call (another step path, a restore, the user): `atomic_norms_old`
+            # is the one state -- the device buffer follows it
+            bal["old"].copy_(torch.stack([torch.as_tensor(t, dtype=torch.float32).to(dev).reshape(()) for t in old]))
         init = self.atomic_norms_old is None or self.dynamic_loss_balancing == "simple"
         out = torch.empty(n + 1, dtype=torch.float32, device=dev)   # fresh per step: last_lambdas of earlier steps stay what they were
         norms = [t.contiguous() for t in atomic_norms]

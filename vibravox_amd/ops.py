@@ -353,10 +353,20 @@ def _pack_key(v, g, d, d_bwd):
             None if g is None else (g.data_ptr(), g._version, _storage_epoch.get(g.data_ptr(), 0)), d.batch, d.l_in, d.math, d_bwd.math)
 
 
+def _buffer(old: Optional[torch.Tensor], numel: int, like: torch.Tensor, reuse: bool) -> torch.Tensor:
+    """A float buffer of ``numel`` elements: ``old`` itself when ``reuse`` and it has that size (``prepack``: the step that read the
+    old contents is complete, and a graph replay needs the buffers it captured to stay the ones in use), else a fresh one."""
+    if reuse and old is not None and old.numel() == numel and old.device == like.device:
+        return old
+    return torch.empty(numel, dtype=torch.float32, device=like.device)
+
+
 def pack_weights(spec: ConvSpec, d: EbenConv1dDesc, v: torch.Tensor, g: Optional[torch.Tensor],
-                 cache: Optional[PackedWeights], need_bwd: bool, d_bwd: Optional[EbenConv1dDesc] = None, pre_scale=None) -> PackedWeights:
+                 cache: Optional[PackedWeights], need_bwd: bool, d_bwd: Optional[EbenConv1dDesc] = None, pre_scale=None,
+                 reuse: bool = False) -> PackedWeights:
     """d_bwd: descriptor of the backward launches when it differs from the forward's (bf16 backward math);
-    pre_scale: (scale, norm) already computed for the current weights (multi-tensor launch in `prepack`)."""
+    pre_scale: (scale, norm) already computed for the current weights (multi-tensor launch in `prepack`);
+    reuse: rebuild into the buffers the cache already holds where their sizes fit (only `prepack` may: nothing reads them any more)."""
     lib = load()
     d_bwd = d if d_bwd is None else d_bwd
     key = _pack_key(v, g, d, d_bwd)
@@ -371,15 +381,13 @@ def pack_weights(spec: ConvSpec, d: EbenConv1dDesc, v: torch.Tensor, g: Optional
     if g is not None and pre_scale is not None:
         pw.scale, pw.norm = pre_scale
     elif g is not None:
-        pw.scale = torch.empty(rows, dtype=torch.float32, device=v.device)
-        pw.norm = torch.empty(rows, dtype=torch.float32, device=v.device)
+        pw.scale = _buffer(pw.scale, rows, v, reuse)
+        pw.norm = _buffer(pw.norm, rows, v, reuse)
         check(lib.eben_wn_scale(ptr(g), ptr(v), rows, v.numel() // rows, ptr(pw.scale), ptr(pw.norm), st), "wn_scale")
     else:
         pw.scale = pw.norm = None
-    pw.wp_fwd = torch.empty(lib.eben_conv1d_packed_floats(ctypes.byref(d), 0), dtype=torch.float32, device=v.device)
-    pw.wp_bwd = (
-        torch.empty(lib.eben_conv1d_packed_floats(ctypes.byref(d_bwd), 1), dtype=torch.float32, device=v.device) if need_bwd else None
-    )
+    pw.wp_fwd = _buffer(pw.wp_fwd, lib.eben_conv1d_packed_floats(ctypes.byref(d), 0), v, reuse)
+    pw.wp_bwd = _buffer(pw.wp_bwd, lib.eben_conv1d_packed_floats(ctypes.byref(d_bwd), 1), v, reuse) if need_bwd else None
     if d_bwd is d or not need_bwd:
         conv1d_pack(d, v, pw.scale, pw.wp_fwd, pw.wp_bwd)
     else:
@@ -395,8 +403,11 @@ class ReplayedPrepack:
     step (one or two per layer and direction) whose cost is entirely host-side: ~3 ms of Python / launch time per step during which
     the GPU has nothing else queued -- on a 19 ms step.  The sequence is static (same kernels, same parameter storage, same image
     buffers every step), so after two eager rounds it is captured into a HIP graph and replayed: one launch call.  ``sig`` names
-    everything the launches depend on besides the weights' values (layers, shapes, storage); a new signature falls back to eager
-    rounds and a new capture.  Tensors allocated by the body while capturing live in the graph's pool for as long as the graph."""
+    everything the launches depend on besides the weights' values (layers, shapes, parameter storage AND the addresses of the image /
+    scale buffers the launches write: a forward at another shape between two train steps -- validation -- reallocates them, and a
+    replay would go on filling the orphaned ones); a new signature falls back to eager rounds and a new capture.  The prepack bodies
+    rebuild INTO the buffers the caches hold (``_buffer(reuse=True)``), so the signature settles after one eager round.  Tensors
+    allocated by the body while capturing live in the graph's pool for as long as the graph."""
 
     enabled = os.environ.get("EBEN_PREPACK_GRAPH", "1") != "0"
 
@@ -468,8 +479,8 @@ def prepack(layers) -> None:
             if m.weight_norm:
                 v, g = params_of(m)
                 rows = v.shape[0]
-                sc = torch.empty(rows, dtype=torch.float32, device=dev)
-                nm = torch.empty(rows, dtype=torch.float32, device=dev)
+                sc = _buffer(m._packed.scale, rows, v, True)
+                nm = _buffer(m._packed.norm, rows, v, True)
                 scales[id(m)] = (sc, nm)
                 jobs.append((g, v, rows, v.numel() // rows, sc, nm))
         wn_scale_multi(jobs)
@@ -477,11 +488,15 @@ def prepack(layers) -> None:
             for m in todo:
                 spec, d, d_bwd = m._packed.last
                 v, g = params_of(m)
-                pack_weights(spec, d, v, g, m._packed, True, d_bwd, scales.get(id(m)))
+                pack_weights(spec, d, v, g, m._packed, True, d_bwd, scales.get(id(m)), reuse=True)
 
     # everything the launch sequence depends on besides the weights' values: the layers, their descriptors, the parameter storage,
-    # and WHICH layers are stale (a layer skipped while capturing would never be rebuilt by the replays)
+    # the buffers the launches write, and WHICH layers are stale (a layer skipped while capturing would never be rebuilt by the replays)
+    def _addr(t):
+        return 0 if t is None else t.data_ptr()
+
     sig = tuple((id(m), m._packed.last[1].batch, m._packed.last[1].l_in, m._packed.last[1].math, m._packed.last[2].math, params_of(m)[0].data_ptr(),
+                 _addr(m._packed.wp_fwd), _addr(m._packed.wp_bwd), _addr(m._packed.scale), _addr(m._packed.norm),
                  m._packed.key != _pack_key(*params_of(m), m._packed.last[1], m._packed.last[2])) for m in todo) + (_storage_epoch.get(-1, 0),)
     with torch.cuda.stream(side), torch.no_grad():
         if _conv_prepack_graph.run(sig, body, side):

@@ -22,6 +22,14 @@ class FusedAdam(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=False))
         self._tables = {}   # group index -> (parameter identities, largest numel, EbenAdamTensor table with the static columns filled)
 
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        self._tables = {}   # Optimizer.__getstate__ keeps defaults / state / param_groups only (pickle, deepcopy)
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._tables = {}   # the restored moments are new tensors: the cached tables point at the old ones
+
     @torch.no_grad()
     def step(self, closure=None, grad_scale: float = 1.0):
         loss = None
@@ -47,14 +55,16 @@ class FusedAdam(torch.optim.Optimizer):
                 # the usual case: every parameter of the group at the same step.  The table's static columns (parameter and
                 # moment pointers, sizes) are kept from step to step; only the gradient pointers are refreshed (this loop runs
                 # at the end of every train step with the GPU idle behind it)
-                cache = self._tables.get(gi)
+                tables = self.__dict__.setdefault("_tables", {})
+                cache = tables.get(gi)
                 ident = tuple(id(p) for p in live)
+                # (the moment tensors are replaced only through load_state_dict / __setstate__, which drop the tables)
                 if cache is None or cache[0] != ident or any(p.data_ptr() != cache[2][i].param for i, p in enumerate(live)):
                     table = (EbenAdamTensor * len(live))()
                     for i, p in enumerate(live):
                         st = self.state[p]
                         table[i] = EbenAdamTensor(ptr(p.data), 0, ptr(st["exp_avg"]), ptr(st["exp_avg_sq"]), p.numel())
-                    cache = self._tables[gi] = (ident, max(p.numel() for p in live), table)
+                    cache = tables[gi] = (ident, max(p.numel() for p in live), table)
                 table = cache[2]
                 keep = []
                 for i, p in enumerate(live):
