@@ -723,7 +723,7 @@ def test_fused_adam_follows_a_restored_state(hip):
     for p, q in zip(w, ref):
         assert torch.allclose(p, q, rtol=0, atol=2e-6)
     for p, q in zip(w, ref):
-        assert torch.allclose(ours.state[p]["exp_avg"], theirs.state[q]["exp_avg"], rtol=1e-6, atol=1e-7)
+        assert torch.allclose(ours.state[p]["exp_avg"], theirs.state[q]["exp_avg"], rtol=1e-5, atol=1e-6)   # a stale table would be off by O(1)
     clone = copy.deepcopy(ours)
     for p in clone.param_groups[0]["params"]:
         p.grad = torch.ones_like(p)
