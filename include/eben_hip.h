@@ -53,6 +53,10 @@ extern "C" {
                            * Gradient operands and weights stay single bf16; the input-gradient launch equals EBEN_MATH_BF16. */
 #define EBEN_MATH_BF16X3 3 /* fused ResidualUnit launches (eben_ru_*_ex): both operands as hi + lo bf16, three MFMAs per product */
 #define EBEN_MATH_BF16X6 4 /* ... as three bf16 pieces each, six MFMAs: every mantissa bit of the fp32 operands, fp32-grade products */
+/* OR-ed into EbenConv1dDesc.math (EBEN_MATH_BF16 | EBEN_LAYOUT_BL, EBEN_MATH_BF16X3 | EBEN_LAYOUT_BL): the layer's activations and
+ * gradients are at rest in the bf16 BUNDLE LAYOUT (see "bundle layout" below) and the layer is served by the eben_bl_* entry points;
+ * the packed weight images come from eben_conv1d_pack / eben_conv1d_packed_floats on the same descriptor. */
+#define EBEN_LAYOUT_BL 0x100
 
 /* One Conv1d / ConvTranspose1d layer (nn.Conv1d / nn.ConvTranspose1d semantics).
  * Replaces the F.conv1d / F.conv_transpose1d call sites behind
@@ -101,6 +105,7 @@ typedef struct EbenWnBwdItem {
   float* dg; float* dv; float* dbias; /* dbias nullable */
   int64_t slab_stride;                /* floats between slabs */
   int32_t nslab, rows, cols, row_stride;
+  int32_t col_perm_k, pad_;           /* k > 0: slab column of weight (c, j) = ((c / 8) k + j) 8 + c % 8, bias column = cols (eben_bl_conv1d_bwd_dw) */
 } EbenWnBwdItem;
 EBEN_API int eben_wn_scale_multi(const EbenWnScaleItem* items, int n, void* stream);
 EBEN_API int eben_wn_bwd_multi(const EbenWnBwdItem* items, int n, void* stream);
@@ -163,6 +168,71 @@ EBEN_API int eben_conv1d_bwd_dx_fm(const EbenConv1dDesc* d, const float* g, cons
  * finish with eben_wn_bwd. */
 EBEN_API int eben_conv1d_bwd_dw(const EbenConv1dDesc* d, const float* dy, const float* y, const float* x, int has_bias,
                        float* slabs, size_t ws_bytes, void* stream);
+
+/* ---- bf16 BUNDLE LAYOUT of the discriminator engine ------------------------------------------------------------------------
+ * A (batch, channels, length) tensor, channels a multiple of 8, at rest as bf16 [batch][channels / 8][length][8]: one 16-byte UNIT =
+ * 8 consecutive channels at one position = the unit the bf16 tap-conv stages into LDS (no conversion: the input tile is a copy) and
+ * the unit the weight-gradient kernel transposes with ds_read_b64_tr_b16.  Two planes: hi = bf16(v) (round to nearest even) and lo =
+ * bf16(v - hi) (optional; hi + lo carries 16 mantissa bits).  The batched discriminator passes that replace the autograd graph of
+ * vibravox/torch_modules/dnn/eben_discriminator.py:27-51,66-163 and melgan_discriminator.py:89-169 keep every embedding and every
+ * stacked gradient between the chain heads and the logits in this form when the plan's contractions are bf16 (BASELINE config 2):
+ * the values the MFMA sees are the values it saw with fp32 tensors at rest (the same RNE of the same fp32 number, at the producer's
+ * store instead of the consumer's load).  Descriptors carry EBEN_LAYOUT_BL in `math`. */
+EBEN_API int eben_bl_from_f32(const float* x, int batch, int channels, int length, void* hi, void* lo /* nullable */, void* stream);
+EBEN_API int eben_bl_to_f32(const void* hi, const void* lo /* nullable */, int batch, int channels, int length, float* x, void* stream);
+/* y = lrelu(conv(x) + bias): x planes (x_lo required for EBEN_MATH_BF16X3: operands hi + lo, three MFMAs per product), y planes
+ * (y_lo nullable).  wp_fwd from eben_conv1d_pack on the same descriptor.  EBEN_EUNSUPPORTED for layers outside the bf16 tap-conv. */
+EBEN_API int eben_bl_conv1d_fwd(const EbenConv1dDesc* d, const void* x_hi, const void* x_lo, const float* wp_fwd, const float* bias,
+                       void* y_hi, void* y_lo, void* stream);
+/* Batched input gradient (cf. eben_conv1d_bwd_dx_fm):
+ *   dx[b] = ( conv^T(g[b]) + (b < fm_rows ? fm_gs (sgn(a[b] - a[b + ref_row_offset]) / s2 - s1 sgn(a[b]) / s2^2) : 0) )
+ *           * lrelu'(a_hi[map(b)], mask_slope),     a = act_hi + act_lo: the saved embedding at the layer's INPUT (2B rows),
+ * map(b) = seg_map[b / seg] * seg + b % seg, (s1, s2) = fm_sums[0..1] on the device.  act_hi NULL: no mask, no feature matching. */
+EBEN_API int eben_bl_conv1d_bwd_dx(const EbenConv1dDesc* d, const void* g_hi, const float* wp_bwd, const void* act_hi, const void* act_lo,
+                          float mask_slope, int seg, const int* seg_map, int fm_rows, int ref_row_offset, const float* fm_sums,
+                          float fm_gs, void* dx_hi, void* dx_lo /* nullable */, void* stream);
+/* Weight (+ bias) gradient with both operands in the bundle layout (csrc/bl_dw.hip): the reduction runs along (batch, time) on
+ * v_mfma_f32_32x32x16_bf16, both operand tiles arrive in LDS by buffer_load ... lds (descriptor bounds = the zero padding) and are
+ * transposed on read -- no packing pre-pass, no conversion.  Slabs [nslab][c_out][row_stride] as eben_conv1d_bwd_dw's, except that
+ * with *col_perm_k = k > 0 the column of weight (c, j) inside a row is ((c / 8) k + j) 8 + c % 8 (EbenWnBwdItem.col_perm_k). */
+EBEN_API size_t eben_bl_conv1d_bwd_dw_workspace(const EbenConv1dDesc* d, int* nslab, int* row_stride, int* col_perm_k);
+EBEN_API int eben_bl_conv1d_bwd_dw(const EbenConv1dDesc* d, const void* dy_hi, const void* x_hi, int has_bias, float* slabs, size_t ws_bytes,
+                          void* stream);
+/* Chain heads: ReflectionPad1d(reflect_pad) + Conv1d(c_in -> c_out, ksize, dilation, groups = c_in, zero padding `pad`, stride 1)
+ * + bias + LeakyReLU(out_slope), fp32 (batch, c_in, l_in) in, bundle planes out (eben_discriminator.py:66-76 layer 0,
+ * melgan_discriminator.py:89-98 layer 0).  `jobs` is a HOST array of up to 4 heads run by ONE launch (the three PQMF-band chains
+ * read the same bands): forward; input gradient dx (rows, c_in, l_in) = SUM over the jobs of conv^T(g) folded through the
+ * reflection (y_hi / y_lo = the gradient planes at the heads' outputs, c_in <= 4); weight gradient of one head (slabs
+ * [nslab][c_out][ksize + 1], column ksize = bias) from `rows` gradient rows y_hi and the `rows` input rows x paired with them. */
+typedef struct EbenBlHeadJob {
+  const float* x;                      /* (batch, c_in, l_in) */
+  const float* v; const float* scale;  /* weight direction (c_out, 1, ksize), weight-norm scale g / ||v|| per row (nullable) */
+  const float* bias;                   /* nullable */
+  void* y_hi; void* y_lo;              /* (batch, c_out, l_out) planes; y_lo nullable */
+  int32_t c_in, c_out, l_in, l_out, ksize, dilation, pad, reflect_pad;
+  float out_slope; int32_t pad_;
+} EbenBlHeadJob;
+EBEN_API int eben_bl_head_fwd(const EbenBlHeadJob* jobs, int njobs, int batch, void* stream);
+EBEN_API int eben_bl_head_dx(const EbenBlHeadJob* jobs, int njobs, int rows, float* dx, void* stream);
+EBEN_API size_t eben_bl_head_dw_workspace(const EbenBlHeadJob* job, int* nslab, int* row_stride);
+EBEN_API int eben_bl_head_dw(const EbenBlHeadJob* job, int rows, float* slabs, size_t ws_bytes, void* stream);
+/* Chain tails: the logits layer Conv1d(channels -> 1, ksize <= 8, zero padding, stride 1) (eben_discriminator.py:150-157,
+ * melgan_discriminator.py:147-156), v (1, channels, ksize), scale / bias one element (nullable): forward from bundle planes to fp32
+ * (batch, 1, l_out); input gradient of `rows` stacked seeds (rows, 1, l_out) with the epilogue of eben_bl_conv1d_bwd_dx (act = the
+ * layer's input embedding); weight gradient slabs [nslab][1][channels ksize + 1] from `rows` seed rows and the `rows` input rows. */
+EBEN_API int eben_bl_tail_fwd(const void* x_hi, const void* x_lo, int batch, int channels, int length, int ksize, int pad, const float* v,
+                     const float* scale, const float* bias, float out_slope, float* y, void* stream);
+EBEN_API int eben_bl_tail_dx(const float* seeds, int rows, int channels, int length, int ksize, int pad, const float* v, const float* scale,
+                    const void* act_hi, const void* act_lo, float mask_slope, int seg, const int* seg_map, int fm_rows,
+                    int ref_row_offset, const float* fm_sums, float fm_gs, void* g_hi, void* g_lo /* nullable */, void* stream);
+EBEN_API size_t eben_bl_tail_dw_workspace(int channels, int ksize, int* nslab, int* row_stride);
+EBEN_API int eben_bl_tail_dw(const float* seeds, const void* x_hi, const void* x_lo, int rows, int channels, int length, int ksize, int pad,
+                    float* slabs, size_t ws_bytes, void* stream);
+/* feature-matching sums (eben_fm_sums) over embeddings in bundle planes: planes = HOST array (hi_0, lo_0, hi_1, lo_1, ...), the
+ * enhanced rows are the first units[i] units of pair i's planes and the reference rows the next units[i] (a = hi + lo). */
+EBEN_API size_t eben_bl_fm_sums_workspace(int npairs);
+EBEN_API int eben_bl_fm_sums(const void* const* planes, const int64_t* units, int npairs, float* partial_ws, size_t ws_bytes, float* sums,
+                    void* stream);
 
 /* ---- fused ResidualUnit forward (vibravox/torch_modules/dnn/eben_generator.py:287-316) ---------------------------------
  *   y = xin + lrelu( W_pw . ( W_dil (*) xin ), out_slope ),  xin = lrelu(x, in_slope)

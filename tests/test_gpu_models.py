@@ -728,3 +728,32 @@ def test_fused_adam_follows_a_restored_state(hip):
     for p in clone.param_groups[0]["params"]:
         p.grad = torch.ones_like(p)
     clone.step()
+
+
+
+@pytest.mark.parametrize("size", ["formula_2x8200", "config2"])
+def test_bundle_layout_step_against_the_fp32_at_rest_bf16_step(hip, golden, size):
+    """Plan "bf16_bl" (embeddings / stacked gradients at rest as bf16 bundles: disc_engine_bl.py) against plan "bf16" (fp32 tensors at
+    rest, rounded when staged): the MFMA operands are the same roundings of the same values, so one step from the same state must give
+    the same losses and the same gradients up to summation order and the 2^-17 of the hi + lo feature-matching operands -- orders of
+    magnitude inside what separates either from the fp32 step (BF16_STEP_TOLERANCES)."""
+    import bench
+
+    if size == "config2":
+        def make():
+            return bench.build_module(DEV, 1234), bench.synthetic_batch(32, 32000, 1234, DEV)
+    else:
+        def make():
+            m, _, _ = make_module(golden, use_mrstft=True)
+            return m, {"audio_body_conducted": formula_audio("step0/bc", 2, 8200).to(DEV), "audio_airborne": formula_audio("step0/air", 2, 8200).to(DEV)}
+
+    a = _one_step(make, "bf16", "bf16", stft_math="folded_x3")
+    b = _one_step(make, "bf16_bl", "bf16", stft_math="folded_x3")
+    assert torch.equal(a[0], b[0])
+    worst = max(abs(b[1][k] - v) / abs(v) for k, v in a[1].items())
+    norms = float(((a[2] - b[2]).abs() / a[2].abs()).max())
+    g_rel, d_rel = _rel(a[3][0], b[3][0]), _rel(a[3][1], b[3][1])
+    print(f"bundle layout vs fp32 at rest ({size}): worst logged value {worst:.2e}, balancing norms {norms:.2e}, generator grad {g_rel:.2e}, discriminator grad {d_rel:.2e}")
+    assert worst < 2e-4 and norms < 2e-3
+    assert g_rel < 2e-3 and d_rel < 1e-2
+

@@ -58,7 +58,13 @@ class EbenWnScaleItem(ctypes.Structure):
 class EbenWnBwdItem(ctypes.Structure):
     _fields_ = [("slabs", c_void_p), ("g", c_void_p), ("v", c_void_p), ("norm", c_void_p), ("dg", c_void_p), ("dv", c_void_p),
                 ("dbias", c_void_p), ("slab_stride", c_int64), ("nslab", c_int32), ("rows", c_int32), ("cols", c_int32),
-                ("row_stride", c_int32)]
+                ("row_stride", c_int32), ("col_perm_k", c_int32), ("pad_", c_int32)]
+
+
+class EbenBlHeadJob(ctypes.Structure):
+    _fields_ = [("x", c_void_p), ("v", c_void_p), ("scale", c_void_p), ("bias", c_void_p), ("y_hi", c_void_p), ("y_lo", c_void_p),
+                ("c_in", c_int32), ("c_out", c_int32), ("l_in", c_int32), ("l_out", c_int32), ("ksize", c_int32), ("dilation", c_int32),
+                ("pad", c_int32), ("reflect_pad", c_int32), ("out_slope", c_float), ("pad_", c_int32)]
 
 
 class EbenAdamTensor(ctypes.Structure):
@@ -101,6 +107,23 @@ SIGNATURES = {
     "eben_conv1d_bwd_dx_ex": (c_int, [_D, _P, _P, _P, c_int, _P, c_float, c_int, POINTER(c_int), _P, _P]),
     "eben_conv1d_bwd_dx_fm": (c_int, [_D, _P, _P, _P, c_int, _P, c_float, _P, c_float, c_int, POINTER(c_int), _P, _P]),
     "eben_conv1d_bwd_dw": (c_int, [_D, _P, _P, _P, c_int, _P, c_size_t, _P]),
+    "eben_bl_from_f32": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P]),
+    "eben_bl_to_f32": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P]),
+    "eben_bl_conv1d_fwd": (c_int, [_D, _P, _P, _P, _P, _P, _P, _P]),
+    "eben_bl_conv1d_bwd_dx": (c_int, [_D, _P, _P, _P, _P, c_float, c_int, POINTER(c_int), c_int, c_int, _P, c_float, _P, _P, _P]),
+    "eben_bl_conv1d_bwd_dw_workspace": (c_size_t, [_D, POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
+    "eben_bl_conv1d_bwd_dw": (c_int, [_D, _P, _P, c_int, _P, c_size_t, _P]),
+    "eben_bl_head_fwd": (c_int, [POINTER(EbenBlHeadJob), c_int, c_int, _P]),
+    "eben_bl_head_dx": (c_int, [POINTER(EbenBlHeadJob), c_int, c_int, _P, _P]),
+    "eben_bl_head_dw_workspace": (c_size_t, [POINTER(EbenBlHeadJob), POINTER(c_int), POINTER(c_int)]),
+    "eben_bl_head_dw": (c_int, [POINTER(EbenBlHeadJob), c_int, _P, c_size_t, _P]),
+    "eben_bl_tail_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_float, _P, _P]),
+    "eben_bl_tail_dx": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_float, c_int, POINTER(c_int), c_int, c_int, _P, c_float,
+                                _P, _P, _P]),
+    "eben_bl_tail_dw_workspace": (c_size_t, [c_int, c_int, POINTER(c_int), POINTER(c_int)]),
+    "eben_bl_tail_dw": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, c_size_t, _P]),
+    "eben_bl_fm_sums_workspace": (c_size_t, [c_int]),
+    "eben_bl_fm_sums": (c_int, [POINTER(c_void_p), POINTER(c_int64), c_int, _P, c_size_t, _P, _P]),
     "eben_ru_packed_floats": (c_size_t, [c_int]),
     "eben_ru_pack": (c_int, [c_int, _P, _P, _P, _P, _P, _P]),
     "eben_ru_fwd": (c_int, [c_int, c_int, c_int, c_int, _P, c_float, c_float, _P, _P, _P, _P, _P]),

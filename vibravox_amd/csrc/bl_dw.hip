@@ -1,0 +1,322 @@
+// bl_dw.hip -- weight (+ bias) gradient of a Conv1d layer with BOTH operands at rest in the bf16 bundle layout (gfx950).
+//
+//   dw[co, c, j] = sum_{b, t} dy[b, co, t] * x[b, c, t*S + j*d - pad],      dbias[co] = sum_{b, t} dy[b, co, t]
+//
+// GEMM per group on v_mfma_f32_32x32x16_bf16: M = output channels, N = (channel bundle, tap, channel in bundle) columns + one bias
+// column bundle, K = (batch item, time) -- the reduction runs ALONG TIME, 16 steps per MFMA.  An MFMA operand wants 8 consecutive k
+// per lane; memory holds 8 consecutive CHANNELS per 16-byte unit ([batch][channels / 8][length][8]), i.e. the transpose.  gfx950
+// transposes on the way out of LDS: ds_read_b64_tr_b16 hands lane l the k-th elements of four 8-byte rows supplied by four other
+// lanes of its 16-lane group (mapping checked on the device, tools/ubench/probe_lds.hip), so that
+//   * both operand tiles are plain COPIES of units: A rows = 64 consecutive time steps of one bundle of dy (1 KB), X rows = the
+//     stride phases of one bundle of x around the chunk (de-interleaved by the source address: consecutive time steps of a tap are
+//     consecutive units of row (bundle, (j d - pad) mod S)), moved by buffer_load ... lds -- no VGPR round trip, no conversion, no
+//     packing pre-pass (conv_dw3.hip: dw3_pack_a + fp32 -> bf16 staging of X); the descriptor's bounds ARE the zero padding, in time
+//     for dy and in position for x (out-of-range lanes write zeros to LDS, same probe);
+//   * a fragment is two transposing reads (k = 0..3 and 4..7 of the lane's eight) at per-lane base addresses fixed for the whole
+//     launch + immediates; row strides = 4 mod 16 units keep the 32 lanes of a half-wave on distinct banks.
+// Block = 4 waves as 2 x 2, (64 FM) x (64 FN) outputs; K chunk = one batch item x 64 time steps, double-buffered: the next chunk's
+// tiles are in flight while the current one is multiplied, one barrier per chunk.  Split-K over blocks into private fp32 slabs
+// (fixed-order reduction by eben_wn_bwd_multi).  Columns are ordered (bundle, tap, channel in bundle), which makes the slab stores
+// contiguous; EbenWnBwdItem.col_perm_k tells the reduction.  Layers whose groups do not start on bundles (4 / 6 / 12 channels per
+// group) run as ONE dense contraction over all channels and store the block-diagonal part in the standard order.
+#include "common.h"
+
+#include <cstdlib>
+
+namespace eben {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BLDW_BKT = 64;    // time steps per K chunk
+constexpr int BLDW_TS = 68;     // A row stride in units (64 + 4: = 4 mod 16)
+constexpr int BLDW_RS = 132;    // X row stride in units (two whole 64-unit LDS-DMA pieces + 4)
+
+struct BlDwArgs {
+  const u32x4* ah; const u32x4* xh;
+  float* slabs;
+  int B, G, Mg, Cg, MgB, CgB, CBa, CBx, La, Lx;
+  int S, d, k, pad, amin;
+  int NQW;                       // weight column bundles (CgB * k); bundle NQW is the bias column
+  int has_bias, nnt, nmt, nsplit, nct, nchunks, XR;
+  int dense, c_in_g, c_out_g, row_stride;
+  long long slab_stride;
+};
+
+__device__ __forceinline__ bf16x8 bl_tr_frag(unsigned addr) {
+  typedef __attribute__((address_space(3))) s16x4* lds4_t;
+  const s16x4 r0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(size_t)(addr));
+  const s16x4 r1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(size_t)(addr + 64u));   // + 4 units: k = 4..7 of the lane's eight
+  const s16x8 v = {r0[0], r0[1], r0[2], r0[3], r1[0], r1[1], r1[2], r1[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+// One LDS-DMA piece: 64 lanes x 16 bytes from descriptor `rs` at byte offsets `voff` (out of range: zeros) to LDS bytes [dst, dst + 1024).
+// Inline asm on purpose: hipcc (ROCm 7.2) does not order a __builtin_amdgcn_raw_ptr_buffer_load_lds against later LDS reads or barriers
+// inside a loop (no wait at all), and puts s_waitcnt vmcnt(0) in front of every ds_read_b64_tr_b16 intrinsic while a DMA it does know
+// about is in flight (no overlap at all).  Hidden from its bookkeeping, the pieces are waited for by the explicit vmcnt(0) in front of
+// the chunk barrier below.  M0 (the DMA's LDS base) is saved and restored inside the statement; s_nop 4: SALU-written descriptor words
+// -> VMEM read; s_nop 0: M0 write -> LDS-DMA.
+__device__ __forceinline__ void bl_dma_piece(const u32x4 rs, unsigned dst, int voff) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(rs), "s"(dst) : "memory");
+}
+__device__ __forceinline__ u32x4 bl_rsrc(const void* base, int bytes) {
+  const unsigned long long a = (unsigned long long)base;
+  u32x4 r;
+  r[0] = __builtin_amdgcn_readfirstlane((unsigned)a);
+  r[1] = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32) & 0xffffu);
+  r[2] = __builtin_amdgcn_readfirstlane((unsigned)bytes);
+  r[3] = 0x00020000u;
+  return r;
+}
+
+template <int FM, int FN>
+__global__ __launch_bounds__(256, 2) void bl_dw_kernel(const BlDwArgs P) {
+  constexpr int BM = 64 * FM, BMB = BM / 8, BNQ = 8 * FN, BKT = BLDW_BKT, TS = BLDW_TS, RS = BLDW_RS;
+  extern __shared__ __attribute__((aligned(16))) u32x4 smem_bldw[];
+  typedef __attribute__((address_space(3))) void* lds_t;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  unsigned id = xcd_remap(blockIdx.x, gridDim.x);
+  const int z = __builtin_amdgcn_readfirstlane(id % P.nsplit); id /= P.nsplit;
+  const int nti = __builtin_amdgcn_readfirstlane(id % P.nnt); id /= P.nnt;
+  const int mt = __builtin_amdgcn_readfirstlane(id % P.nmt);
+  const int g = __builtin_amdgcn_readfirstlane(id / P.nmt);
+
+  const int q0 = nti * BNQ;
+  int cb_lo = q0 / P.k;
+  if (cb_lo > P.CgB - 1) cb_lo = P.CgB - 1;
+  int qlast = q0 + BNQ < P.NQW ? q0 + BNQ : P.NQW;
+  int cb_hi = (qlast - 1) / P.k;
+  if (cb_hi < cb_lo) cb_hi = cb_lo;
+  const int xrows = (cb_hi - cb_lo + 1) * P.S;        // X rows of this tile: (channel bundle, stride phase)
+
+  const int a_units = BMB * TS, buf_units = a_units + P.XR * RS;
+  // LDS: [ones row: RS units of (1, 0, 0, 0 | 0, 0, 0, 0)] [buffer 0: A rows, X rows] [buffer 1]
+  for (int i = tid; i < RS; i += 256) smem_bldw[i] = u32x4{0x00003f80u, 0u, 0u, 0u};
+  const unsigned lds0 = (unsigned)(unsigned long long)(lds_t)smem_bldw;
+  const unsigned ones_addr = lds0, buf_addr = lds0 + RS * 16;
+
+  // ---- per-lane fragment addresses (bytes inside a buffer), fixed for the launch -----------------------------------------------
+  // ds_read_b64_tr_b16: this lane SUPPLIES the 8-byte row (4 consecutive channels at one time step) of
+  //   channel quad 4 (2 (G & 1) + (qs >> 1)) + ... i.e. bundle +2 (G & 1) + (qs >> 1), half qs & 1, time step 8 (G >> 1) + js (+ 4 for the second read)
+  const int G4 = lane >> 4, js = (lane & 15) >> 2, qs = lane & 3;
+  const int koff = 8 * (G4 >> 1) + js;
+  unsigned aoff[FM], boff[FN];
+  bool bconst[FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+    const int bundle = (wm * FM + i) * 4 + 2 * (G4 & 1) + (qs >> 1);
+    aoff[i] = (unsigned)((bundle * TS + koff) * 16 + 8 * (qs & 1));
+  }
+#pragma unroll
+  for (int f = 0; f < FN; ++f) {
+    const int q = q0 + 4 * (wn * FN + f) + 2 * (G4 & 1) + (qs >> 1);
+    if (q < P.NQW) {
+      const int cb = q / P.k, j = q - cb * P.k;
+      const int off = j * P.d - P.pad;
+      int a = off / P.S;
+      if (off < 0 && a * P.S != off) --a;                // floor
+      const int p = off - a * P.S;
+      const int row = (cb - cb_lo) * P.S + p;
+      boff[f] = (unsigned)(a_units * 16 + (row * RS + (a - P.amin) + koff) * 16 + 8 * (qs & 1));
+      bconst[f] = false;
+    } else {                                             // the bias column bundle (and the padding behind it): constant rows
+      boff[f] = (unsigned)(koff * 16 + 8 * (qs & 1));
+      bconst[f] = true;
+    }
+  }
+
+  f32x16 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int f = 0; f < FN; ++f)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][f][r] = 0.f;
+
+  // ---- tile movement: every row is a run of 64 (A) / 2 x 64 (X) units, one LDS-DMA piece each ---------------------------------------
+  auto issue = [&](int q, int bsel) {
+    const int b = q / P.nct;
+    const int t0 = (q - b * P.nct) * BKT;
+    const unsigned dst = buf_addr + (unsigned)(bsel * buf_units * 16);
+    for (int r = wave; r < BMB; r += 4) {
+      int bundle = g * P.MgB + mt * BMB + r;
+      if (bundle > P.CBa - 1) bundle = P.CBa - 1;       // rows past the tensor: any valid row, the results are not stored
+      const u32x4 rs = bl_rsrc(P.ah + ((long long)b * P.CBa + bundle) * P.La, P.La * 16);
+      bl_dma_piece(rs, __builtin_amdgcn_readfirstlane(dst + (unsigned)(r * TS * 16)), (t0 + lane) * 16);
+    }
+    for (int xr = wave; xr < xrows; xr += 4) {
+      const int cbl = xr / P.S, p = xr - cbl * P.S;
+      int cb = cb_lo + cbl;
+      if (cb > P.CgB - 1) cb = P.CgB - 1;
+      const u32x4 rs = bl_rsrc(P.xh + ((long long)b * P.CBx + (long long)g * P.CgB + cb) * P.Lx, P.Lx * 16);
+      const unsigned rdst = dst + (unsigned)((a_units + xr * RS) * 16);
+#pragma unroll
+      for (int piece = 0; piece < 2; ++piece) {
+        // unit u of the row = position (t0 + amin + u) S + p; negative / beyond Lx: out of the descriptor's range -> zeros
+        const int pos = (t0 + P.amin + piece * 64 + lane) * P.S + p;
+        bl_dma_piece(rs, __builtin_amdgcn_readfirstlane(rdst + (unsigned)(piece * 64 * 16)), pos * 16);
+      }
+    }
+  };
+
+  int bsel = 0;
+  if (z < P.nchunks) issue(z, 0);
+  for (int q = z; q < P.nchunks; q += P.nsplit) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of chunk q have landed ...
+    __syncthreads();                                   // ... and everybody's; buffer bsel ^ 1 (read during the previous chunk) is free
+    const int qn = q + P.nsplit;
+    if (qn < P.nchunks) issue(qn, bsel ^ 1);
+    const unsigned base = buf_addr + (unsigned)(bsel * buf_units * 16);
+#pragma unroll
+    for (int ks = 0; ks < BKT / 16; ++ks) {
+      bf16x8 av[FM], bv[FN];
+#pragma unroll
+      for (int i = 0; i < FM; ++i) av[i] = bl_tr_frag(base + aoff[i] + (unsigned)(ks * 256));
+#pragma unroll
+      for (int f = 0; f < FN; ++f) bv[f] = bl_tr_frag((bconst[f] ? ones_addr : base) + boff[f] + (unsigned)(ks * 256));
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int f = 0; f < FN; ++f) acc[i][f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[f], acc[i][f], 0, 0, 0);
+    }
+    bsel ^= 1;
+  }
+
+  // ---- epilogue: slab[z][row][column] ------------------------------------------------------------------------------------------------
+  float* slab = P.slabs + (long long)z * P.slab_stride;
+  const int m_base = mt * BM + wm * FM * 32 + 4 * (lane >> 5);
+#pragma unroll
+  for (int f = 0; f < FN; ++f) {
+    const int nl = lane & 31;
+    const int q = q0 + 4 * (wn * FN + f) + (nl >> 3), e = nl & 7;
+    long long col = -1;
+    int cgrp = -1;
+    if (!P.dense) {
+      // bundle-major columns: 8 q + e (contiguous over the lanes); the bias bundle keeps its first column
+      if (q < P.NQW || (q == P.NQW && e == 0 && P.has_bias)) col = 8LL * q + e;
+    } else if (q < P.NQW) {
+      const int cb = q / P.k, j = q - cb * P.k, c = 8 * cb + e;
+      cgrp = c / P.c_in_g;
+      col = (long long)(c - cgrp * P.c_in_g) * P.k + j;
+    } else if (q == P.NQW && e == 0 && P.has_bias) {
+      col = (long long)P.c_in_g * P.k;
+    }
+    if (col < 0) continue;
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m_base + i * 32 + (r & 3) + 8 * (r >> 2);
+        if (m >= P.Mg) continue;
+        if (P.dense && cgrp >= 0 && m / P.c_out_g != cgrp) continue;
+        slab[((long long)g * P.Mg + m) * P.row_stride + col] = acc[i][f][r];
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+struct BlDwPlan {
+  int ok, G, Mg, Cg, MgB, CgB, dense, FM, FN, nmt, nnt, NQW, nct, nchunks, nsplit, XR, amin, row_stride, perm_k;
+  size_t lds_bytes;
+  long long slab_stride;
+};
+
+static int bldw_floordiv(int a, int b) { int q = a / b; if ((a % b != 0) && ((a < 0) != (b < 0))) --q; return q; }
+
+static void make_bldw_plan(const Canon& c, BlDwPlan* p) {
+  p->ok = 0;
+  if (!c.bl || c.reflect || c.np != 1) return;          // single bf16 operands (EBEN_MATH_BF16)
+  p->G = c.g; p->Mg = c.Cout / c.g; p->Cg = c.Cin / c.g; p->dense = 0;
+  if ((p->Mg & 7) || (p->Cg & 7)) { p->dense = 1; p->G = 1; p->Mg = c.Cout; p->Cg = c.Cin; }
+  if ((p->Mg & 7) || (p->Cg & 7)) return;
+  p->MgB = p->Mg / 8; p->CgB = p->Cg / 8;
+  p->amin = bldw_floordiv(-c.pl, c.s);
+  const int amax = bldw_floordiv((c.k - 1) * c.d - c.pl, c.s);
+  if (amax - p->amin > 60 || c.s > 8) return;           // BKT + halo units per X row must fit the two DMA pieces
+  p->FM = (p->Mg > 64 && round_up(p->Mg, 128) == round_up(p->Mg, 64)) ? 2 : 1;
+  p->NQW = p->CgB * c.k;
+  p->FN = p->NQW + 1 > 8 ? 2 : 1;
+  const int BNQ = 8 * p->FN;
+  p->nmt = ceil_div(p->Mg, 64 * p->FM);
+  p->nnt = ceil_div(p->NQW + 1, BNQ);
+  int ncb = (BNQ - 1) / c.k + 2;
+  if (ncb > p->CgB) ncb = p->CgB;
+  p->XR = ncb * c.s;
+  p->lds_bytes = 16ull * (BLDW_RS + 2ull * ((64 * p->FM / 8) * BLDW_TS + p->XR * BLDW_RS));
+  if (p->lds_bytes > 160 * 1024) return;
+  p->nct = ceil_div(c.Lout, BLDW_BKT);
+  p->nchunks = c.B * p->nct;
+  const int tiles = p->nnt * p->nmt * p->G;
+  static const int target = getenv("EBEN_BLDW_BLOCKS") ? atoi(getenv("EBEN_BLDW_BLOCKS")) : 768;
+  int ns = tiles >= target / 2 ? 1 : ceil_div(target, tiles);
+  if (ns > 256) ns = 256;
+  if (ns > p->nchunks) ns = p->nchunks;
+  if (ns < 1) ns = 1;
+  p->nsplit = ns;
+  if (p->dense) { p->row_stride = (c.Cin / c.g) * c.k + 1; p->perm_k = 0; }
+  else { p->row_stride = p->Cg * c.k + 1; p->perm_k = c.k; }
+  p->slab_stride = (long long)c.Cout * p->row_stride;
+  p->ok = 1;
+}
+
+template <int FM, int FN>
+static int launch_bldw(const BlDwArgs& a, const BlDwPlan& p, hipStream_t st) {
+  static bool attr_set = false;
+  auto kern = bl_dw_kernel<FM, FN>;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(bl_dw)");
+    attr_set = true;
+  }
+  const long long nb = (long long)p.nnt * p.nmt * p.G * p.nsplit;
+  hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(256), p.lds_bytes, st, a);
+  EBEN_CHECK_LAUNCH("bl_dw_kernel");
+  return EBEN_OK;
+}
+
+}  // namespace eben
+
+using namespace eben;
+
+extern "C" size_t eben_bl_conv1d_bwd_dw_workspace(const EbenConv1dDesc* d, int* nslab, int* row_stride, int* col_perm_k) {
+  Canon c;
+  if (canon_from_desc(d, &c) != EBEN_OK || d->transposed) return 0;
+  BlDwPlan p;
+  make_bldw_plan(c, &p);
+  if (!p.ok) return 0;
+  if (nslab) *nslab = p.nsplit;
+  if (row_stride) *row_stride = p.row_stride;
+  if (col_perm_k) *col_perm_k = p.perm_k;
+  return sizeof(float) * (size_t)p.slab_stride * p.nsplit;
+}
+
+extern "C" int eben_bl_conv1d_bwd_dw(const EbenConv1dDesc* d, const void* dy_hi, const void* x_hi, int has_bias, float* slabs, size_t ws_bytes,
+                                     void* stream) {
+  Canon c;
+  int rc = canon_from_desc(d, &c);
+  if (rc) return rc;
+  EBEN_REQUIRE(!d->transposed && dy_hi && x_hi && slabs, "eben_bl_conv1d_bwd_dw: a Conv1d descriptor and non-null operands");
+  BlDwPlan p;
+  make_bldw_plan(c, &p);
+  if (!p.ok) return fail(EBEN_EUNSUPPORTED, "eben_bl_conv1d_bwd_dw: layer not covered by the bundle-layout weight-gradient kernel");
+  const size_t need = sizeof(float) * (size_t)p.slab_stride * p.nsplit;
+  if (ws_bytes < need) return fail(EBEN_EWORKSPACE, "bl bwd_dw needs %zu workspace bytes, got %zu", need, ws_bytes);
+  BlDwArgs a;
+  a.ah = static_cast<const u32x4*>(dy_hi); a.xh = static_cast<const u32x4*>(x_hi); a.slabs = slabs;
+  a.B = c.B; a.G = p.G; a.Mg = p.Mg; a.Cg = p.Cg; a.MgB = p.MgB; a.CgB = p.CgB; a.CBa = c.Cout / 8; a.CBx = c.Cin / 8; a.La = c.Lout; a.Lx = c.Lin;
+  a.S = c.s; a.d = c.d; a.k = c.k; a.pad = c.pl; a.amin = p.amin; a.NQW = p.NQW; a.has_bias = has_bias ? 1 : 0;
+  a.nnt = p.nnt; a.nmt = p.nmt; a.nsplit = p.nsplit; a.nct = p.nct; a.nchunks = p.nchunks; a.XR = p.XR;
+  a.dense = p.dense; a.c_in_g = c.Cin / c.g; a.c_out_g = c.Cout / c.g; a.row_stride = p.row_stride; a.slab_stride = p.slab_stride;
+  hipStream_t st = as_stream(stream);
+  if (p.FM == 2) return p.FN == 2 ? launch_bldw<2, 2>(a, p, st) : launch_bldw<2, 1>(a, p, st);
+  return p.FN == 2 ? launch_bldw<1, 2>(a, p, st) : launch_bldw<1, 1>(a, p, st);
+}

@@ -1,0 +1,602 @@
+// bl_edge.hip -- the ends of the discriminator chains in the bf16 BUNDLE LAYOUT (include/eben_hip.h, "bundle layout"), gfx950.
+//
+// Between the chain heads and the logits every activation / gradient of the batched discriminator engine is at rest as bf16
+// [batch][channels / 8][length][8] (planes hi = bf16(v), lo = bf16(v - hi)): one 16-byte unit = 8 channels at one position = the unit
+// the bf16 tap-conv stages into LDS (tapconv3.hip, template flag BL) and the weight-gradient kernel transposes on read (bl_dw.hip).
+// The layers at the two ends have one side in plain fp32 (batch, channel, time) -- the band / waveform inputs, the logits and their
+// seeds -- and a handful of channels there: they are streaming kernels (fp32 FMA, one thread = one position x one bundle), bound by
+// the bundle side's HBM traffic:
+//   head:  ReflectionPad1d(P) + Conv1d(c_in -> c_out, k, dilation, groups = c_in, zero padding) + bias + LeakyReLU
+//          (eben_discriminator.py:66-76 layer 0: 4 -> 24, k 3, dilation 1 / 2 / 3;  melgan_discriminator.py:89-98 layer 0: 1 -> 16, k 15)
+//          forward, input gradient (with the reflect fold, summed over the chains that share the input) and weight gradient;
+//   tail:  Conv1d(C -> 1, k 3, padding 1) (eben_discriminator.py:150-157, melgan_discriminator.py:147-156: the logits)
+//          forward, input gradient (+ the feature-matching term and the LeakyReLU mask of the embedding below) and weight gradient;
+//   feature-matching sums over bundle planes (feature_loss.py:40-47), fp32 <-> bundle conversions (tests, tools).
+#include "common.h"
+
+namespace eben {
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned bl_pk(float a, float b) {
+  const f32x2v v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2v));   // v_cvt_pk_bf16_f32 (RNE)
+}
+__device__ __forceinline__ void bl_unpack8(const u32x4 w, float (&f)[8]) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    f[2 * e] = __builtin_bit_cast(float, w[e] << 16);
+    f[2 * e + 1] = __builtin_bit_cast(float, w[e] & 0xffff0000u);
+  }
+}
+__device__ __forceinline__ u32x4 bl_pack8(const float (&f)[8]) {
+  u32x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o[e] = bl_pk(f[2 * e], f[2 * e + 1]);
+  return o;
+}
+// lo plane of values whose hi plane is `hi`: bf16(v - hi), the residual exact in fp32
+__device__ __forceinline__ u32x4 bl_pack8_lo(const float (&f)[8], const u32x4 hi) {
+  float h[8];
+  bl_unpack8(hi, h);
+  u32x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o[e] = bl_pk(f[2 * e] - h[2 * e], f[2 * e + 1] - h[2 * e + 1]);
+  return o;
+}
+// hi (+ lo) planes -> fp32 values
+__device__ __forceinline__ void bl_load8(const u32x4* __restrict__ hi, const u32x4* __restrict__ lo, long long idx, float (&f)[8]) {
+  bl_unpack8(hi[idx], f);
+  if (lo) {
+    float l[8];
+    bl_unpack8(lo[idx], l);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] += l[e];
+  }
+}
+
+// ---- conversions ----------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bl_from_f32_kernel(const float* __restrict__ x, long long units, int CB, int L, u32x4* __restrict__ hi,
+                                                          u32x4* __restrict__ lo) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < units; i += (long long)gridDim.x * 256) {
+    const long long row = i / L;              // (batch, bundle)
+    const int t = (int)(i - row * L);
+    const float* p = x + row * 8 * L + t;     // channel 8 * bundle of that batch item
+    float f[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = p[(long long)e * L];
+    const u32x4 h = bl_pack8(f);
+    hi[i] = h;
+    if (lo) lo[i] = bl_pack8_lo(f, h);
+  }
+}
+__global__ __launch_bounds__(256) void bl_to_f32_kernel(const u32x4* __restrict__ hi, const u32x4* __restrict__ lo, long long units, int L,
+                                                        float* __restrict__ x) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < units; i += (long long)gridDim.x * 256) {
+    const long long row = i / L;
+    const int t = (int)(i - row * L);
+    float f[8];
+    bl_load8(hi, lo, i, f);
+    float* p = x + row * 8 * L + t;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) p[(long long)e * L] = f[e];
+  }
+}
+
+// ---- chain heads ----------------------------------------------------------------------------------------------------------------
+constexpr int BL_HEAD_JOBS = 4;
+constexpr int BL_HEAD_WMAX = 256;   // c_out * ksize floats of one job's weights held in LDS
+struct BlHeadJob {
+  const float* x; const float* v; const float* scale; const float* bias;
+  u32x4* yh; u32x4* yl;               // forward outputs / input-gradient inputs (g planes)
+  int c_in, c_out, l_in, l_out, k, dil, pad, rpad;
+  float out_slope;
+};
+struct BlHeadTable { BlHeadJob job[BL_HEAD_JOBS]; int n, batch; };
+
+// position u of the reflect-padded (rpad) and then zero-extended signal: index into the row, or -1
+__device__ __forceinline__ int bl_head_src(int p, int rpad, int l_in) {
+  if (p < 0 || p >= l_in + 2 * rpad) return -1;
+  int u = p - rpad;
+  u = u < 0 ? -u : u;
+  return u >= l_in ? 2 * (l_in - 1) - u : u;
+}
+
+// one block = 256 output positions of one (batch item, output bundle) of one job; groups = c_in (one input channel per output channel)
+__global__ __launch_bounds__(256) void bl_head_fwd_kernel(const BlHeadTable T) {
+  __shared__ float wsh[8 * 16 + 8];
+  const BlHeadJob& J = T.job[blockIdx.z];
+  const int CB = J.c_out >> 3;
+  const int b = blockIdx.y / CB, ob = blockIdx.y - b * CB;
+  if (b >= T.batch || (int)blockIdx.x * 256 >= J.l_out) return;
+  const int og = J.c_out / J.c_in;          // output channels per group
+  for (int i = threadIdx.x; i < 8 * J.k + 8; i += 256) {
+    if (i < 8 * J.k) {
+      const int e = i / J.k, j = i - e * J.k, co = 8 * ob + e;
+      wsh[e * 16 + j] = J.v[(long long)co * J.k + j] * (J.scale ? J.scale[co] : 1.f);
+    } else {
+      wsh[8 * 16 + (i - 8 * J.k)] = J.bias ? J.bias[8 * ob + (i - 8 * J.k)] : 0.f;
+    }
+  }
+  __syncthreads();
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= J.l_out) return;
+  float acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = wsh[8 * 16 + e];
+  const float* xb = J.x + (long long)b * J.c_in * J.l_in;
+  const int ci0 = (8 * ob) / og, ci1 = (8 * ob + 7) / og;   // at most two input channels feed one bundle when og >= 4
+  for (int j = 0; j < J.k; ++j) {
+    const int u = bl_head_src(t - J.pad + j * J.dil, J.rpad, J.l_in);
+    const float x0 = u >= 0 ? xb[(long long)ci0 * J.l_in + u] : 0.f;
+    const float x1 = (u >= 0 && ci1 != ci0) ? xb[(long long)ci1 * J.l_in + u] : x0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int ci = (8 * ob + e) / og;
+      float xv = ci == ci0 ? x0 : x1;
+      if (ci != ci0 && ci != ci1) xv = u >= 0 ? xb[(long long)ci * J.l_in + u] : 0.f;   // og < 4: more than two groups per bundle
+      acc[e] = fmaf(wsh[e * 16 + j], xv, acc[e]);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = lrelu(acc[e], J.out_slope);
+  const long long idx = ((long long)b * CB + ob) * J.l_out + t;
+  const u32x4 h = bl_pack8(acc);
+  J.yh[idx] = h;
+  if (J.yl) J.yl[idx] = bl_pack8_lo(acc, h);
+}
+
+// Input gradient of the heads, summed over the jobs (the three PQMF-band chains share their input):
+//   dxp[b, ci, p] = sum_{co in group ci} sum_j w[co, j] g[b, co, p + pad - j dil],   dx[u] = dxp[u + P] + reflect folds
+// one thread = one (batch item, position u), all c_in <= 4 input channels
+__global__ __launch_bounds__(256) void bl_head_dx_kernel(const BlHeadTable T, float* __restrict__ dx) {
+  __shared__ float wsh[BL_HEAD_JOBS][BL_HEAD_WMAX];
+  for (int jb = 0; jb < T.n; ++jb) {
+    const BlHeadJob& J = T.job[jb];
+    for (int i = threadIdx.x; i < J.c_out * J.k; i += 256) wsh[jb][i] = J.v[i] * (J.scale ? J.scale[i / J.k] : 1.f);
+  }
+  __syncthreads();
+  const int l_in = T.job[0].l_in, c_in = T.job[0].c_in;
+  const int b = blockIdx.y;
+  const int u = blockIdx.x * 256 + threadIdx.x;
+  if (u >= l_in) return;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int jb = 0; jb < T.n; ++jb) {
+    const BlHeadJob& J = T.job[jb];
+    const int CB = J.c_out >> 3, og = J.c_out / J.c_in, P = J.rpad;
+    // the padded positions that fold onto u (nn.ReflectionPad1d's adjoint)
+    int pts[3];
+    int np = 0;
+    pts[np++] = u + P;
+    if (u >= 1 && u <= P) pts[np++] = P - u;
+    if (u >= l_in - 1 - P && u <= l_in - 2) pts[np++] = P + 2 * (l_in - 1) - u;
+    for (int q = 0; q < np; ++q) {
+      for (int j = 0; j < J.k; ++j) {
+        const int t = pts[q] + J.pad - j * J.dil;
+        if (t < 0 || t >= J.l_out) continue;
+        for (int ob = 0; ob < CB; ++ob) {
+          float gv[8];
+          bl_load8(J.yh, J.yl, ((long long)b * CB + ob) * J.l_out + t, gv);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int co = 8 * ob + e, ci = co / og;
+            const float w = wsh[jb][co * J.k + j] * gv[e];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[c] += c == ci ? w : 0.f;
+          }
+        }
+      }
+    }
+  }
+  for (int c = 0; c < c_in; ++c) dx[((long long)b * c_in + c) * l_in + u] = acc[c];
+}
+
+// Weight (+ bias) gradient of a head: slab[z][co][j] = sum over the (batch item, position) pairs of slice z of g[b, co, t] xp[b, ci(co), t - pad + j dil],
+// column k = sum g.  One block = one output bundle x one slice; KT = padded tap count.
+template <int KT>
+__global__ __launch_bounds__(256) void bl_head_dw_kernel(const u32x4* __restrict__ gh, const float* __restrict__ x, int rows, int c_in, int c_out,
+                                                         int l_in, int l_out, int k, int dil, int pad, int rpad, int nslab, float* __restrict__ slabs) {
+  __shared__ float red[4][8 * (KT + 1)];
+  const int CB = c_out >> 3, og = c_out / c_in;
+  const int ob = blockIdx.x, z = blockIdx.y;
+  const long long total = (long long)rows * l_out;
+  const long long per = (total + nslab - 1) / nslab;
+  const long long lo = (long long)z * per, hi = lo + per < total ? lo + per : total;
+  float acc[8][KT + 1];
+#pragma unroll
+  for (int e = 0; e < 8; ++e)
+#pragma unroll
+    for (int j = 0; j <= KT; ++j) acc[e][j] = 0.f;
+  const int ci0 = (8 * ob) / og, ci1 = (8 * ob + 7) / og;
+  for (long long i = lo + threadIdx.x; i < hi; i += 256) {
+    const int b = (int)(i / l_out), t = (int)(i - (long long)b * l_out);
+    float gv[8];
+    bl_unpack8(gh[((long long)b * CB + ob) * l_out + t], gv);
+    const float* xb = x + (long long)b * c_in * l_in;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e][KT] += gv[e];
+#pragma unroll
+    for (int j = 0; j < KT; ++j) {
+      if (j < k) {
+        const int u = bl_head_src(t - pad + j * dil, rpad, l_in);
+        const float x0 = u >= 0 ? xb[(long long)ci0 * l_in + u] : 0.f;
+        const float x1 = (u >= 0 && ci1 != ci0) ? xb[(long long)ci1 * l_in + u] : x0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int ci = (8 * ob + e) / og;
+          float xv = ci == ci0 ? x0 : x1;
+          if (ci != ci0 && ci != ci1) xv = u >= 0 ? xb[(long long)ci * l_in + u] : 0.f;
+          acc[e][j] = fmaf(gv[e], xv, acc[e][j]);
+        }
+      }
+    }
+  }
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int e = 0; e < 8; ++e)
+#pragma unroll
+    for (int j = 0; j <= KT; ++j) {
+      const float s = wave_sum(acc[e][j]);
+      if (lane == 0) red[w][e * (KT + 1) + j] = s;
+    }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 8 * (KT + 1); i += 256) {
+    const int e = i / (KT + 1), j = i - e * (KT + 1);
+    if (j < k || j == KT) {
+      const float s = red[0][i] + red[1][i] + red[2][i] + red[3][i];
+      slabs[((long long)z * c_out + 8 * ob + e) * (k + 1) + (j == KT ? k : j)] = s;
+    }
+  }
+}
+
+// ---- chain tails (the logits layer: C -> 1, k taps, zero padding) ------------------------------------------------------------------
+// forward: one block = 64 output positions of one batch item; wave w sums the bundles cb = w, w + 4, ...; fp32 FMA on hi + lo
+__global__ __launch_bounds__(256) void bl_tail_fwd_kernel(const u32x4* __restrict__ xh, const u32x4* __restrict__ xl, int CB, int L, int k, int pad,
+                                                          int l_out, const float* __restrict__ v, const float* __restrict__ scale,
+                                                          const float* __restrict__ bias, float out_slope, float* __restrict__ y) {
+  extern __shared__ __attribute__((aligned(16))) float wt[];   // [CB * 8 * k] scaled weights, then 4 x 64 partial sums
+  float* part = wt + CB * 8 * k;
+  const float sc = scale ? scale[0] : 1.f;
+  for (int i = threadIdx.x; i < CB * 8 * k; i += 256) wt[i] = v[i] * sc;
+  __syncthreads();
+  const int b = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int t = blockIdx.x * 64 + lane;
+  float acc = 0.f;
+  if (t < l_out) {
+    for (int cb = w; cb < CB; cb += 4) {
+      const long long row = ((long long)b * CB + cb) * L;
+      for (int j = 0; j < k; ++j) {
+        const int q = t - pad + j;
+        if (q < 0 || q >= L) continue;
+        float f[8];
+        bl_load8(xh, xl, row + q, f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc = fmaf(wt[(cb * 8 + e) * k + j], f[e], acc);
+      }
+    }
+  }
+  part[w * 64 + lane] = acc;
+  __syncthreads();
+  if (w == 0 && t < l_out) {
+    const float s = (bias ? bias[0] : 0.f) + part[lane] + part[64 + lane] + part[128 + lane] + part[192 + lane];
+    y[(long long)b * l_out + t] = lrelu(s, out_slope);
+  }
+}
+
+// input gradient of the logits layer, with the epilogue of the engine's stacked backward:
+//   g[b, c, t] = ( sum_j w[c, j] seed[b, t + pad - j] + (b < fm_rows ? fm term of the embedding : 0) ) * lrelu'(act[map(b), c, t])
+struct BlTailDxArgs {
+  const float* seeds; const float* v; const float* scale;
+  const u32x4* ah; const u32x4* al;
+  u32x4* gh; u32x4* gl;
+  const float* fm_sums; float fm_gs, mask_slope;
+  int rows, CB, L, k, pad, l_out, fm_rows, ref_off, seg, map[4];
+};
+__global__ __launch_bounds__(256) void bl_tail_dx_kernel(const BlTailDxArgs P) {
+  __shared__ float wsh[8 * 8];
+  const int cb = blockIdx.y, b = blockIdx.z;
+  const float sc = P.scale ? P.scale[0] : 1.f;
+  if (threadIdx.x < 8 * P.k) wsh[threadIdx.x] = P.v[(long long)cb * 8 * P.k + threadIdx.x] * sc;   // [e][j], k <= 8
+  __syncthreads();
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= P.L) return;
+  float val[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) val[e] = 0.f;
+  const float* sd = P.seeds + (long long)b * P.l_out;
+  for (int j = 0; j < P.k; ++j) {
+    const int q = t + P.pad - j;
+    const float s = (q >= 0 && q < P.l_out) ? sd[q] : 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) val[e] = fmaf(wsh[e * P.k + j], s, val[e]);
+  }
+  const int eb = P.seg > 0 ? P.map[b / P.seg] * P.seg + b % P.seg : b;
+  float a0[8];
+  const long long ai = ((long long)eb * P.CB + cb) * P.L + t;
+  bl_unpack8(P.ah[ai], a0);
+  if (P.fm_sums != nullptr && b < P.fm_rows) {
+    const float s1 = P.fm_sums[0], s2 = P.fm_sums[1];
+    const float k1 = P.fm_gs / s2, k2 = P.fm_gs * s1 / (s2 * s2);
+    float a1[8], r[8];
+    bl_unpack8(P.al[ai], a1);
+    bl_load8(P.ah, P.al, ((long long)(b + P.ref_off) * P.CB + cb) * P.L + t, r);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float av = a0[e] + a1[e], dv = av - r[e];
+      val[e] += k1 * (float)((dv > 0.f) - (dv < 0.f)) - k2 * (float)((av > 0.f) - (av < 0.f));
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) val[e] *= dlrelu(a0[e], P.mask_slope);
+  const long long gi = ((long long)b * P.CB + cb) * P.L + t;
+  const u32x4 h = bl_pack8(val);
+  P.gh[gi] = h;
+  if (P.gl) P.gl[gi] = bl_pack8_lo(val, h);
+}
+
+// weight (+ bias) gradient of the logits layer: slab[z][0][c k + j] = sum_{(b, t) in slice z} seed[b, t] x[b, c, t - pad + j]; column C k = sum seed
+__global__ __launch_bounds__(256) void bl_tail_dw_kernel(const float* __restrict__ seeds, const u32x4* __restrict__ xh, const u32x4* __restrict__ xl,
+                                                         int rows, int CB, int L, int k, int pad, int l_out, int nslab, float* __restrict__ slabs) {
+  __shared__ float red[4][8 * 8 + 1];
+  const int cb = blockIdx.x, z = blockIdx.y;
+  const long long total = (long long)rows * l_out;
+  const long long per = (total + nslab - 1) / nslab;
+  const long long lo = (long long)z * per, hi = lo + per < total ? lo + per : total;
+  float acc[8][8], sb = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[e][j] = 0.f;
+  for (long long i = lo + threadIdx.x; i < hi; i += 256) {
+    const int b = (int)(i / l_out), t = (int)(i - (long long)b * l_out);
+    const float s = seeds[i];
+    sb += s;
+    const long long row = ((long long)b * CB + cb) * L;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (j < k) {
+        const int q = t - pad + j;
+        if (q >= 0 && q < L) {
+          float f[8];
+          bl_load8(xh, xl, row + q, f);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[e][j] = fmaf(s, f[e], acc[e][j]);
+        }
+      }
+    }
+  }
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int e = 0; e < 8; ++e)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float s = wave_sum(acc[e][j]);
+      if (lane == 0) red[w][e * 8 + j] = s;
+    }
+  sb = wave_sum(sb);
+  if (lane == 0) red[w][64] = sb;
+  __syncthreads();
+  const long long rs = (long long)CB * 8 * k + 1;
+  for (int i = threadIdx.x; i < 65; i += 256) {
+    const float s = red[0][i] + red[1][i] + red[2][i] + red[3][i];
+    if (i == 64) { if (cb == 0) slabs[(long long)z * rs + rs - 1] = s; }
+    else {
+      const int e = i >> 3, j = i & 7;
+      if (j < k) slabs[(long long)z * rs + (long long)(cb * 8 + e) * k + j] = s;
+    }
+  }
+}
+
+// ---- feature-matching sums over bundle planes -------------------------------------------------------------------------------------
+constexpr int BLFM_MAX_PAIRS = 32;
+constexpr int BLFM_BLOCKS = 1024;   // == FM_BLOCKS of direct.hip: the partial sums are finished by the same fixed-order pass
+struct BlFmTable {
+  const u32x4* hi[BLFM_MAX_PAIRS]; const u32x4* lo[BLFM_MAX_PAIRS];
+  long long units[BLFM_MAX_PAIRS];   // units of the enhanced rows; the reference rows follow them in the same planes
+};
+__global__ __launch_bounds__(256) void bl_fm_partial_kernel(const BlFmTable T, float* __restrict__ partial) {
+  __shared__ float red[4];
+  const int p = blockIdx.y;
+  const u32x4* hi = T.hi[p];
+  const u32x4* lo = T.lo[p];
+  const long long n = T.units[p];
+  const long long per = (n + BLFM_BLOCKS - 1) / BLFM_BLOCKS;
+  const long long b0 = (long long)blockIdx.x * per;
+  const long long b1 = b0 + per < n ? b0 + per : n;
+  float s1 = 0.f, s2 = 0.f;
+  for (long long i = b0 + threadIdx.x; i < b1; i += 256) {
+    float a[8], r[8];
+    bl_load8(hi, lo, i, a);
+    bl_load8(hi, lo, i + n, r);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s1 += fabsf(a[e] - r[e]); s2 += fabsf(a[e]); }
+  }
+  s1 = block_sum_256(s1, red);
+  s2 = block_sum_256(s2, red);
+  if (threadIdx.x == 0) {
+    partial[(p * BLFM_BLOCKS + blockIdx.x) * 2 + 0] = s1;
+    partial[(p * BLFM_BLOCKS + blockIdx.x) * 2 + 1] = s2;
+  }
+}
+__global__ __launch_bounds__(64) void bl_fm_final_kernel(const float* __restrict__ partial, float* __restrict__ sums) {
+  const int p = blockIdx.x, l = threadIdx.x;
+  float s1 = 0.f, s2 = 0.f;
+  for (int k = l; k < BLFM_BLOCKS; k += 64) {   // fixed order: deterministic
+    s1 += partial[(p * BLFM_BLOCKS + k) * 2 + 0];
+    s2 += partial[(p * BLFM_BLOCKS + k) * 2 + 1];
+  }
+  s1 = wave_sum(s1);
+  s2 = wave_sum(s2);
+  if (l == 0) { sums[2 * p] = s1; sums[2 * p + 1] = s2; }
+}
+
+static unsigned bl_grid(long long n, int cap = 8192) {
+  long long b = (n + 255) / 256;
+  if (b > cap) b = cap;
+  return (unsigned)(b < 1 ? 1 : b);
+}
+
+}  // namespace eben
+
+using namespace eben;
+
+extern "C" int eben_bl_from_f32(const float* x, int batch, int channels, int length, void* hi, void* lo, void* stream) {
+  EBEN_REQUIRE(x && hi && batch > 0 && channels > 0 && length > 0 && channels % 8 == 0, "bl_from_f32: channels must be a positive multiple of 8");
+  const long long units = (long long)batch * (channels / 8) * length;
+  hipLaunchKernelGGL(bl_from_f32_kernel, dim3(bl_grid(units)), dim3(256), 0, as_stream(stream), x, units, channels / 8, length,
+                     static_cast<u32x4*>(hi), static_cast<u32x4*>(lo));
+  EBEN_CHECK_LAUNCH("bl_from_f32_kernel");
+  return EBEN_OK;
+}
+
+extern "C" int eben_bl_to_f32(const void* hi, const void* lo, int batch, int channels, int length, float* x, void* stream) {
+  EBEN_REQUIRE(x && hi && batch > 0 && channels > 0 && length > 0 && channels % 8 == 0, "bl_to_f32: channels must be a positive multiple of 8");
+  const long long units = (long long)batch * (channels / 8) * length;
+  hipLaunchKernelGGL(bl_to_f32_kernel, dim3(bl_grid(units)), dim3(256), 0, as_stream(stream), static_cast<const u32x4*>(hi),
+                     static_cast<const u32x4*>(lo), units, length, x);
+  EBEN_CHECK_LAUNCH("bl_to_f32_kernel");
+  return EBEN_OK;
+}
+
+static int bl_head_table(const EbenBlHeadJob* jobs, int n, int batch, bool backward, BlHeadTable* T) {
+  EBEN_REQUIRE(jobs && n >= 1 && n <= BL_HEAD_JOBS && batch > 0, "1..%d head jobs", BL_HEAD_JOBS);
+  T->n = n; T->batch = batch;
+  for (int i = 0; i < n; ++i) {
+    const EbenBlHeadJob& s = jobs[i];
+    BlHeadJob& d = T->job[i];
+    EBEN_REQUIRE(s.v && s.y_hi && (backward || s.x), "null pointer in head job %d", i);
+    EBEN_REQUIRE(s.c_in >= 1 && s.c_out % 8 == 0 && s.c_out % s.c_in == 0 && s.ksize >= 1 && s.ksize <= 16 && s.dilation >= 1,
+                 "head job %d: groups = c_in, c_out a multiple of 8 and of c_in, ksize <= 16", i);
+    EBEN_REQUIRE(s.l_out == s.l_in + 2 * s.reflect_pad + 2 * s.pad - s.dilation * (s.ksize - 1) && s.l_out > 0 && s.reflect_pad < s.l_in,
+                 "head job %d: l_out %d does not match the layer", i, s.l_out);
+    if (backward) {
+      EBEN_REQUIRE(s.c_in <= 4 && s.c_out * s.ksize <= BL_HEAD_WMAX, "head input gradient: c_in <= 4, c_out * ksize <= %d", BL_HEAD_WMAX);
+      EBEN_REQUIRE(s.c_in == jobs[0].c_in && s.l_in == jobs[0].l_in, "head input gradient: jobs must share the input shape");
+    }
+    d.x = s.x; d.v = s.v; d.scale = s.scale; d.bias = s.bias; d.yh = static_cast<u32x4*>(s.y_hi); d.yl = static_cast<u32x4*>(s.y_lo);
+    d.c_in = s.c_in; d.c_out = s.c_out; d.l_in = s.l_in; d.l_out = s.l_out; d.k = s.ksize; d.dil = s.dilation; d.pad = s.pad; d.rpad = s.reflect_pad;
+    d.out_slope = s.out_slope;
+  }
+  return EBEN_OK;
+}
+
+extern "C" int eben_bl_head_fwd(const EbenBlHeadJob* jobs, int njobs, int batch, void* stream) {
+  BlHeadTable T;
+  int rc = bl_head_table(jobs, njobs, batch, false, &T);
+  if (rc) return rc;
+  int lmax = 0, cbmax = 0;
+  for (int i = 0; i < njobs; ++i) { if (jobs[i].l_out > lmax) lmax = jobs[i].l_out; if (jobs[i].c_out / 8 > cbmax) cbmax = jobs[i].c_out / 8; }
+  hipLaunchKernelGGL(bl_head_fwd_kernel, dim3(ceil_div(lmax, 256), batch * cbmax, njobs), dim3(256), 0, as_stream(stream), T);
+  EBEN_CHECK_LAUNCH("bl_head_fwd_kernel");
+  return EBEN_OK;
+}
+
+extern "C" int eben_bl_head_dx(const EbenBlHeadJob* jobs, int njobs, int rows, float* dx, void* stream) {
+  BlHeadTable T;
+  int rc = bl_head_table(jobs, njobs, rows, true, &T);
+  if (rc) return rc;
+  EBEN_REQUIRE(dx != nullptr, "null dx");
+  hipLaunchKernelGGL(bl_head_dx_kernel, dim3(ceil_div(jobs[0].l_in, 256), rows), dim3(256), 0, as_stream(stream), T, dx);
+  EBEN_CHECK_LAUNCH("bl_head_dx_kernel");
+  return EBEN_OK;
+}
+
+static const int kBlHeadSlabs = 96;
+extern "C" size_t eben_bl_head_dw_workspace(const EbenBlHeadJob* job, int* nslab, int* row_stride) {
+  if (!job) return 0;
+  if (nslab) *nslab = kBlHeadSlabs;
+  if (row_stride) *row_stride = job->ksize + 1;
+  return sizeof(float) * (size_t)kBlHeadSlabs * job->c_out * (job->ksize + 1);
+}
+
+// job->y_hi: the gradient at the head's output (rows x c_out x l_out, hi plane); job->x: the head's input rows it is paired with
+extern "C" int eben_bl_head_dw(const EbenBlHeadJob* job, int rows, float* slabs, size_t ws_bytes, void* stream) {
+  BlHeadTable T;
+  int rc = bl_head_table(job, 1, rows, false, &T);
+  if (rc) return rc;
+  EBEN_REQUIRE(slabs != nullptr, "null slabs");
+  if (ws_bytes < eben_bl_head_dw_workspace(job, nullptr, nullptr)) return fail(EBEN_EWORKSPACE, "bl_head_dw workspace too small");
+  const BlHeadJob& J = T.job[0];
+  if (J.k <= 4)
+    hipLaunchKernelGGL((bl_head_dw_kernel<4>), dim3(J.c_out / 8, kBlHeadSlabs), dim3(256), 0, as_stream(stream), J.yh, J.x, rows, J.c_in, J.c_out, J.l_in,
+                       J.l_out, J.k, J.dil, J.pad, J.rpad, kBlHeadSlabs, slabs);
+  else
+    hipLaunchKernelGGL((bl_head_dw_kernel<16>), dim3(J.c_out / 8, kBlHeadSlabs), dim3(256), 0, as_stream(stream), J.yh, J.x, rows, J.c_in, J.c_out, J.l_in,
+                       J.l_out, J.k, J.dil, J.pad, J.rpad, kBlHeadSlabs, slabs);
+  EBEN_CHECK_LAUNCH("bl_head_dw_kernel");
+  return EBEN_OK;
+}
+
+extern "C" int eben_bl_tail_fwd(const void* x_hi, const void* x_lo, int batch, int channels, int length, int ksize, int pad, const float* v,
+                                const float* scale, const float* bias, float out_slope, float* y, void* stream) {
+  EBEN_REQUIRE(x_hi && v && y && batch > 0 && channels % 8 == 0 && channels > 0 && length > 0 && ksize >= 1 && ksize <= 8 && pad >= 0, "bad tail forward arguments");
+  const int l_out = length + 2 * pad - (ksize - 1);
+  EBEN_REQUIRE(l_out > 0, "tail forward: empty output");
+  const size_t lds = sizeof(float) * ((size_t)channels * ksize + 256);
+  EBEN_REQUIRE(lds <= 64 * 1024, "tail forward: %d channels x %d taps exceed the weight buffer", channels, ksize);
+  hipLaunchKernelGGL(bl_tail_fwd_kernel, dim3(ceil_div(l_out, 64), batch), dim3(256), lds, as_stream(stream), static_cast<const u32x4*>(x_hi),
+                     static_cast<const u32x4*>(x_lo), channels / 8, length, ksize, pad, l_out, v, scale, bias, out_slope, y);
+  EBEN_CHECK_LAUNCH("bl_tail_fwd_kernel");
+  return EBEN_OK;
+}
+
+extern "C" int eben_bl_tail_dx(const float* seeds, int rows, int channels, int length, int ksize, int pad, const float* v, const float* scale,
+                               const void* act_hi, const void* act_lo, float mask_slope, int seg, const int* seg_map, int fm_rows,
+                               int ref_row_offset, const float* fm_sums, float fm_gs, void* g_hi, void* g_lo, void* stream) {
+  EBEN_REQUIRE(seeds && v && act_hi && g_hi && rows > 0 && channels % 8 == 0 && channels > 0 && length > 0 && ksize >= 1 && ksize <= 8, "bad tail input-gradient arguments");
+  EBEN_REQUIRE(seg >= 0 && (seg == 0 || (seg_map && rows <= 4 * seg)), "bad batch segment map");
+  EBEN_REQUIRE(fm_rows == 0 || (fm_sums && act_lo && fm_rows > 0), "feature-matching rows need the sums and both planes of the embedding");
+  BlTailDxArgs P;
+  P.seeds = seeds; P.v = v; P.scale = scale; P.ah = static_cast<const u32x4*>(act_hi); P.al = static_cast<const u32x4*>(act_lo);
+  P.gh = static_cast<u32x4*>(g_hi); P.gl = static_cast<u32x4*>(g_lo);
+  P.fm_sums = fm_rows > 0 ? fm_sums : nullptr; P.fm_gs = fm_gs; P.mask_slope = mask_slope;
+  P.rows = rows; P.CB = channels / 8; P.L = length; P.k = ksize; P.pad = pad; P.l_out = length + 2 * pad - (ksize - 1);
+  P.fm_rows = fm_rows; P.ref_off = ref_row_offset; P.seg = seg;
+  for (int i = 0; i < 4; ++i) P.map[i] = (seg > 0 && seg_map) ? seg_map[i] : i;
+  hipLaunchKernelGGL(bl_tail_dx_kernel, dim3(ceil_div(length, 256), channels / 8, rows), dim3(256), 0, as_stream(stream), P);
+  EBEN_CHECK_LAUNCH("bl_tail_dx_kernel");
+  return EBEN_OK;
+}
+
+static const int kBlTailSlabs = 32;
+extern "C" size_t eben_bl_tail_dw_workspace(int channels, int ksize, int* nslab, int* row_stride) {
+  if (nslab) *nslab = kBlTailSlabs;
+  if (row_stride) *row_stride = channels * ksize + 1;
+  return sizeof(float) * (size_t)kBlTailSlabs * ((size_t)channels * ksize + 1);
+}
+
+extern "C" int eben_bl_tail_dw(const float* seeds, const void* x_hi, const void* x_lo, int rows, int channels, int length, int ksize, int pad,
+                               float* slabs, size_t ws_bytes, void* stream) {
+  EBEN_REQUIRE(seeds && x_hi && slabs && rows > 0 && channels % 8 == 0 && channels > 0 && length > 0 && ksize >= 1 && ksize <= 8, "bad tail weight-gradient arguments");
+  if (ws_bytes < eben_bl_tail_dw_workspace(channels, ksize, nullptr, nullptr)) return fail(EBEN_EWORKSPACE, "bl_tail_dw workspace too small");
+  const int l_out = length + 2 * pad - (ksize - 1);
+  hipLaunchKernelGGL(bl_tail_dw_kernel, dim3(channels / 8, kBlTailSlabs), dim3(256), 0, as_stream(stream), seeds, static_cast<const u32x4*>(x_hi),
+                     static_cast<const u32x4*>(x_lo), rows, channels / 8, length, ksize, pad, l_out, kBlTailSlabs, slabs);
+  EBEN_CHECK_LAUNCH("bl_tail_dw_kernel");
+  return EBEN_OK;
+}
+
+extern "C" size_t eben_bl_fm_sums_workspace(int npairs) { return sizeof(float) * 2 * BLFM_BLOCKS * (size_t)(npairs > 0 ? npairs : 0); }
+
+extern "C" int eben_bl_fm_sums(const void* const* planes, const int64_t* units, int npairs, float* partial_ws, size_t ws_bytes, float* sums, void* stream) {
+  EBEN_REQUIRE(planes && units && npairs > 0 && partial_ws && sums, "bad bl_fm_sums arguments");
+  if (ws_bytes < eben_bl_fm_sums_workspace(npairs)) return fail(EBEN_EWORKSPACE, "bl_fm_sums workspace too small");
+  for (int p0 = 0; p0 < npairs; p0 += BLFM_MAX_PAIRS) {
+    const int cnt = npairs - p0 < BLFM_MAX_PAIRS ? npairs - p0 : BLFM_MAX_PAIRS;
+    BlFmTable T;
+    for (int i = 0; i < cnt; ++i) {
+      T.hi[i] = static_cast<const u32x4*>(planes[2 * (p0 + i)]);
+      T.lo[i] = static_cast<const u32x4*>(planes[2 * (p0 + i) + 1]);
+      T.units[i] = units[p0 + i];
+      if (!T.hi[i] || T.units[i] <= 0) return fail(EBEN_EINVAL, "feature-matching pair %d is null or empty", p0 + i);
+    }
+    float* part = partial_ws + (size_t)p0 * BLFM_BLOCKS * 2;
+    hipLaunchKernelGGL(bl_fm_partial_kernel, dim3(BLFM_BLOCKS, cnt), dim3(256), 0, as_stream(stream), T, part);
+    EBEN_CHECK_LAUNCH("bl_fm_partial_kernel");
+    hipLaunchKernelGGL(bl_fm_final_kernel, dim3(cnt), dim3(64), 0, as_stream(stream), part, sums + 2 * p0);
+    EBEN_CHECK_LAUNCH("bl_fm_final_kernel");
+  }
+  return EBEN_OK;
+}

@@ -81,6 +81,7 @@ struct Canon {
   // tensor (the layer's forward) -- staged as hi + lo bf16 tiles there and in the weight gradient; -1 otherwise
   int xsplit_dir;
   int np;     // pieces per MFMA operand in the bf16 tap-conv: 1 (EBEN_MATH_BF16 / BF16X2), 2 (BF16X3), 3 (BF16X6)
+  int bl;     // EBEN_LAYOUT_BL: activations / gradients at rest as bf16 bundles (include/eben_hip.h), eben_bl_* entry points
 };
 int canon_from_desc(const EbenConv1dDesc* d, Canon* c);
 
@@ -97,6 +98,9 @@ struct TapIO {
   // embedding the mask is read from, and rows b < res_rows receive c1 sgn(mask - res) - c2 sgn(mask) with c1 = fm_gs / s2,
   // c2 = fm_gs s1 / s2^2, (s1, s2) = fm_sums[0..1] on the device (feature_loss.py:40-47); nullptr = plain residual
   const float* fm_sums; float fm_gs;
+  // bundle layout (Canon.bl): input planes (xl: the lo plane of a split input), output planes (yl nullable), the saved activation
+  // planes the epilogue takes its mask and feature-matching operands from (reference rows bl_ref_off batch rows behind the enhanced)
+  const void* xh; const void* xl; void* yh; void* yl; const void* eh; const void* el; int bl_ref_off;
 };
 
 // Tap geometry of one output phase.  mode 0 (gather-strided): every block uses (J0, off0_gs, nt_gs).

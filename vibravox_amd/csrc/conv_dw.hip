@@ -545,19 +545,26 @@ __global__ __launch_bounds__(256) void wn_bwd_multi_kernel(const WnBwdTable T) {
   const float* srow = e.slabs + (long long)r * e.row_stride;
   float* orow = e.dv + (long long)r * cols;
   if (e.dbias && threadIdx.x == 0) e.dbias[r] = srow[cols];
+  // slab column of weight element i = c k + j: i itself, or the bundle-major order of bl_dw.hip (its stores are contiguous that way)
+  const int pk = e.col_perm_k;
+  auto sidx = [&](int i) -> int {
+    if (pk <= 0) return i;
+    const int c = i / pk, j = i - c * pk;
+    return ((c >> 3) * pk + j) * 8 + (c & 7);
+  };
   if (!e.g) {
-    for (int i = threadIdx.x; i < cols; i += 256) orow[i] = srow[i];
+    for (int i = threadIdx.x; i < cols; i += 256) orow[i] = srow[sidx(i)];
     return;
   }
   const float* vrow = e.v + (long long)r * cols;
   float dot = 0.f;
-  for (int i = threadIdx.x; i < cols; i += 256) dot += srow[i] * vrow[i];
+  for (int i = threadIdx.x; i < cols; i += 256) dot += srow[sidx(i)] * vrow[i];
   dot = block_sum_256(dot, red);
   const float n = e.norm[r], gr = e.g[r];
   const float dgr = dot / n;
   if (threadIdx.x == 0) e.dg[r] = dgr;
   const float c1 = gr / n, c2 = gr * dgr / (n * n);
-  for (int i = threadIdx.x; i < cols; i += 256) orow[i] = c1 * srow[i] - c2 * vrow[i];
+  for (int i = threadIdx.x; i < cols; i += 256) orow[i] = c1 * srow[sidx(i)] - c2 * vrow[i];
 }
 
 }  // namespace eben
@@ -594,6 +601,7 @@ extern "C" int eben_wn_bwd_multi(const EbenWnBwdItem* items, int n, void* stream
       EBEN_REQUIRE(e.slabs && e.dv && e.nslab > 0 && e.rows > 0 && e.cols > 0 && e.row_stride >= e.cols, "bad wn_bwd_multi item %d", base + i);
       EBEN_REQUIRE(!e.g || (e.v && e.norm && e.dg), "weight-norm backward needs v, norm and dg (item %d)", base + i);
       EBEN_REQUIRE(!e.dbias || e.row_stride > e.cols, "no bias column in the slabs (item %d)", base + i);
+      EBEN_REQUIRE(e.col_perm_k == 0 || (e.col_perm_k > 0 && e.cols % (8 * e.col_perm_k) == 0), "bundle-major slab columns need cols = 8 n k (item %d)", base + i);
       EBEN_REQUIRE(e.nslab == 1 || e.slab_stride >= (long long)e.rows * e.row_stride, "slab stride smaller than a slab (item %d)", base + i);
       T.t[i] = e;
       if (e.rows > max_rows) max_rows = e.rows;

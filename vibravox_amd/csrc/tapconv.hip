@@ -325,10 +325,13 @@ int canon_from_desc(const EbenConv1dDesc* d, Canon* c) {
   EBEN_REQUIRE(d->stride <= 1024 && d->pad_l >= 0 && d->pad_r >= 0, "bad stride / padding");
   c->B = d->batch; c->k = d->ksize; c->s = d->stride; c->d = d->dilation; c->g = d->groups;
   c->pl = d->pad_l; c->pr = d->pad_r;
-  EBEN_REQUIRE(d->math >= EBEN_MATH_F32 && d->math <= EBEN_MATH_BF16X6, "unknown math mode %d", d->math);
-  c->bf16 = d->math != EBEN_MATH_F32;
-  c->np = d->math == EBEN_MATH_BF16X3 ? 2 : (d->math == EBEN_MATH_BF16X6 ? 3 : 1);
-  c->xsplit_dir = d->math == EBEN_MATH_BF16X2 ? (d->transposed ? 1 : 0) : -1;
+  const int math = d->math & ~EBEN_LAYOUT_BL;
+  EBEN_REQUIRE(math >= EBEN_MATH_F32 && math <= EBEN_MATH_BF16X6, "unknown math mode %d", d->math);
+  c->bl = (d->math & EBEN_LAYOUT_BL) != 0;
+  EBEN_REQUIRE(!c->bl || math == EBEN_MATH_BF16 || math == EBEN_MATH_BF16X3, "the bundle layout carries EBEN_MATH_BF16 / EBEN_MATH_BF16X3 only");
+  c->bf16 = math != EBEN_MATH_F32;
+  c->np = math == EBEN_MATH_BF16X3 ? 2 : (math == EBEN_MATH_BF16X6 ? 3 : 1);
+  c->xsplit_dir = math == EBEN_MATH_BF16X2 ? (d->transposed ? 1 : 0) : -1;
   if (!d->transposed) {
     c->Cin = d->c_in; c->Cout = d->c_out; c->Lin = d->l_in; c->Lout = d->l_out;
     c->reflect = d->pad_mode == EBEN_PAD_REFLECT;
@@ -661,6 +664,7 @@ using namespace eben;
 namespace eben {
 int tap_generation(const Canon& c, int dir) {
   static const int thin_first = getenv("EBEN_THIN_FIRST") ? atoi(getenv("EBEN_THIN_FIRST")) : 0;
+  if (c.bl) return tap3_applicable(c, dir) ? 4 : 0;  // bundle layout: the bf16 tap-conv or nothing (eben_bl_* report EBEN_EUNSUPPORTED)
   if (c.bf16 && tap3_applicable(c, dir)) return 4;   // layers the bf16 kernel does not cover keep their fp32 kernel
   const int t2 = tap2_applicable(c, dir), th = thin_applicable(c, dir);
   if (th && (thin_first || !t2)) return 3;
@@ -896,4 +900,39 @@ static int bwd_dx_batched(const EbenConv1dDesc* d, const float* g, const float* 
   TapPlan p;
   make_plan(c, dir, &p);
   return launch_tap(c, p, io, 0, st);
+}
+
+// ---- bundle layout (EBEN_LAYOUT_BL): the discriminator layers between the chain heads and the logits ------------------------------
+extern "C" int eben_bl_conv1d_fwd(const EbenConv1dDesc* d, const void* x_hi, const void* x_lo, const float* wp_fwd, const float* bias,
+                                  void* y_hi, void* y_lo, void* stream) {
+  Canon c;
+  int rc = canon_from_desc(d, &c);
+  if (rc) return rc;
+  EBEN_REQUIRE(c.bl && !d->transposed && d->in_slope == 1.f, "eben_bl_conv1d_fwd: a Conv1d descriptor with EBEN_LAYOUT_BL and no input activation");
+  EBEN_REQUIRE(x_hi && wp_fwd && y_hi, "null pointer in eben_bl_conv1d_fwd");
+  if (tap_generation(c, 0) != 4) return fail(EBEN_EUNSUPPORTED, "eben_bl_conv1d_fwd: layer not covered by the bundle-layout tap-conv");
+  TapIO io{};
+  io.in_slope = 1.f; io.wp = wp_fwd; io.bias = bias; io.res_slope = 1.f; io.emask_slope = 1.f; io.out_slope = d->out_slope;
+  io.xh = x_hi; io.xl = x_lo; io.yh = y_hi; io.yl = y_lo;
+  return tap3_launch(c, 0, io, 0, as_stream(stream));
+}
+
+extern "C" int eben_bl_conv1d_bwd_dx(const EbenConv1dDesc* d, const void* g_hi, const float* wp_bwd, const void* act_hi, const void* act_lo,
+                                     float mask_slope, int seg, const int* seg_map, int fm_rows, int ref_row_offset, const float* fm_sums,
+                                     float fm_gs, void* dx_hi, void* dx_lo, void* stream) {
+  Canon c;
+  int rc = canon_from_desc(d, &c);
+  if (rc) return rc;
+  EBEN_REQUIRE(c.bl && !d->transposed, "eben_bl_conv1d_bwd_dx: a Conv1d descriptor with EBEN_LAYOUT_BL");
+  EBEN_REQUIRE(g_hi && wp_bwd && dx_hi, "null pointer in eben_bl_conv1d_bwd_dx");
+  EBEN_REQUIRE(seg >= 0 && (seg == 0 || (seg_map && c.B <= 4 * seg)), "bad batch segment map");
+  EBEN_REQUIRE(fm_rows == 0 || (fm_sums && act_hi && act_lo && fm_rows > 0), "feature-matching rows need the sums and both planes of the embedding");
+  if (tap_generation(c, 1) != 4) return fail(EBEN_EUNSUPPORTED, "eben_bl_conv1d_bwd_dx: layer not covered by the bundle-layout tap-conv");
+  TapIO io{};
+  io.in_slope = 1.f; io.wp = wp_bwd; io.out_slope = 1.f; io.res_slope = 1.f;
+  io.res_rows = fm_rows; io.fm_sums = fm_rows > 0 ? fm_sums : nullptr; io.fm_gs = fm_gs;
+  io.emask_slope = mask_slope; io.em_seg = act_hi ? seg : 0;
+  for (int i = 0; i < 4; ++i) io.em_map[i] = (seg > 0 && seg_map) ? seg_map[i] : i;
+  io.xh = g_hi; io.yh = dx_hi; io.yl = dx_lo; io.eh = act_hi; io.el = act_lo; io.bl_ref_off = ref_row_offset;
+  return tap3_launch(c, 1, io, 0, as_stream(stream));
 }

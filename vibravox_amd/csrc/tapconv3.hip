@@ -59,6 +59,13 @@ struct Tap3Args {
   long long w_tile, w_phase;                     // in 16-byte units
   // host-side arithmetic of the block prologue (integer divisions are ~40 instructions each on the device, the 64-bit one
   // behind span_magic ~150): the block-id decomposition by multiply-high, and the per-phase tap geometry for up to 8 phases
+  // bundle layout (BL: bf16 [batch][channels / 8][length][8] planes hi = bf16(v), lo = bf16(v - hi); template flag BL): the input
+  // planes (xl: split input, NPX = 2), the output planes (yl nullable), the saved activation the epilogue reads its mask /
+  // feature-matching operands from (eh / el; the reference rows of a feature-matching pair start bl_ref_off batch rows further)
+  const u32x4* xh; const u32x4* xl;
+  uint2* yh; uint2* yl;
+  const uint2* eh; const uint2* el;
+  int CBx, CBy, bl_ref_off, bl_pad;
   unsigned xq, xr;                               // gridDim.x / 8, gridDim.x % 8 (xcd_remap)
   unsigned m_nph, m_ntt, m_B, m_nmt;             // ceil(2^32 / d); valid when id_fast
   int id_fast, pg_n;
@@ -72,7 +79,11 @@ struct Tap3Args {
 //   (2, 2) EBEN_MATH_BF16X3: three products, ~2^-17 per product;
 //   (3, 3) EBEN_MATH_BF16X6: six products, all 24 mantissa bits of both operands, dropped terms <= 2^-26: fp32-grade products at
 //          6/16 of the fp32 MFMA's cost (and 0.6 LDS fragment reads per MFMA instead of 1.25: this form is MFMA-bound).
-template <int FM, int XRB, bool IM = false, int NPW = 1, int NPX = 1>
+// BL: both operands at rest in the bundle layout -- the input tile is a COPY of 16-byte units (8 channels at one position: exactly
+// the staged LDS unit; no conversion, an eighth of the loads), the epilogue packs its four consecutive rows per lane into 8-byte
+// halves of the output units (lanes 0-31 channels +0..3, lanes 32-63 channels +4..7 of a bundle: a wave stores 512 contiguous
+// bytes per row quad) and reads the mask / feature-matching operands the same way.
+template <int FM, int XRB, bool IM = false, int NPW = 1, int NPX = 1, bool BL = false>
 __global__ __launch_bounds__(256, NPW >= 2 ? 1 : 2) void tap3_kernel(const Tap3Args P) {
   constexpr int NT = 256, BN = 128, BM = FM * 32, KSC = t3_ksc(NPW);
   constexpr bool SP = NPX > 1;
@@ -217,7 +228,16 @@ __global__ __launch_bounds__(256, NPW >= 2 ? 1 : 2) void tap3_kernel(const Tap3A
     const int bb = (int)__umulhi((unsigned)i, span_magic);
     xg[u] = (P.ncc > 1 && i < xtot) ? ((bb << 16) | (i - bb * span)) : -1;
   }
-  float xreg[XRB][8], mreg[IM ? XRB : 1][8];
+  // BL: unit (bundle cbn of this group, position qq) of the input planes; bundles past the group's last re-read bundle 0 (zeroed later)
+  const int CgB = P.Cg >> 3;
+  const long long xrowB = ((long long)b * P.CBx + (long long)g * CgB) * P.Lx;
+  auto loadu = [&](int cbn, int qq, u32x4 (&v)[NPX]) {
+    const long long idx = xrowB + (long long)(cbn < CgB ? cbn : 0) * P.Lx + qq;
+    v[0] = P.xh[idx];
+    if constexpr (NPX > 1) v[1] = P.xl[idx];
+  };
+  float xreg[BL ? 1 : XRB][8], mreg[IM ? XRB : 1][8];
+  u32x4 xru[BL ? XRB : 1][NPX];
   unsigned okmask = 0;
   auto fetch_x = [&](int cc) {
     const float* xp = P.x + xrow0;
@@ -228,9 +248,16 @@ __global__ __launch_bounds__(256, NPW >= 2 ? 1 : 2) void tap3_kernel(const Tap3A
       int ok;
       const int qq = x_pos(xg[u] >= 0 ? (xg[u] & 0xffff) : 0, ok);   // lanes without a unit re-read the tile's first position
       ok &= (int)(xg[u] >= 0);
-      okmask |= (unsigned)ok << u;
-      load8(xp, cc * P.CI_T + (xg[u] >= 0 ? (xg[u] >> 16) * 8 : 0), qq, xreg[u]);
-      if constexpr (IM) load8(mp, cc * P.CI_T + (xg[u] >= 0 ? (xg[u] >> 16) * 8 : 0), qq, mreg[u]);
+      if constexpr (BL) {
+        const int cbn = cc * P.CI_B + (xg[u] >= 0 ? (xg[u] >> 16) : 0);
+        ok &= (int)(cbn < CgB);
+        okmask |= (unsigned)ok << u;
+        loadu(cbn, qq, xru[u]);
+      } else {
+        okmask |= (unsigned)ok << u;
+        load8(xp, cc * P.CI_T + (xg[u] >= 0 ? (xg[u] >> 16) * 8 : 0), qq, xreg[u]);
+        if constexpr (IM) load8(mp, cc * P.CI_T + (xg[u] >= 0 ? (xg[u] >> 16) * 8 : 0), qq, mreg[u]);
+      }
     }
   };
   const int dead_slot = P.nxb * XBUF;
@@ -241,10 +268,16 @@ __global__ __launch_bounds__(256, NPW >= 2 ? 1 : 2) void tap3_kernel(const Tap3A
     for (int u = 0; u < XRB; ++u) {
       const int bb = xg[u] >> 16;
       const int sl = xg[u] >= 0 ? x_slot(bb, xg[u] & 0xffff) : dead_slot - bsel * XBUF;
-      u32x4 pc[NPX];
-      cvt8(xreg[u], mreg[IM ? u : 0], cc * P.CI_T + (xg[u] >= 0 ? bb * 8 : 0), (int)((okmask >> u) & 1u), pc);
+      if constexpr (BL) {
+        const bool live = (okmask >> u) & 1u;
 #pragma unroll
-      for (int q = 0; q < NPX; ++q) dst[sl + q * LO] = pc[q];
+        for (int q = 0; q < NPX; ++q) dst[sl + q * LO] = live ? xru[u][q] : u32x4{0u, 0u, 0u, 0u};
+      } else {
+        u32x4 pc[NPX];
+        cvt8(xreg[u], mreg[IM ? u : 0], cc * P.CI_T + (xg[u] >= 0 ? bb * 8 : 0), (int)((okmask >> u) & 1u), pc);
+#pragma unroll
+        for (int q = 0; q < NPX; ++q) dst[sl + q * LO] = pc[q];
+      }
     }
   };
 
@@ -271,7 +304,7 @@ __global__ __launch_bounds__(256, NPW >= 2 ? 1 : 2) void tap3_kernel(const Tap3A
     // two rounds of (2 units = 16 loads per thread) in flight: round r + 1 is asked for before round r is converted and written --
     // a single-tile layer (every PQMF-band layer, the k = 1 STFT contractions) runs 3-5 such rounds back to back with nothing else
     // of the block to hide them behind
-    struct Round { float v[2][8]; float mk[IM ? 2 : 1][8]; int sl[2], ok[2], c0[2]; };
+    struct Round { float v[BL ? 1 : 2][8]; float mk[IM ? 2 : 1][8]; u32x4 w[BL ? 2 : 1][NPX]; int sl[2], ok[2], c0[2]; };
     auto pro_load = [&](int base, Round& R) {
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
@@ -280,9 +313,15 @@ __global__ __launch_bounds__(256, NPW >= 2 ? 1 : 2) void tap3_kernel(const Tap3A
         const int r = i - bb * span;
         const int qq = x_pos(i < xtot ? r : 0, R.ok[u]);
         R.ok[u] &= (int)(i < xtot);
-        R.c0[u] = i < xtot ? bb * 8 : 0;
-        load8(xp, R.c0[u], qq, R.v[u]);
-        if constexpr (IM) load8(mp, R.c0[u], qq, R.mk[u]);
+        if constexpr (BL) {
+          R.c0[u] = i < xtot ? bb : 0;
+          R.ok[u] &= (int)(R.c0[u] < CgB);
+          loadu(R.c0[u], qq, R.w[u]);
+        } else {
+          R.c0[u] = i < xtot ? bb * 8 : 0;
+          load8(xp, R.c0[u], qq, R.v[u]);
+          if constexpr (IM) load8(mp, R.c0[u], qq, R.mk[u]);
+        }
         R.sl[u] = i < xtot ? x_slot(bb, r) : -1;
       }
     };
@@ -290,10 +329,15 @@ __global__ __launch_bounds__(256, NPW >= 2 ? 1 : 2) void tap3_kernel(const Tap3A
 #pragma unroll
       for (int u = 0; u < 2; ++u)
         if (R.sl[u] >= 0) {
-          u32x4 pc[NPX];
-          cvt8(R.v[u], R.mk[IM ? u : 0], R.c0[u], R.ok[u], pc);
+          if constexpr (BL) {
 #pragma unroll
-          for (int q = 0; q < NPX; ++q) Xs[R.sl[u] + q * LO] = pc[q];
+            for (int q = 0; q < NPX; ++q) Xs[R.sl[u] + q * LO] = R.ok[u] ? R.w[u][q] : u32x4{0u, 0u, 0u, 0u};
+          } else {
+            u32x4 pc[NPX];
+            cvt8(R.v[u], R.mk[IM ? u : 0], R.c0[u], R.ok[u], pc);
+#pragma unroll
+            for (int q = 0; q < NPX; ++q) Xs[R.sl[u] + q * LO] = pc[q];
+          }
         }
     };
     Round ra, rb;
@@ -371,6 +415,79 @@ __global__ __launch_bounds__(256, NPW >= 2 ? 1 : 2) void tap3_kernel(const Tap3A
   // compiler waits for each load in turn -- ~32 exposed round trips per lane, several times the whole reduction of a short layer.
   const int t = t0 + wn * 32 + (lane & 31);
   if (t >= nt) return;
+  if constexpr (BL) {
+    // row quad r4 of accumulator tile i: channels m4 .. m4+3 of the group, m4 = m0 + 32 i + 8 r4 + 4 (lane >> 5), i.e. half (lane >> 5)
+    // of bundle (m0 >> 3) + 4 i + r4 -- one 8-byte piece per lane, 512 contiguous bytes per wave and quad
+    const unsigned colb = (unsigned)t * (unsigned)P.OS + (unsigned)oo;
+    const int hb = lane >> 5;
+    const int gB = (g * P.Mg) >> 3;                       // first bundle of the group in the output / activation planes
+    const long long yrow = ((long long)b * P.CBy + gB) * P.Ly;
+    const long long erow = ((long long)eb * P.CBy + gB) * P.Ly;
+    const long long rrow = ((long long)(b + P.bl_ref_off) * P.CBy + gB) * P.Ly;
+    const float* __restrict__ bbp = P.bias + (long long)g * P.Mg;
+    const bool fmr = P.fm_sums != nullptr && P.res_rows > 0 && b < P.res_rows;
+    float fk1 = 0.f, fk2 = 0.f;
+    if (fmr) { const float s1 = P.fm_sums[0], s2 = P.fm_sums[1]; fk1 = P.fm_gs / s2; fk2 = P.fm_gs * s1 / (s2 * s2); }
+    const bool masked = P.eh != nullptr;
+    auto unpack = [](uint2 w, float (&f)[4]) {
+      f[0] = __builtin_bit_cast(float, w.x << 16); f[1] = __builtin_bit_cast(float, w.x & 0xffff0000u);
+      f[2] = __builtin_bit_cast(float, w.y << 16); f[3] = __builtin_bit_cast(float, w.y & 0xffff0000u);
+    };
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      uint2 ah[4], al[4], rh[4], rl[4];
+      float bz[4][4];
+      long long off[4];
+      bool live[4];
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const int m4 = m0 + i * 32 + 8 * r4 + 4 * hb;
+        live[r4] = m4 < P.Mg;
+        const int mb = live[r4] ? (m4 >> 3) : 0;
+        off[r4] = ((long long)mb * P.Ly + colb) * 2 + hb;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bz[r4][e] = (P.bias && live[r4]) ? bbp[m4 + e] : 0.f;
+        if (masked) {
+          ah[r4] = P.eh[erow * 2 + off[r4]];
+          if (fmr) { al[r4] = P.el[erow * 2 + off[r4]]; rh[r4] = P.eh[rrow * 2 + off[r4]]; rl[r4] = P.el[rrow * 2 + off[r4]]; }
+        }
+      }
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        float v[4], a0[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[i][4 * r4 + e] + bz[r4][e];
+        if (masked) {
+          unpack(ah[r4], a0);
+          if (fmr) {
+            float a1[4], r0[4], r1[4];
+            unpack(al[r4], a1); unpack(rh[r4], r0); unpack(rl[r4], r1);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float av = a0[e] + a1[e], dv = av - (r0[e] + r1[e]);
+              v[e] += fk1 * (float)((dv > 0.f) - (dv < 0.f)) - fk2 * (float)((av > 0.f) - (av < 0.f));
+            }
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] *= dlrelu(a0[e], P.emask_slope);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = lrelu(v[e], P.out_slope);
+        }
+        uint2 h;
+        h.x = pack_bf16(v[0], v[1]); h.y = pack_bf16(v[2], v[3]);
+        if (live[r4]) P.yh[yrow * 2 + off[r4]] = h;
+        if (P.yl) {
+          float hf[4];
+          unpack(h, hf);
+          uint2 l;
+          l.x = pack_bf16(v[0] - hf[0], v[1] - hf[1]); l.y = pack_bf16(v[2] - hf[2], v[3] - hf[3]);
+          if (live[r4]) P.yl[yrow * 2 + off[r4]] = l;
+        }
+      }
+    }
+    return;
+  }
   // addresses: a block-uniform 64-bit base per tensor (scalar registers) + a 32-bit per-lane element offset (one group's rows of one
   // batch item span < 2^31 elements), so that every access is the scalar-base form and no 64-bit vector arithmetic is left
   const unsigned col = (unsigned)t * (unsigned)P.OS + (unsigned)oo;
@@ -511,9 +628,12 @@ static void make_plan3(const Canon& c, int dir, Tap3Plan* p) {
   static const int dense_max_c = env_int3("EBEN_TAP3_DENSE_MAX_C", 8);
   static const int dense_max_c_dx = env_int3("EBEN_TAP3_DENSE_MAX_C_DX", 12);
   p->dense = 0;
-  if (c.g > 1 && c.Cin / c.g >= 4 && c.Cin / c.g <= (dir == 0 ? dense_max_c : dense_max_c_dx) && c.Cin <= 64 && c.Cout <= 128) {
+  // bundle layout: a group's channels must start on a bundle (8 channels) in both operands -- the layers with 4 / 6 / 12 channels per
+  // group (MelGAN L1, PQMF-band L1 / L2) run dense in BOTH directions there (L2's forward: 2.2x the MFMAs of a 12 us launch)
+  if (c.g > 1 && c.Cin / c.g >= 4 && c.Cin / c.g <= (dir == 0 && !c.bl ? dense_max_c : dense_max_c_dx) && c.Cin <= 64 && c.Cout <= 128) {
     p->dense = 1; p->G = 1; p->Cg *= c.g; p->Mg *= c.g;
   }
+  if (c.bl && ((p->Cg & 7) || (p->Mg & 7) || c.np > 2 || c.xsplit_dir >= 0 || c.reflect)) return;
   static const int enabled = env_int3("EBEN_TAP3", 1);
   static const int min_m = env_int3("EBEN_TAP3_MIN_M", 4);
   static const int min_c = env_int3("EBEN_TAP3_MIN_C", 4);
@@ -712,10 +832,10 @@ __global__ __launch_bounds__(256) void pack3_multi_kernel(const Pack3Table T) {
   pack3_body(T.job[j], blockIdx.x - T.first[j], T.first[j + 1] - T.first[j]);
 }
 
-template <int FM, int XRB, bool IM, int NPW = 1, int NPX = 1>
+template <int FM, int XRB, bool IM, int NPW = 1, int NPX = 1, bool BL = false>
 static int launch3_im(const Tap3Args& a, int nblocks, size_t lds, hipStream_t st) {
   static bool attr_set = false;
-  auto kern = tap3_kernel<FM, XRB, IM, NPW, NPX>;
+  auto kern = tap3_kernel<FM, XRB, IM, NPW, NPX, BL>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(tap3)");
@@ -727,6 +847,11 @@ static int launch3_im(const Tap3Args& a, int nblocks, size_t lds, hipStream_t st
 }
 template <int FM, int XRB>
 static int launch3_cfg(const Tap3Args& a, int nblocks, size_t lds, int npw, int npx, hipStream_t st) {
+  if (a.xh) {   // bundle layout
+    if (a.in_mode || npw != npx || npw > 2) return fail(EBEN_EUNSUPPORTED, "tap3: bundle layout with %d / %d operand pieces", npw, npx);
+    if (npw == 2) return launch3_im<FM, XRB, false, 2, 2, true>(a, nblocks, lds, st);
+    return launch3_im<FM, XRB, false, 1, 1, true>(a, nblocks, lds, st);
+  }
   if (npx > 1) {
     if (a.in_mode) return fail(EBEN_EUNSUPPORTED, "tap3: split operand with a mask on load");
     if (npw == 1) return launch3_im<FM, XRB, false, 1, 2>(a, nblocks, lds, st);
@@ -805,6 +930,17 @@ int tap3_launch(const Canon& c, int dir, const TapIO& io, int reflect, hipStream
   Tap3Args a;
   a.x = io.x; a.xmask = io.in_mode ? io.xmask : io.x; a.in_mode = io.in_mode; a.wp = reinterpret_cast<const u32x4*>(io.wp); a.tab = reinterpret_cast<const int*>(io.wp + p.tab_off_floats);
   a.bias = io.bias; a.res = io.res; a.emask = io.emask; a.y = io.y;
+  a.xh = a.xl = nullptr; a.yh = a.yl = nullptr; a.eh = a.el = nullptr; a.CBx = a.CBy = a.bl_ref_off = a.bl_pad = 0;
+  if (c.bl) {
+    if (!io.xh || !io.yh || (p.npx > 1 && !io.xl)) return fail(EBEN_EINVAL, "tap3: null bundle-layout plane");
+    a.xh = static_cast<const u32x4*>(io.xh); a.xl = static_cast<const u32x4*>(io.xl);
+    a.yh = static_cast<uint2*>(io.yh); a.yl = static_cast<uint2*>(io.yl);
+    a.eh = static_cast<const uint2*>(io.eh); a.el = static_cast<const uint2*>(io.el);
+    a.CBx = p.Cx >> 3; a.CBy = p.Cy >> 3; a.bl_ref_off = io.bl_ref_off;
+    a.x = nullptr; a.xmask = nullptr;
+  } else if (io.xh) {
+    return fail(EBEN_EINVAL, "tap3: bundle-layout planes on a descriptor without EBEN_LAYOUT_BL");
+  }
   a.B = c.B; a.G = p.G; a.Cg = p.Cg; a.Mg = p.Mg; a.Cx = p.Cx; a.Cy = p.Cy; a.Lx = p.Lx; a.Ly = p.Ly;
   a.S = p.S; a.OS = p.OS; a.dstep = p.dstep; a.J0 = p.J; a.mode = p.mode; a.off0 = p.off0; a.nt = p.nt; a.nph = p.nph;
   a.ps_pad = p.ps_pad; a.ps_k = c.k; a.ps_d = c.d; a.ps_kstep = p.kstep;

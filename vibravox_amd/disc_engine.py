@@ -57,6 +57,19 @@ class _Layer:
         self.scale_key = None
         self.scale = self.norm = None
         self.reuse = False   # inside prepack(): rebuild into the buffers already held (ops._buffer)
+        self.keep_scale = False   # the layer's kernels take (v, scale) directly (bundle-layout heads / tails): prepack refreshes the scale
+
+    def ensure_scale(self) -> None:
+        """Weight-norm scale g / ||v|| and norm ||v|| of the current weights (what ``packed`` computes on the way)."""
+        v, g, _ = self.params()
+        v, g = v.detach(), g.detach()
+        wkey = self._weights_key()
+        if self.scale_key != wkey:
+            rows = v.shape[0]
+            self.scale = ops._buffer(self.scale, rows, v, self.reuse)
+            self.norm = ops._buffer(self.norm, rows, v, self.reuse)
+            check(load().eben_wn_scale(ptr(g), ptr(v), rows, v.numel() // rows, ptr(self.scale), ptr(self.norm), _stream()), "wn_scale")
+            self.scale_key = wkey
 
     def params(self):
         prm = self.conv.parametrizations["weight"]
@@ -320,6 +333,13 @@ def inject_grads(params: Sequence[torch.nn.Parameter], grads: Sequence[torch.Ten
 
 
 class DiscriminatorEngine:
+    def __new__(cls, disc, math=ops.MATH_F32):
+        if cls is DiscriminatorEngine and isinstance(math, dict) and math.get("layout") == "bl":
+            from .disc_engine_bl import DiscriminatorEngineBL   # embeddings / gradients at rest as bf16 bundles
+
+            return super().__new__(DiscriminatorEngineBL)
+        return super().__new__(cls)
+
     def __init__(self, disc, math=ops.MATH_F32):
         """math: what the contractions of the layers tapconv3.hip / conv_dw3.hip cover compute in (fp32 accumulation, storage
         and element-wise stages either way) -- one EBEN_MATH_* for everything, a (forward, input gradient, weight gradient)
@@ -353,9 +373,9 @@ class DiscriminatorEngine:
     fm_in_epilogue = os.environ.get("EBEN_FM_EPILOGUE", "1") != "0"
     spread_backward = os.environ.get("EBEN_D_BWD_SPREAD", "1") != "0"   # [MI355X] 19.6 -> 19.35 ms/step (the input-gradient phase shortens by 0.4 ms, the generator backward, which then shares the GPU with more weight-gradient work, lengthens by 0.15)
 
-    def _launch_on_streams(self, fn, forward: bool = False):
+    def _launch_on_streams(self, fn, forward: bool = False, order=None):
         """fn(i) for each sub-discriminator on its own HIP stream, the longest chain (MelGAN, last) first so that it
-        is never queued behind a short one; results in chain order.  The caller joins with ``_join_streams``."""
+        is never queued behind a short one (or in ``order``); results in chain order.  The caller joins with ``_join_streams``."""
         main = torch.cuda.current_stream()
         dev = main.device
         if self._streams is None or self._streams[0].device != dev:
@@ -370,7 +390,7 @@ class DiscriminatorEngine:
         results = [None] * len(self.chains)
         n = len(self.chains)
         ev = getattr(self, "_prepack_ev", None)
-        for i in [n - 1] + list(range(n - 1)):
+        for i in (order if order is not None else [n - 1] + list(range(n - 1))):
             st = streams[i]
             st.wait_stream(main)
             if ev is not None:
@@ -439,9 +459,9 @@ class DiscriminatorEngine:
         """Rebuilds every packed weight image the last step used (forward at 2B rows, input gradients at 4B / 2B rows)
         on the side stream, right after the discriminator's optimiser step: the ~100 small launches then run under the
         next step's generator forward instead of at the head of the four chains."""
-        if not self.chains or not any(lay.packs for ch in self.chains for lay in ch.layers):
+        if not self.chains or not any(lay.packs or (lay.keep_scale and lay.scale is not None) for ch in self.chains for lay in ch.layers):
             return
-        dev = next(lay for ch in self.chains for lay in ch.layers if lay.packs).params()[0].device
+        dev = self.chains[0].layers[0].params()[0].device
         main = torch.cuda.current_stream(dev)
         side = ops._side_stream(dev)
         side.wait_stream(main)
@@ -451,7 +471,7 @@ class DiscriminatorEngine:
             jobs = []
             for lay in layers:   # weight-norm scales of all layers: one multi-tensor launch
                 wkey = lay._weights_key()
-                if lay.packs and lay.scale_key != wkey:
+                if (lay.packs or (lay.keep_scale and lay.scale is not None)) and lay.scale_key != wkey:
                     v, g, _ = lay.params()
                     rows = v.shape[0]
                     lay.scale = ops._buffer(lay.scale, rows, v, True)
@@ -630,7 +650,7 @@ class DiscriminatorEngine:
         real_loss + fake_loss aligned with ``list(disc.parameters())`` (None if none were requested)."""
         if getattr(self, "_pending", None) is None:
             return None
-        pend, _keep = self._pending
+        pend, *_keep = self._pending
         main = torch.cuda.current_stream()
         for st in set(self._streams):
             main.wait_stream(st)

@@ -1,0 +1,421 @@
+"""The batched discriminator passes of ``disc_engine.DiscriminatorEngine`` with every embedding and every stacked gradient at rest in
+the bf16 BUNDLE LAYOUT (``include/eben_hip.h``: bf16 ``[rows][channels / 8][length][8]``, planes hi = bf16(v) and lo = bf16(v - hi)).
+
+Same step, same seeds, same arithmetic plan as the fp32-at-rest engine with bf16 contractions (``DISC_MATH_PLANS["bf16"]``): the values the
+MFMAs see are the values they saw there -- the same round-to-nearest-even of the same fp32 number, applied by the producer's epilogue
+instead of by every consumer's tile staging.  What changes is the traffic and the instruction stream around the contractions:
+
+  * the tap-conv's input tile is a copy of 16-byte units (``tapconv3.hip``, flag BL): an eighth of the loads, no conversion;
+  * its epilogue reads the LeakyReLU mask / the feature-matching operands and writes its output as 8-byte halves of units;
+  * the weight gradients read both operands as they are (``bl_dw.hip``: LDS-DMA tiles, transposing LDS reads) -- no ``dw3_pack_a``
+    pre-pass, no fp32 -> bf16 staging;
+  * the two ends of every chain are streaming kernels of their own (``bl_edge.hip``): the heads of the three PQMF-band chains
+    (``eben_discriminator.py:66-76``) run as ONE launch forward and ONE backward (they read the same bands, their input gradients
+    are summed in the launch), the logits layers (``eben_discriminator.py:150-157``, ``melgan_discriminator.py:147-156``) read
+    bundles and produce / consume fp32 logits.
+
+The feature-matching sums and gradient read hi + lo (16 mantissa bits, ~2^-17 relative: the loss value moves by ~1e-6, a sign only
+where two embeddings agree to 16 bits).
+"""
+from __future__ import annotations
+
+import ctypes
+import dataclasses
+from typing import Dict, List, Optional
+
+import torch
+
+from . import ops
+from ._lib import EbenBlHeadJob, check, load, ptr
+from ._lib import stream as _stream
+from .disc_engine import DiscriminatorEngine, _Layer
+
+BL = 0x100   # EBEN_LAYOUT_BL
+
+
+def _addr(t: Optional[torch.Tensor]) -> Optional[int]:
+    """Device address of a bundle plane (bf16 tensor (rows, channels / 8, length, 8)) or of a view of its leading rows."""
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous() and t.dtype is torch.bfloat16
+    return t.data_ptr()
+
+
+class Planes:
+    """hi / lo planes of one (rows, channels, length) tensor in the bundle layout."""
+
+    __slots__ = ("hi", "lo", "rows", "channels", "length")
+
+    def __init__(self, rows: int, channels: int, length: int, device, lo: bool = True):
+        assert channels % 8 == 0
+        self.rows, self.channels, self.length = rows, channels, length
+        self.hi = torch.empty((rows, channels // 8, length, 8), dtype=torch.bfloat16, device=device)
+        self.lo = torch.empty_like(self.hi) if lo else None
+
+    def to_f32(self) -> torch.Tensor:
+        """(rows, channels, length) fp32 = hi + lo (tests / tools)."""
+        out = torch.empty((self.rows, self.channels, self.length), dtype=torch.float32, device=self.hi.device)
+        check(load().eben_bl_to_f32(_addr(self.hi), _addr(self.lo), self.rows, self.channels, self.length, ptr(out), _stream()), "bl_to_f32")
+        return out
+
+    @staticmethod
+    def from_f32(x: torch.Tensor, lo: bool = True) -> "Planes":
+        x = x.contiguous()
+        p = Planes(x.shape[0], x.shape[1], x.shape[2], x.device, lo)
+        check(load().eben_bl_from_f32(ptr(x), p.rows, p.channels, p.length, _addr(p.hi), _addr(p.lo), _stream()), "bl_from_f32")
+        return p
+
+
+class _ChainBL:
+    """A sub-discriminator in the bundle layout: head (ReflectionPad1d + layer 0), tap-conv layers 1 .. n-2, tail (logits layer)."""
+
+    def __init__(self, modules, math):
+        self.layers: List[_Layer] = []
+        self.pad = 0
+        convs = []
+        for m in modules:
+            if isinstance(m, torch.nn.Sequential):
+                for sub in m:
+                    if hasattr(sub, "padding") and not hasattr(sub, "spec"):
+                        self.pad = int(sub.padding)
+                    else:
+                        convs.append(sub)
+            else:
+                convs.append(m)
+        n = len(convs)
+        for i, conv in enumerate(convs):
+            mth = math(i, n) if callable(math) else math
+            mth = (mth, mth, mth) if isinstance(mth, int) else tuple(mth)
+            lay = _Layer(conv, tuple(v | BL for v in mth))
+            lay.keep_scale = i == 0 or i == n - 1   # head / tail: no packed image, the kernels take (v, scale)
+            self.layers.append(lay)
+        head, tail = self.layers[0].spec, self.layers[-1].spec
+        if not (head.groups == head.c_in and head.stride == 1 and head.pad_l == head.pad_r and head.c_out % 8 == 0 and head.ksize <= 16 and head.c_in <= 4):
+            raise ops._lib.EbenError("bundle-layout engine: unexpected chain head")
+        if not (tail.c_out == 1 and tail.groups == 1 and tail.stride == 1 and tail.dilation == 1 and tail.ksize <= 8 and tail.pad_l == tail.pad_r):
+            raise ops._lib.EbenError("bundle-layout engine: unexpected logits layer")
+
+    # ---- pieces the engine assembles into multi-job launches -------------------------------------------------------------------
+    def head_job(self, x: Optional[torch.Tensor], l_in: int, out: Planes) -> EbenBlHeadJob:
+        lay = self.layers[0]
+        sp = lay.spec
+        v, _, bias = lay.params()
+        lay.ensure_scale()
+        j = EbenBlHeadJob()
+        j.x, j.v, j.scale, j.bias = ptr(x) if x is not None else None, ptr(v.detach()), ptr(lay.scale), ptr(bias.detach()) if bias is not None else None
+        j.y_hi, j.y_lo = _addr(out.hi), _addr(out.lo)
+        j.c_in, j.c_out, j.l_in, j.l_out = sp.c_in, sp.c_out, l_in, out.length
+        j.ksize, j.dilation, j.pad, j.reflect_pad, j.out_slope = sp.ksize, sp.dilation, sp.pad_l, self.pad, sp.out_slope
+        return j
+
+    def head_out_len(self, l_in: int) -> int:
+        sp = self.layers[0].spec
+        return l_in + 2 * self.pad + 2 * sp.pad_l - sp.dilation * (sp.ksize - 1)
+
+    # ---- forward: layers 1 .. n-1 from the head's output ------------------------------------------------------------------------
+    def forward_body(self, act0: Planes):
+        lib = load()
+        acts = [act0]
+        rows = act0.rows
+        cur = act0
+        n = len(self.layers)
+        for i in range(1, n - 1):
+            lay = self.layers[i]
+            d = ops.conv_desc(lay.spec, rows, cur.length, lay.math_fwd)
+            y = Planes(rows, lay.spec.c_out, d.l_out, act0.hi.device)
+            _, _, bias = lay.params()
+            wp = lay.packed(0, rows, cur.length)
+            tm = ops.kernel_timer_for(lay.spec, "fwd")
+            e0 = tm.start() if tm is not None else None
+            split = (lay.math_fwd & 0xff) == ops.MATH_BF16X3
+            check(lib.eben_bl_conv1d_fwd(ctypes.byref(d), _addr(cur.hi), _addr(cur.lo) if split else None, ptr(wp), ptr(bias), _addr(y.hi), _addr(y.lo),
+                                         _stream()), "bl_conv1d_fwd")
+            if tm is not None:
+                tm.stop(e0, rows)
+            acts.append(y)
+            cur = y
+        tail = self.layers[-1]
+        sp = tail.spec
+        v, _, bias = tail.params()
+        tail.ensure_scale()
+        l_out = cur.length + sp.pad_l + sp.pad_r - (sp.ksize - 1)
+        logits = torch.empty((rows, 1, l_out), dtype=torch.float32, device=act0.hi.device)
+        check(lib.eben_bl_tail_fwd(_addr(cur.hi), _addr(cur.lo), rows, cur.channels, cur.length, sp.ksize, sp.pad_l, ptr(v.detach()), ptr(tail.scale),
+                                   ptr(bias.detach()) if bias is not None else None, sp.out_slope, ptr(logits), _stream()), "bl_tail_fwd")
+        return acts, logits
+
+    # ---- backward: stacked input gradients down to the head's output; weight-gradient jobs ---------------------------------------
+    def backward_body(self, acts: List[Planes], seeds: torch.Tensor, half: int, want_param_grads: bool, fm_sums_addr: int, fm_gs: float):
+        """seeds (4 half, 1, L) rows [fm | adv | fake | real]; returns (gradient planes at the head's output, 4 half rows, and the
+        weight-gradient jobs (layer index, gradient at the layer's output, the layer's input))."""
+        lib = load()
+        st = _stream()
+        n = len(self.layers)
+        rows = 4 * half
+        seg_map = (ctypes.c_int * 4)(0, 0, 0, 1)
+        jobs = []
+        tail = self.layers[-1]
+        sp = tail.spec
+        x_in = acts[n - 2]
+        v, _, _ = tail.params()
+        if want_param_grads:
+            jobs.append((n - 1, seeds, x_in))
+        g = Planes(rows, x_in.channels, x_in.length, seeds.device, lo=False)
+        check(lib.eben_bl_tail_dx(ptr(seeds), rows, x_in.channels, x_in.length, sp.ksize, sp.pad_l, ptr(v.detach()), ptr(tail.scale), _addr(x_in.hi),
+                                  _addr(x_in.lo), self.layers[n - 2].spec.out_slope, half, seg_map, half, half, fm_sums_addr + 8 * (n - 2), fm_gs,
+                                  _addr(g.hi), None, st), "bl_tail_dx")
+        for i in range(n - 2, 0, -1):
+            lay = self.layers[i]
+            x_in = acts[i - 1]
+            if want_param_grads:
+                jobs.append((i, g, x_in))
+            d = ops.conv_desc(lay.spec_lin, rows, x_in.length, lay.math_dx)
+            gp = Planes(rows, x_in.channels, x_in.length, seeds.device, lo=(i == 1))   # the head's input gradient reads hi + lo
+            wp = lay.packed(1, rows, x_in.length)
+            tm = ops.kernel_timer_for(lay.spec, "dx")
+            e0 = tm.start() if tm is not None else None
+            check(lib.eben_bl_conv1d_bwd_dx(ctypes.byref(d), _addr(g.hi), ptr(wp), _addr(x_in.hi), _addr(x_in.lo), self.layers[i - 1].spec.out_slope, half,
+                                            seg_map, half, half, fm_sums_addr + 8 * (i - 1), fm_gs, _addr(gp.hi), _addr(gp.lo), st), "bl_conv1d_bwd_dx")
+            if tm is not None:
+                tm.stop(e0, rows)
+            g = gp
+        return g, jobs
+
+    def weight_grads(self, jobs, x_full: torch.Tensor, g0: Optional[Planes], half: int, sink=None):
+        """Weight gradients of every layer (rows [fake | real] of the stacked gradients against the layer inputs [enhanced |
+        reference]): head from (g0, the chain's fp32 input), tap-conv layers by ``eben_bl_conv1d_bwd_dw``, the logits layer per branch."""
+        lib = load()
+        st = _stream()
+        n = len(self.layers)
+        grads = [None] * n
+        wn_jobs = []
+        logits = None
+        for i, g, x_in in jobs:
+            lay = self.layers[i]
+            if i == n - 1:
+                gf = self._tail_dw(lay, g[2 * half:3 * half], x_in, 0, half, st, wn_jobs)
+                gr = self._tail_dw(lay, g[3 * half:], x_in, half, half, st, wn_jobs)
+                logits = (i, gf, gr)
+            else:
+                grads[i] = self._mid_dw(lay, g, x_in, half, st, wn_jobs, sink)
+        if g0 is not None:
+            grads[0] = self._head_dw(g0, x_full, half, st, wn_jobs, sink)
+        ops.wn_bwd_multi(wn_jobs)
+        if logits is not None:
+            i, gf, gr = logits
+            outs = [None if sink is None or p is None else sink.grad_buffer(p) for p in self.layers[i].params()]
+            grads[i] = tuple(None if a is None else (a + b if o is None else torch.add(a, b, out=o)) for a, b, o in zip(gf, gr, outs))
+        return grads
+
+    @staticmethod
+    def _outputs(lay: _Layer, sink, device):
+        v, gain, bias = lay.params()
+        dv = dg = dbias = None
+        if sink is not None:
+            dv, dg, dbias = sink.grad_buffer(v), sink.grad_buffer(gain), (sink.grad_buffer(bias) if bias is not None else None)
+        dv = torch.empty_like(v) if dv is None else dv
+        dg = torch.empty_like(gain) if dg is None else dg
+        if bias is not None and dbias is None:
+            dbias = torch.empty(v.shape[0], dtype=torch.float32, device=device)
+        return dv, dg, dbias
+
+    def _mid_dw(self, lay: _Layer, g: Planes, x_in: Planes, half: int, st: int, wn_jobs: list, sink=None):
+        lib = load()
+        v, gain, bias = lay.params()
+        d = ops.conv_desc(lay.spec_lin, 2 * half, x_in.length, lay.math_dw)
+        ws = getattr(d, "_bl_dw_ws", None)
+        if ws is None:
+            nslab, row_stride, perm = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+            nbytes = lib.eben_bl_conv1d_bwd_dw_workspace(ctypes.byref(d), ctypes.byref(nslab), ctypes.byref(row_stride), ctypes.byref(perm))
+            if nbytes == 0:
+                raise ops._lib.EbenError(f"bundle-layout weight gradient does not cover {lay.spec}")
+            ws = d._bl_dw_ws = (nbytes, nslab.value, row_stride.value, perm.value)
+        nbytes, nslab, row_stride, perm = ws
+        slabs = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=g.hi.device)
+        check(lib.eben_bl_conv1d_bwd_dw(ctypes.byref(d), _addr(g.hi[2 * half:]), _addr(x_in.hi), 1 if bias is not None else 0, ptr(slabs), nbytes, st),
+              "bl_conv1d_bwd_dw")
+        dv, dg, dbias = self._outputs(lay, sink, g.hi.device)
+        rows = v.shape[0]
+        wn_jobs.append((slabs, nslab, rows * row_stride, rows, v.numel() // rows, row_stride, gain.detach(), v.detach(), lay.norm, dg, dv, dbias, perm))
+        return dv, dg, dbias
+
+    def _head_dw(self, g0: Planes, x_full: torch.Tensor, half: int, st: int, wn_jobs: list, sink=None):
+        lib = load()
+        lay = self.layers[0]
+        v, gain, bias = lay.params()
+        view = Planes.__new__(Planes)
+        view.hi, view.lo, view.rows, view.channels, view.length = g0.hi[2 * half:], None, 2 * half, g0.channels, g0.length
+        job = self.head_job(x_full, x_full.shape[2], view)
+        nslab, row_stride = ctypes.c_int(0), ctypes.c_int(0)
+        nbytes = lib.eben_bl_head_dw_workspace(ctypes.byref(job), ctypes.byref(nslab), ctypes.byref(row_stride))
+        slabs = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=x_full.device)
+        check(lib.eben_bl_head_dw(ctypes.byref(job), 2 * half, ptr(slabs), nbytes, st), "bl_head_dw")
+        dv, dg, dbias = self._outputs(lay, sink, x_full.device)
+        rows = v.shape[0]
+        wn_jobs.append((slabs, nslab.value, rows * row_stride.value, rows, v.numel() // rows, row_stride.value, gain.detach(), v.detach(), lay.norm, dg, dv,
+                        dbias))
+        return dv, dg, dbias
+
+    @staticmethod
+    def _tail_dw(lay: _Layer, seeds: torch.Tensor, x_in: Planes, row0: int, nrows: int, st: int, wn_jobs: list):
+        lib = load()
+        v, gain, bias = lay.params()
+        sp = lay.spec
+        nslab, row_stride = ctypes.c_int(0), ctypes.c_int(0)
+        nbytes = lib.eben_bl_tail_dw_workspace(x_in.channels, sp.ksize, ctypes.byref(nslab), ctypes.byref(row_stride))
+        slabs = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=seeds.device)
+        check(lib.eben_bl_tail_dw(ptr(seeds), _addr(x_in.hi[row0:row0 + nrows]), _addr(x_in.lo[row0:row0 + nrows]), nrows, x_in.channels, x_in.length,
+                                  sp.ksize, sp.pad_l, ptr(slabs), nbytes, st), "bl_tail_dw")
+        dv, dg = torch.empty_like(v), torch.empty_like(gain)
+        dbias = torch.empty(1, dtype=torch.float32, device=seeds.device) if bias is not None else None
+        wn_jobs.append((slabs, nslab.value, row_stride.value, 1, v.numel(), row_stride.value, gain.detach(), v.detach(), lay.norm, dg, dv, dbias))
+        return dv, dg, dbias
+
+
+class DiscriminatorEngineBL(DiscriminatorEngine):
+    """``DiscriminatorEngine`` over bundle-layout tensors (selected by ``math = {..., "layout": "bl"}``)."""
+
+    def __init__(self, disc, math):
+        self.disc = disc
+        self.q = disc.q
+        self.math = math
+        self.chains = [_ChainBL(d.discriminator, math["pqmf"]) for d in disc.pqmf_discriminators] + [
+            _ChainBL(disc.melgan_discriminator.discriminator, math["melgan"])]
+        self._streams = None
+        self._state = None
+        self._prepack_graph = ops.ReplayedPrepack()
+        self.seed_weights = (1.0, 1.0, 1.0)
+
+    # ---- forward ---------------------------------------------------------------------------------------------------------------
+    def forward_reference(self, bands_ref, audio_ref):
+        raise ops._lib.EbenError("the bundle-layout engine runs the two halves of the batch in one pass (split_discriminator_forward = False)")
+
+    @torch.no_grad()
+    def forward(self, bands, audio, bands_ref, audio_ref, join: bool = True):
+        lib = load()
+        half = bands.shape[0]
+        dev = audio.device
+        sub = torch.cat((bands[:, -self.q:, :], bands_ref[:, -self.q:, :]), dim=0).contiguous()
+        wav = torch.cat((audio, audio_ref), dim=0).contiguous()
+        n = len(self.chains)
+        inputs = [sub] * (n - 1) + [wav]
+        rows = 2 * half
+        # heads: the PQMF-band chains' in one launch (on the stream of the first of them), MelGAN's on its own stream
+        act0 = [Planes(rows, ch.layers[0].spec.c_out, ch.head_out_len(inputs[i].shape[2]), dev) for i, ch in enumerate(self.chains)]
+        self._head_done = None
+
+        def run(i):
+            ch = self.chains[i]
+            if i == n - 1:
+                jobs = (EbenBlHeadJob * 1)(ch.head_job(wav, wav.shape[2], act0[i]))
+                check(lib.eben_bl_head_fwd(jobs, 1, rows, _stream()), "bl_head_fwd")
+            elif i == 0:
+                jobs = (EbenBlHeadJob * (n - 1))(*[self.chains[k].head_job(sub, sub.shape[2], act0[k]) for k in range(n - 1)])
+                check(lib.eben_bl_head_fwd(jobs, n - 1, rows, _stream()), "bl_head_fwd")
+                self._head_done = torch.cuda.Event()
+                self._head_done.record()
+            else:
+                torch.cuda.current_stream().wait_event(self._head_done)   # chains 1, 2 may run on another stream than chain 0
+            return ch.forward_body(act0[i])
+
+        res = self._launch_on_streams(run, forward=True, order=[n - 1] + list(range(n - 1)))
+        if join:
+            self._join_streams()
+        self._state = dict(half=half, acts=[r[0] for r in res], logits=[r[1] for r in res], inputs=inputs, bands_shape=tuple(bands.shape))
+        return self._state
+
+    # ---- losses ----------------------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def losses(self) -> Dict[str, torch.Tensor]:
+        lib = load()
+        s = self._state
+        half = s["half"]
+        dev = s["logits"][0].device
+        planes = [a for acts in s["acts"] for a in acts]          # every embedding but the inputs and the logits, chain by chain
+        n = len(planes)
+        ptrs = (ctypes.c_void_p * (2 * n))()
+        units = (ctypes.c_int64 * n)()
+        for i, p in enumerate(planes):
+            ptrs[2 * i], ptrs[2 * i + 1] = _addr(p.hi), _addr(p.lo)
+            units[i] = half * (p.channels // 8) * p.length
+        ws_bytes = lib.eben_bl_fm_sums_workspace(n)
+        ws = torch.empty(max(1, (ws_bytes + 3) // 4), dtype=torch.float32, device=dev)
+        sums = torch.empty(2 * n, dtype=torch.float32, device=dev)
+        check(lib.eben_bl_fm_sums(ptrs, units, n, ptr(ws), ws_bytes, ptr(sums), _stream()), "bl_fm_sums")
+        nch = len(self.chains)
+        inv = 1.0 / (nch * len(s["acts"][-1]))
+        s.update(fm_sums=sums, fm_inv=inv, fm_first=[sum(len(a) for a in s["acts"][:i]) for i in range(nch)])
+        hinge = torch.empty(3 * nch, dtype=torch.float32, device=dev)
+        terms = [(rows, target) for lg in s["logits"] for rows, target in ((lg[:half], 1.0), (lg[:half], -1.0), (lg[half:], 1.0))]
+        nt = len(terms)
+        check(lib.eben_hinge_fwd_multi((ctypes.c_void_p * nt)(*[ptr(r) for r, _ in terms]), (ctypes.c_int64 * nt)(*[r.numel() for r, _ in terms]),
+                                       (ctypes.c_float * nt)(*[t for _, t in terms]), nt, ptr(hinge), _stream()), "hinge_fwd_multi")
+        vals = torch.empty(4, dtype=torch.float32, device=dev)
+        check(lib.eben_disc_losses(ptr(sums), n, inv, ptr(hinge), nch, ptr(vals), _stream()), "disc_losses")
+        return {"feature_matching_loss": vals[0], "adv_loss_gen": vals[1], "fake_loss": vals[2], "real_loss": vals[3]}
+
+    # ---- backward --------------------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def backward_launch(self, want_param_grads: bool = True, sink=None):
+        self._sink = sink
+        lib = load()
+        s = self._state
+        half = s["half"]
+        dev = s["logits"][0].device
+        one = torch.ones(1, dtype=torch.float32, device=dev)
+        inv_scales = 1.0 / len(self.chains)
+        sums_ptr = ptr(s["fm_sums"])
+
+        def run(i):
+            lg = s["logits"][i]
+            seeds = torch.zeros((4 * half,) + tuple(lg.shape[1:]), dtype=torch.float32, device=dev)
+            per = lg[:half].numel()
+            flat = seeds.reshape(-1)
+            for k2, (rows, target) in enumerate(((lg[:half], 1.0), (lg[:half], -1.0), (lg[half:], 1.0))):
+                check(lib.eben_hinge_bwd(ptr(rows), rows.numel(), target, ptr(one), inv_scales * self.seed_weights[k2], ptr(flat[(k2 + 1) * per:]),
+                                         _stream()), "hinge_bwd")
+            return self.chains[i].backward_body(s["acts"][i], seeds, half, want_param_grads, sums_ptr + 8 * s["fm_first"][i], s["fm_inv"]) + (seeds,)
+
+        self._bwd = (self._launch_on_streams(run), want_param_grads, (one,))
+
+    @torch.no_grad()
+    def backward_finish(self):
+        lib = load()
+        res, want_param_grads, _keep = self._bwd
+        self._join_streams()
+        self._bwd = _keep = None
+        s = self._state
+        half = s["half"]
+        dev = s["logits"][0].device
+        main = torch.cuda.current_stream()
+        n = len(self.chains)
+        for r in res:
+            r[0].hi.record_stream(main)
+            if r[0].lo is not None:
+                r[0].lo.record_stream(main)
+        # input gradients of the heads, rows [fm | adv]: the PQMF-band chains share the bands (one launch sums them), MelGAN reads the waveform
+        rows = 2 * half
+        sub, wav = s["inputs"][0], s["inputs"][-1]
+        bshape = s["bands_shape"]
+        gb = torch.zeros((rows,) + bshape[1:], dtype=torch.float32, device=dev) if bshape[1] != self.q else None
+        gsub = torch.empty((rows, self.q, sub.shape[2]), dtype=torch.float32, device=dev)
+        jobs = (EbenBlHeadJob * (n - 1))(*[self.chains[k].head_job(None, sub.shape[2], res[k][0]) for k in range(n - 1)])
+        check(lib.eben_bl_head_dx(jobs, n - 1, rows, ptr(gsub), _stream()), "bl_head_dx")
+        if gb is None:
+            gb = gsub
+        else:
+            gb[:, -self.q:, :] = gsub
+        ga = torch.empty((rows, 1, wav.shape[2]), dtype=torch.float32, device=dev)
+        jobs = (EbenBlHeadJob * 1)(self.chains[-1].head_job(None, wav.shape[2], res[-1][0]))
+        check(lib.eben_bl_head_dx(jobs, 1, rows, ptr(ga), _stream()), "bl_head_dx")
+        self._pending = None
+        if want_param_grads:
+            pend = [None] * n
+            for i in [n - 1] + list(range(n - 1)):   # the longest chain first
+                with torch.cuda.stream(self._streams[i]):
+                    pend[i] = self.chains[i].weight_grads(res[i][1], s["inputs"][i], res[i][0], half, self._sink)
+                    if self._sink is not None:
+                        self._sink.mark_ready([p for lay in self.chains[i].layers for p in lay.params() if p is not None and p.requires_grad])
+            self._pending = (pend, s, res)   # keeps the saved activations and the stacked gradients alive until the kernels have run
+        self._state = None
+        return gb[:half], ga[:half], gb[half:], ga[half:]

@@ -55,6 +55,9 @@ DISC_MATH_PLANS = {
     # fp32 step at config 2: 3.378e-2 with that forward in exact fp32, in six-piece (fp32-grade) or in three-piece products alike --
     # what is left comes from MelGAN's bf16 forward and the bf16 gradient contractions; 0.18 with every contraction on single bf16.
     "bf16": {"pqmf": (ops.MATH_BF16X3, ops.MATH_BF16, ops.MATH_BF16), "melgan": ops.MATH_BF16},
+    # the same plan with every embedding / stacked gradient of the engine at rest in the bf16 bundle layout (disc_engine_bl.py): the
+    # MFMA operands are the same roundings of the same fp32 values, produced by the writer's epilogue instead of each reader's staging
+    "bf16_bl": {"pqmf": (ops.MATH_BF16X3, ops.MATH_BF16, ops.MATH_BF16), "melgan": ops.MATH_BF16, "layout": "bl"},
     "bf16_f32fwd": {"pqmf": (ops.MATH_F32, ops.MATH_BF16, ops.MATH_BF16), "melgan": ops.MATH_BF16},
     "bf16x2": (ops.MATH_BF16X2, ops.MATH_BF16, ops.MATH_BF16X2),
     # fp32 arithmetic on the bf16 matrix pipe: forward and input gradients with both operands as three bf16 pieces (six piece

@@ -167,13 +167,16 @@ def _side_stream(device, deal: bool = False) -> "torch.cuda.Stream":
 
 
 def wn_bwd_multi(jobs) -> None:
-    """jobs: (slabs, nslab, slab_stride, rows, cols, row_stride, g, v, norm, dg, dv, dbias) per layer -- the arguments of
-    ``eben_wn_bwd`` -- on the current stream, as one multi-tensor call."""
+    """jobs: (slabs, nslab, slab_stride, rows, cols, row_stride, g, v, norm, dg, dv, dbias[, col_perm_k]) per layer -- the arguments
+    of ``eben_wn_bwd`` (col_perm_k: the slabs' columns are in the bundle-major order of ``eben_bl_conv1d_bwd_dw``) -- on the current
+    stream, as one multi-tensor call."""
     if not jobs:
         return
     items = (EbenWnBwdItem * len(jobs))()
     p = lambda t: t if t is None or isinstance(t, int) else ptr(t)   # outputs may arrive as raw device pointers
-    for it, (slabs, nslab, slab_stride, rows, cols, row_stride, g, v, norm, dg, dv, dbias) in zip(items, jobs):
+    for it, job in zip(items, jobs):
+        slabs, nslab, slab_stride, rows, cols, row_stride, g, v, norm, dg, dv, dbias = job[:12]
+        it.col_perm_k = job[12] if len(job) > 12 else 0
         it.slabs, it.g, it.v, it.norm = ptr(slabs), ptr(g), ptr(v), ptr(norm)
         it.dg, it.dv, it.dbias = p(dg), p(dv), p(dbias)
         it.slab_stride, it.nslab, it.rows, it.cols, it.row_stride = slab_stride, nslab, rows, cols, row_stride
