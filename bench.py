@@ -153,7 +153,7 @@ def main():
     ap.add_argument("--cpu-batch", type=int, default=32)
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--force-ddp", action="store_true", help="run the bucketed RCCL gradient path even with one rank")
-    ap.add_argument("--disc-math", default=os.environ.get("EBEN_DISC_MATH", "bf16"), choices=["bf16", "f32", "bf16_plain"],
+    ap.add_argument("--disc-math", default=os.environ.get("EBEN_DISC_MATH", "bf16"), choices=["bf16", "bf16_bl", "f32", "bf16_plain"],
                     help="discriminator contractions: 'bf16' = bf16 MFMA operands with fp32 accumulate (BASELINE config 2 names bf16; the "
                          "PQMF-band discriminators' forward stays fp32, see DESIGN.md), 'f32' = exact fp32 products, 'bf16_plain' = every "
                          "contraction on single bf16 operands; the generator's forward computes in fp32 either way")
@@ -300,24 +300,35 @@ def main():
         from vibravox_amd.lightning_modules.eben import DISC_MATH_PLANS
         lib = load()
         plan = DISC_MATH_PLANS[args.disc_math]
+        bundle = isinstance(plan, dict) and plan.get("layout") == "bl"
         plan = plan["melgan"] if isinstance(plan, dict) else plan
         math = plan if isinstance(plan, int) else plan[0]
         lb = timer.batch or 2 * args.batch
         lx = cut
         for (k, s_, p_) in [(15, 1, 7), (41, 4, 20), (41, 4, 20), (41, 4, 20)]:
             lx = (lx + 2 * p_ - (k - 1) - 1) // s_ + 1
-        d = ops.conv_desc(layer.spec, lb, lx, math)
+        d = ops.conv_desc(layer.spec, lb, lx, math | (0x100 if bundle else 0))
         prm = layer.parametrizations["weight"]
         pw = ops.pack_weights(layer.spec, d, prm.original1.detach(), prm.original0.detach(), None, False)
         xin = torch.randn(lb, layer.spec.c_in, lx, device=device)
-        yout = torch.empty(lb, layer.spec.c_out, d.l_out, device=device)
+        if bundle:
+            from vibravox_amd.disc_engine_bl import Planes
+            xpl, ypl = Planes.from_f32(xin, lo=False), Planes(lb, layer.spec.c_out, d.l_out, device)
+
+            def launch():
+                check(lib.eben_bl_conv1d_fwd(ctypes.byref(d), xpl.hi.data_ptr(), None, ptr(pw.wp_fwd), ptr(layer.bias), ypl.hi.data_ptr(), ypl.lo.data_ptr(), stream()))
+        else:
+            yout = torch.empty(lb, layer.spec.c_out, d.l_out, device=device)
+
+            def launch():
+                check(lib.eben_conv1d_fwd(ctypes.byref(d), ptr(xin), ptr(pw.wp_fwd), ptr(layer.bias), None, ptr(yout), stream()))
         torch.cuda.synchronize()
         for _ in range(3):
-            check(lib.eben_conv1d_fwd(ctypes.byref(d), ptr(xin), ptr(pw.wp_fwd), ptr(layer.bias), None, ptr(yout), stream()))
+            launch()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(20):
-            check(lib.eben_conv1d_fwd(ctypes.byref(d), ptr(xin), ptr(pw.wp_fwd), ptr(layer.bias), None, ptr(yout), stream()))
+            launch()
         e1.record()
         torch.cuda.synchronize()
         iso_ms = e0.elapsed_time(e1) / 20
@@ -370,7 +381,7 @@ def main():
                                      f"discriminators: input / weight gradients -- their forward takes hi + lo bf16 operands (3 MFMAs per product), which keeps the discriminator "
                                      f"gradient within 3.4e-2 of the fp32 step's, tests/test_gpu_models.py); generator forward, losses, Adam, "
                                      f"storage: fp32; generator backward contractions: {gen_bwd_math}; MRSTFT DFT contractions: {stft_desc}"
-                                     if args.disc_math == "bf16" else
+                                     if args.disc_math in ("bf16", "bf16_bl") else
                                      "every contraction on single bf16 MFMA operands (bf16_plain)" if bf16 else "fp32 throughout (exact fp32 MFMA products)")},
             "step_ms": {"median": round(percentile(per_step, 0.5), 3), "p10": round(percentile(per_step, 0.1), 3),
                         "p90": round(percentile(per_step, 0.9), 3), "clock": "HIP events at the step boundaries on the main stream"},
