@@ -214,19 +214,21 @@ typedef struct EbenBlHeadJob {
 } EbenBlHeadJob;
 EBEN_API int eben_bl_head_fwd(const EbenBlHeadJob* jobs, int njobs, int batch, void* stream);
 EBEN_API int eben_bl_head_dx(const EbenBlHeadJob* jobs, int njobs, int rows, float* dx, void* stream);
-EBEN_API size_t eben_bl_head_dw_workspace(const EbenBlHeadJob* job, int* nslab, int* row_stride);
+EBEN_API size_t eben_bl_head_dw_workspace(const EbenBlHeadJob* job, int rows, int* nslab, int* row_stride);
 EBEN_API int eben_bl_head_dw(const EbenBlHeadJob* job, int rows, float* slabs, size_t ws_bytes, void* stream);
 /* Chain tails: the logits layer Conv1d(channels -> 1, ksize <= 8, zero padding, stride 1) (eben_discriminator.py:150-157,
  * melgan_discriminator.py:147-156), v (1, channels, ksize), scale / bias one element (nullable): forward from bundle planes to fp32
  * (batch, 1, l_out); input gradient of `rows` stacked seeds (rows, 1, l_out) with the epilogue of eben_bl_conv1d_bwd_dx (act = the
- * layer's input embedding); weight gradient slabs [nslab][1][channels ksize + 1] from `rows` seed rows and the `rows` input rows. */
+ * layer's input embedding); weight gradient of `nbranch` hinge branches in one launch -- branch br pairs seed rows and input rows
+ * [br rows, (br + 1) rows) of the given pointers -- into slabs [nbranch][nslab][channels ksize + 1] (last column = bias).  The built
+ * head shapes are the two of DiscriminatorEBENMultiScales (4 -> 24 k 3, 1 -> 16 k 15): EBEN_EUNSUPPORTED otherwise. */
 EBEN_API int eben_bl_tail_fwd(const void* x_hi, const void* x_lo, int batch, int channels, int length, int ksize, int pad, const float* v,
                      const float* scale, const float* bias, float out_slope, float* y, void* stream);
 EBEN_API int eben_bl_tail_dx(const float* seeds, int rows, int channels, int length, int ksize, int pad, const float* v, const float* scale,
                     const void* act_hi, const void* act_lo, float mask_slope, int seg, const int* seg_map, int fm_rows,
                     int ref_row_offset, const float* fm_sums, float fm_gs, void* g_hi, void* g_lo /* nullable */, void* stream);
-EBEN_API size_t eben_bl_tail_dw_workspace(int channels, int ksize, int* nslab, int* row_stride);
-EBEN_API int eben_bl_tail_dw(const float* seeds, const void* x_hi, const void* x_lo, int rows, int channels, int length, int ksize, int pad,
+EBEN_API size_t eben_bl_tail_dw_workspace(int rows, int channels, int l_out, int ksize, int nbranch, int* nslab, int* row_stride);
+EBEN_API int eben_bl_tail_dw(const float* seeds, const void* x_hi, const void* x_lo, int rows, int nbranch, int channels, int length, int ksize, int pad,
                     float* slabs, size_t ws_bytes, void* stream);
 /* feature-matching sums (eben_fm_sums) over embeddings in bundle planes: planes = HOST array (hi_0, lo_0, hi_1, lo_1, ...), the
  * enhanced rows are the first units[i] units of pair i's planes and the reference rows the next units[i] (a = hi + lo). */

@@ -114,7 +114,7 @@ def test_chain_head_forward_backward(hip, name):
     hi_only.hi, hi_only.lo, hi_only.rows, hi_only.channels, hi_only.length = masked.hi, None, batch, c_out, l_out
     wj = head_job(hip, x, v, scale, bias, hi_only, c_in, c_out, length, k, dil, pad, rpad, 0.2)
     nslab, rs = ctypes.c_int(0), ctypes.c_int(0)
-    nbytes = hip.eben_bl_head_dw_workspace(ctypes.byref(wj), ctypes.byref(nslab), ctypes.byref(rs))
+    nbytes = hip.eben_bl_head_dw_workspace(ctypes.byref(wj), batch, ctypes.byref(nslab), ctypes.byref(rs))
     slabs = torch.empty(nbytes // 4, dtype=torch.float32, device=DEV)
     check(hip.eben_bl_head_dw(ctypes.byref(wj), batch, slabs.data_ptr(), nbytes, st), "head_dw")
     got = slabs.reshape(nslab.value, c_out, rs.value).double().sum(0)
@@ -196,18 +196,19 @@ def test_chain_tail_forward_backward(hip, channels, length):
     mask_rows = torch.cat((a_hi[:half], a_hi[:half], a_hi[:half], a_hi[half:]), dim=0)
     want = base * torch.where(mask_rows > 0, 1.0, 0.2)
     assert rel_err(g.to_f32(), want) < 2e-5
-    # weight gradient of one hinge branch: `half` seed rows against `half` rows of the embedding
+    # weight gradient of the two hinge branches in one launch: seed rows [fake | real] against embedding rows [enhanced | reference]
     nslab, rs = ctypes.c_int(0), ctypes.c_int(0)
-    nbytes = hip.eben_bl_tail_dw_workspace(channels, k, ctypes.byref(nslab), ctypes.byref(rs))
+    nbytes = hip.eben_bl_tail_dw_workspace(half, channels, length, k, 2, ctypes.byref(nslab), ctypes.byref(rs))
     slabs = torch.empty(nbytes // 4, dtype=torch.float32, device=DEV)
-    sd = seeds[2 * half:3 * half].contiguous()
-    check(hip.eben_bl_tail_dw(sd.data_ptr(), act.hi[half:].data_ptr(), act.lo[half:].data_ptr(), half, channels, length, k, pad, slabs.data_ptr(), nbytes, st),
-          "tail_dw")
-    got = slabs.reshape(nslab.value, rs.value).double().sum(0)
-    wr = w.clone().requires_grad_(True)
-    (F.conv1d(a[half:], wr, None, padding=pad) * sd.double()).sum().backward()
-    assert rel_err(got[:-1], wr.grad.reshape(-1)) < 2e-5
-    assert abs(float(got[-1]) - float(sd.double().sum())) < 1e-4 * float(sd.double().abs().sum())
+    sd = seeds[2 * half:].contiguous()
+    check(hip.eben_bl_tail_dw(sd.data_ptr(), act.hi.data_ptr(), act.lo.data_ptr(), half, 2, channels, length, k, pad, slabs.data_ptr(), nbytes, st), "tail_dw")
+    got = slabs.reshape(2, nslab.value, rs.value).double().sum(1)
+    for br in range(2):
+        wr = w.clone().requires_grad_(True)
+        sb = sd[br * half:(br + 1) * half].double()
+        (F.conv1d(a[br * half:(br + 1) * half], wr, None, padding=pad) * sb).sum().backward()
+        assert rel_err(got[br, :-1], wr.grad.reshape(-1)) < 2e-5
+        assert abs(float(got[br, -1]) - float(sb.sum())) < 1e-4 * float(sb.abs().sum())
 
 
 def test_feature_matching_sums_over_planes(hip):

@@ -115,13 +115,13 @@ SIGNATURES = {
     "eben_bl_conv1d_bwd_dw": (c_int, [_D, _P, _P, c_int, _P, c_size_t, _P]),
     "eben_bl_head_fwd": (c_int, [POINTER(EbenBlHeadJob), c_int, c_int, _P]),
     "eben_bl_head_dx": (c_int, [POINTER(EbenBlHeadJob), c_int, c_int, _P, _P]),
-    "eben_bl_head_dw_workspace": (c_size_t, [POINTER(EbenBlHeadJob), POINTER(c_int), POINTER(c_int)]),
+    "eben_bl_head_dw_workspace": (c_size_t, [POINTER(EbenBlHeadJob), c_int, POINTER(c_int), POINTER(c_int)]),
     "eben_bl_head_dw": (c_int, [POINTER(EbenBlHeadJob), c_int, _P, c_size_t, _P]),
     "eben_bl_tail_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_float, _P, _P]),
     "eben_bl_tail_dx": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_float, c_int, POINTER(c_int), c_int, c_int, _P, c_float,
                                 _P, _P, _P]),
-    "eben_bl_tail_dw_workspace": (c_size_t, [c_int, c_int, POINTER(c_int), POINTER(c_int)]),
-    "eben_bl_tail_dw": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, c_size_t, _P]),
+    "eben_bl_tail_dw_workspace": (c_size_t, [c_int, c_int, c_int, c_int, c_int, POINTER(c_int), POINTER(c_int)]),
+    "eben_bl_tail_dw": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_size_t, _P]),
     "eben_bl_fm_sums_workspace": (c_size_t, [c_int]),
     "eben_bl_fm_sums": (c_int, [POINTER(c_void_p), POINTER(c_int64), c_int, _P, c_size_t, _P, _P]),
     "eben_ru_packed_floats": (c_size_t, [c_int]),

@@ -87,7 +87,6 @@ __global__ __launch_bounds__(256) void bl_to_f32_kernel(const u32x4* __restrict_
 
 // ---- chain heads ----------------------------------------------------------------------------------------------------------------
 constexpr int BL_HEAD_JOBS = 4;
-constexpr int BL_HEAD_WMAX = 256;   // c_out * ksize floats of one job's weights held in LDS
 struct BlHeadJob {
   const float* x; const float* v; const float* scale; const float* bias;
   u32x4* yh; u32x4* yl;               // forward outputs / input-gradient inputs (g planes)
@@ -104,183 +103,212 @@ __device__ __forceinline__ int bl_head_src(int p, int rpad, int l_in) {
   return u >= l_in ? 2 * (l_in - 1) - u : u;
 }
 
-// one block = 256 output positions of one (batch item, output bundle) of one job; groups = c_in (one input channel per output channel)
+typedef const __attribute__((address_space(4))) float* cfloat_t;   // uniform reads through the scalar cache (s_load)
+
+// One thread = one output position x ALL output channels of one (job, batch item): the CIN * K input samples are loaded once (coalesced
+// along time), the weights are block-uniform and arrive in SGPRs (static offsets into the job's v: s_load_dwordx8/16), the weight-norm
+// scale is applied once per channel to the finished sum (the layer is linear in v).  OG = output channels per input channel.
+template <int CIN, int OG, int K>
 __global__ __launch_bounds__(256) void bl_head_fwd_kernel(const BlHeadTable T) {
-  __shared__ float wsh[8 * 16 + 8];
+  constexpr int COUT = CIN * OG, CB = COUT / 8;
   const BlHeadJob& J = T.job[blockIdx.z];
-  const int CB = J.c_out >> 3;
-  const int b = blockIdx.y / CB, ob = blockIdx.y - b * CB;
-  if (b >= T.batch || (int)blockIdx.x * 256 >= J.l_out) return;
-  const int og = J.c_out / J.c_in;          // output channels per group
-  for (int i = threadIdx.x; i < 8 * J.k + 8; i += 256) {
-    if (i < 8 * J.k) {
-      const int e = i / J.k, j = i - e * J.k, co = 8 * ob + e;
-      wsh[e * 16 + j] = J.v[(long long)co * J.k + j] * (J.scale ? J.scale[co] : 1.f);
-    } else {
-      wsh[8 * 16 + (i - 8 * J.k)] = J.bias ? J.bias[8 * ob + (i - 8 * J.k)] : 0.f;
-    }
-  }
-  __syncthreads();
+  const int b = blockIdx.y;
   const int t = blockIdx.x * 256 + threadIdx.x;
   if (t >= J.l_out) return;
-  float acc[8];
+  const float* xb = J.x + (long long)b * CIN * J.l_in;
+  float xv[CIN][K];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) acc[e] = wsh[8 * 16 + e];
-  const float* xb = J.x + (long long)b * J.c_in * J.l_in;
-  const int ci0 = (8 * ob) / og, ci1 = (8 * ob + 7) / og;   // at most two input channels feed one bundle when og >= 4
-  for (int j = 0; j < J.k; ++j) {
+  for (int j = 0; j < K; ++j) {
     const int u = bl_head_src(t - J.pad + j * J.dil, J.rpad, J.l_in);
-    const float x0 = u >= 0 ? xb[(long long)ci0 * J.l_in + u] : 0.f;
-    const float x1 = (u >= 0 && ci1 != ci0) ? xb[(long long)ci1 * J.l_in + u] : x0;
+#pragma unroll
+    for (int c = 0; c < CIN; ++c) xv[c][j] = u >= 0 ? xb[(long long)c * J.l_in + u] : 0.f;
+  }
+  cfloat_t v = (cfloat_t)J.v;
+  cfloat_t sc = (cfloat_t)J.scale;
+  cfloat_t bs = (cfloat_t)J.bias;
+#pragma unroll
+  for (int ob = 0; ob < CB; ++ob) {
+    float acc[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const int ci = (8 * ob + e) / og;
-      float xv = ci == ci0 ? x0 : x1;
-      if (ci != ci0 && ci != ci1) xv = u >= 0 ? xb[(long long)ci * J.l_in + u] : 0.f;   // og < 4: more than two groups per bundle
-      acc[e] = fmaf(wsh[e * 16 + j], xv, acc[e]);
-    }
-  }
+      const int co = 8 * ob + e, ci = co / OG;
+      float a = 0.f;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) acc[e] = lrelu(acc[e], J.out_slope);
-  const long long idx = ((long long)b * CB + ob) * J.l_out + t;
-  const u32x4 h = bl_pack8(acc);
-  J.yh[idx] = h;
-  if (J.yl) J.yl[idx] = bl_pack8_lo(acc, h);
+      for (int j = 0; j < K; ++j) a = fmaf(v[co * K + j], xv[ci][j], a);
+      a = a * (J.scale ? sc[co] : 1.f) + (J.bias ? bs[co] : 0.f);
+      acc[e] = lrelu(a, J.out_slope);
+    }
+    const long long idx = ((long long)b * CB + ob) * J.l_out + t;
+    const u32x4 h = bl_pack8(acc);
+    J.yh[idx] = h;
+    if (J.yl) J.yl[idx] = bl_pack8_lo(acc, h);
+  }
 }
 
 // Input gradient of the heads, summed over the jobs (the three PQMF-band chains share their input):
 //   dxp[b, ci, p] = sum_{co in group ci} sum_j w[co, j] g[b, co, p + pad - j dil],   dx[u] = dxp[u + P] + reflect folds
-// one thread = one (batch item, position u), all c_in <= 4 input channels
+// One block = 256 consecutive input positions of one batch item.  Per job the gradient tile those positions touch (hi + lo planes ->
+// fp32, [channel][position]) is staged in LDS once -- every unit is read from memory once instead of K times -- and a thread's K * OG
+// products per input channel read it with conflict-free ds_read_b32 (lanes = consecutive positions); weights through the scalar cache.
+// The <= 2 P positions next to each end of a row receive their folded terms from a slow path on global memory.
+template <int CIN, int OG, int K>
 __global__ __launch_bounds__(256) void bl_head_dx_kernel(const BlHeadTable T, float* __restrict__ dx) {
-  __shared__ float wsh[BL_HEAD_JOBS][BL_HEAD_WMAX];
-  for (int jb = 0; jb < T.n; ++jb) {
-    const BlHeadJob& J = T.job[jb];
-    for (int i = threadIdx.x; i < J.c_out * J.k; i += 256) wsh[jb][i] = J.v[i] * (J.scale ? J.scale[i / J.k] : 1.f);
-  }
-  __syncthreads();
-  const int l_in = T.job[0].l_in, c_in = T.job[0].c_in;
+  constexpr int COUT = CIN * OG, CB = COUT / 8;
+  extern __shared__ __attribute__((aligned(16))) float gt[];   // [COUT][TL]
+  const int l_in = T.job[0].l_in;
   const int b = blockIdx.y;
-  const int u = blockIdx.x * 256 + threadIdx.x;
-  if (u >= l_in) return;
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  const int u0 = blockIdx.x * 256;
+  const int u = u0 + threadIdx.x;
+  float acc[CIN];
+#pragma unroll
+  for (int c = 0; c < CIN; ++c) acc[c] = 0.f;
   for (int jb = 0; jb < T.n; ++jb) {
     const BlHeadJob& J = T.job[jb];
-    const int CB = J.c_out >> 3, og = J.c_out / J.c_in, P = J.rpad;
-    // the padded positions that fold onto u (nn.ReflectionPad1d's adjoint)
-    int pts[3];
-    int np = 0;
-    pts[np++] = u + P;
-    if (u >= 1 && u <= P) pts[np++] = P - u;
-    if (u >= l_in - 1 - P && u <= l_in - 2) pts[np++] = P + 2 * (l_in - 1) - u;
-    for (int q = 0; q < np; ++q) {
-      for (int j = 0; j < J.k; ++j) {
-        const int t = pts[q] + J.pad - j * J.dil;
-        if (t < 0 || t >= J.l_out) continue;
-        for (int ob = 0; ob < CB; ++ob) {
-          float gv[8];
-          bl_load8(J.yh, J.yl, ((long long)b * CB + ob) * J.l_out + t, gv);
+    const int P = J.rpad, span = (K - 1) * J.dil, TL = 256 + span;
+    // gradient positions t = p + pad - j dil for p = u + P, u in the block: [tlo, tlo + TL)
+    const int tlo = u0 + P + J.pad - span;
+    __syncthreads();   // the previous job's tile has been consumed
+    for (int i = threadIdx.x; i < CB * TL; i += 256) {
+      const int cb = i / TL, r = i - cb * TL, t = tlo + r;
+      float f[8];
+      if (t >= 0 && t < J.l_out) bl_load8(J.yh, J.yl, ((long long)b * CB + cb) * J.l_out + t, f);
+      else {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const int co = 8 * ob + e, ci = co / og;
-            const float w = wsh[jb][co * J.k + j] * gv[e];
+        for (int e = 0; e < 8; ++e) f[e] = 0.f;
+      }
 #pragma unroll
-            for (int c = 0; c < 4; ++c) acc[c] += c == ci ? w : 0.f;
+      for (int e = 0; e < 8; ++e) gt[(8 * cb + e) * TL + r] = f[e];
+    }
+    __syncthreads();
+    cfloat_t v = (cfloat_t)J.v;
+    cfloat_t sc = (cfloat_t)J.scale;
+    if (u < l_in) {
+#pragma unroll
+      for (int c = 0; c < CIN; ++c) {
+        float a = 0.f;
+#pragma unroll
+        for (int m = 0; m < OG; ++m) {
+          const int co = c * OG + m;
+          float s = 0.f;
+#pragma unroll
+          for (int j = 0; j < K; ++j) s = fmaf(v[co * K + j], gt[co * TL + (int)threadIdx.x + span - j * J.dil], s);
+          a = fmaf(s, J.scale ? sc[co] : 1.f, a);
+        }
+        acc[c] += a;
+      }
+      // folded terms of the reflection (nn.ReflectionPad1d's adjoint): padded positions P - u and P + 2 (l_in - 1) - u
+      int pts[2], np = 0;
+      if (u >= 1 && u <= P) pts[np++] = P - u;
+      if (u >= l_in - 1 - P && u <= l_in - 2) pts[np++] = P + 2 * (l_in - 1) - u;
+      for (int q = 0; q < np; ++q)
+        for (int j = 0; j < K; ++j) {
+          const int t = pts[q] + J.pad - j * J.dil;
+          if (t < 0 || t >= J.l_out) continue;
+          for (int cb = 0; cb < CB; ++cb) {
+            float gv[8];
+            bl_load8(J.yh, J.yl, ((long long)b * CB + cb) * J.l_out + t, gv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const int co = 8 * cb + e, ci = co / OG;
+              const float w = J.v[co * K + j] * (J.scale ? J.scale[co] : 1.f) * gv[e];
+#pragma unroll
+              for (int c = 0; c < CIN; ++c) acc[c] += c == ci ? w : 0.f;
+            }
           }
         }
-      }
     }
   }
-  for (int c = 0; c < c_in; ++c) dx[((long long)b * c_in + c) * l_in + u] = acc[c];
+  if (u < l_in) {
+#pragma unroll
+    for (int c = 0; c < CIN; ++c) dx[((long long)b * CIN + c) * l_in + u] = acc[c];
+  }
 }
 
 // Weight (+ bias) gradient of a head: slab[z][co][j] = sum over the (batch item, position) pairs of slice z of g[b, co, t] xp[b, ci(co), t - pad + j dil],
-// column k = sum g.  One block = one output bundle x one slice; KT = padded tap count.
-template <int KT>
-__global__ __launch_bounds__(256) void bl_head_dw_kernel(const u32x4* __restrict__ gh, const float* __restrict__ x, int rows, int c_in, int c_out,
-                                                         int l_in, int l_out, int k, int dil, int pad, int rpad, int nslab, float* __restrict__ slabs) {
-  __shared__ float red[4][8 * (KT + 1)];
-  const int CB = c_out >> 3, og = c_out / c_in;
+// column K = sum g.  One block = one output bundle x one slice; the 8 (K + 1) per-thread sums meet in a fixed-order block reduction.
+template <int CIN, int OG, int K>
+__global__ __launch_bounds__(256) void bl_head_dw_kernel(const u32x4* __restrict__ gh, const float* __restrict__ x, int rows, int l_in, int l_out,
+                                                         int dil, int pad, int rpad, int nslab, float* __restrict__ slabs) {
+  constexpr int COUT = CIN * OG, CB = COUT / 8;
+  __shared__ float red[4][8 * (K + 1)];
   const int ob = blockIdx.x, z = blockIdx.y;
   const long long total = (long long)rows * l_out;
   const long long per = (total + nslab - 1) / nslab;
   const long long lo = (long long)z * per, hi = lo + per < total ? lo + per : total;
-  float acc[8][KT + 1];
+  float acc[8][K + 1];
 #pragma unroll
   for (int e = 0; e < 8; ++e)
 #pragma unroll
-    for (int j = 0; j <= KT; ++j) acc[e][j] = 0.f;
-  const int ci0 = (8 * ob) / og, ci1 = (8 * ob + 7) / og;
+    for (int j = 0; j <= K; ++j) acc[e][j] = 0.f;
+  const int ci0 = (8 * ob) / OG, ci1 = (8 * ob + 7) / OG;   // OG >= 4: at most two input channels feed one bundle
   for (long long i = lo + threadIdx.x; i < hi; i += 256) {
     const int b = (int)(i / l_out), t = (int)(i - (long long)b * l_out);
     float gv[8];
     bl_unpack8(gh[((long long)b * CB + ob) * l_out + t], gv);
-    const float* xb = x + (long long)b * c_in * l_in;
+    const float* xb = x + (long long)b * CIN * l_in;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) acc[e][KT] += gv[e];
+    for (int e = 0; e < 8; ++e) acc[e][K] += gv[e];
 #pragma unroll
-    for (int j = 0; j < KT; ++j) {
-      if (j < k) {
-        const int u = bl_head_src(t - pad + j * dil, rpad, l_in);
-        const float x0 = u >= 0 ? xb[(long long)ci0 * l_in + u] : 0.f;
-        const float x1 = (u >= 0 && ci1 != ci0) ? xb[(long long)ci1 * l_in + u] : x0;
+    for (int j = 0; j < K; ++j) {
+      const int u = bl_head_src(t - pad + j * dil, rpad, l_in);
+      const float x0 = u >= 0 ? xb[(long long)ci0 * l_in + u] : 0.f;
+      const float x1 = (u >= 0 && ci1 != ci0) ? xb[(long long)ci1 * l_in + u] : x0;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const int ci = (8 * ob + e) / og;
-          float xv = ci == ci0 ? x0 : x1;
-          if (ci != ci0 && ci != ci1) xv = u >= 0 ? xb[(long long)ci * l_in + u] : 0.f;
-          acc[e][j] = fmaf(gv[e], xv, acc[e][j]);
-        }
-      }
+      for (int e = 0; e < 8; ++e) acc[e][j] = fmaf(gv[e], (8 * ob + e) / OG == ci0 ? x0 : x1, acc[e][j]);
     }
   }
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
   for (int e = 0; e < 8; ++e)
 #pragma unroll
-    for (int j = 0; j <= KT; ++j) {
-      const float s = wave_sum(acc[e][j]);
-      if (lane == 0) red[w][e * (KT + 1) + j] = s;
+    for (int j = 0; j <= K; ++j) {
+      const float sm = wave_sum(acc[e][j]);
+      if (lane == 0) red[w][e * (K + 1) + j] = sm;
     }
   __syncthreads();
-  for (int i = threadIdx.x; i < 8 * (KT + 1); i += 256) {
-    const int e = i / (KT + 1), j = i - e * (KT + 1);
-    if (j < k || j == KT) {
-      const float s = red[0][i] + red[1][i] + red[2][i] + red[3][i];
-      slabs[((long long)z * c_out + 8 * ob + e) * (k + 1) + (j == KT ? k : j)] = s;
-    }
-  }
+  for (int i = threadIdx.x; i < 8 * (K + 1); i += 256)
+    slabs[((long long)z * COUT + 8 * ob + i / (K + 1)) * (K + 1) + i % (K + 1)] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
 }
 
 // ---- chain tails (the logits layer: C -> 1, k taps, zero padding) ------------------------------------------------------------------
-// forward: one block = 64 output positions of one batch item; wave w sums the bundles cb = w, w + 4, ...; fp32 FMA on hi + lo
-__global__ __launch_bounds__(256) void bl_tail_fwd_kernel(const u32x4* __restrict__ xh, const u32x4* __restrict__ xl, int CB, int L, int k, int pad,
-                                                          int l_out, const float* __restrict__ v, const float* __restrict__ scale,
-                                                          const float* __restrict__ bias, float out_slope, float* __restrict__ y) {
-  extern __shared__ __attribute__((aligned(16))) float wt[];   // [CB * 8 * k] scaled weights, then 4 x 64 partial sums
+// forward: one block = 64 output positions of one batch item x 16 waves; wave w sums the bundles cb = w, w + 16, ... (fp32 FMA on
+// hi + lo), the 16 partial sums meet in LDS; weights staged once per block as [bundle][tap][8] (two ds_read_b128 per unit)
+__global__ __launch_bounds__(1024) void bl_tail_fwd_kernel(const u32x4* __restrict__ xh, const u32x4* __restrict__ xl, int CB, int L, int k, int pad,
+                                                           int l_out, const float* __restrict__ v, const float* __restrict__ scale,
+                                                           const float* __restrict__ bias, float out_slope, float* __restrict__ y) {
+  extern __shared__ __attribute__((aligned(16))) float wt[];   // [CB][k][8] scaled weights, then 16 x 64 partial sums
   float* part = wt + CB * 8 * k;
   const float sc = scale ? scale[0] : 1.f;
-  for (int i = threadIdx.x; i < CB * 8 * k; i += 256) wt[i] = v[i] * sc;
+  for (int i = threadIdx.x; i < CB * 8 * k; i += 1024) {
+    const int cb = i / (8 * k), r = i - cb * 8 * k, j = r >> 3, e = r & 7;
+    wt[i] = v[(cb * 8 + e) * k + j] * sc;
+  }
   __syncthreads();
   const int b = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int t = blockIdx.x * 64 + lane;
   float acc = 0.f;
   if (t < l_out) {
-    for (int cb = w; cb < CB; cb += 4) {
+    for (int cb = w; cb < CB; cb += 16) {
       const long long row = ((long long)b * CB + cb) * L;
       for (int j = 0; j < k; ++j) {
         const int q = t - pad + j;
-        if (q < 0 || q >= L) continue;
+        const int qc = q < 0 ? 0 : (q >= L ? L - 1 : q);
         float f[8];
-        bl_load8(xh, xl, row + q, f);
+        bl_load8(xh, xl, row + qc, f);
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(wt + (cb * k + j) * 8), w1 = *reinterpret_cast<const f32x4*>(wt + (cb * k + j) * 8 + 4);
+        float s = 0.f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc = fmaf(wt[(cb * 8 + e) * k + j], f[e], acc);
+        for (int e = 0; e < 4; ++e) s = fmaf(w0[e], f[e], fmaf(w1[e], f[4 + e], s));
+        acc += (q == qc) ? s : 0.f;
       }
     }
   }
   part[w * 64 + lane] = acc;
   __syncthreads();
   if (w == 0 && t < l_out) {
-    const float s = (bias ? bias[0] : 0.f) + part[lane] + part[64 + lane] + part[128 + lane] + part[192 + lane];
+    float s = bias ? bias[0] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += part[i * 64 + lane];
     y[(long long)b * l_out + t] = lrelu(s, out_slope);
   }
 }
@@ -336,14 +364,17 @@ __global__ __launch_bounds__(256) void bl_tail_dx_kernel(const BlTailDxArgs P) {
   if (P.gl) P.gl[gi] = bl_pack8_lo(val, h);
 }
 
-// weight (+ bias) gradient of the logits layer: slab[z][0][c k + j] = sum_{(b, t) in slice z} seed[b, t] x[b, c, t - pad + j]; column C k = sum seed
+// weight (+ bias) gradient of the logits layer, one launch for the `nbranch` hinge branches (seed rows / embedding rows br * rows ..):
+//   slab[br][z][c k + j] = sum_{(b, t) in slice z of branch br} seed[b, t] x[b, c, t - pad + j];   column C k = sum seed
+// One block = one input bundle x one slice x one branch: 8 k + 1 sums per thread, fixed-order block reduction.
 __global__ __launch_bounds__(256) void bl_tail_dw_kernel(const float* __restrict__ seeds, const u32x4* __restrict__ xh, const u32x4* __restrict__ xl,
                                                          int rows, int CB, int L, int k, int pad, int l_out, int nslab, float* __restrict__ slabs) {
   __shared__ float red[4][8 * 8 + 1];
-  const int cb = blockIdx.x, z = blockIdx.y;
+  const int cb = blockIdx.x, z = blockIdx.y, br = blockIdx.z;
   const long long total = (long long)rows * l_out;
   const long long per = (total + nslab - 1) / nslab;
   const long long lo = (long long)z * per, hi = lo + per < total ? lo + per : total;
+  const float* sd = seeds + (long long)br * total;
   float acc[8][8], sb = 0.f;
 #pragma unroll
   for (int e = 0; e < 8; ++e)
@@ -351,19 +382,19 @@ __global__ __launch_bounds__(256) void bl_tail_dw_kernel(const float* __restrict
     for (int j = 0; j < 8; ++j) acc[e][j] = 0.f;
   for (long long i = lo + threadIdx.x; i < hi; i += 256) {
     const int b = (int)(i / l_out), t = (int)(i - (long long)b * l_out);
-    const float s = seeds[i];
+    const float s = sd[i];
     sb += s;
-    const long long row = ((long long)b * CB + cb) * L;
+    const long long row = ((long long)(br * rows + b) * CB + cb) * L;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       if (j < k) {
         const int q = t - pad + j;
-        if (q >= 0 && q < L) {
-          float f[8];
-          bl_load8(xh, xl, row + q, f);
+        const int qc = q < 0 ? 0 : (q >= L ? L - 1 : q);
+        float f[8];
+        bl_load8(xh, xl, row + qc, f);
+        const float sq = q == qc ? s : 0.f;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) acc[e][j] = fmaf(s, f[e], acc[e][j]);
-        }
+        for (int e = 0; e < 8; ++e) acc[e][j] = fmaf(sq, f[e], acc[e][j]);
       }
     }
   }
@@ -379,12 +410,13 @@ __global__ __launch_bounds__(256) void bl_tail_dw_kernel(const float* __restrict
   if (lane == 0) red[w][64] = sb;
   __syncthreads();
   const long long rs = (long long)CB * 8 * k + 1;
+  float* out = slabs + ((long long)br * nslab + z) * rs;
   for (int i = threadIdx.x; i < 65; i += 256) {
     const float s = red[0][i] + red[1][i] + red[2][i] + red[3][i];
-    if (i == 64) { if (cb == 0) slabs[(long long)z * rs + rs - 1] = s; }
+    if (i == 64) { if (cb == 0) out[rs - 1] = s; }
     else {
       const int e = i >> 3, j = i & 7;
-      if (j < k) slabs[(long long)z * rs + (long long)(cb * 8 + e) * k + j] = s;
+      if (j < k) out[(long long)(cb * 8 + e) * k + j] = s;
     }
   }
 }
@@ -467,14 +499,10 @@ static int bl_head_table(const EbenBlHeadJob* jobs, int n, int batch, bool backw
     const EbenBlHeadJob& s = jobs[i];
     BlHeadJob& d = T->job[i];
     EBEN_REQUIRE(s.v && s.y_hi && (backward || s.x), "null pointer in head job %d", i);
-    EBEN_REQUIRE(s.c_in >= 1 && s.c_out % 8 == 0 && s.c_out % s.c_in == 0 && s.ksize >= 1 && s.ksize <= 16 && s.dilation >= 1,
-                 "head job %d: groups = c_in, c_out a multiple of 8 and of c_in, ksize <= 16", i);
-    EBEN_REQUIRE(s.l_out == s.l_in + 2 * s.reflect_pad + 2 * s.pad - s.dilation * (s.ksize - 1) && s.l_out > 0 && s.reflect_pad < s.l_in,
-                 "head job %d: l_out %d does not match the layer", i, s.l_out);
-    if (backward) {
-      EBEN_REQUIRE(s.c_in <= 4 && s.c_out * s.ksize <= BL_HEAD_WMAX, "head input gradient: c_in <= 4, c_out * ksize <= %d", BL_HEAD_WMAX);
-      EBEN_REQUIRE(s.c_in == jobs[0].c_in && s.l_in == jobs[0].l_in, "head input gradient: jobs must share the input shape");
-    }
+    EBEN_REQUIRE(s.dilation >= 1 && s.pad >= 0 && s.reflect_pad >= 0 && s.reflect_pad < s.l_in, "head job %d: bad geometry", i);
+    EBEN_REQUIRE(s.l_out == s.l_in + 2 * s.reflect_pad + 2 * s.pad - s.dilation * (s.ksize - 1) && s.l_out > 0, "head job %d: l_out %d does not match the layer", i, s.l_out);
+    EBEN_REQUIRE(s.c_in == jobs[0].c_in && s.c_out == jobs[0].c_out && s.ksize == jobs[0].ksize && s.l_in == jobs[0].l_in,
+                 "the head jobs of one launch must share channels, taps and the input length");
     d.x = s.x; d.v = s.v; d.scale = s.scale; d.bias = s.bias; d.yh = static_cast<u32x4*>(s.y_hi); d.yl = static_cast<u32x4*>(s.y_lo);
     d.c_in = s.c_in; d.c_out = s.c_out; d.l_in = s.l_in; d.l_out = s.l_out; d.k = s.ksize; d.dil = s.dilation; d.pad = s.pad; d.rpad = s.reflect_pad;
     d.out_slope = s.out_slope;
@@ -482,13 +510,25 @@ static int bl_head_table(const EbenBlHeadJob* jobs, int n, int batch, bool backw
   return EBEN_OK;
 }
 
+// the two head shapes of DiscriminatorEBENMultiScales: 0 = PQMF-band (4 -> 24, k 3), 1 = MelGAN (1 -> 16, k 15); -1: not built
+static int bl_head_shape(const EbenBlHeadJob& j) {
+  if (j.c_in == 4 && j.c_out == 24 && j.ksize == 3) return 0;
+  if (j.c_in == 1 && j.c_out == 16 && j.ksize == 15) return 1;
+  return -1;
+}
+
 extern "C" int eben_bl_head_fwd(const EbenBlHeadJob* jobs, int njobs, int batch, void* stream) {
   BlHeadTable T;
   int rc = bl_head_table(jobs, njobs, batch, false, &T);
   if (rc) return rc;
-  int lmax = 0, cbmax = 0;
-  for (int i = 0; i < njobs; ++i) { if (jobs[i].l_out > lmax) lmax = jobs[i].l_out; if (jobs[i].c_out / 8 > cbmax) cbmax = jobs[i].c_out / 8; }
-  hipLaunchKernelGGL(bl_head_fwd_kernel, dim3(ceil_div(lmax, 256), batch * cbmax, njobs), dim3(256), 0, as_stream(stream), T);
+  int lmax = 0;
+  for (int i = 0; i < njobs; ++i) if (jobs[i].l_out > lmax) lmax = jobs[i].l_out;
+  const dim3 grid(ceil_div(lmax, 256), batch, njobs);
+  switch (bl_head_shape(jobs[0])) {
+    case 0: hipLaunchKernelGGL((bl_head_fwd_kernel<4, 6, 3>), grid, dim3(256), 0, as_stream(stream), T); break;
+    case 1: hipLaunchKernelGGL((bl_head_fwd_kernel<1, 16, 15>), grid, dim3(256), 0, as_stream(stream), T); break;
+    default: return fail(EBEN_EUNSUPPORTED, "chain head %d -> %d, k %d: not one of the built shapes", jobs[0].c_in, jobs[0].c_out, jobs[0].ksize);
+  }
   EBEN_CHECK_LAUNCH("bl_head_fwd_kernel");
   return EBEN_OK;
 }
@@ -498,17 +538,31 @@ extern "C" int eben_bl_head_dx(const EbenBlHeadJob* jobs, int njobs, int rows, f
   int rc = bl_head_table(jobs, njobs, rows, true, &T);
   if (rc) return rc;
   EBEN_REQUIRE(dx != nullptr, "null dx");
-  hipLaunchKernelGGL(bl_head_dx_kernel, dim3(ceil_div(jobs[0].l_in, 256), rows), dim3(256), 0, as_stream(stream), T, dx);
+  int span = 0;
+  for (int i = 0; i < njobs; ++i) if ((jobs[i].ksize - 1) * jobs[i].dilation > span) span = (jobs[i].ksize - 1) * jobs[i].dilation;
+  const size_t lds = sizeof(float) * (size_t)jobs[0].c_out * (256 + span);
+  EBEN_REQUIRE(lds <= 64 * 1024, "head input gradient: the gradient tile does not fit");
+  const dim3 grid(ceil_div(jobs[0].l_in, 256), rows);
+  switch (bl_head_shape(jobs[0])) {
+    case 0: hipLaunchKernelGGL((bl_head_dx_kernel<4, 6, 3>), grid, dim3(256), lds, as_stream(stream), T, dx); break;
+    case 1: hipLaunchKernelGGL((bl_head_dx_kernel<1, 16, 15>), grid, dim3(256), lds, as_stream(stream), T, dx); break;
+    default: return fail(EBEN_EUNSUPPORTED, "chain head %d -> %d, k %d: not one of the built shapes", jobs[0].c_in, jobs[0].c_out, jobs[0].ksize);
+  }
   EBEN_CHECK_LAUNCH("bl_head_dx_kernel");
   return EBEN_OK;
 }
 
-static const int kBlHeadSlabs = 96;
-extern "C" size_t eben_bl_head_dw_workspace(const EbenBlHeadJob* job, int* nslab, int* row_stride) {
-  if (!job) return 0;
-  if (nslab) *nslab = kBlHeadSlabs;
+// split-K slices of a head's weight gradient: ~2048 (batch item, position) pairs per thread block column
+static int bl_head_slabs(long long pairs) {
+  long long n = pairs / (256 * 24);
+  return (int)(n < 32 ? 32 : (n > 256 ? 256 : n));
+}
+extern "C" size_t eben_bl_head_dw_workspace(const EbenBlHeadJob* job, int rows, int* nslab, int* row_stride) {
+  if (!job || rows <= 0) return 0;
+  const int ns = bl_head_slabs((long long)rows * job->l_out);
+  if (nslab) *nslab = ns;
   if (row_stride) *row_stride = job->ksize + 1;
-  return sizeof(float) * (size_t)kBlHeadSlabs * job->c_out * (job->ksize + 1);
+  return sizeof(float) * (size_t)ns * job->c_out * (job->ksize + 1);
 }
 
 // job->y_hi: the gradient at the head's output (rows x c_out x l_out, hi plane); job->x: the head's input rows it is paired with
@@ -517,14 +571,15 @@ extern "C" int eben_bl_head_dw(const EbenBlHeadJob* job, int rows, float* slabs,
   int rc = bl_head_table(job, 1, rows, false, &T);
   if (rc) return rc;
   EBEN_REQUIRE(slabs != nullptr, "null slabs");
-  if (ws_bytes < eben_bl_head_dw_workspace(job, nullptr, nullptr)) return fail(EBEN_EWORKSPACE, "bl_head_dw workspace too small");
+  int ns = 0;
+  if (ws_bytes < eben_bl_head_dw_workspace(job, rows, &ns, nullptr)) return fail(EBEN_EWORKSPACE, "bl_head_dw workspace too small");
   const BlHeadJob& J = T.job[0];
-  if (J.k <= 4)
-    hipLaunchKernelGGL((bl_head_dw_kernel<4>), dim3(J.c_out / 8, kBlHeadSlabs), dim3(256), 0, as_stream(stream), J.yh, J.x, rows, J.c_in, J.c_out, J.l_in,
-                       J.l_out, J.k, J.dil, J.pad, J.rpad, kBlHeadSlabs, slabs);
-  else
-    hipLaunchKernelGGL((bl_head_dw_kernel<16>), dim3(J.c_out / 8, kBlHeadSlabs), dim3(256), 0, as_stream(stream), J.yh, J.x, rows, J.c_in, J.c_out, J.l_in,
-                       J.l_out, J.k, J.dil, J.pad, J.rpad, kBlHeadSlabs, slabs);
+  const dim3 grid(J.c_out / 8, ns);
+  switch (bl_head_shape(*job)) {
+    case 0: hipLaunchKernelGGL((bl_head_dw_kernel<4, 6, 3>), grid, dim3(256), 0, as_stream(stream), J.yh, J.x, rows, J.l_in, J.l_out, J.dil, J.pad, J.rpad, ns, slabs); break;
+    case 1: hipLaunchKernelGGL((bl_head_dw_kernel<1, 16, 15>), grid, dim3(256), 0, as_stream(stream), J.yh, J.x, rows, J.l_in, J.l_out, J.dil, J.pad, J.rpad, ns, slabs); break;
+    default: return fail(EBEN_EUNSUPPORTED, "chain head %d -> %d, k %d: not one of the built shapes", job->c_in, job->c_out, job->ksize);
+  }
   EBEN_CHECK_LAUNCH("bl_head_dw_kernel");
   return EBEN_OK;
 }
@@ -534,9 +589,9 @@ extern "C" int eben_bl_tail_fwd(const void* x_hi, const void* x_lo, int batch, i
   EBEN_REQUIRE(x_hi && v && y && batch > 0 && channels % 8 == 0 && channels > 0 && length > 0 && ksize >= 1 && ksize <= 8 && pad >= 0, "bad tail forward arguments");
   const int l_out = length + 2 * pad - (ksize - 1);
   EBEN_REQUIRE(l_out > 0, "tail forward: empty output");
-  const size_t lds = sizeof(float) * ((size_t)channels * ksize + 256);
+  const size_t lds = sizeof(float) * ((size_t)channels * ksize + 16 * 64);
   EBEN_REQUIRE(lds <= 64 * 1024, "tail forward: %d channels x %d taps exceed the weight buffer", channels, ksize);
-  hipLaunchKernelGGL(bl_tail_fwd_kernel, dim3(ceil_div(l_out, 64), batch), dim3(256), lds, as_stream(stream), static_cast<const u32x4*>(x_hi),
+  hipLaunchKernelGGL(bl_tail_fwd_kernel, dim3(ceil_div(l_out, 64), batch), dim3(1024), lds, as_stream(stream), static_cast<const u32x4*>(x_hi),
                      static_cast<const u32x4*>(x_lo), channels / 8, length, ksize, pad, l_out, v, scale, bias, out_slope, y);
   EBEN_CHECK_LAUNCH("bl_tail_fwd_kernel");
   return EBEN_OK;
@@ -560,20 +615,28 @@ extern "C" int eben_bl_tail_dx(const float* seeds, int rows, int channels, int l
   return EBEN_OK;
 }
 
-static const int kBlTailSlabs = 32;
-extern "C" size_t eben_bl_tail_dw_workspace(int channels, int ksize, int* nslab, int* row_stride) {
-  if (nslab) *nslab = kBlTailSlabs;
+static int bl_tail_slabs(long long pairs) {
+  long long n = pairs / (256 * 8);
+  return (int)(n < 1 ? 1 : (n > 32 ? 32 : n));
+}
+extern "C" size_t eben_bl_tail_dw_workspace(int rows, int channels, int length, int ksize, int nbranch, int* nslab, int* row_stride) {
+  if (rows <= 0 || channels <= 0 || length <= 0 || ksize <= 0 || nbranch <= 0) return 0;
+  const int ns = bl_tail_slabs((long long)rows * length);
+  if (nslab) *nslab = ns;
   if (row_stride) *row_stride = channels * ksize + 1;
-  return sizeof(float) * (size_t)kBlTailSlabs * ((size_t)channels * ksize + 1);
+  return sizeof(float) * (size_t)nbranch * ns * ((size_t)channels * ksize + 1);
 }
 
-extern "C" int eben_bl_tail_dw(const float* seeds, const void* x_hi, const void* x_lo, int rows, int channels, int length, int ksize, int pad,
+// `nbranch` branches in one launch: seed rows / embedding rows [br * rows, (br + 1) * rows) of the given pointers, slabs [br][nslab][row]
+extern "C" int eben_bl_tail_dw(const float* seeds, const void* x_hi, const void* x_lo, int rows, int nbranch, int channels, int length, int ksize, int pad,
                                float* slabs, size_t ws_bytes, void* stream) {
-  EBEN_REQUIRE(seeds && x_hi && slabs && rows > 0 && channels % 8 == 0 && channels > 0 && length > 0 && ksize >= 1 && ksize <= 8, "bad tail weight-gradient arguments");
-  if (ws_bytes < eben_bl_tail_dw_workspace(channels, ksize, nullptr, nullptr)) return fail(EBEN_EWORKSPACE, "bl_tail_dw workspace too small");
+  EBEN_REQUIRE(seeds && x_hi && slabs && rows > 0 && nbranch > 0 && channels % 8 == 0 && channels > 0 && length > 0 && ksize >= 1 && ksize <= 8,
+               "bad tail weight-gradient arguments");
   const int l_out = length + 2 * pad - (ksize - 1);
-  hipLaunchKernelGGL(bl_tail_dw_kernel, dim3(channels / 8, kBlTailSlabs), dim3(256), 0, as_stream(stream), seeds, static_cast<const u32x4*>(x_hi),
-                     static_cast<const u32x4*>(x_lo), rows, channels / 8, length, ksize, pad, l_out, kBlTailSlabs, slabs);
+  int ns = 0;
+  if (ws_bytes < eben_bl_tail_dw_workspace(rows, channels, l_out, ksize, nbranch, &ns, nullptr)) return fail(EBEN_EWORKSPACE, "bl_tail_dw workspace too small");
+  hipLaunchKernelGGL(bl_tail_dw_kernel, dim3(channels / 8, ns, nbranch), dim3(256), 0, as_stream(stream), seeds, static_cast<const u32x4*>(x_hi),
+                     static_cast<const u32x4*>(x_lo), rows, channels / 8, length, ksize, pad, l_out, ns, slabs);
   EBEN_CHECK_LAUNCH("bl_tail_dw_kernel");
   return EBEN_OK;
 }

@@ -193,8 +193,7 @@ class _ChainBL:
         for i, g, x_in in jobs:
             lay = self.layers[i]
             if i == n - 1:
-                gf = self._tail_dw(lay, g[2 * half:3 * half], x_in, 0, half, st, wn_jobs)
-                gr = self._tail_dw(lay, g[3 * half:], x_in, half, half, st, wn_jobs)
+                gf, gr = self._tail_dw(lay, g[2 * half:], x_in, half, st, wn_jobs)
                 logits = (i, gf, gr)
             else:
                 grads[i] = self._mid_dw(lay, g, x_in, half, st, wn_jobs, sink)
@@ -247,7 +246,7 @@ class _ChainBL:
         view.hi, view.lo, view.rows, view.channels, view.length = g0.hi[2 * half:], None, 2 * half, g0.channels, g0.length
         job = self.head_job(x_full, x_full.shape[2], view)
         nslab, row_stride = ctypes.c_int(0), ctypes.c_int(0)
-        nbytes = lib.eben_bl_head_dw_workspace(ctypes.byref(job), ctypes.byref(nslab), ctypes.byref(row_stride))
+        nbytes = lib.eben_bl_head_dw_workspace(ctypes.byref(job), 2 * half, ctypes.byref(nslab), ctypes.byref(row_stride))
         slabs = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=x_full.device)
         check(lib.eben_bl_head_dw(ctypes.byref(job), 2 * half, ptr(slabs), nbytes, st), "bl_head_dw")
         dv, dg, dbias = self._outputs(lay, sink, x_full.device)
@@ -257,19 +256,27 @@ class _ChainBL:
         return dv, dg, dbias
 
     @staticmethod
-    def _tail_dw(lay: _Layer, seeds: torch.Tensor, x_in: Planes, row0: int, nrows: int, st: int, wn_jobs: list):
+    def _tail_dw(lay: _Layer, seeds: torch.Tensor, x_in: Planes, half: int, st: int, wn_jobs: list):
+        """Logits layer, the two hinge branches by ONE launch: seed rows [fake | real] (2 half rows) against embedding rows [enhanced |
+        reference]; the branches stay separate results (the engine adds them: see ``disc_engine._Chain.weight_grads``)."""
         lib = load()
         v, gain, bias = lay.params()
         sp = lay.spec
+        l_out = seeds.shape[2]
         nslab, row_stride = ctypes.c_int(0), ctypes.c_int(0)
-        nbytes = lib.eben_bl_tail_dw_workspace(x_in.channels, sp.ksize, ctypes.byref(nslab), ctypes.byref(row_stride))
+        nbytes = lib.eben_bl_tail_dw_workspace(half, x_in.channels, l_out, sp.ksize, 2, ctypes.byref(nslab), ctypes.byref(row_stride))
         slabs = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=seeds.device)
-        check(lib.eben_bl_tail_dw(ptr(seeds), _addr(x_in.hi[row0:row0 + nrows]), _addr(x_in.lo[row0:row0 + nrows]), nrows, x_in.channels, x_in.length,
-                                  sp.ksize, sp.pad_l, ptr(slabs), nbytes, st), "bl_tail_dw")
-        dv, dg = torch.empty_like(v), torch.empty_like(gain)
-        dbias = torch.empty(1, dtype=torch.float32, device=seeds.device) if bias is not None else None
-        wn_jobs.append((slabs, nslab.value, row_stride.value, 1, v.numel(), row_stride.value, gain.detach(), v.detach(), lay.norm, dg, dv, dbias))
-        return dv, dg, dbias
+        check(lib.eben_bl_tail_dw(ptr(seeds), _addr(x_in.hi), _addr(x_in.lo), half, 2, x_in.channels, x_in.length, sp.ksize, sp.pad_l, ptr(slabs), nbytes, st),
+              "bl_tail_dw")
+        outs = []
+        per = nslab.value * row_stride.value
+        for br in range(2):
+            dv, dg = torch.empty_like(v), torch.empty_like(gain)
+            dbias = torch.empty(1, dtype=torch.float32, device=seeds.device) if bias is not None else None
+            wn_jobs.append((slabs[br * per:(br + 1) * per], nslab.value, row_stride.value, 1, v.numel(), row_stride.value, gain.detach(), v.detach(), lay.norm,
+                            dg, dv, dbias))
+            outs.append((dv, dg, dbias))
+        return outs[0], outs[1]
 
 
 class DiscriminatorEngineBL(DiscriminatorEngine):
