@@ -38,22 +38,10 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
 #ifndef EBEN_T3_DBG
 #define EBEN_T3_DBG 0   // scratch-build ablations (wrong results): 1 no weight stream, 2 no tile refresh, 4 no barrier, 8 no MFMA, 16 phase-major stores
 #endif
-constexpr int T3_KSC = EBEN_T3_KSC;   // k-steps (of 16 reduction elements) per weight chunk at FM = 4 (single-piece weights)
-// K-steps per weight chunk.  A chunk is the unit of the weight stream (one barrier, one LDS-DMA wait each): it is kept at ~16 KB = 16
-// MFMAs per wave whatever the row tile (FM = 1 blocks used to run 4 MFMAs per barrier and spent their time in the barrier's DMA wait),
-// and at a whole number of LDS-DMA instructions per thread (KSC NPW FM a multiple of 4: the counted vmcnt of the ring needs every wave
-// to issue the same number of pieces).  Split weights (NPW pieces, EBEN_MATH_BF16X3 / X6) carry NPW times the bytes per k-step.
-__host__ __device__ constexpr int t3_ksc(int npw, int fm) {
-  return npw == 1 ? (fm == 1 ? 4 * T3_KSC : fm == 2 ? 2 * T3_KSC : T3_KSC)
-       : npw == 2 ? (fm == 1 ? 8 : fm == 2 ? 4 : 2)
-                  : 2;   // six-product form: MFMA-bound at two k-steps per chunk, chunks of 6-24 KB
-}
-// the ring (more than one chunk of look-ahead) needs every wave to issue the same number of pieces per chunk
-__host__ __device__ constexpr bool t3_ring_ok(int npw, int fm) { return (t3_ksc(npw, fm) * npw * fm * 64) % 256 == 0; }
-#ifndef EBEN_T3_WRING
-#define EBEN_T3_WRING 3
-#endif
-constexpr int T3_WRING = EBEN_T3_WRING;   // weight chunks resident in LDS: chunk ch + WRING - 1 is in flight while chunk ch is multiplied
+constexpr int T3_KSC = EBEN_T3_KSC;   // k-steps (of 16 reduction elements) per weight chunk (single-piece weights)
+// split weights (NPW pieces per weight, EBEN_MATH_BF16X3 / X6): a k-step carries NPW times the weight bytes and 3 / 6 times the
+// MFMAs, so two k-steps per chunk keep the chunk at 4-6 KB per 32 rows and the barrier at >= 24 MFMAs per wave
+__host__ __device__ constexpr int t3_ksc(int npw) { return npw == 1 ? T3_KSC : 2; }
 
 struct Tap3Args {
   const float* x; const float* xmask; const u32x4* wp; const int* tab;
@@ -68,7 +56,6 @@ struct Tap3Args {
   int CI_T, CI_B, CP, ncc, PLEN, CSTRIDE, nxb;   // CI_T channels = CI_B bundles per input tile; CP = CI_B / 2 k-steps per tap
   unsigned s_magic;
   int ntt, nmt, tab_phase;
-  int nwb;                                       // weight chunk buffers in LDS: min(T3_WRING, chunks of the longest phase)
   long long w_tile, w_phase;                     // in 16-byte units
   // host-side arithmetic of the block prologue (integer divisions are ~40 instructions each on the device, the 64-bit one
   // behind span_magic ~150): the block-id decomposition by multiply-high, and the per-phase tap geometry for up to 8 phases
@@ -98,16 +85,15 @@ struct Tap3Args {
 // bytes per row quad) and reads the mask / feature-matching operands the same way.
 template <int FM, int XRB, bool IM = false, int NPW = 1, int NPX = 1, bool BL = false>
 __global__ __launch_bounds__(256, NPW >= 2 ? 1 : 2) void tap3_kernel(const Tap3Args P) {
-  constexpr int NT = 256, BN = 128, BM = FM * 32, KSC = t3_ksc(NPW, FM);
+  constexpr int NT = 256, BN = 128, BM = FM * 32, KSC = t3_ksc(NPW);
   constexpr bool SP = NPX > 1;
   constexpr int NPM = NPW > NPX ? NPW : NPX;
   constexpr int WCHU = KSC * NPW * FM * 64;       // 16-byte units per weight chunk
   static_assert(WCHU % 64 == 0, "weight chunk must split into whole wave pieces");
-  constexpr int WPC = WCHU / NT;                  // LDS-DMA instructions per thread and chunk where the ring is used (t3_ring_ok)
 
   extern __shared__ __attribute__((aligned(16))) u32x4 smem3[];
-  u32x4* Ws = smem3;                  // nwb x WCHU: ring of weight chunks
-  u32x4* Xs = smem3 + P.nwb * WCHU;   // nxb input tiles of CI_B * CSTRIDE units + one spare unit (SP: the lo tiles behind them)
+  u32x4* Ws = smem3;              // 2 x WCHU
+  u32x4* Xs = smem3 + 2 * WCHU;   // nxb input tiles of CI_B * CSTRIDE units + one spare unit (SP: the lo tiles behind them)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -295,38 +281,24 @@ __global__ __launch_bounds__(256, NPW >= 2 ? 1 : 2) void tap3_kernel(const Tap3A
     }
   };
 
-  // Weight stream: chunk ch lives in ring slot ch % nwb.  The LDS-DMA is issued from inline asm, i.e. hidden from hipcc's wait-count
-  // bookkeeping: tracked, every __syncthreads() drains ALL of it (s_waitcnt vmcnt(0)), which allows exactly one chunk of look-ahead and
-  // leaves the barrier waiting for a DMA round trip (~1000 cycles) that was issued one chunk (128-512 MFMA cycles) earlier -- the
-  // matrix pipe sat at 39 % in the heavy layers and far below in the thin ones.  Hidden, the pieces are waited for by the counted
-  // s_waitcnt of wait_w() below: only the chunk the next iteration reads has to have landed, the later ones stay in flight across
-  // the barrier.  (vmcnt retires in order, so the compiler's own counted waits for its tracked loads can only over-wait.)
-  const unsigned ws_addr = (unsigned)(unsigned long long)(__attribute__((address_space(3))) void*)Ws;
   auto issue_w = [&](int ch) {
     const u32x4* src = wsrc + (long long)ch * WCHU;
-    const unsigned dst = ws_addr + (unsigned)((ch % P.nwb) * WCHU * 16);
+    u32x4* dst = Ws + (ch & 1) * WCHU;
 #pragma unroll
     for (int u = 0; u * NT < WCHU; ++u) {
       const int idx = u * NT + tid;
-      if (WCHU % NT != 0 && idx >= WCHU) continue;   // wave-uniform (whole waves); such kernels run with two ring slots: wait_w(0) only
-      const unsigned m0v = __builtin_amdgcn_readfirstlane(dst + (unsigned)((idx & ~63) * 16));
-      unsigned keep;
-      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                   : "=&s"(keep) : "v"(src + idx), "s"(m0v) : "memory");
+      if (WCHU % NT == 0 || idx < WCHU)   // wave-uniform
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + idx),
+                                         (__attribute__((address_space(3))) void*)(dst + (idx & ~63)), 16, 0, 0);
     }
-  };
-  // this wave's pieces of every chunk but the `later` most recently issued ones have landed
-  auto wait_w = [&](int later) {
-    if (later >= 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * WPC) : "memory");
-    else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WPC) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   };
 
   int written = 0;
   if (nch > 0) {
-    // the whole ring at once: the round trips run under the tile staging -- short reductions (the PQMF-band layers) hold all their
-    // weights in the ring and never wait again
-    for (int c = 0; c < P.nwb && c < nch; ++c) issue_w(c);
+    issue_w(0);
+    // the second chunk too (its buffer is free until the loop's first barrier): its LDS-DMA round trip then runs under the tile
+    // staging instead of under the four k-steps of chunk 0 -- short reductions (the PQMF-band layers: 2-6 chunks) are bound by it
+    if ((EBEN_T3_DBG & 1) == 0 && nch > 1) issue_w(1);
     const float* xp = P.x + xrow0;
     const float* mp = P.xmask + xrow0;
     // two rounds of (2 units = 16 loads per thread) in flight: round r + 1 is asked for before round r is converted and written --
@@ -380,7 +352,6 @@ __global__ __launch_bounds__(256, NPW >= 2 ? 1 : 2) void tap3_kernel(const Tap3A
       }
     }
     if (P.ncc > 1) fetch_x(1);
-    wait_w((P.nwb < nch ? P.nwb : nch) - 1);   // chunk 0 has landed
   }
   __syncthreads();
 
@@ -390,10 +361,9 @@ __global__ __launch_bounds__(256, NPW >= 2 ? 1 : 2) void tap3_kernel(const Tap3A
   for (int ks = 0; ks < KSC; ++ks) te[ks] = nch > 0 ? tab[ks] : 0;
   int pending = -1;   // tile whose global loads are issued at the top of the next chunk (not in front of the barrier)
   for (int ch = 0; ch < nch; ++ch) {
-    // ring slot (ch - 1) % nwb was read during the previous chunk and every wave has passed the barrier since
-    if ((EBEN_T3_DBG & 1) == 0 && ch > 0 && ch - 1 + P.nwb < nch) issue_w(ch - 1 + P.nwb);
+    if ((EBEN_T3_DBG & 1) == 0 && ch > 0 && ch + 1 < nch) issue_w(ch + 1);
     if ((EBEN_T3_DBG & 2) == 0 && pending >= 0) { fetch_x(pending); pending = -1; }
-    const u32x4* wb = Ws + (ch % P.nwb) * WCHU + lane;
+    const u32x4* wb = Ws + (ch & 1) * WCHU + lane;
     const u32x4* xb = Xs + lanebase;
     u32x4 bv[KSC][NPX], a[KSC][NPW][FM];
     auto rd = [&](int ks) {
@@ -433,11 +403,6 @@ __global__ __launch_bounds__(256, NPW >= 2 ? 1 : 2) void tap3_kernel(const Tap3A
       ++written;
       store_x(written);
       if (written + 1 < P.ncc) pending = written + 1;
-    }
-    if (ch + 1 < nch) {
-      // chunk ch + 1 is read next: the chunks issued behind it (up to ch - 1 + nwb) may stay in flight across the barrier
-      const int last = ch - 1 + P.nwb < nch - 1 ? ch - 1 + P.nwb : nch - 1;
-      wait_w(last - (ch + 1) > 0 ? last - (ch + 1) : 0);
     }
     if ((EBEN_T3_DBG & 4) == 0) __syncthreads();
   }
@@ -613,7 +578,7 @@ struct Tap3Plan {
   int mode, G, Cg, Mg, S, OS, dstep, kstep, nph, J, Lx, Ly, Cx, Cy, off0, nt, ps_pad;
   int FM, BM, BN, WCHU;
   int dense;   // groups folded into ONE block-diagonal contraction (layers with a handful of channels per group)
-  int npw, npx, KSC, nwb;   // pieces per weight / per input element (tap3_kernel), k-steps per weight chunk, chunks in the LDS ring
+  int npw, npx, KSC;   // pieces per weight / per input element (tap3_kernel), k-steps per weight chunk
   int CI_T, CI_B, CP, ncc, PLEN, CSTRIDE, nxbuf, XRB;
   int nmt, ntt, NCH, tab_phase;
   long long w_tile, w_phase, tab_off_floats;
@@ -633,6 +598,7 @@ static void make_plan3(const Canon& c, int dir, Tap3Plan* p) {
   p->G = c.g;
   p->npw = c.np;
   p->npx = c.np > 1 ? c.np : (c.xsplit_dir == dir ? 2 : 1);
+  p->KSC = t3_ksc(p->npw);
   const int ub = 16 * p->npx;          // LDS bytes per staged bundle position
   const int spare = p->npx > 1 ? 16 * p->npx : 0;   // one spare unit per piece region
   if (dir == 0) {
@@ -697,7 +663,6 @@ static void make_plan3(const Canon& c, int dir, Tap3Plan* p) {
   static const int force_bm = env_int3("EBEN_TAP3_BM", 0);
   if (force_bm == 32 || force_bm == 64 || force_bm == 96 || force_bm == 128) best = force_bm;
   p->BM = best; p->FM = best / 32; p->BN = 128;
-  p->KSC = t3_ksc(p->npw, p->FM);
   p->WCHU = p->KSC * p->npw * p->FM * 64;
   p->nmt = ceil_div(p->Mg, p->BM);
   p->ntt = ceil_div(p->nt, p->BN);
@@ -715,11 +680,8 @@ static void make_plan3(const Canon& c, int dir, Tap3Plan* p) {
   static const int lds_budget1 = env_int3("EBEN_TAP3_LDS_KB", 48) * 1024;
   static const int lds_budget_split = env_int3("EBEN_TAP3_SPLIT_LDS_KB", 150) * 1024;   // split weights: one MFMA-bound block per CU
   static const int lds_budget_x3 = env_int3("EBEN_TAP3_X3_LDS_KB", 64) * 1024;
-  // ring of T3_WRING weight chunks, or all the chunks of the reduction when there are fewer
+  const int wbytes = 2 * p->WCHU * 16;
   const int Cg2 = round_up(p->Cg, 16);
-  const int nch_all = ceil_div((Cg2 / 16) * p->J, p->KSC);
-  p->nwb = !t3_ring_ok(p->npw, p->FM) ? 2 : (nch_all < T3_WRING ? (nch_all > 2 ? nch_all : 2) : T3_WRING);
-  const int wbytes = p->nwb * p->WCHU * 16;
   // input tiles inside `lds_budget` bytes per block (weights included); a three-buffer scheme may go up to `big`
   auto size_tiles = [&](int lds_budget, int big) -> bool {
     const int xbudget = lds_budget - wbytes - 16;
@@ -754,7 +716,8 @@ static void make_plan3(const Canon& c, int dir, Tap3Plan* p) {
   static const int big_ks = env_int3("EBEN_TAP3_BIG_KS", 128);   // [MI355X] neutral in the step (18.0-18.3 ms either way), MelGAN L4 forward alone 0.30 -> 0.20 ms
   static const int lds_budget_big = env_int3("EBEN_TAP3_BIG_LDS_KB", 78) * 1024;
   const long long ks_total = (long long)ceil_div(p->Cg, 16) * p->J;
-  if (p->npw == 1) sized = size_tiles(ks_total >= big_ks ? lds_budget_big : lds_budget1, 110 * 1024);
+  if (p->npw == 1) sized = size_tiles(ks_total >= big_ks ? lds_budget_big : lds_budget1, 110 * 1024) || size_tiles(lds_budget_big, 110 * 1024) ||
+                           size_tiles(lds_budget_split, lds_budget_split);
   else if (p->npw == 2) sized = size_tiles(lds_budget_x3, 110 * 1024) || size_tiles(lds_budget_split, lds_budget_split);
   else sized = size_tiles(lds_budget_split, lds_budget_split);
   if (!sized) return;
@@ -988,7 +951,7 @@ int tap3_launch(const Canon& c, int dir, const TapIO& io, int reflect, hipStream
   a.in_slope = io.in_slope; a.out_slope = io.out_slope; a.res_slope = io.res_slope; a.emask_slope = io.emask_slope;
   a.CI_T = p.CI_T; a.CI_B = p.CI_B; a.CP = p.CP; a.ncc = p.ncc; a.PLEN = p.PLEN; a.CSTRIDE = p.CSTRIDE; a.nxb = p.nxbuf;
   a.s_magic = p.S > 1 ? (unsigned)((0x100000000ull + p.S - 1) / p.S) : 0u;
-  a.ntt = p.ntt; a.nmt = p.nmt; a.tab_phase = p.tab_phase; a.nwb = p.nwb;
+  a.ntt = p.ntt; a.nmt = p.nmt; a.tab_phase = p.tab_phase;
   a.w_tile = p.w_tile; a.w_phase = p.w_phase;
   const long long nb = (long long)p.ntt * c.B * p.nph * p.nmt * p.G;
   if (nb <= 0 || nb > 0x7fffffffLL) return fail(EBEN_EINVAL, "tap3 grid of %lld blocks", nb);
