@@ -9,9 +9,9 @@
 // lanes of its 16-lane group (mapping checked on the device, tools/ubench/probe_lds.hip), so that
 //   * both operand tiles are plain COPIES of units: A rows = 64 consecutive time steps of one bundle of dy (1 KB), X rows = the
 //     stride phases of one bundle of x around the chunk (de-interleaved by the source address: consecutive time steps of a tap are
-//     consecutive units of row (bundle, (j d - pad) mod S)), moved by buffer_load ... lds -- no VGPR round trip, no conversion, no
-//     packing pre-pass (conv_dw3.hip: dw3_pack_a + fp32 -> bf16 staging of X); the descriptor's bounds ARE the zero padding, in time
-//     for dy and in position for x (out-of-range lanes write zeros to LDS, same probe);
+//     consecutive units of row (bundle, (j d - pad) mod S)), moved by global_load_lds_dwordx4 -- no VGPR round trip, no conversion, no
+//     packing pre-pass (conv_dw3.hip: dw3_pack_a + fp32 -> bf16 staging of X); lanes outside the row (the end of dy in time, the zero
+//     padding of x in position) copy a zero unit instead;
 //   * a fragment is two transposing reads (k = 0..3 and 4..7 of the lane's eight) at per-lane base addresses fixed for the whole
 //     launch + immediates; row strides = 4 mod 16 units keep the 32 lanes of a half-wave on distinct banks.
 // Block = 4 waves as 2 x 2, (64 FM) x (64 FN) outputs; K chunk = one batch item x 64 time steps, double-buffered: the next chunk's
@@ -54,25 +54,18 @@ __device__ __forceinline__ bf16x8 bl_tr_frag(unsigned addr) {
   return __builtin_bit_cast(bf16x8, v);
 }
 
-// One LDS-DMA piece: 64 lanes x 16 bytes from descriptor `rs` at byte offsets `voff` (out of range: zeros) to LDS bytes [dst, dst + 1024).
-// Inline asm on purpose: hipcc (ROCm 7.2) does not order a __builtin_amdgcn_raw_ptr_buffer_load_lds against later LDS reads or barriers
-// inside a loop (no wait at all), and puts s_waitcnt vmcnt(0) in front of every ds_read_b64_tr_b16 intrinsic while a DMA it does know
-// about is in flight (no overlap at all).  Hidden from its bookkeeping, the pieces are waited for by the explicit vmcnt(0) in front of
-// the chunk barrier below.  M0 (the DMA's LDS base) is saved and restored inside the statement; s_nop 4: SALU-written descriptor words
-// -> VMEM read; s_nop 0: M0 write -> LDS-DMA.
-__device__ __forceinline__ void bl_dma_piece(const u32x4 rs, unsigned dst, int voff) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(voff), "s"(rs), "s"(dst) : "memory");
-}
-__device__ __forceinline__ u32x4 bl_rsrc(const void* base, int bytes) {
-  const unsigned long long a = (unsigned long long)base;
-  u32x4 r;
-  r[0] = __builtin_amdgcn_readfirstlane((unsigned)a);
-  r[1] = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32) & 0xffffu);
-  r[2] = __builtin_amdgcn_readfirstlane((unsigned)bytes);
-  r[3] = 0x00020000u;
-  return r;
+// 16 zero bytes in device memory: where the lanes of an LDS-DMA piece that fall outside their row (time steps past the end of dy,
+// positions in x's zero padding) read from
+__device__ u32x4 bl_zero_unit = {0u, 0u, 0u, 0u};
+
+// One LDS-DMA piece: lane i copies the 16-byte unit at `src` (per lane) to LDS bytes dst + 16 i (dst wave-uniform).
+// Inline asm on purpose: hipcc (ROCm 7.2) puts s_waitcnt vmcnt(0) in front of every ds_read_b64_tr_b16 intrinsic while an LDS-DMA it
+// knows about is in flight (no overlap of the next chunk's tiles with this chunk's MFMAs at all).  Hidden from its bookkeeping, the
+// pieces are waited for by the explicit vmcnt(0) in front of the chunk barrier.  M0 (the DMA's LDS base) is written in the same
+// statement; nothing else in this kernel keeps a value there.  (First version: buffer_load ... lds with one descriptor per row,
+// the descriptor's bounds as the zero padding -- 13 scalar instructions per MFMA, the CU's scalar unit was the bottleneck.)
+__device__ __forceinline__ void bl_dma_piece(const u32x4* src, unsigned dst) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(src), "s"(dst) : "memory");
 }
 
 template <int FM, int FN>
@@ -143,27 +136,40 @@ __global__ __launch_bounds__(256, 2) void bl_dw_kernel(const BlDwArgs P) {
       for (int r = 0; r < 16; ++r) acc[i][f][r] = 0.f;
 
   // ---- tile movement: every row is a run of 64 (A) / 2 x 64 (X) units, one LDS-DMA piece each ---------------------------------------
+  // rows of this wave (fixed for the launch): A rows r = wave, wave + 4, ... (bundle clamped into the tensor: rows past it are
+  // computed and not stored), X rows xr = wave, wave + 4, ... = (channel bundle, stride phase)
+  const u32x4* zero = &bl_zero_unit;
+  constexpr int AR = (BMB + 3) / 4;
+  long long arow[AR];
+#pragma unroll
+  for (int i = 0; i < AR; ++i) {
+    int bundle = g * P.MgB + mt * BMB + wave + 4 * i;
+    if (bundle > P.CBa - 1) bundle = P.CBa - 1;
+    arow[i] = (long long)bundle * P.La;
+  }
   auto issue = [&](int q, int bsel) {
     const int b = q / P.nct;
     const int t0 = (q - b * P.nct) * BKT;
     const unsigned dst = buf_addr + (unsigned)(bsel * buf_units * 16);
-    for (int r = wave; r < BMB; r += 4) {
-      int bundle = g * P.MgB + mt * BMB + r;
-      if (bundle > P.CBa - 1) bundle = P.CBa - 1;       // rows past the tensor: any valid row, the results are not stored
-      const u32x4 rs = bl_rsrc(P.ah + ((long long)b * P.CBa + bundle) * P.La, P.La * 16);
-      bl_dma_piece(rs, __builtin_amdgcn_readfirstlane(dst + (unsigned)(r * TS * 16)), (t0 + lane) * 16);
+    const u32x4* ab = P.ah + (long long)b * P.CBa * P.La;
+    const bool a_ok = t0 + lane < P.La;
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+      const int r = wave + 4 * i;
+      if (r < BMB) bl_dma_piece(a_ok ? ab + arow[i] + t0 + lane : zero, __builtin_amdgcn_readfirstlane(dst + (unsigned)(r * TS * 16)));
     }
+    const u32x4* xb = P.xh + ((long long)b * P.CBx + (long long)g * P.CgB) * P.Lx;
     for (int xr = wave; xr < xrows; xr += 4) {
       const int cbl = xr / P.S, p = xr - cbl * P.S;
       int cb = cb_lo + cbl;
       if (cb > P.CgB - 1) cb = P.CgB - 1;
-      const u32x4 rs = bl_rsrc(P.xh + ((long long)b * P.CBx + (long long)g * P.CgB + cb) * P.Lx, P.Lx * 16);
+      const u32x4* row = xb + (long long)cb * P.Lx;
       const unsigned rdst = dst + (unsigned)((a_units + xr * RS) * 16);
 #pragma unroll
       for (int piece = 0; piece < 2; ++piece) {
-        // unit u of the row = position (t0 + amin + u) S + p; negative / beyond Lx: out of the descriptor's range -> zeros
+        // unit u of the row = position (t0 + amin + u) S + p; outside [0, Lx): the zero unit
         const int pos = (t0 + P.amin + piece * 64 + lane) * P.S + p;
-        bl_dma_piece(rs, __builtin_amdgcn_readfirstlane(rdst + (unsigned)(piece * 64 * 16)), pos * 16);
+        bl_dma_piece((pos >= 0 && pos < P.Lx) ? row + pos : zero, __builtin_amdgcn_readfirstlane(rdst + (unsigned)(piece * 64 * 16)));
       }
     }
   };
@@ -256,11 +262,24 @@ static void make_bldw_plan(const Canon& c, BlDwPlan* p) {
   p->nct = ceil_div(c.Lout, BLDW_BKT);
   p->nchunks = c.B * p->nct;
   const int tiles = p->nnt * p->nmt * p->G;
-  static const int target = getenv("EBEN_BLDW_BLOCKS") ? atoi(getenv("EBEN_BLDW_BLOCKS")) : 768;
-  int ns = tiles >= target / 2 ? 1 : ceil_div(target, tiles);
-  if (ns > 256) ns = 256;
-  if (ns > p->nchunks) ns = p->nchunks;
-  if (ns < 1) ns = 1;
+  // Split-K factor: the grid runs in rounds of (CUs x resident blocks per CU) blocks and a kernel this short pays for the empty part
+  // of its last round (664 tiles on 512 slots = two rounds for 1.3 rounds of work), while every extra slab is one more write of the
+  // gradient by the epilogue and one more read by the reduction.  Pick the factor with the least estimated time: rounds x the work of
+  // one block + slab traffic at ~4 TB/s.
+  static const int cus = getenv("EBEN_BLDW_CUS") ? atoi(getenv("EBEN_BLDW_CUS")) : 256;
+  const int per_cu = (int)(160 * 1024 / p->lds_bytes) < 1 ? 1 : (int)(160 * 1024 / p->lds_bytes);
+  const int slots = cus * (per_cu > 4 ? 4 : per_cu);
+  const double macs = (double)c.B * c.Lout * (double)c.Cout * (c.Cin / c.g) * c.k;
+  const double t_all = 2.0 * macs / 1.0e15;                                   // the whole contraction at ~1 PFLOP/s
+  const double slab_bytes = 4.0 * (double)c.Cout * ((c.Cin / c.g) * c.k + 1);
+  int ns = 1;
+  double best = 1e30;
+  for (int cand = 1; cand <= 256 && cand <= p->nchunks; ++cand) {
+    const long long blocks = (long long)tiles * cand;
+    const double rounds = (double)((blocks + slots - 1) / slots);
+    const double t = rounds * (t_all * slots / blocks) + 2.0 * cand * slab_bytes / 4.0e12 + (cand > 1 ? slab_bytes / 4.0e12 : 0.0);
+    if (t < best * 0.97) { best = t; ns = cand; }
+  }
   p->nsplit = ns;
   if (p->dense) { p->row_stride = (c.Cin / c.g) * c.k + 1; p->perm_k = 0; }
   else { p->row_stride = p->Cg * c.k + 1; p->perm_k = c.k; }
