@@ -277,7 +277,8 @@ static void make_bldw_plan(const Canon& c, BlDwPlan* p) {
   for (int cand = 1; cand <= 256 && cand <= p->nchunks; ++cand) {
     const long long blocks = (long long)tiles * cand;
     const double rounds = (double)((blocks + slots - 1) / slots);
-    const double t = rounds * (t_all * slots / blocks) + 2.0 * cand * slab_bytes / 4.0e12 + (cand > 1 ? slab_bytes / 4.0e12 : 0.0);
+    // [MI355X] MelGAN L4 (43 MB per slab): one slab 0.327 ms, two 0.339 -- the slab traffic costs more than its 4 TB/s share
+    const double t = rounds * (t_all * slots / blocks) + 2.0 * cand * slab_bytes / 2.0e12 + (cand > 1 ? slab_bytes / 2.0e12 + 5e-6 : 0.0);
     if (t < best * 0.97) { best = t; ns = cand; }
   }
   p->nsplit = ns;
