@@ -3,7 +3,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 dev = torch.device('cuda', 0)
 mod = bench.build_module(dev, 1234)
-mod.disc_math = mod.gen_backward_math = os.environ.get("EBEN_DISC_MATH", "bf16")
+mod.disc_math = os.environ.get("EBEN_DISC_MATH", "bf16_bl"); mod.gen_backward_math = "bf16"; mod.stft_math = "folded_x3"
 batch = bench.synthetic_batch(32, 32000, 1234, dev)
 for _ in range(3): mod.training_step(batch)
 torch.cuda.synchronize()

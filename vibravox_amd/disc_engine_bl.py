@@ -292,6 +292,49 @@ class DiscriminatorEngineBL(DiscriminatorEngine):
         self._state = None
         self._prepack_graph = ops.ReplayedPrepack()
         self.seed_weights = (1.0, 1.0, 1.0)
+        n = len(self.chains)
+        # graph replay of each chain's three launch sequences (ops.ReplayedChain) and the buffers they start from, per input shape
+        self._graphs = {k: [ops.ReplayedChain() for _ in range(n)] for k in ("fwd", "bwd", "dw")}
+        self._static: Dict[tuple, dict] = {}
+
+    def _static_for(self, half: int, bands, audio) -> dict:
+        """Persistent buffers of one (batch, lengths) shape: the chain inputs [enhanced | reference], the heads' outputs, the
+        feature-matching sums -- what the replayed launch sequences read at fixed addresses."""
+        key = (half, tuple(bands.shape[1:]), tuple(audio.shape[1:]), str(audio.device))
+        st = self._static.get(key)
+        if st is None:
+            if len(self._static) >= 4:   # variable clip lengths: keep the buffers (and graphs) of the recent shapes only
+                self._static.pop(next(iter(self._static)))
+            dev = audio.device
+            rows = 2 * half
+            sub = torch.empty((rows, self.q) + tuple(bands.shape[2:]), dtype=torch.float32, device=dev)
+            wav = torch.empty((rows,) + tuple(audio.shape[1:]), dtype=torch.float32, device=dev)
+            inputs = [sub] * (len(self.chains) - 1) + [wav]
+            act0 = [Planes(rows, ch.layers[0].spec.c_out, ch.head_out_len(inputs[i].shape[2]), dev) for i, ch in enumerate(self.chains)]
+            npairs = sum(len(ch.layers) - 1 for ch in self.chains)
+            st = self._static[key] = dict(sub=sub, wav=wav, inputs=inputs, act0=act0, one=torch.ones(1, dtype=torch.float32, device=dev),
+                                          fm_sums=torch.empty(2 * npairs, dtype=torch.float32, device=dev))
+        return st
+
+    @staticmethod
+    def _mark_used(ch: "_ChainBL", which: int) -> None:
+        """A replayed sequence reads the chain's packed images without passing through ``_Layer.packed``: tell ``prepack`` they are in
+        use (it drops the images the last step did not touch)."""
+        for lay in ch.layers:
+            lay.used.update(slot for slot in lay.packs if slot[0] == which)
+
+    @staticmethod
+    def _chain_sig(ch: "_ChainBL", which: int):
+        """Everything a chain's launches depend on besides tensor values: per layer the parameter storage, the weight-norm scale buffer,
+        the packed images of direction `which` (address + whether they are current) and the arithmetic."""
+        out = []
+        for lay in ch.layers:
+            v, g, b = lay.params()
+            wkey = lay._weights_key()
+            imgs = tuple(sorted((slot, wp.data_ptr(), key == wkey) for slot, (key, wp) in lay.packs.items() if slot[0] == which)) if which >= 0 else ()
+            out.append((v.data_ptr(), g.data_ptr(), 0 if b is None else b.data_ptr(), 0 if lay.scale is None else lay.scale.data_ptr(),
+                        lay.scale_key == wkey, imgs, lay.math_fwd, lay.math_dx, lay.math_dw))
+        return tuple(out)
 
     # ---- forward ---------------------------------------------------------------------------------------------------------------
     def forward_reference(self, bands_ref, audio_ref):
@@ -301,17 +344,19 @@ class DiscriminatorEngineBL(DiscriminatorEngine):
     def forward(self, bands, audio, bands_ref, audio_ref, join: bool = True):
         lib = load()
         half = bands.shape[0]
-        dev = audio.device
-        sub = torch.cat((bands[:, -self.q:, :], bands_ref[:, -self.q:, :]), dim=0).contiguous()
-        wav = torch.cat((audio, audio_ref), dim=0).contiguous()
+        st = self._static_for(half, bands, audio)
+        sub, wav, inputs, act0 = st["sub"], st["wav"], st["inputs"], st["act0"]
+        sub[:half].copy_(bands[:, -self.q:, :])
+        sub[half:].copy_(bands_ref[:, -self.q:, :])
+        wav[:half].copy_(audio)
+        wav[half:].copy_(audio_ref)
         n = len(self.chains)
-        inputs = [sub] * (n - 1) + [wav]
         rows = 2 * half
-        # heads: the PQMF-band chains' in one launch (on the stream of the first of them), MelGAN's on its own stream
-        act0 = [Planes(rows, ch.layers[0].spec.c_out, ch.head_out_len(inputs[i].shape[2]), dev) for i, ch in enumerate(self.chains)]
         self._head_done = None
 
         def run(i):
+            # heads (eager, so that the chains that share one can be released by an event): the PQMF-band chains' in one launch on the
+            # stream of the first of them, MelGAN's on its own stream; then the chain's body, replayed as a graph once it has settled
             ch = self.chains[i]
             if i == n - 1:
                 jobs = (EbenBlHeadJob * 1)(ch.head_job(wav, wav.shape[2], act0[i]))
@@ -323,12 +368,15 @@ class DiscriminatorEngineBL(DiscriminatorEngine):
                 self._head_done.record()
             else:
                 torch.cuda.current_stream().wait_event(self._head_done)   # chains 1, 2 may run on another stream than chain 0
-            return ch.forward_body(act0[i])
+            sig = (rows, act0[i].hi.data_ptr(), act0[i].lo.data_ptr(), act0[i].length, self._chain_sig(ch, 0))
+            out = self._graphs["fwd"][i].run(sig, lambda: ch.forward_body(act0[i]), torch.cuda.current_stream())
+            self._mark_used(ch, 0)
+            return out
 
         res = self._launch_on_streams(run, forward=True, order=[n - 1] + list(range(n - 1)))
         if join:
             self._join_streams()
-        self._state = dict(half=half, acts=[r[0] for r in res], logits=[r[1] for r in res], inputs=inputs, bands_shape=tuple(bands.shape))
+        self._state = dict(half=half, acts=[r[0] for r in res], logits=[r[1] for r in res], inputs=inputs, bands_shape=tuple(bands.shape), static=st)
         return self._state
 
     # ---- losses ----------------------------------------------------------------------------------------------------------------
@@ -347,7 +395,7 @@ class DiscriminatorEngineBL(DiscriminatorEngine):
             units[i] = half * (p.channels // 8) * p.length
         ws_bytes = lib.eben_bl_fm_sums_workspace(n)
         ws = torch.empty(max(1, (ws_bytes + 3) // 4), dtype=torch.float32, device=dev)
-        sums = torch.empty(2 * n, dtype=torch.float32, device=dev)
+        sums = s["static"]["fm_sums"]   # fixed address: the replayed input-gradient sequences read it
         check(lib.eben_bl_fm_sums(ptrs, units, n, ptr(ws), ws_bytes, ptr(sums), _stream()), "bl_fm_sums")
         nch = len(self.chains)
         inv = 1.0 / (nch * len(s["acts"][-1]))
@@ -369,11 +417,11 @@ class DiscriminatorEngineBL(DiscriminatorEngine):
         s = self._state
         half = s["half"]
         dev = s["logits"][0].device
-        one = torch.ones(1, dtype=torch.float32, device=dev)
+        one = s["static"]["one"]
         inv_scales = 1.0 / len(self.chains)
         sums_ptr = ptr(s["fm_sums"])
 
-        def run(i):
+        def body(i):
             lg = s["logits"][i]
             seeds = torch.zeros((4 * half,) + tuple(lg.shape[1:]), dtype=torch.float32, device=dev)
             per = lg[:half].numel()
@@ -382,6 +430,13 @@ class DiscriminatorEngineBL(DiscriminatorEngine):
                 check(lib.eben_hinge_bwd(ptr(rows), rows.numel(), target, ptr(one), inv_scales * self.seed_weights[k2], ptr(flat[(k2 + 1) * per:]),
                                          _stream()), "hinge_bwd")
             return self.chains[i].backward_body(s["acts"][i], seeds, half, want_param_grads, sums_ptr + 8 * s["fm_first"][i], s["fm_inv"]) + (seeds,)
+
+        def run(i):
+            sig = (half, want_param_grads, tuple(self.seed_weights), s["fm_inv"], sums_ptr, s["logits"][i].data_ptr(),
+                   tuple((a.hi.data_ptr(), a.lo.data_ptr(), a.length) for a in s["acts"][i]), self._chain_sig(self.chains[i], 1))
+            out = self._graphs["bwd"][i].run(sig, lambda: body(i), torch.cuda.current_stream())
+            self._mark_used(self.chains[i], 1)
+            return out
 
         self._bwd = (self._launch_on_streams(run), want_param_grads, (one,))
 
@@ -420,7 +475,13 @@ class DiscriminatorEngineBL(DiscriminatorEngine):
             pend = [None] * n
             for i in [n - 1] + list(range(n - 1)):   # the longest chain first
                 with torch.cuda.stream(self._streams[i]):
-                    pend[i] = self.chains[i].weight_grads(res[i][1], s["inputs"][i], res[i][0], half, self._sink)
+                    if self._sink is not None:   # gradients straight into the data-parallel buckets: eager (ReplayedChain is single-rank)
+                        pend[i] = self.chains[i].weight_grads(res[i][1], s["inputs"][i], res[i][0], half, self._sink)
+                    else:
+                        jobs_sig = tuple((k, (g.hi.data_ptr() if isinstance(g, Planes) else g.data_ptr()), x.hi.data_ptr(), x.lo.data_ptr()) for k, g, x in res[i][1])
+                        sig = (half, s["inputs"][i].data_ptr(), res[i][0].hi.data_ptr(), jobs_sig, self._chain_sig(self.chains[i], -1))
+                        pend[i] = self._graphs["dw"][i].run(sig, lambda i=i: self.chains[i].weight_grads(res[i][1], s["inputs"][i], res[i][0], half, None),
+                                                            torch.cuda.current_stream())
                     if self._sink is not None:
                         self._sink.mark_ready([p for lay in self.chains[i].layers for p in lay.params() if p is not None and p.requires_grad])
             self._pending = (pend, s, res)   # keeps the saved activations and the stacked gradients alive until the kernels have run

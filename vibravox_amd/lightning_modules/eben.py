@@ -180,7 +180,13 @@ class EBENLightningModule(BaseSELightningModule):
     #: tools/phase_times.py: list that receives (label, event) pairs recorded on the main stream between the phases
     phase_events = None
 
+    #: tools/host_times.py: list that receives (label, time.perf_counter()) at the same points -- where the HOST spends the step
+    phase_host = None
+
     def _mark(self, label: str) -> None:
+        if self.phase_host is not None:
+            import time
+            self.phase_host.append((label, time.perf_counter()))
         if self.phase_events is not None:
             ev = torch.cuda.Event(enable_timing=True)
             ev.record()

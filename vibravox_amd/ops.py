@@ -455,6 +455,51 @@ class ReplayedPrepack:
         return False   # the body ran (under capture): its bookkeeping is current
 
 
+class ReplayedChain:
+    """Graph replay of one LINEAR launch sequence with device-side results (a sub-discriminator's forward body, stacked input
+    gradients or weight gradients on its stream).  ``run(sig, fn, stream)`` returns what ``fn()`` returned -- tensors allocated by the
+    body, which from the capture on live in the graph's pool and are REWRITTEN IN PLACE by every replay: valid until the next call.
+    ``sig`` names everything the launches read besides values -- shapes, every input / weight-image / parameter address, arithmetic
+    plan -- a new signature falls back to eager calls and, once it has been seen three times in a row, a new capture.  Bodies chained
+    through their results settle one after the other (the consumer's signature contains the producer's output addresses, which only
+    stop changing once the producer replays).  One graph per chain and phase: no cross-stream edge inside a graph (the HIP runtime
+    would serve parallel branches from extra hardware queues, see ``aux_stream``); events between chains stay outside."""
+
+    enabled = os.environ.get("EBEN_CHAIN_GRAPHS", "1") != "0"
+
+    def __init__(self):
+        self.graph, self.sig, self.rounds, self.out = None, None, 0, None
+
+    def run(self, sig, fn, stream_):
+        if not self.enabled or ReplayedPrepack._multi_rank() or _timers_enabled():
+            return fn()
+        if sig != self.sig:
+            self.graph, self.sig, self.rounds, self.out = None, sig, 0, None
+        self.rounds += 1
+        if self.graph is not None:
+            self.graph.replay()
+            return self.out
+        if self.rounds < 3:
+            return fn()
+        graph = torch.cuda.CUDAGraph()
+        try:
+            with torch.cuda.graph(graph, stream=stream_, capture_error_mode="thread_local"):
+                out = fn()
+        except Exception as exc:   # capture is an optimisation: fall back to eager launches for good
+            import warnings
+
+            warnings.warn(f"chain graph capture failed ({exc!r}): staying with eager launches")
+            ReplayedChain.enabled = False
+            return fn()
+        self.graph, self.out = graph, out
+        graph.replay()   # the capture recorded the launches without running them
+        return out
+
+
+def _timers_enabled() -> bool:
+    return any(t.enabled for t in _timers)
+
+
 _conv_prepack_graph = ReplayedPrepack()
 
 
