@@ -56,10 +56,10 @@ def build_module(device, batch_seed):
 
 
 def pmc_traffic(batch, math):
-    """HBM bytes per launch of the roofline kernel from this round's rocprofv3 PMC passes (profiles/r02_pmc_melgan_l4_fwd_<math>.json,
+    """HBM bytes per launch of the roofline kernel from this round's rocprofv3 PMC passes (profiles/r03_pmc_melgan_l4_fwd_<math>.json,
     written by tools/pmc_traffic.sh + tools/pmc_summary.py for the build whose commit it records, at the batch the step launches;
     FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  None when the record is missing or of another batch."""
-    path = os.path.join(ROOT, "profiles", f"r02_pmc_melgan_l4_fwd_{math}.json")
+    path = os.path.join(ROOT, "profiles", f"r03_pmc_melgan_l4_fwd_{math}.json")
     if not os.path.exists(path):
         return None
     with open(path) as f:
@@ -153,10 +153,12 @@ def main():
     ap.add_argument("--cpu-batch", type=int, default=32)
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--force-ddp", action="store_true", help="run the bucketed RCCL gradient path even with one rank")
-    ap.add_argument("--disc-math", default=os.environ.get("EBEN_DISC_MATH", "bf16"), choices=["bf16", "bf16_bl", "f32", "bf16_plain"],
-                    help="discriminator contractions: 'bf16' = bf16 MFMA operands with fp32 accumulate (BASELINE config 2 names bf16; the "
-                         "PQMF-band discriminators' forward stays fp32, see DESIGN.md), 'f32' = exact fp32 products, 'bf16_plain' = every "
-                         "contraction on single bf16 operands; the generator's forward computes in fp32 either way")
+    ap.add_argument("--disc-math", default=os.environ.get("EBEN_DISC_MATH", "bf16_bl"), choices=["bf16_bl", "bf16", "f32", "bf16_plain"],
+                    help="discriminator contractions: 'bf16_bl' (default) = bf16 MFMA operands with fp32 accumulate, embeddings and stacked "
+                         "gradients at rest as bf16 bundles (hi + lo planes, disc_engine_bl.py; BASELINE config 2 names bf16; the PQMF-band "
+                         "discriminators' forward takes hi + lo operands, see DESIGN.md), 'bf16' = the same arithmetic on fp32 tensors at rest, "
+                         "'f32' = exact fp32 products, 'bf16_plain' = every contraction on single bf16 operands; the generator's forward is "
+                         "fp32-grade either way")
     ap.add_argument("--gen-bwd-math", default=None, choices=["bf16", "f32"],
                     help="generator backward contractions (default: bf16 with a bf16 discriminator, else f32)")
     ap.add_argument("--stft-math", default=None, choices=["bf16x3", "folded", "dense", "folded_x3", "folded_x6"],
@@ -179,6 +181,26 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    # The CPU-baseline leg runs FIRST (rank 0, one rank only): everything after it is GPU work, so a sampler watching the device over the
+    # run (the driver's rocm-smi trace) sees the timed region and not a host-only tail.
+    cpu_rec = None
+    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+        # torch's intra-op pool.  Measured on the GPU host (2 x EPYC 9575F, 256 hardware threads) at the full batch 32: 8 threads 9.9,
+        # 16 threads 14.8, 32 threads 10.6 audio-s/s, 256 threads > 20x slower -- these convolutions do not scale past ~16 threads, so
+        # 16 is the setting that is fair to the CPU; the 8-thread leg is comparable with the survey's measurement of the reference.
+        avail = len(os.sched_getaffinity(0))
+        cores = int(os.environ.get("EBEN_CPU_THREADS", "0")) or max(1, min(16, avail))
+        threads_before = torch.get_num_threads()
+        v16, dt16, times = cpu_baseline(args.cpu_batch, args.length, args.cpu_steps, cores)
+        v8, dt8, _ = cpu_baseline(args.cpu_batch, args.length, 1, min(8, avail))
+        torch.set_num_threads(threads_before)
+        cpu_rec = {"value": round(v16, 3), "unit": "audio-seconds/sec", "cores": cores, "kind": "port",
+                   "sample": f"{args.cpu_steps} timed steps after 1 warm-up ({', '.join(f'{t:.2f}' for t in times)} s), batch {args.cpu_batch} x "
+                             f"{args.length} samples, fp32, reference as-executed order; host has {avail} hardware threads "
+                             f"(more than ~16 threads is slower for these convolutions); run before the GPU legs",
+                   "threads_8": {"value": round(v8, 3), "s_per_step": round(dt8, 2), "steps": 1}}
+        print(f"[bench] CPU oracle: {v16:.2f} audio-s/s on {cores} threads", file=sys.stderr, flush=True)
 
     from vibravox_amd import ops
     from vibravox_amd.ddp import BucketedZeroGrad, GradSync
@@ -362,9 +384,10 @@ def main():
         stft_desc = {"folded_x6": "fp32-grade (three bf16 pieces per operand)",
                      "folded_x3": "hi + lo bf16 operands (three MFMAs per product, ~2^-17; the generator gradient against the fp32 step stays at 5.5e-3)"
                      }.get(stft_math, "fp32 (" + stft_math + ")")
-        kn = "tap3_kernel<4,*> (v_mfma_f32_32x32x16_bf16)" if bf16 else "tap2_kernel<4,4,16> (v_mfma_f32_32x32x2_f32)"
+        kn = ("tap3_kernel<4,*,BL> (v_mfma_f32_32x32x16_bf16, bf16 bundles at rest)" if args.disc_math == "bf16_bl" else
+              "tap3_kernel<4,*> (v_mfma_f32_32x32x16_bf16)" if bf16 else "tap2_kernel<4,4,16> (v_mfma_f32_32x32x2_f32)")
         roof, flops = launch_record(timer, "fwd", kn)
-        roof["traffic"] = pmc_traffic(timer.batch or 2 * args.batch, "bf16" if bf16 else "f32")
+        roof["traffic"] = pmc_traffic(timer.batch or 2 * args.batch, args.disc_math if bf16 else "f32")
         if iso_ms:
             roof["isolated"] = {"launch_ms": round(iso_ms, 4), "achieved": round(flops / (iso_ms * 1e-3) / 1e12, 2),
                                 "frac": round(flops / (iso_ms * 1e-3) / 1e12 / peak, 4),
@@ -384,7 +407,8 @@ def main():
                        "precision": (f"discriminator contractions on bf16 MFMA operands with fp32 accumulate (MelGAN: every pass; PQMF-band "
                                      f"discriminators: input / weight gradients -- their forward takes hi + lo bf16 operands (3 MFMAs per product), which keeps the discriminator "
                                      f"gradient within 3.4e-2 of the fp32 step's, tests/test_gpu_models.py); generator forward, losses, Adam, "
-                                     f"storage: fp32; generator backward contractions: {gen_bwd_math}; MRSTFT DFT contractions: {stft_desc}"
+                                     f"parameters: fp32; discriminator embeddings / stacked gradients at rest: "
+                                     f"{'bf16 bundles [row][channels / 8][position][8], hi + lo planes where the fp32 value is needed' if args.disc_math == 'bf16_bl' else 'fp32'}; generator backward contractions: {gen_bwd_math}; MRSTFT DFT contractions: {stft_desc}"
                                      if args.disc_math in ("bf16", "bf16_bl") else
                                      "every contraction on single bf16 MFMA operands (bf16_plain)" if bf16 else "fp32 throughout (exact fp32 MFMA products)")},
             "step_ms": {"median": round(percentile(per_step, 0.5), 3), "p10": round(percentile(per_step, 0.1), 3),
@@ -398,6 +422,9 @@ def main():
         # whole-step arithmetic rate on SURVEY section 8d's minimal algorithmic count F_min = 2*(3G + 8D) (no credit for redundant passes)
         f_min = 2.0 * (3 * 6.727e8 + 8 * 2.5255e9) * audio_s
         line["step_work"] = {"f_min_flop": f_min, "achieved_tflops": round(f_min / (dt / args.steps) / 1e12, 1)}
+        line["step_roofline_f_min"] = {"ideal_ms": round(f_min / (peak * 1e12) * 1e3, 3), "frac": round(f_min / (peak * 1e12) * 1e3 / ms, 4),
+                                       "note": "F_min alone on the dense MFMA peak of `dtype` (no credit for the hi + lo forward products, the "
+                                               "fp32-grade generator forward or any byte)"}
         if dt32 is not None:
             ms32 = dt32 / args.steps * 1e3
             line["value_f32"] = round(audio_s / (dt32 / args.steps), 2)
@@ -417,19 +444,8 @@ def main():
                             "buckets": {name: len(sy.buckets) for name, sy in syncs},
                             "note": "exposed = main-stream time spent waiting for the bucket all-reduces in front of each Adam"}
         print(f"[bench] GPU: {ms:.1f} ms/step, {value:.1f} audio-s/s", file=sys.stderr, flush=True)
-        if world == 1 and not args.no_cpu_baseline:
-            # torch's intra-op pool.  Measured on the GPU host (2 x EPYC 9575F, 256 hardware threads) at the full batch 32: 8 threads 9.9,
-            # 16 threads 14.8, 32 threads 10.6 audio-s/s, 256 threads > 20x slower -- these convolutions do not scale past ~16 threads, so
-            # 16 is the setting that is fair to the CPU; the 8-thread leg is comparable with the survey's measurement of the reference.
-            avail = len(os.sched_getaffinity(0))
-            cores = int(os.environ.get("EBEN_CPU_THREADS", "0")) or max(1, min(16, avail))
-            v16, dt16, times = cpu_baseline(args.cpu_batch, args.length, args.cpu_steps, cores)
-            v8, dt8, _ = cpu_baseline(args.cpu_batch, args.length, 1, min(8, avail))
-            line["cpu_baseline"] = {"value": round(v16, 3), "unit": "audio-seconds/sec", "cores": cores, "kind": "port",
-                                    "sample": f"{args.cpu_steps} timed steps after 1 warm-up ({', '.join(f'{t:.2f}' for t in times)} s), batch {args.cpu_batch} x "
-                                              f"{args.length} samples, fp32, reference as-executed order; host has {avail} hardware threads "
-                                              f"(more than ~16 threads is slower for these convolutions)",
-                                    "threads_8": {"value": round(v8, 3), "s_per_step": round(dt8, 2), "steps": 1}}
+        if cpu_rec is not None:
+            line["cpu_baseline"] = cpu_rec
     # the JSON line is the LAST thing on stdout: the process group is torn down and every C stdio buffer (RCCL's log stream) is
     # flushed first
     if use_ddp:

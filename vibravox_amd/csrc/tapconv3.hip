@@ -36,12 +36,18 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
 #define EBEN_T3_KSC 4
 #endif
 #ifndef EBEN_T3_DBG
-#define EBEN_T3_DBG 0   // scratch-build ablations (wrong results): 1 no weight stream, 2 no tile refresh, 4 no barrier, 8 no MFMA, 16 phase-major stores
+#define EBEN_T3_DBG 0   // scratch-build ablations (wrong results): 1 no weight stream, 2 no tile refresh, 4 no barrier, 8 no MFMA, 16 phase-major stores, 32 no mask / feature-matching loads in the bundle epilogue, 64 no tile staging in the prologue, 128 no output stores (bundle epilogue), 256 one k-step per chunk
 #endif
 constexpr int T3_KSC = EBEN_T3_KSC;   // k-steps (of 16 reduction elements) per weight chunk (single-piece weights)
 // split weights (NPW pieces per weight, EBEN_MATH_BF16X3 / X6): a k-step carries NPW times the weight bytes and 3 / 6 times the
 // MFMAs, so two k-steps per chunk keep the chunk at 4-6 KB per 32 rows and the barrier at >= 24 MFMAs per wave
-__host__ __device__ constexpr int t3_ksc(int npw) { return npw == 1 ? T3_KSC : 2; }
+#ifndef EBEN_T3_KSC1
+#define EBEN_T3_KSC1 EBEN_T3_KSC   // ... of the 32-row tiles (FM = 1)
+#endif
+#ifndef EBEN_T3_KSC2
+#define EBEN_T3_KSC2 EBEN_T3_KSC   // ... of the 64-row tiles (FM = 2)
+#endif
+__host__ __device__ constexpr int t3_ksc(int npw, int fm = 4) { return npw == 1 ? (fm == 1 ? EBEN_T3_KSC1 : fm == 2 ? EBEN_T3_KSC2 : T3_KSC) : 2; }
 
 struct Tap3Args {
   const float* x; const float* xmask; const u32x4* wp; const int* tab;
@@ -85,7 +91,7 @@ struct Tap3Args {
 // bytes per row quad) and reads the mask / feature-matching operands the same way.
 template <int FM, int XRB, bool IM = false, int NPW = 1, int NPX = 1, bool BL = false>
 __global__ __launch_bounds__(256, NPW >= 2 ? 1 : 2) void tap3_kernel(const Tap3Args P) {
-  constexpr int NT = 256, BN = 128, BM = FM * 32, KSC = t3_ksc(NPW);
+  constexpr int NT = 256, BN = 128, BM = FM * 32, KSC = t3_ksc(NPW, FM);
   constexpr bool SP = NPX > 1;
   constexpr int NPM = NPW > NPX ? NPW : NPX;
   constexpr int WCHU = KSC * NPW * FM * 64;       // 16-byte units per weight chunk
@@ -342,7 +348,7 @@ __global__ __launch_bounds__(256, NPW >= 2 ? 1 : 2) void tap3_kernel(const Tap3A
     };
     Round ra, rb;
     if (xtot > 0) pro_load(0, ra);
-    for (int base = 0; base < xtot; base += 4 * NT) {
+    for (int base = 0; base < ((EBEN_T3_DBG & 64) ? 0 : xtot); base += 4 * NT) {
       const bool second = base + 2 * NT < xtot;
       if (second) pro_load(base + 2 * NT, rb);
       pro_store(ra);
@@ -377,7 +383,7 @@ __global__ __launch_bounds__(256, NPW >= 2 ? 1 : 2) void tap3_kernel(const Tap3A
     rd(0);
     if (KSC > 1) rd(1);
 #pragma unroll
-    for (int ks = 0; ks < KSC; ++ks) {
+    for (int ks = 0; ks < ((EBEN_T3_DBG & 256) ? 1 : KSC); ++ks) {
       if (ks + 2 < KSC) rd(ks + 2);
       __builtin_amdgcn_sched_barrier(0);
       // piece products, smallest first: (qw, qx) with qw + qx = lvl
@@ -428,7 +434,7 @@ __global__ __launch_bounds__(256, NPW >= 2 ? 1 : 2) void tap3_kernel(const Tap3A
     const bool fmr = P.fm_sums != nullptr && P.res_rows > 0 && b < P.res_rows;
     float fk1 = 0.f, fk2 = 0.f;
     if (fmr) { const float s1 = P.fm_sums[0], s2 = P.fm_sums[1]; fk1 = P.fm_gs / s2; fk2 = P.fm_gs * s1 / (s2 * s2); }
-    const bool masked = P.eh != nullptr;
+    const bool masked = P.eh != nullptr && !(EBEN_T3_DBG & 32);
     auto unpack = [](uint2 w, float (&f)[4]) {
       f[0] = __builtin_bit_cast(float, w.x << 16); f[1] = __builtin_bit_cast(float, w.x & 0xffff0000u);
       f[2] = __builtin_bit_cast(float, w.y << 16); f[3] = __builtin_bit_cast(float, w.y & 0xffff0000u);
@@ -476,13 +482,13 @@ __global__ __launch_bounds__(256, NPW >= 2 ? 1 : 2) void tap3_kernel(const Tap3A
         }
         uint2 h;
         h.x = pack_bf16(v[0], v[1]); h.y = pack_bf16(v[2], v[3]);
-        if (live[r4]) P.yh[yrow * 2 + off[r4]] = h;
+        if (live[r4] && !((EBEN_T3_DBG & 128) && h.x != 0x12345u)) P.yh[yrow * 2 + off[r4]] = h;
         if (P.yl) {
           float hf[4];
           unpack(h, hf);
           uint2 l;
           l.x = pack_bf16(v[0] - hf[0], v[1] - hf[1]); l.y = pack_bf16(v[2] - hf[2], v[3] - hf[3]);
-          if (live[r4]) P.yl[yrow * 2 + off[r4]] = l;
+          if (live[r4] && !((EBEN_T3_DBG & 128) && l.x != 0x12345u)) P.yl[yrow * 2 + off[r4]] = l;
         }
       }
     }
@@ -598,7 +604,6 @@ static void make_plan3(const Canon& c, int dir, Tap3Plan* p) {
   p->G = c.g;
   p->npw = c.np;
   p->npx = c.np > 1 ? c.np : (c.xsplit_dir == dir ? 2 : 1);
-  p->KSC = t3_ksc(p->npw);
   const int ub = 16 * p->npx;          // LDS bytes per staged bundle position
   const int spare = p->npx > 1 ? 16 * p->npx : 0;   // one spare unit per piece region
   if (dir == 0) {
@@ -663,6 +668,7 @@ static void make_plan3(const Canon& c, int dir, Tap3Plan* p) {
   static const int force_bm = env_int3("EBEN_TAP3_BM", 0);
   if (force_bm == 32 || force_bm == 64 || force_bm == 96 || force_bm == 128) best = force_bm;
   p->BM = best; p->FM = best / 32; p->BN = 128;
+  p->KSC = t3_ksc(p->npw, p->FM);
   p->WCHU = p->KSC * p->npw * p->FM * 64;
   p->nmt = ceil_div(p->Mg, p->BM);
   p->ntt = ceil_div(p->nt, p->BN);
