@@ -283,6 +283,13 @@ def main():
         torch.cuda.synchronize()
         if rank == 0:
             print(f"[bench] warm-up step {i}: {(time.perf_counter() - tw) * 1e3:.1f} ms", file=sys.stderr, flush=True)
+    # Launch sequences on their way into a HIP graph (ops.ReplayedChain / ReplayedPrepack: the capture of a sequence takes tens of ms and
+    # the chained ones settle one after the other) finish settling before the clock starts; reported as `settle_steps`
+    settle = 0
+    while ops.graphs_pending() and settle < 12:
+        mod.training_step(next_batch())
+        settle += 1
+    torch.cuda.synchronize()
     # Python's cyclic GC walks every tracked object of the process on a full collection (~100 ms here, a few times per
     # 40 steps: +2..5 ms/step and most of the run-to-run spread): the objects alive after warm-up are moved to the
     # permanent generation, as a long-running training process would do once after set-up (run.py does the same)
@@ -396,7 +403,7 @@ def main():
         ideal = step_roofline_ms("f32" if not bf16 else "bf16", scale)
         line = {
             "metric": "EBEN train-step audio-seconds/sec (gen+disc)", "value": round(value, 2), "unit": "audio-seconds/sec",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "settle_steps": settle, "ms_per_step": round(ms, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
             "config": {"workload": (f"EBEN full GAN train step (gen+disc+MRSTFT+feature-matching+hinge, EMA balancing, Adam), batch {args.batch} x "
                                     f"{length} samples @16kHz per GPU (cut to {cut})"
@@ -412,7 +419,8 @@ def main():
                                      if args.disc_math in ("bf16", "bf16_bl") else
                                      "every contraction on single bf16 MFMA operands (bf16_plain)" if bf16 else "fp32 throughout (exact fp32 MFMA products)")},
             "step_ms": {"median": round(percentile(per_step, 0.5), 3), "p10": round(percentile(per_step, 0.1), 3),
-                        "p90": round(percentile(per_step, 0.9), 3), "clock": "HIP events at the step boundaries on the main stream"},
+                        "p90": round(percentile(per_step, 0.9), 3), "max": round(per_step[-1], 3),
+                        "mean": round(sum(per_step) / len(per_step), 3), "clock": "HIP events at the step boundaries on the main stream"},
             "roofline": roof,
             "roofline_time_dominant": roof_t,
             "step_roofline": {"ideal_ms": round(ideal, 3), "frac": round(ideal / ms, 4),

@@ -38,16 +38,41 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
 #ifndef EBEN_T3_DBG
 #define EBEN_T3_DBG 0   // scratch-build ablations (wrong results): 1 no weight stream, 2 no tile refresh, 4 no barrier, 8 no MFMA, 16 phase-major stores, 32 no mask / feature-matching loads in the bundle epilogue, 64 no tile staging in the prologue, 128 no output stores (bundle epilogue), 256 one k-step per chunk
 #endif
-constexpr int T3_KSC = EBEN_T3_KSC;   // k-steps (of 16 reduction elements) per weight chunk (single-piece weights)
-// split weights (NPW pieces per weight, EBEN_MATH_BF16X3 / X6): a k-step carries NPW times the weight bytes and 3 / 6 times the
-// MFMAs, so two k-steps per chunk keep the chunk at 4-6 KB per 32 rows and the barrier at >= 24 MFMAs per wave
-#ifndef EBEN_T3_KSC1
-#define EBEN_T3_KSC1 EBEN_T3_KSC   // ... of the 32-row tiles (FM = 1)
+#if EBEN_T3_DBG & 512
+// scratch build: cycle stamps (s_memtime) of wave 0 of every block at the phase boundaries, one row of 8 per block
+constexpr int T3_STAMP_ROWS = 65536;
+__device__ unsigned long long t3_stamp[T3_STAMP_ROWS * 16];
+#define T3_STAMP(k) do { if (tid == 0 && blockIdx.x < T3_STAMP_ROWS) { t3_stamp[blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memtime(); \
+  if ((k) == 0) { t3_stamp[blockIdx.x * 16 + 8] = __builtin_amdgcn_s_getreg(4 | (31 << 11)); t3_stamp[blockIdx.x * 16 + 9] = __builtin_amdgcn_s_getreg(20 | (31 << 11)); } } } while (0)
+#else
+#define T3_STAMP(k) do { } while (0)
 #endif
-#ifndef EBEN_T3_KSC2
-#define EBEN_T3_KSC2 EBEN_T3_KSC   // ... of the 64-row tiles (FM = 2)
+// Weight stream: chunks of KSC k-steps go into a RING of LDS slots by LDS-DMA, DIST = RING - 1 chunks ahead of the one being multiplied.
+// The end of a chunk waits only for the NEXT chunk's pieces (s_waitcnt vmcnt(N) with the younger chunks' DMAs left in flight) and
+// crosses a raw s_barrier: a __syncthreads() there carries a fence, i.e. vmcnt(0), which exposes one full DMA round trip
+// (~1-1.8k cycles) per chunk of 128-576 MFMA cycles -- measured with cycle stamps: the loop of a 3-chunk input-gradient block took
+// 2.9k cycles for 384 cycles of MFMAs, the 11-chunk hi + lo forward of a PQMF-band layer 20k for 6k.
+// [MI355X] the stamps then showed that the DMA was NOT what a chunk waited for: with 4 slots of <= 8 KB (3 of the larger chunks) the loops
+// shortened by 0-7 % only (the per-chunk cost is the k-step table's scalar load + barrier + first fragment reads, see the loop), while
+// the larger LDS footprint took the thin launches from 2-3 blocks per CU to 1: whole discriminator forward 1.64 -> 2.18 ms.  Two slots
+// (DIST = 1: the wait is vmcnt(0) again, one chunk of cover) is the default; the depth stays a build knob.
+#ifndef EBEN_T3_RING_SMALL
+#define EBEN_T3_RING_SMALL 2   // slots of chunks <= 8 KB
 #endif
-__host__ __device__ constexpr int t3_ksc(int npw, int fm = 4) { return npw == 1 ? (fm == 1 ? EBEN_T3_KSC1 : fm == 2 ? EBEN_T3_KSC2 : T3_KSC) : 2; }
+#ifndef EBEN_T3_RING_BIG
+#define EBEN_T3_RING_BIG 2     // slots of larger chunks
+#endif
+#ifndef EBEN_T3_KSC_BIGFM
+#define EBEN_T3_KSC_BIGFM EBEN_T3_KSC   // k-steps per chunk of the 96 / 128-row tiles (single-piece weights)
+#endif
+// k-steps (of 16 reduction elements) per weight chunk; split weights (NPW pieces per weight, EBEN_MATH_BF16X3 / X6): a k-step carries
+// NPW times the weight bytes and 3 / 6 times the MFMAs
+__host__ __device__ constexpr int t3_ksc(int npw, int fm = 4) { return npw == 1 ? (fm <= 2 ? EBEN_T3_KSC : EBEN_T3_KSC_BIGFM) : 2; }
+__host__ __device__ constexpr int t3_ring(int npw, int fm) { return t3_ksc(npw, fm) * npw * fm <= 8 ? EBEN_T3_RING_SMALL : EBEN_T3_RING_BIG; }
+template <int N> __device__ __forceinline__ void t3_wait_vm() {   // s_waitcnt vmcnt(N) lgkmcnt(0)
+  static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit count");
+  __builtin_amdgcn_s_waitcnt((N & 15) | ((N >> 4) << 14) | 0x70);
+}
 
 struct Tap3Args {
   const float* x; const float* xmask; const u32x4* wp; const int* tab;
@@ -95,15 +120,19 @@ __global__ __launch_bounds__(256, NPW >= 2 ? 1 : 2) void tap3_kernel(const Tap3A
   constexpr bool SP = NPX > 1;
   constexpr int NPM = NPW > NPX ? NPW : NPX;
   constexpr int WCHU = KSC * NPW * FM * 64;       // 16-byte units per weight chunk
+  constexpr int RING = t3_ring(NPW, FM), DIST = RING - 1;
+  constexpr int WU = (WCHU + NT - 1) / NT;        // LDS-DMA instructions per thread and chunk
   static_assert(WCHU % 64 == 0, "weight chunk must split into whole wave pieces");
+  static_assert(DIST >= 1 && DIST <= 3, "ring depth");
 
   extern __shared__ __attribute__((aligned(16))) u32x4 smem3[];
-  u32x4* Ws = smem3;              // 2 x WCHU
-  u32x4* Xs = smem3 + 2 * WCHU;   // nxb input tiles of CI_B * CSTRIDE units + one spare unit (SP: the lo tiles behind them)
+  u32x4* Ws = smem3;              // RING x WCHU
+  u32x4* Xs = smem3 + RING * WCHU;   // nxb input tiles of CI_B * CSTRIDE units + one spare unit (SP: the lo tiles behind them)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);
+  T3_STAMP(0);
 
   unsigned id;
   {
@@ -289,22 +318,46 @@ __global__ __launch_bounds__(256, NPW >= 2 ? 1 : 2) void tap3_kernel(const Tap3A
 
   auto issue_w = [&](int ch) {
     const u32x4* src = wsrc + (long long)ch * WCHU;
-    u32x4* dst = Ws + (ch & 1) * WCHU;
+    u32x4* dst = Ws + (ch % RING) * WCHU;
 #pragma unroll
-    for (int u = 0; u * NT < WCHU; ++u) {
-      const int idx = u * NT + tid;
-      if (WCHU % NT == 0 || idx < WCHU)   // wave-uniform
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + idx),
-                                         (__attribute__((address_space(3))) void*)(dst + (idx & ~63)), 16, 0, 0);
+    for (int u = 0; u < WU; ++u) {
+      int idx = u * NT + tid;
+      // every wave issues WU instructions per chunk (the counted waits below rely on it): a wave past the chunk's end repeats its
+      // previous piece (same bytes to the same place)
+      if (WCHU % NT != 0 && idx >= WCHU) idx -= NT;   // wave-uniform
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + idx),
+                                       (__attribute__((address_space(3))) void*)(dst + (idx & ~63)), 16, 0, 0);
     }
   };
 
   int written = 0;
+  T3_STAMP(1);
+  // ---- bundle layout: what the epilogue needs besides the accumulators is asked for HERE, under the tile staging and the reduction ----
+  // (cycle stamps: the epilogue written as load-then-use took 4-10k cycles of a 15-37k block life: the bias values one exec-masked load
+  // each, the feature-matching sums a dependent round trip of their own, several kernel-argument loads in sequence)
+  const int eb = P.em_seg > 0 ? P.em_map[(int)(b >= P.em_seg) + (int)(b >= 2 * P.em_seg) + (int)(b >= 3 * P.em_seg)] * P.em_seg +
+                                    (b - ((int)(b >= P.em_seg) + (int)(b >= 2 * P.em_seg) + (int)(b >= 3 * P.em_seg)) * P.em_seg) : b;
+  float* Bs = reinterpret_cast<float*>(Xs + NPX * (P.nxb * XBUF + 1));   // BM bias values of this block's rows (BL)
+  float fk1 = 0.f, fk2 = 0.f;
+  const bool fmr = BL && P.fm_sums != nullptr && P.res_rows > 0 && b < P.res_rows;
+  if constexpr (BL) {
+    if (tid < BM) {
+      const int m = m0 + tid;
+      Bs[tid] = P.bias ? P.bias[(long long)g * P.Mg + (m < P.Mg ? m : P.Mg - 1)] : 0.f;
+    }
+    if (fmr) {
+      typedef const __attribute__((address_space(4))) float* cf_t;
+      const float s1 = ((cf_t)P.fm_sums)[0], s2 = ((cf_t)P.fm_sums)[1];
+      fk1 = P.fm_gs / s2; fk2 = P.fm_gs * s1 / (s2 * s2);
+    }
+  }
   if (nch > 0) {
+    // the first DIST chunks: their LDS-DMA round trips run under the tile staging (short reductions -- the PQMF-band layers'
+    // input gradients: 3 chunks -- are complete before the loop starts)
     issue_w(0);
-    // the second chunk too (its buffer is free until the loop's first barrier): its LDS-DMA round trip then runs under the tile
-    // staging instead of under the four k-steps of chunk 0 -- short reductions (the PQMF-band layers: 2-6 chunks) are bound by it
-    if ((EBEN_T3_DBG & 1) == 0 && nch > 1) issue_w(1);
+#pragma unroll
+    for (int c = 1; c < DIST; ++c)
+      if (c < nch) issue_w(c);
     const float* xp = P.x + xrow0;
     const float* mp = P.xmask + xrow0;
     // two rounds of (2 units = 16 loads per thread) in flight: round r + 1 is asked for before round r is converted and written --
@@ -348,6 +401,7 @@ __global__ __launch_bounds__(256, NPW >= 2 ? 1 : 2) void tap3_kernel(const Tap3A
     };
     Round ra, rb;
     if (xtot > 0) pro_load(0, ra);
+    T3_STAMP(2);
     for (int base = 0; base < ((EBEN_T3_DBG & 64) ? 0 : xtot); base += 4 * NT) {
       const bool second = base + 2 * NT < xtot;
       if (second) pro_load(base + 2 * NT, rb);
@@ -359,7 +413,27 @@ __global__ __launch_bounds__(256, NPW >= 2 ? 1 : 2) void tap3_kernel(const Tap3A
     }
     if (P.ncc > 1) fetch_x(1);
   }
+  T3_STAMP(3);
   __syncthreads();
+  T3_STAMP(4);
+  // activation mask (hi plane of the saved embedding) of this lane's outputs: asked for before the reduction where the registers allow
+  constexpr bool PREF = BL && FM <= 2;
+  uint2 pah[PREF ? FM : 1][4];
+  if constexpr (PREF) {
+    if (P.eh != nullptr && !(EBEN_T3_DBG & 32)) {
+      const int tq = t0 + wn * 32 + (lane & 31);
+      const unsigned colq = (unsigned)(tq < nt ? tq : nt - 1) * (unsigned)P.OS + (unsigned)oo;
+      const long long erowq = ((long long)eb * P.CBy + ((g * P.Mg) >> 3)) * P.Ly;
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          const int m4 = m0 + i * 32 + 8 * r4 + 4 * (lane >> 5);
+          const int mb = m4 < P.Mg ? (m4 >> 3) : 0;
+          pah[i][r4] = P.eh[erowq * 2 + ((long long)mb * P.Ly + colq) * 2 + (lane >> 5)];
+        }
+    }
+  }
 
   const int lanebase = (lane >> 5) * P.CSTRIDE + wn * 32 + (lane & 31);
   int te[KSC];
@@ -367,9 +441,14 @@ __global__ __launch_bounds__(256, NPW >= 2 ? 1 : 2) void tap3_kernel(const Tap3A
   for (int ks = 0; ks < KSC; ++ks) te[ks] = nch > 0 ? tab[ks] : 0;
   int pending = -1;   // tile whose global loads are issued at the top of the next chunk (not in front of the barrier)
   for (int ch = 0; ch < nch; ++ch) {
-    if ((EBEN_T3_DBG & 1) == 0 && ch > 0 && ch + 1 < nch) issue_w(ch + 1);
+    // the next chunk's table entries are asked for FIRST: their scalar-load round trip (~300 cycles) runs under this chunk's fragment
+    // reads and MFMAs -- asked for behind the MFMAs it was waited for in front of every barrier
+    int tn[KSC];
+#pragma unroll
+    for (int ks = 0; ks < KSC; ++ks) tn[ks] = tab[(ch + 1 < nch ? ch + 1 : ch) * KSC + ks];
+    if ((EBEN_T3_DBG & 1) == 0 && ch + DIST < nch) issue_w(ch + DIST);   // into the slot of chunk ch - 1 (behind the barrier that ended it)
     if ((EBEN_T3_DBG & 2) == 0 && pending >= 0) { fetch_x(pending); pending = -1; }
-    const u32x4* wb = Ws + (ch & 1) * WCHU + lane;
+    const u32x4* wb = Ws + (ch % RING) * WCHU + lane;
     const u32x4* xb = Xs + lanebase;
     u32x4 bv[KSC][NPX], a[KSC][NPW][FM];
     auto rd = [&](int ks) {
@@ -401,20 +480,27 @@ __global__ __launch_bounds__(256, NPW >= 2 ? 1 : 2) void tap3_kernel(const Tap3A
         }
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (ch + 1 < nch) {
 #pragma unroll
-      for (int ks = 0; ks < KSC; ++ks) te[ks] = tab[(ch + 1) * KSC + ks];
-    }
+    for (int ks = 0; ks < KSC; ++ks) te[ks] = tn[ks];
     if ((EBEN_T3_DBG & 2) == 0 && P.ncc > 1 && written + 1 < P.ncc && (written + 1) * KS_CC < (ch + 2) * KSC) {
       ++written;
       store_x(written);
       if (written + 1 < P.ncc) pending = written + 1;
     }
-    if ((EBEN_T3_DBG & 4) == 0) __syncthreads();
+    // chunk ch + 1 has landed once at most the DMAs of the chunks issued after it (ch + 2 .. ch + DIST) are in flight; tile loads of
+    // fetch_x issued meanwhile only make the count stricter.  lgkmcnt(0): this wave's tile writes (store_x) and table loads.
+    {
+      int ahead = nch - 2 - ch;
+      ahead = ahead > DIST - 1 ? DIST - 1 : ahead;
+      if (ahead <= 0) t3_wait_vm<0>();
+      else if (DIST < 3 || ahead == 1) t3_wait_vm<WU>();
+      else t3_wait_vm<2 * WU>();
+    }
+    if ((EBEN_T3_DBG & 4) == 0) __builtin_amdgcn_s_barrier();
   }
+  T3_STAMP(5);
 
   const bool use_res = P.res != nullptr && (P.res_rows == 0 || b < P.res_rows);
-  const int eb = P.em_seg > 0 ? P.em_map[b / P.em_seg] * P.em_seg + b % P.em_seg : b;
   // ---- epilogue: 32x32 D tile: column = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) ----
   // Every operand of the fused stages (bias, residual, activation mask, accumulate target) is read for all 16 rows of a tile in ONE
   // batch of loads (clamped addresses, no per-value branch), then the 16 values are formed and stored: written value by value the
@@ -430,10 +516,6 @@ __global__ __launch_bounds__(256, NPW >= 2 ? 1 : 2) void tap3_kernel(const Tap3A
     const long long yrow = ((long long)b * P.CBy + gB) * P.Ly;
     const long long erow = ((long long)eb * P.CBy + gB) * P.Ly;
     const long long rrow = ((long long)(b + P.bl_ref_off) * P.CBy + gB) * P.Ly;
-    const float* __restrict__ bbp = P.bias + (long long)g * P.Mg;
-    const bool fmr = P.fm_sums != nullptr && P.res_rows > 0 && b < P.res_rows;
-    float fk1 = 0.f, fk2 = 0.f;
-    if (fmr) { const float s1 = P.fm_sums[0], s2 = P.fm_sums[1]; fk1 = P.fm_gs / s2; fk2 = P.fm_gs * s1 / (s2 * s2); }
     const bool masked = P.eh != nullptr && !(EBEN_T3_DBG & 32);
     auto unpack = [](uint2 w, float (&f)[4]) {
       f[0] = __builtin_bit_cast(float, w.x << 16); f[1] = __builtin_bit_cast(float, w.x & 0xffff0000u);
@@ -451,10 +533,13 @@ __global__ __launch_bounds__(256, NPW >= 2 ? 1 : 2) void tap3_kernel(const Tap3A
         live[r4] = m4 < P.Mg;
         const int mb = live[r4] ? (m4 >> 3) : 0;
         off[r4] = ((long long)mb * P.Ly + colb) * 2 + hb;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) bz[r4][e] = (P.bias && live[r4]) ? bbp[m4 + e] : 0.f;
+        {
+          const float4 bq = *reinterpret_cast<const float4*>(Bs + i * 32 + 8 * r4 + 4 * hb);
+          bz[r4][0] = bq.x; bz[r4][1] = bq.y; bz[r4][2] = bq.z; bz[r4][3] = bq.w;
+        }
         if (masked) {
-          ah[r4] = P.eh[erow * 2 + off[r4]];
+          if constexpr (PREF) ah[r4] = pah[i][r4];
+          else ah[r4] = P.eh[erow * 2 + off[r4]];
           if (fmr) { al[r4] = P.el[erow * 2 + off[r4]]; rh[r4] = P.eh[rrow * 2 + off[r4]]; rl[r4] = P.el[rrow * 2 + off[r4]]; }
         }
       }
@@ -492,6 +577,11 @@ __global__ __launch_bounds__(256, NPW >= 2 ? 1 : 2) void tap3_kernel(const Tap3A
         }
       }
     }
+    T3_STAMP(6);
+#if EBEN_T3_DBG & 512
+    __builtin_amdgcn_s_waitcnt(0);   // vmcnt(0): the stores have left
+    T3_STAMP(7);
+#endif
     return;
   }
   // addresses: a block-uniform 64-bit base per tensor (scalar registers) + a 32-bit per-lane element offset (one group's rows of one
@@ -686,7 +776,7 @@ static void make_plan3(const Canon& c, int dir, Tap3Plan* p) {
   static const int lds_budget1 = env_int3("EBEN_TAP3_LDS_KB", 48) * 1024;
   static const int lds_budget_split = env_int3("EBEN_TAP3_SPLIT_LDS_KB", 150) * 1024;   // split weights: one MFMA-bound block per CU
   static const int lds_budget_x3 = env_int3("EBEN_TAP3_X3_LDS_KB", 64) * 1024;
-  const int wbytes = 2 * p->WCHU * 16;
+  const int wbytes = t3_ring(p->npw, p->FM) * p->WCHU * 16;
   const int Cg2 = round_up(p->Cg, 16);
   // input tiles inside `lds_budget` bytes per block (weights included); a three-buffer scheme may go up to `big`
   auto size_tiles = [&](int lds_budget, int big) -> bool {
@@ -737,6 +827,7 @@ static void make_plan3(const Canon& c, int dir, Tap3Plan* p) {
   p->tab_off_floats = p->w_phase * p->nph * 4;
   p->packed_floats = (size_t)p->tab_off_floats + (size_t)p->tab_phase * p->nph;
   p->lds_bytes = (size_t)wbytes + ((size_t)p->nxbuf * p->CI_B * p->CSTRIDE * 16 + 16) * p->npx;   // + the spare unit of every piece
+  if (c.bl) p->lds_bytes += (size_t)p->BM * 4;   // the block's bias rows
   if (p->lds_bytes > 160 * 1024) return;
   p->ok = 1;
 }
@@ -1000,3 +1091,15 @@ int tap3_launch(const Canon& c, int dir, const TapIO& io, int reflect, hipStream
 }
 
 }  // namespace eben
+
+#if EBEN_T3_DBG & 512
+extern "C" __attribute__((visibility("default"))) int eben_debug_t3_stamps(unsigned long long* out, int rows) {
+  if (rows > eben::T3_STAMP_ROWS) rows = eben::T3_STAMP_ROWS;
+  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(eben::t3_stamp), (size_t)rows * 128) != hipSuccess) return 1;
+  if (!out) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(eben::t3_stamp)) != hipSuccess || hipMemset(p, 0, sizeof(unsigned long long) * eben::T3_STAMP_ROWS * 16) != hipSuccess) return 1;
+  }
+  return 0;
+}
+#endif

@@ -9,6 +9,7 @@ from __future__ import annotations
 import contextlib
 import ctypes
 import os
+import weakref
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -401,6 +402,19 @@ def pack_weights(spec: ConvSpec, d: EbenConv1dDesc, v: torch.Tensor, g: Optional
     return pw
 
 
+_replayed = weakref.WeakSet()   # every ReplayedPrepack / ReplayedChain alive: graphs_pending() asks them
+
+
+def graphs_pending() -> int:
+    """Launch sequences that are in use but still run eagerly on their way to a capture (a step that captures takes tens of ms: a
+    measurement waits until this is 0)."""
+    n = 0
+    for r in list(_replayed):
+        if type(r).enabled and r.sig is not None and r.graph is None and not ReplayedPrepack._multi_rank():
+            n += 1
+    return n
+
+
 class ReplayedPrepack:
     """Graph replay of a prepack sequence.  Rebuilding the packed weight images after an optimiser step is ~150 tiny launches per
     step (one or two per layer and direction) whose cost is entirely host-side: ~3 ms of Python / launch time per step during which
@@ -416,6 +430,7 @@ class ReplayedPrepack:
 
     def __init__(self):
         self.graph, self.sig, self.rounds = None, None, 0
+        _replayed.add(self)
 
     @staticmethod
     def _multi_rank() -> bool:
@@ -460,7 +475,7 @@ class ReplayedChain:
     gradients or weight gradients on its stream).  ``run(sig, fn, stream)`` returns what ``fn()`` returned -- tensors allocated by the
     body, which from the capture on live in the graph's pool and are REWRITTEN IN PLACE by every replay: valid until the next call.
     ``sig`` names everything the launches read besides values -- shapes, every input / weight-image / parameter address, arithmetic
-    plan -- a new signature falls back to eager calls and, once it has been seen three times in a row, a new capture.  Bodies chained
+    plan -- a new signature falls back to eager calls and, the second time in a row it is seen, a new capture.  Bodies chained
     through their results settle one after the other (the consumer's signature contains the producer's output addresses, which only
     stop changing once the producer replays).  One graph per chain and phase: no cross-stream edge inside a graph (the HIP runtime
     would serve parallel branches from extra hardware queues, see ``aux_stream``); events between chains stay outside."""
@@ -469,6 +484,7 @@ class ReplayedChain:
 
     def __init__(self):
         self.graph, self.sig, self.rounds, self.out = None, None, 0, None
+        _replayed.add(self)
 
     def run(self, sig, fn, stream_):
         if not self.enabled or ReplayedPrepack._multi_rank() or _timers_enabled():
@@ -479,7 +495,7 @@ class ReplayedChain:
         if self.graph is not None:
             self.graph.replay()
             return self.out
-        if self.rounds < 3:
+        if self.rounds < 2:
             return fn()
         graph = torch.cuda.CUDAGraph()
         try:
