@@ -704,6 +704,42 @@ def test_prepack_graph_survives_a_forward_at_another_shape(hip, golden):
     assert [k for k in a if not torch.equal(a[k], b[k])] == []
 
 
+def test_generator_graphs_match_eager_launches(hip, golden):
+    """The generator's training forward, input-gradient chain and weight-gradient launches replayed as HIP graphs (gen_engine.py:
+    forward_train / backward_train) against the same launches issued one by one: train x5 (the three sequences settle and are
+    captured) -> validation forward at another shape (image caches reallocate: the signatures change, eager rounds, new captures)
+    -> train x5, a new batch tensor every step: bit-identical parameters and outputs."""
+    from vibravox_amd import gen_engine, ops
+
+    def run(graphs):
+        prev = gen_engine.USE_GRAPHS
+        gen_engine.USE_GRAPHS = graphs
+        try:
+            mod, _, _ = make_module(golden, use_mrstft=True)
+            mod.gen_backward_math = "bf16"
+            captured = []
+            for i in range(10):
+                if i == 5:
+                    mod.validation_step({"audio_body_conducted": formula_audio("gg/val/bc", 3, 5000).to(DEV),
+                                         "audio_airborne": formula_audio("gg/val/air", 3, 5000).to(DEV)}, 0)
+                batch = {"audio_body_conducted": formula_audio(f"gg/{i}/bc", 2, 8200).to(DEV), "audio_airborne": formula_audio(f"gg/{i}/air", 2, 8200).to(DEV)}
+                mod.training_step(batch)
+                if i in (4, 9):
+                    e = mod.generator._engine
+                    captured.append(sum(g.graph is not None for g in [e._fwd_graph] + e._dx_graphs + e._dw_graphs))
+            torch.cuda.synchronize()
+            out = {f"G.{k}": v.clone() for k, v in mod.generator.state_dict().items()}
+            out.update({f"D.{k}": v.clone() for k, v in mod.discriminator.state_dict().items()})
+            out["enhanced"] = mod.generator(mod.generator.cut_to_valid_length(formula_audio("gg/probe", 2, 8200).to(DEV)))[0].detach().clone()
+            return out, captured
+        finally:
+            gen_engine.USE_GRAPHS = prev
+
+    (a, cap_a), (b, cap_b) = run(True), run(False)
+    assert cap_a == [7, 7] and cap_b == [0, 0], (cap_a, cap_b)   # forward + 3 segment groups x (input gradients, weight gradients)
+    assert [k for k in a if not torch.equal(a[k], b[k])] == []
+
+
 def test_fused_adam_follows_a_restored_state(hip):
     """optimizer.load_state_dict() after a step replaces the moment tensors: the kernel's cached table must follow (and a deep copy
     of the optimiser must step at all)."""

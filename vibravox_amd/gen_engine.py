@@ -41,6 +41,9 @@ from ._lib import check, load, ptr, stream
 USE_FUSED_RU = os.environ.get("EBEN_RU_FUSED", "1") != "0"
 USE_FUSED_RU_BWD = os.environ.get("EBEN_RU_FUSED_BWD", "1") != "0"
 USE_FUSED_RU_DW = os.environ.get("EBEN_RU_FUSED_DW", "1") != "0"
+USE_GRAPHS = os.environ.get("EBEN_GEN_GRAPHS", "1") != "0"   # training forward / backward sequences replayed as HIP graphs
+#: backward segments (3 decoder blocks, latent convs, 3 encoder blocks) per replayed graph
+BWD_GROUPS = os.environ.get("EBEN_GEN_BWD_GROUPS", "2,2,3")
 # arithmetic of the fused ResidualUnit launches (include/eben_hip.h, eben_ru_*_ex): the forward and the fp32 backward run on the bf16
 # matrix pipe with three bf16 pieces per operand (EBEN_MATH_BF16X6: every mantissa bit of the fp32 operands, fp32 accumulate --
 # fp32 arithmetic at 6/16 of the fp32 MFMA's cost); "f32" selects the v_mfma_f32_32x32x2_f32 kernels (bisecting aid).
@@ -77,6 +80,13 @@ class GeneratorEngine:
         self._s2d_images: Dict[int, tuple] = {}  # id(conv) -> (key, image of the space-to-depth form, permuted weights)
         self._prepack_graph = ops.ReplayedPrepack()
         self._ru_batch = None
+        # the training forward and, per backward segment, the input-gradient and the weight-gradient launches as replayed HIP graphs (ops.ReplayedChain)
+        self._fwd_graph = ops.ReplayedChain()
+        self._dx_graphs: List[ops.ReplayedChain] = []   # per backward segment (decoder block / latent / encoder block)
+        self._dw_graphs: List[ops.ReplayedChain] = []
+        self._static: Dict[tuple, torch.Tensor] = {}   # (name, shape) -> buffer the graphs read their per-step input from
+        self._dwq: Optional[list] = None               # while the input-gradient chain runs in queue mode: its weight-gradient work items
+        self._core_convs = None
 
     # ---- helpers ------------------------------------------------------------------------------------
     def _spec(self, m, in_slope=None, out_slope=None) -> ops.ConvSpec:
@@ -365,9 +375,11 @@ class GeneratorEngine:
                                          ptr(ws), ws_bytes, stream()), "conv1d_bwd_dx_res")
         return dx
 
-    @staticmethod
-    def _dw(rec: _ConvRec, dy):
+    def _dw(self, rec: _ConvRec, dy):
         if ops._skip_weight_grads[0]:
+            return
+        if self._dwq is not None:
+            self._dwq.append(("conv", rec, dy))
             return
         v, g = _params(rec.m)
         if not v.requires_grad:
@@ -391,6 +403,9 @@ class GeneratorEngine:
         """Weight gradients of both convs of a fused unit: one ``eben_ru_dw`` launch (reduction along time, operands straight from
         the activation tensors) where both are weight-normalised bias-free parameters, else layer by layer."""
         if ops._skip_weight_grads[0]:
+            return
+        if self._dwq is not None:
+            self._dwq.append(("ru", dil, pwc, gy, gh, bm))
             return
         (vd, gd), (vp, gp) = _params(dil.m), _params(pwc.m)
         fusable = (USE_FUSED_RU_DW and gd is not None and gp is not None and dil.m.bias is None and pwc.m.bias is None
@@ -423,37 +438,206 @@ class GeneratorEngine:
         self._dw(dil, gh)
         return gx
 
-    @torch.no_grad()
-    def backward(self, saved, g_pre: torch.Tensor) -> None:
-        """Input-gradient chain on the current stream, weight gradients through ``ops.weight_grads`` (inside
-        ``ops.weight_grads_on_side_stream()``: beside the chain, joined by the caller)."""
-        g = g_pre.contiguous()
-        skip_grads: List[Optional[torch.Tensor]] = []
-        for recs in reversed(saved["dec"]):           # decoder blocks, last first: [conv_trans, ru, ru, ru]
+    def _n_segments(self, saved) -> int:
+        return len(saved["dec"]) + 1 + len(saved["enc"])
+
+    def _bwd_segment(self, saved, k: int, g: torch.Tensor, skip_grads: list) -> torch.Tensor:
+        """Segment k of the backward -- decoder blocks (last first), the latent convs, encoder blocks (last first; the first block's
+        segment ends with first_conv's weight gradient): takes the gradient at the segment's output, returns the one at its input.
+        ``skip_grads`` collects the decoder segments' results (the gradients that join the encoder outputs)."""
+        n_dec, n_enc = len(saved["dec"]), len(saved["enc"])
+        if k < n_dec:                                 # decoder blocks, last first: [conv_trans, ru, ru, ru]
+            recs = saved["dec"][n_dec - 1 - k]
             for rec in reversed(recs[1:]):
                 g = self._ru_backward(rec, g)
             ct = recs[0]
             gs = self._dx(ct, g)                      # gradient at (x + skip)
             self._dw(ct, g)
             skip_grads.append(gs)                     # dec2 -> a1, dec1 -> a2, dec0 -> a3
-            g = gs
-        c1, c2 = saved["latent"]
-        gl1 = self._dx(c2, g)
-        self._dw(c2, g)
-        g = self._dx(c1, gl1, res_post=skip_grads[-1])   # a3: latent path (masked by lrelu'(a3)) + the decoder's skip
-        self._dw(c1, gl1)
-        n_enc = len(saved["enc"])
-        for i in range(n_enc - 1, -1, -1):            # encoder blocks, last first: [ru, ru, ru, conv]
-            recs = saved["enc"][i]
-            conv = recs[-1]
-            gy = self._dx(conv, g)
-            self._dw(conv, g)
-            for rec in reversed(recs[1:-1]):
-                gy = self._ru_backward(rec, gy)
-            # the block's input a_i is also a decoder block's skip: that gradient joins behind the activation mask
-            post = skip_grads[i - 1] if i >= 1 else None   # skip_grads: [a1 (dec2), a2 (dec1), a3 (dec0)]
-            g = self._ru_backward(recs[0], gy, res_post=post)
-        self._dw(saved["misc"][0], g)                 # first_conv: its input is data, only the weight gradient
+            return gs
+        if k == n_dec:
+            c1, c2 = saved["latent"]
+            gl1 = self._dx(c2, g)
+            self._dw(c2, g)
+            g = self._dx(c1, gl1, res_post=skip_grads[-1])   # a3: latent path (masked by lrelu'(a3)) + the decoder's skip
+            self._dw(c1, gl1)
+            return g
+        i = n_enc - 1 - (k - n_dec - 1)               # encoder blocks, last first: [ru, ru, ru, conv]
+        recs = saved["enc"][i]
+        conv = recs[-1]
+        gy = self._dx(conv, g)
+        self._dw(conv, g)
+        for rec in reversed(recs[1:-1]):
+            gy = self._ru_backward(rec, gy)
+        # the block's input a_i is also a decoder block's skip: that gradient joins behind the activation mask
+        post = skip_grads[i - 1] if i >= 1 else None   # skip_grads: [a1 (dec2), a2 (dec1), a3 (dec0)]
+        g = self._ru_backward(recs[0], gy, res_post=post)
+        if i == 0:
+            self._dw(saved["misc"][0], g)             # first_conv: its input is data, only the weight gradient
+        return g
+
+    @torch.no_grad()
+    def backward(self, saved, g_pre: torch.Tensor) -> None:
+        """Input-gradient chain on the current stream, weight gradients through ``ops.weight_grads`` (inside
+        ``ops.weight_grads_on_side_stream()``: beside the chain, joined by the caller)."""
+        g = g_pre.contiguous()
+        skip_grads: List[Optional[torch.Tensor]] = []
+        for k in range(self._n_segments(saved)):
+            g = self._bwd_segment(saved, k, g, skip_grads)
+
+    # ---- the training step's three launch sequences as replayed graphs ----------------------------------------------------------
+    # ~36 launches forward, ~50 along the input-gradient chain and ~30 weight-gradient launches per step, each a few microseconds of
+    # GPU-side dispatch but 15-30 us of Python + ctypes on the host: 1.2 + 2.2 + 0.5 ms of host time per step ([MI355X]
+    # tools/host_times.py) on a 12 ms step whose host side took 11.3 ms in all.  Every per-step input is copied into a static
+    # buffer, every tensor the bodies allocate lives in the graph's pool (rewritten in place by the next replay: valid until then,
+    # which is as long as the step needs it), and the weight images are the ones prepack() rebuilds in place.
+    @staticmethod
+    def _graphs_usable() -> bool:
+        return USE_GRAPHS and ops.ReplayedChain.enabled and not ops.ReplayedPrepack._multi_rank() and not ops._timers_enabled()
+
+    def _static_buf(self, name: str, like: torch.Tensor) -> torch.Tensor:
+        key = (name, tuple(like.shape), like.dtype, like.device)
+        buf = self._static.get(key)
+        if buf is None:
+            buf = self._static[key] = torch.empty_like(like, memory_format=torch.contiguous_format)
+        return buf
+
+    def _fwd_sig(self, buf: torch.Tensor) -> tuple:
+        """Everything the captured forward depends on besides values: input buffer, arithmetic, and per layer the weight-image
+        buffers and whether they are current (a stale image makes the eager path rebuild it -- a replay would not)."""
+        if self._core_convs is None:
+            gen = self.gen
+            from .torch_modules.utils import HipConv1d
+            self._core_convs = [m for part in (gen.first_conv, gen.encoder_blocks, gen.latent_conv, gen.decoder_blocks)
+                                for m in part.modules() if isinstance(m, HipConv1d)]
+            self._core_units = [ru for blk in list(gen.encoder_blocks) + list(gen.decoder_blocks) for ru in blk.residuals]
+        addr = lambda t: 0 if t is None else t.data_ptr()
+        parts = [buf.data_ptr(), tuple(buf.shape), ops._backward_math[0], CONV_FWD_MATH, RU_FWD_MATH]
+        for m in self._core_convs:
+            pw = m._packed
+            if pw is None or pw.last is None:
+                parts.append(None)
+                continue
+            v, g = _params(m)
+            parts.append((addr(pw.wp_fwd), addr(pw.wp_bwd), addr(pw.scale), addr(pw.norm), pw.key == ops._pack_key(v, g, pw.last[1], pw.last[2])))
+        e = ops._storage_epoch
+        for ru in self._core_units:
+            hit = self._ru_images.get(id(ru))
+            if hit is None:
+                parts.append(None)
+                continue
+            ts = _params(ru.dilated_conv) + _params(ru.pointwise_conv)
+            key = tuple((t.data_ptr(), t._version, e.get(t.data_ptr(), 0)) for t in ts) + (e.get(-1, 0),)
+            parts.append((hit["fwd"].data_ptr(), tuple((k, hit["bwd"][k].data_ptr()) for k in sorted(hit["bwd"])), hit["scales"].data_ptr(), hit["key"] == key))
+        return tuple(parts)
+
+    def forward_train(self, x: torch.Tensor):
+        """``forward(x, True)``, replayed as a graph once the sequence has settled."""
+        self._fwd_replayed = False
+        if not self._graphs_usable():
+            return self.forward(x, True)
+        ops.join_prepack()
+        ev = getattr(self, "_prepacked", None)
+        if ev is not None:   # the waits stay outside the graph
+            self._prepacked = None
+            torch.cuda.current_stream().wait_event(ev)
+        buf = self._static_buf("x", x)
+        buf.copy_(x)
+        out = self._fwd_graph.run(self._fwd_sig(buf), lambda: self.forward(buf, True), None)
+        self._fwd_replayed = self._fwd_graph.graph is not None
+        return out
+
+    def _deferrable(self) -> bool:
+        """Weight gradients of the whole core go through ``weight_grads_on_side_stream().join()``'s assignment (no gradient held, no
+        hook, no data-parallel sink)."""
+        if not ops._side["enabled"] or ops._side["sink"] is not None or ops._skip_weight_grads[0]:
+            return False
+        for m in self._core_convs:
+            for p in _params(m) + (m.bias,):
+                if p is not None and (not p.requires_grad or p.grad is not None or not ops._no_grad_hooks(p)):
+                    return False
+        return True
+
+    def _dw_body(self, queue: list) -> list:
+        """The queued weight-gradient work on the current stream: every layer's kernel, then ONE slab-sum / weight-norm launch.
+        Returns [(parameter, gradient)]."""
+        jobs, assign = [], []
+        with ops.collect_wn_jobs(jobs):
+            for item in queue:
+                if item[0] == "conv":
+                    _, rec, dy = item
+                    v, g = _params(rec.m)
+                    grads = ops.weight_grads(rec.d, dy, rec.y, rec.x, v, g, rec.m.bias, rec.norm)
+                    assign.extend((p, t) for p, t in zip((v, g, rec.m.bias), grads) if p is not None and t is not None)
+                else:
+                    _, dil, pwc, gy, gh, bm = item
+                    (vd, gd), (vp, gp) = _params(dil.m), _params(pwc.m)
+                    res = False
+                    if USE_FUSED_RU_DW and gd is not None and gp is not None and dil.m.bias is None and pwc.m.bias is None and bm in (ops.MATH_BF16, ops.MATH_BF16X6):
+                        res = ops.weight_grads_ru(bm, dil.spec.dilation, gy, pwc.y, float(pwc.spec.out_slope), pwc.x, gh, dil.x, float(dil.spec.in_slope),
+                                                  (vp, gp, pwc.norm), (vd, gd, dil.norm))
+                    if res is False:
+                        for rec, dy in ((pwc, gy), (dil, gh)):
+                            v, g = _params(rec.m)
+                            grads = ops.weight_grads(rec.d, dy, rec.y, rec.x, v, g, rec.m.bias, rec.norm)
+                            assign.extend((p, t) for p, t in zip((v, g, rec.m.bias), grads) if p is not None and t is not None)
+                    else:
+                        assign.extend(zip((vp, gp), res[0][:2]))
+                        assign.extend(zip((vd, gd), res[1][:2]))
+        ops.wn_bwd_multi(jobs)
+        return assign
+
+    @torch.no_grad()
+    def backward_train(self, saved, g_pre: torch.Tensor) -> None:
+        """``backward(saved, g_pre)``; behind a replayed forward and inside ``ops.weight_grads_on_side_stream()``: per segment (decoder
+        block / latent convs / encoder block) the input-gradient launches as one graph on the current stream and the segment's
+        weight-gradient launches as one graph on the side stream behind it -- the weight gradients of segment k run beside the
+        input-gradient chain of segment k + 1, as the launch-by-launch schedule has them.  Results are assigned by the context's
+        ``join()``.  ([MI355X] as two graphs -- the whole chain, then all weight gradients -- the step went 12.0 -> 12.5 ms: the chain
+        alone fills a fraction of the GPU.)"""
+        if not (self._graphs_usable() and getattr(self, "_fwd_replayed", False) and saved is self._fwd_graph.out[2] and self._deferrable()):
+            return self.backward(saved, g_pre)
+        gbuf = self._static_buf("g", g_pre)
+        gbuf.copy_(g_pre)
+        n = self._n_segments(saved)
+        # segments per graph: a replay costs ~70 us of host time, a graph per segment (14 replays) 1.35 ms per step against 0.74 for two
+        # graphs; three groups keep the weight gradients beside the chain at 0.5 ms
+        sizes = [int(t) for t in BWD_GROUPS.split(",")] if BWD_GROUPS else []
+        if sum(sizes) != n:
+            sizes = [1] * n
+        bounds = [sum(sizes[:i]) for i in range(len(sizes) + 1)]
+        while len(self._dx_graphs) < len(sizes):
+            self._dx_graphs.append(ops.ReplayedChain())
+            self._dw_graphs.append(ops.ReplayedChain())
+        dev = gbuf.device
+        main = torch.cuda.current_stream(dev)
+        side = ops._side_stream(dev)
+        g, skip_grads = gbuf, []
+        for k in range(len(sizes)):
+            def dx_body(k=k, g=g):
+                self._dwq = []
+                sk = list(skip_grads)
+                try:
+                    out = g
+                    for seg in range(bounds[k], bounds[k + 1]):
+                        out = self._bwd_segment(saved, seg, out, sk)
+                finally:
+                    queue, self._dwq = self._dwq, None
+                return out, sk[len(skip_grads):], queue
+
+            # one signature for all segments: they settle, and are captured, in the same step, each on the results of the one before
+            g, new_skips, queue = self._dx_graphs[k].run((self._fwd_graph.captures, gbuf.data_ptr(), ops._backward_math[0]), dx_body, None)
+            skip_grads.extend(new_skips)
+            if not queue:
+                continue
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                if self._dx_graphs[k].graph is not None:
+                    assign = self._dw_graphs[k].run((self._dx_graphs[k].captures,), lambda: self._dw_body(queue), side)
+                else:
+                    assign = self._dw_body(queue)
+                    ops._side["keep"].append(queue)   # eager tensors: referenced until join()
+            ops._side["assign"].extend((p, t) for p, t in assign if p.requires_grad)
 
 
 class _CoreFn(torch.autograd.Function):
@@ -462,14 +646,17 @@ class _CoreFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, engine, *params):
-        pre, first_bands, saved = engine.forward(x, True)
+        pre, first_bands, saved = engine.forward_train(x)
         ctx.engine, ctx.saved = engine, saved
+        # fresh tensor objects: behind a replayed forward `pre` is the SAME object every step, and autograd writes this call's history
+        # into what it is handed
+        pre, first_bands = pre.detach(), first_bands.detach()
         ctx.mark_non_differentiable(first_bands)
         return pre, first_bands
 
     @staticmethod
     def backward(ctx, g_pre, _g_fb):
-        ctx.engine.backward(ctx.saved, g_pre)
+        ctx.engine.backward_train(ctx.saved, g_pre)
         return (None, None) + (None,) * (len(ctx.needs_input_grad) - 2)
 
 

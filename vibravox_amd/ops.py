@@ -484,6 +484,7 @@ class ReplayedChain:
 
     def __init__(self):
         self.graph, self.sig, self.rounds, self.out = None, None, 0, None
+        self.captures = 0   # how many times this chain has been captured: names the generation of the tensors in ``out``
         _replayed.add(self)
 
     def run(self, sig, fn, stream_):
@@ -499,6 +500,8 @@ class ReplayedChain:
             return fn()
         graph = torch.cuda.CUDAGraph()
         try:
+            # stream_ None: torch's own capture stream (a sequence that normally runs on the default stream, which cannot capture);
+            # the replays are launched on whatever stream is current then
             with torch.cuda.graph(graph, stream=stream_, capture_error_mode="thread_local"):
                 out = fn()
         except Exception as exc:   # capture is an optimisation: fall back to eager launches for good
@@ -508,6 +511,7 @@ class ReplayedChain:
             ReplayedChain.enabled = False
             return fn()
         self.graph, self.out = graph, out
+        self.captures += 1
         graph.replay()   # the capture recorded the launches without running them
         return out
 
@@ -633,8 +637,31 @@ def weight_grads(d: EbenConv1dDesc, dy: torch.Tensor, y: Optional[torch.Tensor],
         _wg_defer(job, outs, v, g, bias, sunk)
         return None, None, None
     check(lib.eben_conv1d_bwd_dw(ctypes.byref(d), ptr(dy), ptr(y), ptr(x), 1 if has_bias else 0, ptr(slabs), ws_bytes, stream()), "conv1d_bwd_dw")
-    wn_bwd_multi([job])
+    if _wn_collect[0] is not None:
+        _wn_collect[0].append(job)
+    else:
+        wn_bwd_multi([job])
     return outs
+
+
+_wn_collect = [None]   # inside collect_wn_jobs(): the list the immediate path appends its slab-sum / weight-norm jobs to
+
+
+class collect_wn_jobs:
+    """Inside this context the immediate path of ``weight_grads`` / ``weight_grads_ru`` (no side-stream deferral: the caller has made
+    the stream the work belongs on current) launches the weight-gradient kernels only and appends the slab-sum + weight-norm job of
+    each layer to ``jobs``: the caller runs them as ONE ``wn_bwd_multi(jobs)`` (gen_engine's graph-captured weight-gradient body)."""
+
+    def __init__(self, jobs: list):
+        self.jobs = jobs
+
+    def __enter__(self):
+        self.prev = (_wn_collect[0], _side["enabled"])
+        _wn_collect[0], _side["enabled"] = self.jobs, False
+        return self
+
+    def __exit__(self, *exc):
+        _wn_collect[0], _side["enabled"] = self.prev
 
 
 def _wg_route(v, g, bias):
@@ -709,7 +736,10 @@ def weight_grads_ru(math: int, dilation: int, gy: torch.Tensor, u: torch.Tensor,
         _wg_defer(job_p, outs_p, vp, gp, None, route_p[1])
         _wg_defer(job_d, outs_d, vd, gd, None, route_d[1])
         return (None, None, None), (None, None, None)
-    wn_bwd_multi([job_p, job_d])
+    if _wn_collect[0] is not None:
+        _wn_collect[0].extend((job_p, job_d))
+    else:
+        wn_bwd_multi([job_p, job_d])
     return outs_p, outs_d
 
 
