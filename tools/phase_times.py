@@ -5,12 +5,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 dev = torch.device("cuda", 0)
 mod = bench.build_module(dev, 1234)
-mod.disc_math = os.environ.get("EBEN_DISC_MATH", "bf16"); mod.gen_backward_math = os.environ.get("EBEN_GEN_BWD_MATH", mod.disc_math)
+mod.disc_math = os.environ.get("EBEN_DISC_MATH", "bf16_bl"); mod.gen_backward_math = os.environ.get("EBEN_GEN_BWD_MATH", "f32" if mod.disc_math == "f32" else "bf16")
+mod.stft_math = "folded" if mod.disc_math == "f32" else "folded_x3"
 if os.environ.get("NO_RECON", "0") == "1":   # the discriminator phases alone: how long the chains take with nothing beside them
     mod.reconstructive_loss_freq_fn = None
     mod.reconstructive_loss_temp_fn = None
 batch = bench.synthetic_batch(32, 32000, 1234, dev)
-for _ in range(3):
+for _ in range(8):
     mod.training_step(batch)
 torch.cuda.synchronize()
 import gc; gc.collect(); gc.freeze()

@@ -250,7 +250,13 @@ static void make_bldw_plan(const Canon& c, BlDwPlan* p) {
   if (amax - p->amin > 60 || c.s > 8) return;           // BKT + halo units per X row must fit the two DMA pieces
   p->FM = (p->Mg > 64 && round_up(p->Mg, 128) == round_up(p->Mg, 64)) ? 2 : 1;
   p->NQW = p->CgB * c.k;
-  p->FN = p->NQW + 1 > 8 ? 2 : 1;
+  // column bundles per wave: the A tile (64 FM rows x 64 time steps) and the X rows (every stride phase of the ~2 channel bundles a
+  // tile's columns touch, 128 units each) are moved per chunk whatever the tile's width -- at 128 columns a 128-row tile asks the
+  // L2 for 32 KB per 64 MFMAs, ~50 TB/s chip-wide at the MFMA rate; 256 columns halve that at the same LDS footprint
+  static const int fn_max = getenv("EBEN_BLDW_FN") ? atoi(getenv("EBEN_BLDW_FN")) : 4;
+  // [MI355X, 64 rows] MelGAN L1-L5 0.124 / 0.106 / 0.286 / 0.331 / 0.175 -> 0.097 / 0.085 / 0.255 / 0.301 / 0.146 ms; the PQMF-band
+  // layers (7 taps, 42-84 column bundles: three 256-column tiles where six 128-column ones covered them as well) lose 10-40 %
+  p->FN = (fn_max >= 4 && (c.k >= 16 || p->NQW >= 256)) ? 4 : p->NQW + 1 > 8 ? 2 : 1;
   const int BNQ = 8 * p->FN;
   p->nmt = ceil_div(p->Mg, 64 * p->FM);
   p->nnt = ceil_div(p->NQW + 1, BNQ);
@@ -337,6 +343,6 @@ extern "C" int eben_bl_conv1d_bwd_dw(const EbenConv1dDesc* d, const void* dy_hi,
   a.nnt = p.nnt; a.nmt = p.nmt; a.nsplit = p.nsplit; a.nct = p.nct; a.nchunks = p.nchunks; a.XR = p.XR;
   a.dense = p.dense; a.c_in_g = c.Cin / c.g; a.c_out_g = c.Cout / c.g; a.row_stride = p.row_stride; a.slab_stride = p.slab_stride;
   hipStream_t st = as_stream(stream);
-  if (p.FM == 2) return p.FN == 2 ? launch_bldw<2, 2>(a, p, st) : launch_bldw<2, 1>(a, p, st);
-  return p.FN == 2 ? launch_bldw<1, 2>(a, p, st) : launch_bldw<1, 1>(a, p, st);
+  if (p.FM == 2) return p.FN == 4 ? launch_bldw<2, 4>(a, p, st) : p.FN == 2 ? launch_bldw<2, 2>(a, p, st) : launch_bldw<2, 1>(a, p, st);
+  return p.FN == 4 ? launch_bldw<1, 4>(a, p, st) : p.FN == 2 ? launch_bldw<1, 2>(a, p, st) : launch_bldw<1, 1>(a, p, st);
 }
