@@ -422,15 +422,16 @@ __global__ __launch_bounds__(256, NPW >= 2 ? 1 : 2) void tap3_kernel(const Tap3A
   if constexpr (PREF) {
     if (P.eh != nullptr && !(EBEN_T3_DBG & 32)) {
       const int tq = t0 + wn * 32 + (lane & 31);
-      const unsigned colq = (unsigned)(tq < nt ? tq : nt - 1) * (unsigned)P.OS + (unsigned)oo;
-      const long long erowq = ((long long)eb * P.CBy + ((g * P.Mg) >> 3)) * P.Ly;
+      const unsigned loffq = (((unsigned)(tq < nt ? tq : nt - 1) * (unsigned)P.OS + (unsigned)oo) * 2u + (unsigned)(lane >> 5)) * 8u;
+      const long long Lrowq = (long long)P.Ly * 16;
+      const char* ehq = reinterpret_cast<const char*>(P.eh) + (long long)eb * P.CBy * Lrowq + ((long long)((g * P.Mg + m0) >> 3)) * Lrowq;
+      const int quadsq = (P.Mg - m0 + 7) >> 3;
 #pragma unroll
       for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int r4 = 0; r4 < 4; ++r4) {
-          const int m4 = m0 + i * 32 + 8 * r4 + 4 * (lane >> 5);
-          const int mb = m4 < P.Mg ? (m4 >> 3) : 0;
-          pah[i][r4] = P.eh[erowq * 2 + ((long long)mb * P.Ly + colq) * 2 + (lane >> 5)];
+          const int q = 4 * i + r4;
+          pah[i][r4] = *reinterpret_cast<const uint2*>(ehq + (long long)(q < quadsq ? q : 0) * Lrowq + loffq);
         }
     }
   }
@@ -509,42 +510,51 @@ __global__ __launch_bounds__(256, NPW >= 2 ? 1 : 2) void tap3_kernel(const Tap3A
   if (t >= nt) return;
   if constexpr (BL) {
     // row quad r4 of accumulator tile i: channels m4 .. m4+3 of the group, m4 = m0 + 32 i + 8 r4 + 4 (lane >> 5), i.e. half (lane >> 5)
-    // of bundle (m0 >> 3) + 4 i + r4 -- one 8-byte piece per lane, 512 contiguous bytes per wave and quad
-    const unsigned colb = (unsigned)t * (unsigned)P.OS + (unsigned)oo;
+    // of bundle (m0 >> 3) + 4 i + r4 -- one 8-byte piece per lane, 512 contiguous bytes per wave and quad.
+    // Addresses: the bundle row is block-uniform (a scalar base per quad), the lane's place in it -- column and half -- is ONE 32-bit
+    // byte offset for the whole epilogue (a group's rows of one batch item span < 2^31 bytes); whether a quad exists (m < Mg) is
+    // uniform too, Mg being a multiple of 8.  (The thin layers are bound by the vector-instruction issue: ~660 VALU instructions per
+    // wave around 41 MFMAs, a third of them this epilogue's 64-bit per-lane address arithmetic and per-lane predicates.)
     const int hb = lane >> 5;
-    const int gB = (g * P.Mg) >> 3;                       // first bundle of the group in the output / activation planes
-    const long long yrow = ((long long)b * P.CBy + gB) * P.Ly;
-    const long long erow = ((long long)eb * P.CBy + gB) * P.Ly;
-    const long long rrow = ((long long)(b + P.bl_ref_off) * P.CBy + gB) * P.Ly;
+    const unsigned loff = (((unsigned)t * (unsigned)P.OS + (unsigned)oo) * 2u + (unsigned)hb) * 8u;   // bytes inside a bundle row
+    const long long Lrow = (long long)P.Ly * 16;                                                           // bytes per bundle row
+    const long long tile0 = ((long long)((g * P.Mg + m0) >> 3)) * Lrow;                                    // this tile's first bundle row
+    const char* ehb = reinterpret_cast<const char*>(P.eh) + (long long)eb * P.CBy * Lrow + tile0;
+    const char* elb = reinterpret_cast<const char*>(P.el) + (long long)eb * P.CBy * Lrow + tile0;
+    const char* rhb = reinterpret_cast<const char*>(P.eh) + (long long)(b + P.bl_ref_off) * P.CBy * Lrow + tile0;
+    const char* rlb = reinterpret_cast<const char*>(P.el) + (long long)(b + P.bl_ref_off) * P.CBy * Lrow + tile0;
+    char* yhb = reinterpret_cast<char*>(P.yh) + (long long)b * P.CBy * Lrow + tile0;
+    char* ylb = reinterpret_cast<char*>(P.yl) + (long long)b * P.CBy * Lrow + tile0;
     const bool masked = P.eh != nullptr && !(EBEN_T3_DBG & 32);
     auto unpack = [](uint2 w, float (&f)[4]) {
       f[0] = __builtin_bit_cast(float, w.x << 16); f[1] = __builtin_bit_cast(float, w.x & 0xffff0000u);
       f[2] = __builtin_bit_cast(float, w.y << 16); f[3] = __builtin_bit_cast(float, w.y & 0xffff0000u);
     };
+    auto ld2 = [&](const char* base, long long row) { return *reinterpret_cast<const uint2*>(base + row + loff); };
+    const int quads = (P.Mg - m0 + 7) >> 3;   // bundle rows of this tile that exist (uniform)
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
       uint2 ah[4], al[4], rh[4], rl[4];
       float bz[4][4];
-      long long off[4];
-      bool live[4];
 #pragma unroll
       for (int r4 = 0; r4 < 4; ++r4) {
-        const int m4 = m0 + i * 32 + 8 * r4 + 4 * hb;
-        live[r4] = m4 < P.Mg;
-        const int mb = live[r4] ? (m4 >> 3) : 0;
-        off[r4] = ((long long)mb * P.Ly + colb) * 2 + hb;
+        const int q = 4 * i + r4;
+        const long long row = (long long)(q < quads ? q : 0) * Lrow;   // uniform; a missing quad re-reads the tile's first row
         {
           const float4 bq = *reinterpret_cast<const float4*>(Bs + i * 32 + 8 * r4 + 4 * hb);
           bz[r4][0] = bq.x; bz[r4][1] = bq.y; bz[r4][2] = bq.z; bz[r4][3] = bq.w;
         }
         if (masked) {
           if constexpr (PREF) ah[r4] = pah[i][r4];
-          else ah[r4] = P.eh[erow * 2 + off[r4]];
-          if (fmr) { al[r4] = P.el[erow * 2 + off[r4]]; rh[r4] = P.eh[rrow * 2 + off[r4]]; rl[r4] = P.el[rrow * 2 + off[r4]]; }
+          else ah[r4] = ld2(ehb, row);
+          if (fmr) { al[r4] = ld2(elb, row); rh[r4] = ld2(rhb, row); rl[r4] = ld2(rlb, row); }
         }
       }
 #pragma unroll
       for (int r4 = 0; r4 < 4; ++r4) {
+        const int q = 4 * i + r4;
+        if (q >= quads) continue;   // uniform
+        const long long row = (long long)q * Lrow;
         float v[4], a0[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = acc[i][4 * r4 + e] + bz[r4][e];
@@ -567,13 +577,13 @@ __global__ __launch_bounds__(256, NPW >= 2 ? 1 : 2) void tap3_kernel(const Tap3A
         }
         uint2 h;
         h.x = pack_bf16(v[0], v[1]); h.y = pack_bf16(v[2], v[3]);
-        if (live[r4] && !((EBEN_T3_DBG & 128) && h.x != 0x12345u)) P.yh[yrow * 2 + off[r4]] = h;
+        if (!((EBEN_T3_DBG & 128) && h.x != 0x12345u)) *reinterpret_cast<uint2*>(yhb + row + loff) = h;
         if (P.yl) {
           float hf[4];
           unpack(h, hf);
           uint2 l;
           l.x = pack_bf16(v[0] - hf[0], v[1] - hf[1]); l.y = pack_bf16(v[2] - hf[2], v[3] - hf[3]);
-          if (live[r4] && !((EBEN_T3_DBG & 128) && l.x != 0x12345u)) P.yl[yrow * 2 + off[r4]] = l;
+          if (!((EBEN_T3_DBG & 128) && l.x != 0x12345u)) *reinterpret_cast<uint2*>(ylb + row + loff) = l;
         }
       }
     }
