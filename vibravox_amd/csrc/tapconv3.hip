@@ -69,6 +69,9 @@ __device__ unsigned long long t3_stamp[T3_STAMP_ROWS * 16];
 // NPW times the weight bytes and 3 / 6 times the MFMAs
 __host__ __device__ constexpr int t3_ksc(int npw, int fm = 4) { return npw == 1 ? (fm <= 2 ? EBEN_T3_KSC : EBEN_T3_KSC_BIGFM) : 2; }
 __host__ __device__ constexpr int t3_ring(int npw, int fm) { return t3_ksc(npw, fm) * npw * fm <= 8 ? EBEN_T3_RING_SMALL : EBEN_T3_RING_BIG; }
+// 16 zero bytes in device memory: where the lanes of an input-tile LDS-DMA piece that fall into the zero padding read from
+__device__ u32x4 t3_zero_unit = {0u, 0u, 0u, 0u};
+
 template <int N> __device__ __forceinline__ void t3_wait_vm() {   // s_waitcnt vmcnt(N) lgkmcnt(0)
   static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit count");
   __builtin_amdgcn_s_waitcnt((N & 15) | ((N >> 4) << 14) | 0x70);
@@ -124,6 +127,7 @@ __global__ __launch_bounds__(256, NPW >= 2 ? 1 : 2) void tap3_kernel(const Tap3A
   constexpr int WU = (WCHU + NT - 1) / NT;        // LDS-DMA instructions per thread and chunk
   static_assert(WCHU % 64 == 0, "weight chunk must split into whole wave pieces");
   static_assert(DIST >= 1 && DIST <= 3, "ring depth");
+  static_assert(!BL || DIST == 1, "the input-tile LDS-DMA of the bundle layout is waited for by the chunk's vmcnt(0)");
 
   extern __shared__ __attribute__((aligned(16))) u32x4 smem3[];
   u32x4* Ws = smem3;              // RING x WCHU
@@ -316,6 +320,38 @@ __global__ __launch_bounds__(256, NPW >= 2 ? 1 : 2) void tap3_kernel(const Tap3A
     }
   };
 
+  // Bundle layout at stride 1 (every input gradient, the stride-1 forwards): a tile row -- one bundle over `span` consecutive positions
+  // -- is a run of consecutive 16-byte units both in the plane and in LDS, so the tile is MOVED by LDS-DMA in pieces of 64 units (one
+  // per wave instruction; lanes past the row's end masked off, lanes in the zero padding / past the group's last bundle reading the
+  // zero unit) instead of loaded, selected and written unit by unit: ~8 vector instructions per piece against ~40 per unit pair, no
+  // ds_write, no staging registers.  (The thin layers are bound by vector-instruction issue, see the epilogue.)
+  // [MI355X, 64 / 128 rows] single-tile launches (PQMF-band input gradients) 0.070 / 0.063 / 0.071 -> 0.067 / 0.058 / 0.068 ms; with
+  // the tile refreshed inside the loop (MelGAN L3 input gradient, L5 forward) the DMA issued at the hand-over has one chunk to land
+  // where the register path had its loads in flight a chunk earlier: 0.405 -> 0.429, 0.091 -> 0.104 -- those keep the register path
+  const bool dma_x = BL && P.S == 1 && P.ncc == 1 && !(EBEN_T3_DBG & 1024);
+  auto dma_tile = [&](int cc, u32x4* dst) {
+    const int ppr = (span + 63) >> 6;   // pieces per bundle row
+    int bb = 0, pr = __builtin_amdgcn_readfirstlane(tid >> 6);
+    while (pr >= ppr) { pr -= ppr; ++bb; }
+    while (bb < P.CI_B) {
+      const int r = pr * 64 + lane;
+      const int qq = q0 + r;
+      const int cbn = cc * P.CI_B + bb;
+      const bool in = qq >= 0 && qq < P.Lx && cbn < CgB;
+      const long long idx = xrowB + (long long)(cbn < CgB ? cbn : 0) * P.Lx + (in ? qq : 0);
+      u32x4* d = dst + bb * P.CSTRIDE + pr * 64;   // uniform
+      if (r < span) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(in ? P.xh + idx : &t3_zero_unit),
+                                         (__attribute__((address_space(3))) void*)d, 16, 0, 0);
+        if constexpr (NPX > 1)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(in ? P.xl + idx : &t3_zero_unit),
+                                           (__attribute__((address_space(3))) void*)(d + LO), 16, 0, 0);
+      }
+      pr += NT / 64;
+      while (pr >= ppr) { pr -= ppr; ++bb; }
+    }
+  };
+
   auto issue_w = [&](int ch) {
     const u32x4* src = wsrc + (long long)ch * WCHU;
     u32x4* dst = Ws + (ch % RING) * WCHU;
@@ -400,9 +436,10 @@ __global__ __launch_bounds__(256, NPW >= 2 ? 1 : 2) void tap3_kernel(const Tap3A
         }
     };
     Round ra, rb;
-    if (xtot > 0) pro_load(0, ra);
+    if (dma_x) dma_tile(0, Xs);
+    else if (xtot > 0) pro_load(0, ra);
     T3_STAMP(2);
-    for (int base = 0; base < ((EBEN_T3_DBG & 64) ? 0 : xtot); base += 4 * NT) {
+    for (int base = 0; base < (((EBEN_T3_DBG & 64) || dma_x) ? 0 : xtot); base += 4 * NT) {
       const bool second = base + 2 * NT < xtot;
       if (second) pro_load(base + 2 * NT, rb);
       pro_store(ra);
@@ -411,7 +448,7 @@ __global__ __launch_bounds__(256, NPW >= 2 ? 1 : 2) void tap3_kernel(const Tap3A
         pro_store(rb);
       }
     }
-    if (P.ncc > 1) fetch_x(1);
+    if (P.ncc > 1 && !dma_x) fetch_x(1);
   }
   T3_STAMP(3);
   __syncthreads();
@@ -448,7 +485,7 @@ __global__ __launch_bounds__(256, NPW >= 2 ? 1 : 2) void tap3_kernel(const Tap3A
 #pragma unroll
     for (int ks = 0; ks < KSC; ++ks) tn[ks] = tab[(ch + 1 < nch ? ch + 1 : ch) * KSC + ks];
     if ((EBEN_T3_DBG & 1) == 0 && ch + DIST < nch) issue_w(ch + DIST);   // into the slot of chunk ch - 1 (behind the barrier that ended it)
-    if ((EBEN_T3_DBG & 2) == 0 && pending >= 0) { fetch_x(pending); pending = -1; }
+    if ((EBEN_T3_DBG & 2) == 0 && pending >= 0 && !dma_x) { fetch_x(pending); pending = -1; }
     const u32x4* wb = Ws + (ch % RING) * WCHU + lane;
     const u32x4* xb = Xs + lanebase;
     u32x4 bv[KSC][NPX], a[KSC][NPW][FM];
