@@ -55,16 +55,16 @@ def build_module(device, batch_seed):
     return mod
 
 
-def pmc_traffic(batch, math):
-    """HBM bytes per launch of the roofline kernel from this round's rocprofv3 PMC passes (profiles/r03_pmc_melgan_l4_fwd_<math>.json,
-    written by tools/pmc_traffic.sh + tools/pmc_summary.py for the build whose commit it records, at the batch the step launches;
-    FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  None when the record is missing or of another batch."""
-    path = os.path.join(ROOT, "profiles", f"r03_pmc_melgan_l4_fwd_{math}.json")
-    if not os.path.exists(path):
-        return None
+def pmc_family(math):
+    """Roofline records with HBM traffic from this round's rocprofv3 PMC passes (tools/pmc_family_bl.sh -> profiles/r03_pmc_family.json:
+    FETCH_SIZE / WRITE_SIZE / TCC hit + miss in separate passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950): the
+    roofline kernel (MelGAN L4 forward), its weight gradient and one PQMF-band mid layer, each launched alone at the step's row
+    counts.  Empty for the plans the passes were not taken in."""
+    path = os.path.join(ROOT, "profiles", "r03_pmc_family.json")
+    if math != "bf16_bl" or not os.path.exists(path):
+        return []
     with open(path) as f:
-        rec = json.load(f)
-    return rec.get("traffic_bytes_per_launch") if rec.get("launch_batch") == batch else None
+        return json.load(f)
 
 
 def noisy_bwe_source(device, n_items=64, seed=4321):
@@ -394,7 +394,8 @@ def main():
         kn = ("tap3_kernel<4,*,BL> (v_mfma_f32_32x32x16_bf16, bf16 bundles at rest)" if args.disc_math == "bf16_bl" else
               "tap3_kernel<4,*> (v_mfma_f32_32x32x16_bf16)" if bf16 else "tap2_kernel<4,4,16> (v_mfma_f32_32x32x2_f32)")
         roof, flops = launch_record(timer, "fwd", kn)
-        roof["traffic"] = pmc_traffic(timer.batch or 2 * args.batch, args.disc_math if bf16 else "f32")
+        family = pmc_family(args.disc_math) if (timer.batch or 2 * args.batch) == 64 else []
+        roof["traffic"] = next((r["traffic_bytes"] for r in family if r["name"] == "melgan_l4_fwd"), None)
         if iso_ms:
             roof["isolated"] = {"launch_ms": round(iso_ms, 4), "achieved": round(flops / (iso_ms * 1e-3) / 1e12, 2),
                                 "frac": round(flops / (iso_ms * 1e-3) / 1e12 / peak, 4),
@@ -423,6 +424,7 @@ def main():
                         "mean": round(sum(per_step) / len(per_step), 3), "clock": "HIP events at the step boundaries on the main stream"},
             "roofline": roof,
             "roofline_time_dominant": roof_t,
+            "roofline_family": family,
             "step_roofline": {"ideal_ms": round(ideal, 3), "frac": round(ideal / ms, 4),
                               "note": "sum over the parts of F_min = 2(3G+8D) of max(FLOP / MFMA peak of the part's dtype, bytes / 8 TB/s) / measured ms per step "
                                       "(SURVEY 8d; G = 6.727e8, D = 2.5255e9 MACs per audio-second)"},

@@ -9,7 +9,7 @@ CS = os.path.join(ROOT, "vibravox_amd", "csrc")
 def analyse(stem, extra=()):
     with tempfile.TemporaryDirectory() as td:
         cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", f"-I{ROOT}/include", f"-I{CS}", "-DEBEN_BUILDING=1",
-               "-c", os.path.join(CS, stem + ".hip"), "-o", os.path.join(td, "o.o"), "-Rpass-analysis=kernel-resource-usage", *extra]
+               "-c", os.path.join(CS, stem + ".hip") if os.path.exists(os.path.join(CS, stem + ".hip")) else os.path.join(CS, "exact_fp32", stem + ".hip"), "-o", os.path.join(td, "o.o"), "-Rpass-analysis=kernel-resource-usage", *extra]
         txt = subprocess.run(cmd, capture_output=True, text=True).stderr
     out = []
     for b in re.split(r"remark: [^\n]*Function Name: ", txt)[1:]:
@@ -25,7 +25,7 @@ def analyse(stem, extra=()):
 
 
 if __name__ == "__main__":
-    stems = [a for a in sys.argv[1:] if not a.startswith("-")] or sorted(f[:-4] for f in os.listdir(CS) if f.endswith(".hip"))
+    stems = [a for a in sys.argv[1:] if not a.startswith("-")] or sorted(f[:-4] for d in (CS, os.path.join(CS, "exact_fp32")) for f in os.listdir(d) if f.endswith(".hip"))
     bad = 0
     for s in stems:
         for k in analyse(s):

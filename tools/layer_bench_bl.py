@@ -52,6 +52,7 @@ def main():
     ap.add_argument("--length", type=int, default=31968)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--filter", default="")
+    ap.add_argument("--only", default="", help="one layer, e.g. melgan.4 (the PMC passes of tools/pmc_family_bl.sh)")
     a = ap.parse_args()
     lib = load()
     dev = torch.device("cuda")
@@ -69,7 +70,7 @@ def main():
     chains = [("pqmf%d" % i, _ChainBL(d.discriminator, plan["pqmf"]), 4, a.length // 4) for i, d in enumerate(disc.pqmf_discriminators)]
     chains.append(("melgan", _ChainBL(disc.melgan_discriminator.discriminator, plan["melgan"]), 1, a.length))
     for cname, ch, c_in, l_in in chains:
-        if a.filter and a.filter not in cname:
+        if (a.filter and a.filter not in cname) or (a.only and a.only.split(".")[0] != cname):
             continue
         n = len(ch.layers)
         x_in = torch.randn(r2, c_in, l_in, device=dev) * 0.1
@@ -82,9 +83,10 @@ def main():
         g0v.hi, g0v.lo, g0v.rows, g0v.channels, g0v.length = g0.hi[:r2], g0.lo[:r2], r2, g0.channels, g0.length
         job_b = (EbenBlHeadJob * 1)(ch.head_job(None, l_in, g0v))
         dxh = torch.empty_like(x_in)
-        t_f = time_ms(lambda: check(lib.eben_bl_head_fwd(job_f, 1, r2, st)), a.iters)
-        t_b = time_ms(lambda: check(lib.eben_bl_head_dx(job_b, 1, r2, ptr(dxh), st)), a.iters)
-        t_w = time_ms(lambda: ch.weight_grads([], x_in, g0, half), a.iters)
+        skip = bool(a.only) and a.only != cname + ".0"
+        t_f = 1.0 if skip else time_ms(lambda: check(lib.eben_bl_head_fwd(job_f, 1, r2, st)), a.iters)
+        t_b = 1.0 if skip else time_ms(lambda: check(lib.eben_bl_head_dx(job_b, 1, r2, ptr(dxh), st)), a.iters)
+        t_w = 1.0 if skip else time_ms(lambda: ch.weight_grads([], x_in, g0, half), a.iters)
         macs2 = r2 * sp.c_out * sp.ksize * act0.length
         el = sp.c_out * act0.length
         cf, rf = cell(t_f, 2.0 * macs2, r2 * (4 * c_in * l_in + 4 * el))
@@ -104,6 +106,10 @@ def main():
             y = Planes(r2, sp.c_out, d.l_out, dev)
             xin = Planes.from_f32(torch.randn(r2, sp.c_in, cur.length, device=dev))
             split = (lay.math_fwd & 0xff) == ops.MATH_BF16X3
+            if a.only and a.only != f"{cname}.{i}":
+                acts.append(y)
+                cur = y
+                continue
             _, _, bias = lay.params()
             wp = lay.packed(0, r2, cur.length)
             t_f = time_ms(lambda: check(lib.eben_bl_conv1d_fwd(ctypes.byref(d), xin.hi.data_ptr(), xin.lo.data_ptr() if split else None, ptr(wp), ptr(bias),
@@ -129,6 +135,8 @@ def main():
                 tot[k][1] += r
             acts.append(y)
             cur = y
+        if a.only and a.only != f"{cname}.{n - 1}":
+            continue
         # ---- tail
         tail = ch.layers[-1]
         sp = tail.spec

@@ -13,7 +13,7 @@ flags=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -Wall -Wno
 obj="$here/../lib/obj"
 mkdir -p "$obj"
 stamp="$(printf '%s\n' "${flags[@]}" | cat - "$here"/*.h "$root"/include/*.h | md5sum | cut -d' ' -f1)"
-srcs=("$here"/*.hip)
+srcs=("$here"/*.hip "$here"/exact_fp32/*.hip)   # exact_fp32/: the kernel families only the exact-fp32 reference plan reaches
 jobs="${EBEN_BUILD_JOBS:-$(nproc)}"
 pids=()
 fail=0
