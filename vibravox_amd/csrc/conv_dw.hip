@@ -487,9 +487,9 @@ __global__ __launch_bounds__(256) void wn_bwd_kernel(const float* __restrict__ d
 
 // ---- multi-tensor forms: one launch for every layer of a network (the per-layer launches are ~5 us kernels whose
 // launch overhead and dependent-launch gaps dominate; 75 + 166 of the ~1070 launches of a train step) -------------
-constexpr int WN_CHUNK = 36;
+constexpr int WN_CHUNK = 32;
 struct WnScaleTable { EbenWnScaleItem t[WN_CHUNK]; };
-struct WnBwdTable { EbenWnBwdItem t[WN_CHUNK]; };
+struct WnBwdTable { EbenWnBwdItem t[WN_CHUNK]; unsigned first[WN_CHUNK + 1]; };   // first[]: prefix sums of the items' slab-reduce blocks
 
 __global__ __launch_bounds__(256) void wn_scale_multi_kernel(const WnScaleTable T) {
   __shared__ float red[4];
@@ -507,16 +507,44 @@ __global__ __launch_bounds__(256) void wn_scale_multi_kernel(const WnScaleTable 
   }
 }
 
-// same arithmetic and summation order as slab_reduce_kernel / wn_bwd_kernel (results are bit-identical)
+// same arithmetic and summation order as slab_reduce_kernel / wn_bwd_kernel (results are bit-identical).  A block belongs to one item
+// (prefix sums of the items' block counts: a grid of max-blocks x items spent most of its blocks on nothing).  Up to 31 slabs -- the
+// tap-conv / bundle-layout weight gradients: 2-16 slabs of up to 10.7 M elements -- one thread sums one element with every slab's
+// load in flight at once (the four z-groups of the fixed order kept as four partial sums in the thread); from 32 slabs up (the thin
+// layers' per-item slabs) the z-groups stay spread over the block's four waves.
+// [MI355X] 0.40 ms of kernel time per step before (64 elements per block pass, two barriers, one or two loads in flight per thread)
 __global__ __launch_bounds__(256) void slab_reduce_multi_kernel(const WnBwdTable T) {
   __shared__ float part[4][64];
-  const EbenWnBwdItem e = T.t[blockIdx.y];
-  if (e.nslab <= 1) return;
+  int it = 0;
+#pragma unroll 1
+  while (blockIdx.x >= T.first[it + 1]) ++it;
+  const EbenWnBwdItem e = T.t[it];
+  const unsigned bid = blockIdx.x - T.first[it], nblk = T.first[it + 1] - T.first[it];
   const long long n = (long long)e.rows * e.row_stride;
   const float* slabs = e.slabs;
   float* out = const_cast<float*>(e.slabs);
+  if (e.nslab < 32) {
+    for (long long i = (long long)bid * 256 + threadIdx.x; i < n; i += (long long)nblk * 256) {
+      float p[4];
+#pragma unroll
+      for (int zg = 0; zg < 4; ++zg) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int z = zg;
+        for (; z + 12 < e.nslab; z += 16) {
+          s0 += slabs[(long long)z * e.slab_stride + i];
+          s1 += slabs[(long long)(z + 4) * e.slab_stride + i];
+          s2 += slabs[(long long)(z + 8) * e.slab_stride + i];
+          s3 += slabs[(long long)(z + 12) * e.slab_stride + i];
+        }
+        for (; z < e.nslab; z += 4) s0 += slabs[(long long)z * e.slab_stride + i];
+        p[zg] = (s0 + s1) + (s2 + s3);
+      }
+      out[i] = (p[0] + p[1]) + (p[2] + p[3]);
+    }
+    return;
+  }
   const int lane = threadIdx.x & 63, zg = threadIdx.x >> 6;
-  for (long long base = (long long)blockIdx.x * 64; base < n; base += (long long)gridDim.x * 64) {
+  for (long long base = (long long)bid * 64; base < n; base += (long long)nblk * 64) {
     const long long i = base + lane;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if (i < n) {
@@ -545,26 +573,48 @@ __global__ __launch_bounds__(256) void wn_bwd_multi_kernel(const WnBwdTable T) {
   const float* srow = e.slabs + (long long)r * e.row_stride;
   float* orow = e.dv + (long long)r * cols;
   if (e.dbias && threadIdx.x == 0) e.dbias[r] = srow[cols];
-  // slab column of weight element i = c k + j: i itself, or the bundle-major order of bl_dw.hip (its stores are contiguous that way)
+  // slab column of weight element i = c k + j: i itself, or the bundle-major order of bl_dw.hip (its stores are contiguous that way):
+  // column s = ((c / 8) k + j) 8 + c % 8.  The permuted rows are walked in SLAB order (contiguous reads of the sums; the element index
+  // follows by carries instead of a division per element and pass)
   const int pk = e.col_perm_k;
-  auto sidx = [&](int i) -> int {
-    if (pk <= 0) return i;
-    const int c = i / pk, j = i - c * pk;
-    return ((c >> 3) * pk + j) * 8 + (c & 7);
-  };
-  if (!e.g) {
-    for (int i = threadIdx.x; i < cols; i += 256) orow[i] = srow[sidx(i)];
+  const float* vrow = e.g ? e.v + (long long)r * cols : nullptr;
+  if (pk > 0) {
+    const int eo = threadIdx.x & 7;
+    int cb0 = (threadIdx.x >> 3) / pk, j0 = (threadIdx.x >> 3) - cb0 * pk;
+    auto walk = [&](auto&& f) {
+      int cb = cb0, j = j0;
+      for (int sc = threadIdx.x; sc < cols; sc += 256) {
+        f(sc, (8 * cb + eo) * pk + j);
+        j += 32;
+        while (j >= pk) { j -= pk; ++cb; }
+      }
+    };
+    if (!e.g) {
+      walk([&](int sc, int i) { orow[i] = srow[sc]; });
+      return;
+    }
+    float dot = 0.f;
+    walk([&](int sc, int i) { dot += srow[sc] * vrow[i]; });
+    dot = block_sum_256(dot, red);
+    const float n = e.norm[r], gr = e.g[r];
+    const float dgr = dot / n;
+    if (threadIdx.x == 0) e.dg[r] = dgr;
+    const float c1 = gr / n, c2 = gr * dgr / (n * n);
+    walk([&](int sc, int i) { orow[i] = c1 * srow[sc] - c2 * vrow[i]; });
     return;
   }
-  const float* vrow = e.v + (long long)r * cols;
+  if (!e.g) {
+    for (int i = threadIdx.x; i < cols; i += 256) orow[i] = srow[i];
+    return;
+  }
   float dot = 0.f;
-  for (int i = threadIdx.x; i < cols; i += 256) dot += srow[sidx(i)] * vrow[i];
+  for (int i = threadIdx.x; i < cols; i += 256) dot += srow[i] * vrow[i];
   dot = block_sum_256(dot, red);
   const float n = e.norm[r], gr = e.g[r];
   const float dgr = dot / n;
   if (threadIdx.x == 0) e.dg[r] = dgr;
   const float c1 = gr / n, c2 = gr * dgr / (n * n);
-  for (int i = threadIdx.x; i < cols; i += 256) orow[i] = c1 * srow[sidx(i)] - c2 * vrow[i];
+  for (int i = threadIdx.x; i < cols; i += 256) orow[i] = c1 * srow[i] - c2 * vrow[i];
 }
 
 }  // namespace eben
@@ -595,7 +645,7 @@ extern "C" int eben_wn_bwd_multi(const EbenWnBwdItem* items, int n, void* stream
     WnBwdTable T;
     const int cnt = n - base < WN_CHUNK ? n - base : WN_CHUNK;
     int max_rows = 0;
-    long long max_blocks = 0;
+    T.first[0] = 0;
     for (int i = 0; i < cnt; ++i) {
       const EbenWnBwdItem& e = items[base + i];
       EBEN_REQUIRE(e.slabs && e.dv && e.nslab > 0 && e.rows > 0 && e.cols > 0 && e.row_stride >= e.cols, "bad wn_bwd_multi item %d", base + i);
@@ -605,14 +655,16 @@ extern "C" int eben_wn_bwd_multi(const EbenWnBwdItem* items, int n, void* stream
       EBEN_REQUIRE(e.nslab == 1 || e.slab_stride >= (long long)e.rows * e.row_stride, "slab stride smaller than a slab (item %d)", base + i);
       T.t[i] = e;
       if (e.rows > max_rows) max_rows = e.rows;
+      long long b = 0;
       if (e.nslab > 1) {
-        const long long b = ((long long)e.rows * e.row_stride + 63) / 64;
-        if (b > max_blocks) max_blocks = b;
+        const long long n = (long long)e.rows * e.row_stride;
+        b = e.nslab < 32 ? (n + 255) / 256 : (n + 63) / 64;
+        if (b > 2048) b = 2048;   // grid-stride beyond
       }
+      T.first[i + 1] = T.first[i] + (unsigned)b;
     }
-    if (max_blocks > 0) {
-      if (max_blocks > 4096) max_blocks = 4096;
-      hipLaunchKernelGGL(slab_reduce_multi_kernel, dim3((unsigned)max_blocks, cnt), dim3(256), 0, as_stream(stream), T);
+    if (T.first[cnt] > 0) {
+      hipLaunchKernelGGL(slab_reduce_multi_kernel, dim3(T.first[cnt]), dim3(256), 0, as_stream(stream), T);
       EBEN_CHECK_LAUNCH("slab_reduce_multi_kernel");
     }
     hipLaunchKernelGGL(wn_bwd_multi_kernel, dim3(max_rows, cnt), dim3(256), 0, as_stream(stream), T);
