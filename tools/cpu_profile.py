@@ -5,7 +5,7 @@ dev = torch.device('cuda', 0)
 mod = bench.build_module(dev, 1234)
 mod.disc_math = os.environ.get("EBEN_DISC_MATH", "bf16_bl"); mod.gen_backward_math = "bf16"; mod.stft_math = "folded_x3"
 batch = bench.synthetic_batch(32, 32000, 1234, dev)
-for _ in range(3): mod.training_step(batch)
+for _ in range(8): mod.training_step(batch)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 for _ in range(10): mod.training_step(batch)
