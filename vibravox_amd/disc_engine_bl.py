@@ -353,6 +353,24 @@ class DiscriminatorEngineBL(DiscriminatorEngine):
         n = len(self.chains)
         rows = 2 * half
         self._head_done = None
+        fm_first = [sum(len(c.layers) - 1 for c in self.chains[:i]) for i in range(n)]
+        fm_sums = st["fm_sums"]
+
+        def body(i):
+            # the chain's layers, then the feature-matching sums of ITS embedding pairs on its own stream: the HBM-bound pass over the
+            # embeddings (1.6 GB at 64 rows) runs beside the other chains' MFMA-bound layers instead of alone behind the join
+            # ([MI355X] one launch over all 35 pairs after the join: 0.27 ms of the step's critical path)
+            acts, logits = self.chains[i].forward_body(act0[i])
+            k = len(acts)
+            ptrs = (ctypes.c_void_p * (2 * k))()
+            units = (ctypes.c_int64 * k)()
+            for j, pl in enumerate(acts):
+                ptrs[2 * j], ptrs[2 * j + 1] = _addr(pl.hi), _addr(pl.lo)
+                units[j] = half * (pl.channels // 8) * pl.length
+            ws_bytes = lib.eben_bl_fm_sums_workspace(k)
+            ws = torch.empty(max(1, (ws_bytes + 3) // 4), dtype=torch.float32, device=acts[0].hi.device)
+            check(lib.eben_bl_fm_sums(ptrs, units, k, ptr(ws), ws_bytes, ptr(fm_sums[2 * fm_first[i]:]), _stream()), "bl_fm_sums")
+            return acts, logits
 
         def run(i):
             # heads (eager, so that the chains that share one can be released by an event): the PQMF-band chains' in one launch on the
@@ -368,8 +386,8 @@ class DiscriminatorEngineBL(DiscriminatorEngine):
                 self._head_done.record()
             else:
                 torch.cuda.current_stream().wait_event(self._head_done)   # chains 1, 2 may run on another stream than chain 0
-            sig = (rows, act0[i].hi.data_ptr(), act0[i].lo.data_ptr(), act0[i].length, self._chain_sig(ch, 0))
-            out = self._graphs["fwd"][i].run(sig, lambda: ch.forward_body(act0[i]), torch.cuda.current_stream())
+            sig = (rows, act0[i].hi.data_ptr(), act0[i].lo.data_ptr(), act0[i].length, fm_sums.data_ptr(), self._chain_sig(ch, 0))
+            out = self._graphs["fwd"][i].run(sig, lambda: body(i), torch.cuda.current_stream())
             self._mark_used(ch, 0)
             return out
 
@@ -386,17 +404,8 @@ class DiscriminatorEngineBL(DiscriminatorEngine):
         s = self._state
         half = s["half"]
         dev = s["logits"][0].device
-        planes = [a for acts in s["acts"] for a in acts]          # every embedding but the inputs and the logits, chain by chain
-        n = len(planes)
-        ptrs = (ctypes.c_void_p * (2 * n))()
-        units = (ctypes.c_int64 * n)()
-        for i, p in enumerate(planes):
-            ptrs[2 * i], ptrs[2 * i + 1] = _addr(p.hi), _addr(p.lo)
-            units[i] = half * (p.channels // 8) * p.length
-        ws_bytes = lib.eben_bl_fm_sums_workspace(n)
-        ws = torch.empty(max(1, (ws_bytes + 3) // 4), dtype=torch.float32, device=dev)
-        sums = s["static"]["fm_sums"]   # fixed address: the replayed input-gradient sequences read it
-        check(lib.eben_bl_fm_sums(ptrs, units, n, ptr(ws), ws_bytes, ptr(sums), _stream()), "bl_fm_sums")
+        n = sum(len(acts) for acts in s["acts"])                  # embedding pairs: every embedding but the inputs and the logits
+        sums = s["static"]["fm_sums"]   # fixed address, filled chain by chain at the end of each forward body
         nch = len(self.chains)
         inv = 1.0 / (nch * len(s["acts"][-1]))
         s.update(fm_sums=sums, fm_inv=inv, fm_first=[sum(len(a) for a in s["acts"][:i]) for i in range(nch)])
