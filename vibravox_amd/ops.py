@@ -415,6 +415,12 @@ def graphs_pending() -> int:
     return n
 
 
+#: replay the collective-free launch sequences as graphs in multi-rank runs too (default off: the captures -- a device-wide synchronisation
+#: and an allocator flush in the first steps, next to RCCL traffic -- have only met a single-rank process group on hardware,
+#: ``bench.py --force-ddp``)
+DDP_GRAPHS = os.environ.get("EBEN_DDP_GRAPHS", "0") != "0"
+
+
 class ReplayedPrepack:
     """Graph replay of a prepack sequence.  Rebuilding the packed weight images after an optimiser step is ~150 tiny launches per
     step (one or two per layer and direction) whose cost is entirely host-side: ~3 ms of Python / launch time per step during which
@@ -436,6 +442,8 @@ class ReplayedPrepack:
     def _multi_rank() -> bool:
         """Eager launches in data-parallel runs: the capture (device-wide synchronisation, cache flush) would run next to RCCL's
         in-flight exchanges on the communication stream; the replay only saves host time, of which a multi-rank step has spare."""
+        if DDP_GRAPHS:
+            return False
         d = torch.distributed
         return d.is_available() and d.is_initialized() and d.get_world_size() > 1
 
