@@ -499,6 +499,8 @@ class GeneratorEngine:
         key = (name, tuple(like.shape), like.dtype, like.device)
         buf = self._static.get(key)
         if buf is None:
+            if len(self._static) >= 8:   # variable clip lengths: keep the buffers of the recent shapes only
+                self._static.pop(next(iter(self._static)))
             buf = self._static[key] = torch.empty_like(like, memory_format=torch.contiguous_format)
         return buf
 
