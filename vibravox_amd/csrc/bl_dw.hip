@@ -287,6 +287,8 @@ static void make_bldw_plan(const Canon& c, BlDwPlan* p) {
     const double t = rounds * (t_all * slots / blocks) + 2.0 * cand * slab_bytes / 2.0e12 + (cand > 1 ? slab_bytes / 2.0e12 + 5e-6 : 0.0);
     if (t < best * 0.97) { best = t; ns = cand; }
   }
+  static const int force_ns = getenv("EBEN_BLDW_NSPLIT") ? atoi(getenv("EBEN_BLDW_NSPLIT")) : 0;
+  if (force_ns > 0 && force_ns <= p->nchunks) ns = force_ns;
   p->nsplit = ns;
   if (p->dense) { p->row_stride = (c.Cin / c.g) * c.k + 1; p->perm_k = 0; }
   else { p->row_stride = p->Cg * c.k + 1; p->perm_k = c.k; }
