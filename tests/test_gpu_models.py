@@ -740,6 +740,33 @@ def test_generator_graphs_match_eager_launches(hip, golden):
     assert [k for k in a if not torch.equal(a[k], b[k])] == []
 
 
+def test_replayed_sequences_follow_changing_batch_shapes(hip, golden):
+    """Train steps at alternating batch shapes (2 x 8200, 3 x 6100, each twice in a row so that the sequences of BOTH shapes are captured,
+    then interleaved) in the benchmarked plan: every replayed sequence -- discriminator chains, generator forward / backward, prepack --
+    against the same steps with all launch sequences issued eagerly: bit-identical parameters."""
+    from vibravox_amd import gen_engine, ops
+
+    shapes = [(2, 8200), (2, 8200), (2, 8200), (3, 6100), (3, 6100), (3, 6100), (2, 8200), (3, 6100), (2, 8200), (2, 8200)]
+
+    def run(graphs):
+        prev = (ops.ReplayedChain.enabled, ops.ReplayedPrepack.enabled, gen_engine.USE_GRAPHS)
+        ops.ReplayedChain.enabled = ops.ReplayedPrepack.enabled = gen_engine.USE_GRAPHS = graphs
+        try:
+            mod, _, _ = make_module(golden, use_mrstft=True)
+            mod.disc_math, mod.gen_backward_math, mod.stft_math = "bf16_bl", "bf16", "folded_x3"
+            for i, (b, t) in enumerate(shapes):
+                mod.training_step({"audio_body_conducted": formula_audio(f"sh/{i}/bc", b, t).to(DEV), "audio_airborne": formula_audio(f"sh/{i}/air", b, t).to(DEV)})
+            torch.cuda.synchronize()
+            out = {f"G.{k}": v.clone() for k, v in mod.generator.state_dict().items()}
+            out.update({f"D.{k}": v.clone() for k, v in mod.discriminator.state_dict().items()})
+            return out
+        finally:
+            ops.ReplayedChain.enabled, ops.ReplayedPrepack.enabled, gen_engine.USE_GRAPHS = prev
+
+    a, b = run(True), run(False)
+    assert [k for k in a if not torch.equal(a[k], b[k])] == []
+
+
 def test_fused_adam_follows_a_restored_state(hip):
     """optimizer.load_state_dict() after a step replaces the moment tensors: the kernel's cached table must follow (and a deep copy
     of the optimiser must step at all)."""
