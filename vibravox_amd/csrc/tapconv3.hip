@@ -478,6 +478,27 @@ __global__ __launch_bounds__(256, NPW >= 2 ? 1 : 2) void tap3_kernel(const Tap3A
 #pragma unroll
   for (int ks = 0; ks < KSC; ++ks) te[ks] = nch > 0 ? tab[ks] : 0;
   int pending = -1;   // tile whose global loads are issued at the top of the next chunk (not in front of the barrier)
+  // The k-steps of a chunk run in two halves.  The first half's fragments are read at the top of the chunk, and the MFMAs issued while
+  // they are in flight are the SECOND half of the PREVIOUS chunk, held back in registers across the barrier: behind every barrier a wave
+  // has H k-steps of matrix work that needs no LDS, so the first fragment reads of a chunk (300-400 cycles with four to eight waves
+  // reading at once) are no longer what the first MFMA of every chunk waits for.  Same order of accumulation as chunk by chunk.
+  constexpr int H = KSC >= 2 ? KSC / 2 : 1, H2 = KSC - H;
+  u32x4 bvA[H][NPX], aA[H][NPW][FM], bvB[H2 > 0 ? H2 : 1][NPX], aB[H2 > 0 ? H2 : 1][NPW][FM];
+  auto mma = [&](const u32x4 (&bq)[NPX], const u32x4 (&aq)[NPW][FM]) {
+    // piece products, smallest first: (qw, qx) with qw + qx = lvl
+#pragma unroll
+    for (int lvl = NPM - 1; lvl >= 0; --lvl)
+#pragma unroll
+      for (int qw = 0; qw < NPW; ++qw) {
+        const int qx = lvl - qw;
+        if (qx < 0 || qx >= NPX) continue;
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+          if (EBEN_T3_DBG & 8) acc[i][0] += __builtin_bit_cast(float, aq[qw][i][0] ^ bq[qx][i & 3]);
+          else acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, aq[qw][i]), __builtin_bit_cast(bf16x8, bq[qx]), acc[i], 0, 0, 0);
+        }
+      }
+  };
   for (int ch = 0; ch < nch; ++ch) {
     // the next chunk's table entries are asked for FIRST: their scalar-load round trip (~300 cycles) runs under this chunk's fragment
     // reads and MFMAs -- asked for behind the MFMAs it was waited for in front of every barrier
@@ -488,36 +509,28 @@ __global__ __launch_bounds__(256, NPW >= 2 ? 1 : 2) void tap3_kernel(const Tap3A
     if ((EBEN_T3_DBG & 2) == 0 && pending >= 0 && !dma_x) { fetch_x(pending); pending = -1; }
     const u32x4* wb = Ws + (ch % RING) * WCHU + lane;
     const u32x4* xb = Xs + lanebase;
-    u32x4 bv[KSC][NPX], a[KSC][NPW][FM];
-    auto rd = [&](int ks) {
+    auto rd = [&](int ks, u32x4 (&bq)[NPX], u32x4 (&aq)[NPW][FM]) {
 #pragma unroll
-      for (int q = 0; q < NPX; ++q) bv[ks][q] = xb[te[ks] + q * LO];
+      for (int q = 0; q < NPX; ++q) bq[q] = xb[te[ks] + q * LO];
 #pragma unroll
       for (int q = 0; q < NPW; ++q)
 #pragma unroll
-        for (int i = 0; i < FM; ++i) a[ks][q][i] = wb[((ks * NPW + q) * FM + i) * 64];
+        for (int i = 0; i < FM; ++i) aq[q][i] = wb[((ks * NPW + q) * FM + i) * 64];
     };
-    rd(0);
-    if (KSC > 1) rd(1);
 #pragma unroll
-    for (int ks = 0; ks < ((EBEN_T3_DBG & 256) ? 1 : KSC); ++ks) {
-      if (ks + 2 < KSC) rd(ks + 2);
-      __builtin_amdgcn_sched_barrier(0);
-      // piece products, smallest first: (qw, qx) with qw + qx = lvl
+    for (int h = 0; h < H; ++h) rd(h, bvA[h], aA[h]);
+    __builtin_amdgcn_sched_barrier(0);
+    if (ch > 0) {
 #pragma unroll
-      for (int lvl = NPM - 1; lvl >= 0; --lvl)
-#pragma unroll
-        for (int qw = 0; qw < NPW; ++qw) {
-          const int qx = lvl - qw;
-          if (qx < 0 || qx >= NPX) continue;
-#pragma unroll
-          for (int i = 0; i < FM; ++i) {
-            if (EBEN_T3_DBG & 8) acc[i][0] += __builtin_bit_cast(float, a[ks][qw][i][0] ^ bv[ks][qx][i & 3]);
-            else acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[ks][qw][i]), __builtin_bit_cast(bf16x8, bv[ks][qx]), acc[i], 0, 0, 0);
-          }
-        }
-      __builtin_amdgcn_sched_barrier(0);
+      for (int h = 0; h < H2; ++h) mma(bvB[h], aB[h]);       // the held-back half of chunk ch - 1
     }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int h = 0; h < H2; ++h) rd(H + h, bvB[h], aB[h]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int h = 0; h < H; ++h) mma(bvA[h], aA[h]);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int ks = 0; ks < KSC; ++ks) te[ks] = tn[ks];
     if ((EBEN_T3_DBG & 2) == 0 && P.ncc > 1 && written + 1 < P.ncc && (written + 1) * KS_CC < (ch + 2) * KSC) {
@@ -535,6 +548,10 @@ __global__ __launch_bounds__(256, NPW >= 2 ? 1 : 2) void tap3_kernel(const Tap3A
       else t3_wait_vm<2 * WU>();
     }
     if ((EBEN_T3_DBG & 4) == 0) __builtin_amdgcn_s_barrier();
+  }
+  if (nch > 0) {
+#pragma unroll
+    for (int h = 0; h < H2; ++h) mma(bvB[h], aB[h]);
   }
   T3_STAMP(5);
 
