@@ -172,6 +172,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}"
+    if world > 1 or args.force_ddp:
+        # One hardware queue per stream of a data-parallel rank: main + the three auxiliary streams of the step + the process group's
+        # RCCL stream + the graph-capture stream.  The HIP runtime's default of four makes two of them share a queue (streams on one
+        # queue execute in submission order): [MI355X] --force-ddp 12.95 ms/step at 4 queues, 13.5 at 5, 12.25 at 6, 15.9 at 8, against
+        # 12.06 without a process group (unchanged at 4 / 5 / 6 / 8).  Read by the runtime when it initialises: set before any HIP call.
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "6")
     assert torch.cuda.is_available(), "bench.py measures the HIP path: no GPU visible"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
@@ -258,6 +264,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    host_s = [0.0]
+
     def timed_steps(n):
         """EXACTLY n steps between two barrier + synchronize brackets (wall clock), with a HIP event at every step boundary on the main
         stream for the per-step distribution."""
@@ -268,6 +276,7 @@ def main():
         for i in range(n):
             mod.training_step(next_batch())
             evs[i + 1].record()
+        host_s[0] = (time.perf_counter() - t0) / n   # what the host needed to enqueue a step (the GPU runs behind it)
         barrier()
         dt = time.perf_counter() - t0
         per = sorted(a.elapsed_time(b) for a, b in zip(evs[:-1], evs[1:]))
@@ -299,6 +308,8 @@ def main():
     for _, sy in syncs:
         sy.exposed_comm_ms()   # drop the warm-up's samples
     dt, per_step = timed_steps(args.steps)
+    host_ms = host_s[0] * 1e3
+    n_graphs = ops.graphs_captured()   # launch sequences replayed as HIP graphs during the timed steps
     exposed = {name: sy.exposed_comm_ms() for name, sy in syncs}
     # The two roofline launches are bracketed by HIP events on the stream they are launched on.  Events cannot sit between the nodes of
     # a replayed HIP graph, and the timed steps above replay the discriminator chains as graphs (ops.ReplayedChain): the brackets are
@@ -404,7 +415,7 @@ def main():
         ideal = step_roofline_ms("f32" if not bf16 else "bf16", scale)
         line = {
             "metric": "EBEN train-step audio-seconds/sec (gen+disc)", "value": round(value, 2), "unit": "audio-seconds/sec",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "settle_steps": settle, "ms_per_step": round(ms, 3), "higher_is_better": True,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "settle_steps": settle, "graphs_replayed": n_graphs, "host_enqueue_ms_per_step": round(host_ms, 3), "ms_per_step": round(ms, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
             "config": {"workload": (f"EBEN full GAN train step (gen+disc+MRSTFT+feature-matching+hinge, EMA balancing, Adam), batch {args.batch} x "
                                     f"{length} samples @16kHz per GPU (cut to {cut})"

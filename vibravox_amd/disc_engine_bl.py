@@ -484,13 +484,14 @@ class DiscriminatorEngineBL(DiscriminatorEngine):
             pend = [None] * n
             for i in [n - 1] + list(range(n - 1)):   # the longest chain first
                 with torch.cuda.stream(self._streams[i]):
-                    if self._sink is not None:   # gradients straight into the data-parallel buckets: eager (ReplayedChain is single-rank)
-                        pend[i] = self.chains[i].weight_grads(res[i][1], s["inputs"][i], res[i][0], half, self._sink)
-                    else:
-                        jobs_sig = tuple((k, (g.hi.data_ptr() if isinstance(g, Planes) else g.data_ptr()), x.hi.data_ptr(), x.lo.data_ptr()) for k, g, x in res[i][1])
-                        sig = (half, s["inputs"][i].data_ptr(), res[i][0].hi.data_ptr(), jobs_sig, self._chain_sig(self.chains[i], -1))
-                        pend[i] = self._graphs["dw"][i].run(sig, lambda i=i: self.chains[i].weight_grads(res[i][1], s["inputs"][i], res[i][0], half, None),
-                                                            torch.cuda.current_stream())
+                    # with a data-parallel sink the launches write straight into its gradient buckets: static addresses, part of the signature
+                    sink = self._sink
+                    sink_sig = None if sink is None else tuple(0 if (b := sink.grad_buffer(p)) is None else b.data_ptr()
+                                                               for lay in self.chains[i].layers for p in lay.params() if p is not None)
+                    jobs_sig = tuple((k, (g.hi.data_ptr() if isinstance(g, Planes) else g.data_ptr()), x.hi.data_ptr(), x.lo.data_ptr()) for k, g, x in res[i][1])
+                    sig = (half, s["inputs"][i].data_ptr(), res[i][0].hi.data_ptr(), jobs_sig, self._chain_sig(self.chains[i], -1), sink_sig)
+                    pend[i] = self._graphs["dw"][i].run(sig, lambda i=i: self.chains[i].weight_grads(res[i][1], s["inputs"][i], res[i][0], half, sink),
+                                                        torch.cuda.current_stream())
                     if self._sink is not None:
                         self._sink.mark_ready([p for lay in self.chains[i].layers for p in lay.params() if p is not None and p.requires_grad])
             self._pending = (pend, s, res)   # keeps the saved activations and the stacked gradients alive until the kernels have run

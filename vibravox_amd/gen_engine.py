@@ -552,19 +552,27 @@ class GeneratorEngine:
     def _deferrable(self) -> bool:
         """Weight gradients of the whole core go through ``weight_grads_on_side_stream().join()``'s assignment (no gradient held, no
         hook, no data-parallel sink)."""
-        if not ops._side["enabled"] or ops._side["sink"] is not None or ops._skip_weight_grads[0]:
+        if not ops._side["enabled"] or ops._skip_weight_grads[0]:
             return False
+        sink = ops._side["sink"]
         for m in self._core_convs:
             for p in _params(m) + (m.bias,):
-                if p is not None and (not p.requires_grad or p.grad is not None or not ops._no_grad_hooks(p)):
+                if p is None:
+                    continue
+                if not p.requires_grad:
+                    return False
+                if sink is not None:
+                    if sink.grad_buffer(p) is None:   # data-parallel: every gradient goes straight into its bucket view
+                        return False
+                elif p.grad is not None or not ops._no_grad_hooks(p):
                     return False
         return True
 
-    def _dw_body(self, queue: list) -> list:
+    def _dw_body(self, queue: list, sink=None) -> list:
         """The queued weight-gradient work on the current stream: every layer's kernel, then ONE slab-sum / weight-norm launch.
-        Returns [(parameter, gradient)]."""
+        Returns [(parameter, gradient)] (with a data-parallel ``sink``: the gradients are its bucket views)."""
         jobs, assign = [], []
-        with ops.collect_wn_jobs(jobs):
+        with ops.collect_wn_jobs(jobs, sink):
             for item in queue:
                 if item[0] == "conv":
                     _, rec, dy = item
@@ -633,13 +641,17 @@ class GeneratorEngine:
             if not queue:
                 continue
             side.wait_stream(main)
+            sink = ops._side["sink"]
             with torch.cuda.stream(side):
                 if self._dx_graphs[k].graph is not None:
-                    assign = self._dw_graphs[k].run((self._dx_graphs[k].captures,), lambda: self._dw_body(queue), side)
+                    assign = self._dw_graphs[k].run((self._dx_graphs[k].captures, id(sink)), lambda: self._dw_body(queue, sink), side)
                 else:
-                    assign = self._dw_body(queue)
+                    assign = self._dw_body(queue, sink)
                     ops._side["keep"].append(queue)   # eager tensors: referenced until join()
-            ops._side["assign"].extend((p, t) for p, t in assign if p.requires_grad)
+            if sink is None:
+                ops._side["assign"].extend((p, t) for p, t in assign if p.requires_grad)
+            else:
+                ops._side["sunk"].extend(p for p, _ in assign)   # join() reports them to the sink once the side stream is joined
 
 
 class _CoreFn(torch.autograd.Function):

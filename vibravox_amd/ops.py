@@ -421,6 +421,11 @@ def graphs_pending() -> int:
 DDP_GRAPHS = os.environ.get("EBEN_DDP_GRAPHS", "0") != "0"
 
 
+def graphs_captured() -> int:
+    """Launch sequences currently replayed as graphs."""
+    return sum(1 for r in list(_replayed) if r.graph is not None)
+
+
 class ReplayedPrepack:
     """Graph replay of a prepack sequence.  Rebuilding the packed weight images after an optimiser step is ~150 tiny launches per
     step (one or two per layer and direction) whose cost is entirely host-side: ~3 ms of Python / launch time per step during which
@@ -652,7 +657,7 @@ def weight_grads(d: EbenConv1dDesc, dy: torch.Tensor, y: Optional[torch.Tensor],
     return outs
 
 
-_wn_collect = [None]   # inside collect_wn_jobs(): the list the immediate path appends its slab-sum / weight-norm jobs to
+_wn_collect = [None, None]   # inside collect_wn_jobs(): the list the immediate path appends its slab-sum / weight-norm jobs to, the sink
 
 
 class collect_wn_jobs:
@@ -660,16 +665,16 @@ class collect_wn_jobs:
     the stream the work belongs on current) launches the weight-gradient kernels only and appends the slab-sum + weight-norm job of
     each layer to ``jobs``: the caller runs them as ONE ``wn_bwd_multi(jobs)`` (gen_engine's graph-captured weight-gradient body)."""
 
-    def __init__(self, jobs: list):
-        self.jobs = jobs
+    def __init__(self, jobs: list, sink=None):
+        self.jobs, self.sink = jobs, sink   # sink: results go straight into its gradient buffers (``grad_buffer(param)``)
 
     def __enter__(self):
-        self.prev = (_wn_collect[0], _side["enabled"])
-        _wn_collect[0], _side["enabled"] = self.jobs, False
+        self.prev = (_wn_collect[0], _wn_collect[1], _side["enabled"])
+        _wn_collect[0], _wn_collect[1], _side["enabled"] = self.jobs, self.sink, False
         return self
 
     def __exit__(self, *exc):
-        _wn_collect[0], _side["enabled"] = self.prev
+        _wn_collect[0], _wn_collect[1], _side["enabled"] = self.prev
 
 
 def _wg_route(v, g, bias):
@@ -679,13 +684,13 @@ def _wg_route(v, g, bias):
     use_side = (_side["enabled"] and is_param and v.grad is None and (g is None or g.grad is None) and (bias is None or bias.grad is None)
                 and _no_grad_hooks(v) and _no_grad_hooks(g) and _no_grad_hooks(bias))
     sunk = None
-    if _side["enabled"] and not use_side and _side["sink"] is not None:
+    sk = _side["sink"] if _side["enabled"] and not use_side else (_wn_collect[1] if _wn_collect[0] is not None else None)
+    if sk is not None:
         # data-parallel run: p.grad is a view of a gradient bucket -- write the results there directly
-        sk = _side["sink"]
         sunk = (sk.grad_buffer(v), sk.grad_buffer(g) if has_g else None, sk.grad_buffer(bias) if has_bias else None)
         if sunk[0] is None or (has_g and sunk[1] is None) or (has_bias and sunk[2] is None):
             sunk = None
-        use_side = sunk is not None
+        use_side = sunk is not None and _wn_collect[0] is None   # collecting: the caller has made the producing stream current
     return use_side, sunk
 
 
