@@ -403,7 +403,8 @@ def test_fused_residual_unit_forward(hip, channels, dilation, length, batch, in_
 @pytest.mark.parametrize("channels,dilation,length,batch,in_slope,post", [
     (32, 1, 1000, 3, 1.0, False), (32, 3, 517, 2, 0.01, True), (32, 9, 8000, 2, 1.0, False), (64, 9, 300, 3, 0.01, True),
     (64, 1, 4000, 2, 1.0, False), (128, 3, 1000, 2, 1.0, True), (128, 9, 131, 2, 0.01, False), (32, 9, 20, 1, 1.0, False),
-    (32, 9, 110, 1, 1.0, False), (64, 3, 123, 2, 1.0, False), (128, 9, 999, 2, 1.0, False), (128, 1, 47, 1, 1.0, True)])
+    (32, 9, 110, 1, 1.0, False), (64, 3, 123, 2, 1.0, False), (128, 9, 999, 2, 1.0, False), (128, 1, 47, 1, 1.0, True),
+    (128, 9, 999, 32, 1.0, True)])   # BASELINE config 2's widest units: the bf16 launch takes the five-wave window (320 -> 256 blocks)
 @pytest.mark.parametrize("math_mode", [0, 4, 3, 1])
 def test_fused_residual_unit_backward(hip, channels, dilation, length, batch, in_slope, post, math_mode):
     """eben_ru_bwd_ex (math modes as the forward's): g_h = W_pw^T (g_y * lrelu'(u)) and g_x = (g_y + fold(W_dil^T g_h)) * lrelu'(x) + post in one launch, against
