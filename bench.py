@@ -295,7 +295,7 @@ def main():
     # Launch sequences on their way into a HIP graph (ops.ReplayedChain / ReplayedPrepack: the capture of a sequence takes tens of ms and
     # the chained ones settle one after the other) finish settling before the clock starts; reported as `settle_steps`
     settle = 0
-    while ops.graphs_pending() and settle < 12:
+    while settle < 12 and (ops.graphs_pending() or args.warmup + settle < 2):   # (no sequence has a signature before its first step)
         mod.training_step(next_batch())
         settle += 1
     torch.cuda.synchronize()
