@@ -702,16 +702,10 @@ int ru3_bwd(int math, int batch, int channels, int length, int dilation, const f
   Ru3BwdArgs a;
   a.gy = gy; a.u = u; a.wimg = reinterpret_cast<const u32x4*>(wimg); a.xmask = in_slope != 1.f ? x : nullptr; a.post = post; a.gx = gx; a.gh = gh;
   a.B = batch; a.L = length; a.d = dilation;
-  // 128 channels: one block per CU (100 KB of LDS), so a launch runs in rounds of 256 blocks and a window whose outputs (32 NW - 2 d)
-  // need one block more than a multiple of 256 pays a whole round for it -- L = 999, 32 items: 8 tiles per item at d = 1 (256 blocks),
-  // 9 / 10 at d = 3 / 9 (288 / 320 blocks: two rounds, [MI355X] 50 us against 30).  A five-wave window (160 columns) brings those to
-  // 7 / 8 tiles: one round of 1.25x the work.
-  int nw = rs_waves(channels);
-  if (channels == 128 && nw == 4 && rs_pieces(math) == 1) {
-    static const int cus = getenv("EBEN_RU3_CUS") ? atoi(getenv("EBEN_RU3_CUS")) : 256;
-    const long long b4 = (long long)batch * ceil_div(length, 128 - 2 * dilation), b5 = (long long)batch * ceil_div(length, 160 - 2 * dilation);
-    if (ceil_div(b5, (long long)cus) * 5 < ceil_div(b4, (long long)cus) * 4) nw = 5;
-  }
+  // (A five-wave, 160-column window for the 128-channel units -- 288 / 320 blocks at d = 3 / 9 are two rounds of one block per CU, 224 / 256
+  // one -- measured 50 -> 41 us per launch in round 3 but needs 2 waves on one SIMD at 256 registers each: 536 bytes of scratch.  Gone;
+  // the bundle-layout backward (ru_bl.hip) halves the LDS per block instead.)
+  const int nw = rs_waves(channels);
   const int wn = nw * 32;
   a.BO = wn - 2 * dilation; a.ntt = ceil_div(length, a.BO);
   a.out_slope = out_slope; a.in_slope = in_slope;
@@ -724,7 +718,7 @@ int ru3_bwd(int math, int batch, int channels, int length, int dilation, const f
       switch (channels / 32) {
         case 1: return launch_ru3_bwd<1, 4, 1, 1>(a, st);
         case 2: return launch_ru3_bwd<2, 4, 1, 2>(a, st);
-        default: return nw == 5 ? launch_ru3_bwd<4, 5, 1, 2>(a, st) : nw == 4 ? launch_ru3_bwd<4, 4, 1, 2>(a, st) : launch_ru3_bwd<4, 2, 1, 2>(a, st);
+        default: return nw == 4 ? launch_ru3_bwd<4, 4, 1, 2>(a, st) : launch_ru3_bwd<4, 2, 1, 2>(a, st);
       }
     case 2:
       switch (channels / 32) {

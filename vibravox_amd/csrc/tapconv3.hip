@@ -482,7 +482,11 @@ __global__ __launch_bounds__(256, NPW >= 2 ? 1 : 2) void tap3_kernel(const Tap3A
   // they are in flight are the SECOND half of the PREVIOUS chunk, held back in registers across the barrier: behind every barrier a wave
   // has H k-steps of matrix work that needs no LDS, so the first fragment reads of a chunk (300-400 cycles with four to eight waves
   // reading at once) are no longer what the first MFMA of every chunk waits for.  Same order of accumulation as chunk by chunk.
-  constexpr int H = KSC >= 2 ? KSC / 2 : 1, H2 = KSC - H;
+  // Not where the mask-on-load staging of the generator backward holds 2 x 5 x 8 tile registers beside four accumulator tiles (the
+  // held-back fragments do not fit in the 256 registers of two blocks per CU: 72 bytes of scratch): those instantiations read two
+  // k-steps ahead inside the chunk.
+  constexpr bool HOLD = !(IM && FM == 4 && XRB == 5);
+  constexpr int H = !HOLD ? 2 : KSC >= 2 ? KSC / 2 : 1, H2 = HOLD ? KSC - H : 0;
   u32x4 bvA[H][NPX], aA[H][NPW][FM], bvB[H2 > 0 ? H2 : 1][NPX], aB[H2 > 0 ? H2 : 1][NPW][FM];
   auto mma = [&](const u32x4 (&bq)[NPX], const u32x4 (&aq)[NPW][FM]) {
     // piece products, smallest first: (qw, qx) with qw + qx = lvl
@@ -517,20 +521,39 @@ __global__ __launch_bounds__(256, NPW >= 2 ? 1 : 2) void tap3_kernel(const Tap3A
 #pragma unroll
         for (int i = 0; i < FM; ++i) aq[q][i] = wb[((ks * NPW + q) * FM + i) * 64];
     };
+    if constexpr (HOLD) {
 #pragma unroll
-    for (int h = 0; h < H; ++h) rd(h, bvA[h], aA[h]);
-    __builtin_amdgcn_sched_barrier(0);
-    if (ch > 0) {
+      for (int h = 0; h < H; ++h) rd(h, bvA[h], aA[h]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (ch > 0) {
 #pragma unroll
-      for (int h = 0; h < H2; ++h) mma(bvB[h], aB[h]);       // the held-back half of chunk ch - 1
+        for (int h = 0; h < H2; ++h) mma(bvB[h], aB[h]);       // the held-back half of chunk ch - 1
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int h = 0; h < H2; ++h) rd(H + h, bvB[h], aB[h]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int h = 0; h < H; ++h) mma(bvA[h], aA[h]);
+      __builtin_amdgcn_sched_barrier(0);
+    } else {   // fragments of k-step ks + 2 asked for before the products of k-step ks (two register slots, used alternately)
+      rd(0, bvA[0], aA[0]);
+      if (KSC > 1) rd(1, bvA[1], aA[1]);
+#pragma unroll
+      for (int ks = 0; ks < KSC; ++ks) {
+        u32x4 bq[NPX], aq[NPW][FM];
+#pragma unroll
+        for (int q = 0; q < NPX; ++q) bq[q] = bvA[ks & 1][q];
+#pragma unroll
+        for (int q = 0; q < NPW; ++q)
+#pragma unroll
+          for (int i = 0; i < FM; ++i) aq[q][i] = aA[ks & 1][q][i];
+        if (ks + 2 < KSC) rd(ks + 2, bvA[ks & 1], aA[ks & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(bq, aq);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int h = 0; h < H2; ++h) rd(H + h, bvB[h], aB[h]);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int h = 0; h < H; ++h) mma(bvA[h], aA[h]);
-    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int ks = 0; ks < KSC; ++ks) te[ks] = tn[ks];
     if ((EBEN_T3_DBG & 2) == 0 && P.ncc > 1 && written + 1 < P.ncc && (written + 1) * KS_CC < (ch + 2) * KSC) {
