@@ -126,16 +126,17 @@ HBM_PEAK = 8.0e12
 
 
 def step_roofline_ms(disc_math, scale):
-    """Mixed roofline of the minimal step F_min = 2 (3 G + 8 D): sum over the parts of max(FLOP / peak(dtype), bytes / HBM).
-    fp32: everything on the fp32 MFMA peak.  bf16: the discriminator passes on the bf16 MFMA peak, the PQMF-band forwards (2 of
-    the 8 passes of those three chains) at three bf16 MFMAs per product; the generator's forward is fp32-grade (six bf16 MFMAs per
-    product), its backward (2 G, bf16 operands) is bound by its activation traffic."""
+    """Mixed roofline of the minimal step F_min = 2 (3 G + 8 D) with NO credit for work this build adds on top of it (the
+    hi + lo products of the PQMF-band forwards, the six-piece products of the fp32-grade generator forward): the eight discriminator
+    passes at max(FLOP / MFMA peak of `dtype`, bytes / HBM), the three generator passes likewise (HBM-bound: G_BYTES per pass; half
+    of it for the two backward passes on bf16 operands)."""
     f32, bf16 = MFMA_F32_PEAK_TFLOPS * 1e12, MFMA_BF16_PEAK_TFLOPS * 1e12
+    d_bytes = 1.627e9   # SURVEY 8d: discriminator activations in + out of one pass, fp32
     if disc_math == "f32":
-        t = 2 * (3 * G_MACS + 8 * D_MACS) / f32
+        t = 8 * max(2 * D_MACS / f32, d_bytes / HBM_PEAK) + 3 * max(2 * G_MACS / f32, G_BYTES / HBM_PEAK)
     else:
-        t = 2 * (8 * D_MACS - 2 * D_PQMF_MACS) / bf16 + 3 * 2 * 2 * D_PQMF_MACS / bf16
-        t += max(6 * 2 * G_MACS / bf16, G_BYTES / HBM_PEAK) + max(2 * 2 * G_MACS / bf16, 2 * G_BYTES / HBM_PEAK)
+        t = 8 * max(2 * D_MACS / bf16, 0.5 * d_bytes / HBM_PEAK)
+        t += max(2 * G_MACS / bf16, G_BYTES / HBM_PEAK) + 2 * max(2 * G_MACS / bf16, 0.5 * G_BYTES / HBM_PEAK)
     return t * scale * 1e3
 
 
@@ -171,13 +172,23 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: this process becomes the launcher of its N ranks (one process per GPU, RCCL;
+        # counterpart of vibravox configs/trainer/ddp.yaml:5-7 `devices` / `strategy`: one command, N ranks).  Rank 0's JSON line is
+        # the only thing the ranks write to stdout.
+        import socket
+        import subprocess
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd, env=env))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}"
-    if world > 1 or args.force_ddp:
-        # One hardware queue per stream of a data-parallel rank: main + the three auxiliary streams of the step + the process group's
-        # RCCL stream + the graph-capture stream.  The HIP runtime's default of four makes two of them share a queue (streams on one
-        # queue execute in submission order): [MI355X] --force-ddp 12.95 ms/step at 4 queues, 13.5 at 5, 12.25 at 6, 15.9 at 8, against
-        # 12.06 without a process group (unchanged at 4 / 5 / 6 / 8).  Read by the runtime when it initialises: set before any HIP call.
-        os.environ.setdefault("GPU_MAX_HW_QUEUES", "6")
+    from vibravox_amd._env import configure_hw_queues
+    hw_queues = configure_hw_queues(world > 1 or args.force_ddp)   # before the first HIP call (vibravox_amd/_env.py)
     assert torch.cuda.is_available(), "bench.py measures the HIP path: no GPU visible"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
@@ -293,12 +304,16 @@ def main():
         if rank == 0:
             print(f"[bench] warm-up step {i}: {(time.perf_counter() - tw) * 1e3:.1f} ms", file=sys.stderr, flush=True)
     # Launch sequences on their way into a HIP graph (ops.ReplayedChain / ReplayedPrepack: the capture of a sequence takes tens of ms and
-    # the chained ones settle one after the other) finish settling before the clock starts; reported as `settle_steps`
-    settle = 0
-    while settle < 12 and (ops.graphs_pending() or args.warmup + settle < 2):   # (no sequence has a signature before its first step)
-        mod.training_step(next_batch())
-        settle += 1
-    torch.cuda.synchronize()
+    # the chained ones settle one after the other) finish settling before ANY leg's clock starts; reported as `settle_steps`
+    def settle_graphs(done_before=0):
+        n = 0
+        while n < 12 and (ops.graphs_pending() or done_before + n < 2):   # (no sequence has a signature before its first step)
+            mod.training_step(next_batch())
+            n += 1
+        torch.cuda.synchronize()
+        return n
+
+    settle = settle_graphs(args.warmup)
     # Python's cyclic GC walks every tracked object of the process on a full collection (~100 ms here, a few times per
     # 40 steps: +2..5 ms/step and most of the run-to-run spread): the objects alive after warm-up are moved to the
     # permanent generation, as a long-running training process would do once after set-up (run.py does the same)
@@ -323,7 +338,7 @@ def main():
     if bf16 and not args.no_f32_leg:
         mod.disc_math = mod.gen_backward_math = "f32"
         mod.stft_math = "folded"
-        mod.training_step(next_batch())
+        settle32 = settle_graphs()   # the plan's own launch sequences are captured before its clock starts (as for the bf16 leg)
         dt32, per32 = timed_steps(args.steps)
 
     # ... and in the fp32-grade plan on the bf16 matrix pipe ("bf16x6": discriminator forward / input gradients and the MRSTFT
@@ -332,7 +347,7 @@ def main():
     dt6 = per6 = None
     if bf16 and not args.no_f32_leg:
         mod.disc_math, mod.gen_backward_math, mod.stft_math = "bf16x6", "f32", "folded_x6"
-        mod.training_step(next_batch())
+        settle6 = settle_graphs()
         dt6, per6 = timed_steps(args.steps)
 
     # the roofline kernel once more, ALONE on the device (inside the step it shares the GPU with the three other
@@ -415,7 +430,7 @@ def main():
         ideal = step_roofline_ms("f32" if not bf16 else "bf16", scale)
         line = {
             "metric": "EBEN train-step audio-seconds/sec (gen+disc)", "value": round(value, 2), "unit": "audio-seconds/sec",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "settle_steps": settle, "graphs_replayed": n_graphs, "host_enqueue_ms_per_step": round(host_ms, 3), "ms_per_step": round(ms, 3), "higher_is_better": True,
+            "n_gpus": world, "gpu_max_hw_queues": hw_queues or "default", "steps": args.steps, "warmup": args.warmup, "settle_steps": settle, "graphs_replayed": n_graphs, "host_enqueue_ms_per_step": round(host_ms, 3), "ms_per_step": round(ms, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
             "config": {"workload": (f"EBEN full GAN train step (gen+disc+MRSTFT+feature-matching+hinge, EMA balancing, Adam), batch {args.batch} x "
                                     f"{length} samples @16kHz per GPU (cut to {cut})"
@@ -437,8 +452,8 @@ def main():
             "roofline_time_dominant": roof_t,
             "roofline_family": family,
             "step_roofline": {"ideal_ms": round(ideal, 3), "frac": round(ideal / ms, 4),
-                              "note": "sum over the parts of F_min = 2(3G+8D) of max(FLOP / MFMA peak of the part's dtype, bytes / 8 TB/s) / measured ms per step "
-                                      "(SURVEY 8d; G = 6.727e8, D = 2.5255e9 MACs per audio-second)"},
+                              "note": "sum over the eleven passes of F_min = 2(3G+8D) of max(FLOP / dense MFMA peak of `dtype`, SURVEY 8d bytes / 8 TB/s) / measured ms per "
+                                      "step; no credit for the build's own extra products (G = 6.727e8, D = 2.5255e9 MACs per audio-second)"},
         }
         # whole-step arithmetic rate on SURVEY section 8d's minimal algorithmic count F_min = 2*(3G + 8D) (no credit for redundant passes)
         f_min = 2.0 * (3 * 6.727e8 + 8 * 2.5255e9) * audio_s
@@ -450,12 +465,15 @@ def main():
             ms32 = dt32 / args.steps * 1e3
             line["value_f32"] = round(audio_s / (dt32 / args.steps), 2)
             line["ms_per_step_f32"] = round(ms32, 3)
-            line["step_ms_f32"] = {"median": round(percentile(per32, 0.5), 3), "p10": round(percentile(per32, 0.1), 3), "p90": round(percentile(per32, 0.9), 3)}
+            line["step_ms_f32"] = {"median": round(percentile(per32, 0.5), 3), "p10": round(percentile(per32, 0.1), 3), "p90": round(percentile(per32, 0.9), 3),
+                                   "settle_steps": settle32}
             line["step_roofline_f32"] = {"ideal_ms": round(step_roofline_ms("f32", scale), 3), "frac": round(step_roofline_ms("f32", scale) / ms32, 4)}
         if dt6 is not None:
             ms6 = dt6 / args.steps * 1e3
             line["value_fp32_grade"] = round(audio_s / (dt6 / args.steps), 2)
             line["ms_per_step_fp32_grade"] = round(ms6, 3)
+            line["step_ms_fp32_grade"] = {"median": round(percentile(per6, 0.5), 3), "p10": round(percentile(per6, 0.1), 3), "p90": round(percentile(per6, 0.9), 3),
+                                          "settle_steps": settle6}
             line["fp32_grade_plan"] = ("disc_math bf16x6 + stft folded_x6 + fp32 generator backward: every contraction either exact fp32 or six bf16 piece "
                                        "products per fp32 product (dropped terms <= 2^-26); tests/test_gpu_models.py runs the golden replay in it")
         if use_ddp:

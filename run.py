@@ -114,6 +114,8 @@ def instantiate(node: Any) -> Any:
 
 
 def main(argv: List[str]) -> int:
+    from vibravox_amd._env import configure_hw_queues
+    configure_hw_queues()   # data-parallel ranks: before the first HIP call
     import torch
 
     cfg = compose(argv)
@@ -123,6 +125,8 @@ def main(argv: List[str]) -> int:
     datamodule = instantiate(cfg["lightning_datamodule"])
     module = instantiate(cfg["lightning_module"]).to(device)
     trainer = cfg.get("trainer", {})
+    if trainer.get("precision") is not None:   # vibravox configs/trainer/ddp.yaml:23-25: the trainer's precision selects the arithmetic plan
+        module.set_precision(trainer["precision"])
     loader = datamodule.train_dataloader()
     import gc
     for step in range(int(trainer.get("max_steps", 10))):

@@ -740,6 +740,53 @@ def test_generator_graphs_match_eager_launches(hip, golden):
     assert [k for k in a if not torch.equal(a[k], b[k])] == []
 
 
+def test_two_generator_forwards_before_one_backward_with_graphs(hip, golden):
+    """Plain PyTorch semantics next to the replayed generator forward (gen_engine.forward_train): y1 = G(x1); y2 = G(x2);
+    loss(y1, y2).backward().  A replay rewrites the previous replay's saved activations in place, so the second forward must not replay
+    while the first is undifferentiated -- gradients bit-identical to the same sequence with graphs off; and a backward through a forward
+    whose buffers a LATER replay has rewritten (retain_graph, new forward, second backward) raises instead of returning wrong gradients."""
+    from vibravox_amd import gen_engine
+
+    def run(graphs):
+        prev = gen_engine.USE_GRAPHS
+        gen_engine.USE_GRAPHS = graphs
+        try:
+            mod, _, _ = make_module(golden, use_mrstft=False)
+            mod.gen_backward_math = "f32"
+            for i in range(5):   # the training forward settles and is captured
+                mod.training_step({"audio_body_conducted": formula_audio(f"tf/{i}/bc", 2, 8200).to(DEV), "audio_airborne": formula_audio(f"tf/{i}/air", 2, 8200).to(DEV)})
+            gen = mod.generator
+            assert (gen._engine._fwd_graph.graph is not None) == graphs
+            for p in gen.parameters():
+                p.grad = None
+            x1 = gen.cut_to_valid_length(formula_audio("tf/x1", 2, 8200).to(DEV))
+            x2 = gen.cut_to_valid_length(formula_audio("tf/x2", 2, 8200).to(DEV))
+            w1, w2 = formula_audio("tf/w1", 2, x1.shape[-1]).to(DEV), formula_audio("tf/w2", 2, x1.shape[-1]).to(DEV)
+            y1 = gen(x1)[0]
+            y2 = gen(x2)[0]
+            ((y1 * w1).sum() + (y2 * w2).sum()).backward()
+            torch.cuda.synchronize()
+            out = {k: p.grad.clone() for k, p in gen.named_parameters() if p.grad is not None}
+            out["y1"], out["y2"] = y1.detach().clone(), y2.detach().clone()
+            return out, gen
+        finally:
+            gen_engine.USE_GRAPHS = prev
+
+    (a, gen), (b, _) = run(True), run(False)
+    assert len(a) > 80 and [k for k in a if not torch.equal(a[k], b[k])] == []
+    prev = gen_engine.USE_GRAPHS
+    gen_engine.USE_GRAPHS = True
+    try:
+        x = gen.cut_to_valid_length(formula_audio("tf/x3", 2, 8200).to(DEV))
+        y = gen(x)[0]
+        y.sum().backward(retain_graph=True)
+        gen(x)[0].sum().backward()              # a newer replay rewrites the buffers y's graph still points at
+        with pytest.raises(RuntimeError, match="rewritten by a later replayed forward"):
+            y.sum().backward()
+    finally:
+        gen_engine.USE_GRAPHS = prev
+
+
 def test_replayed_sequences_follow_changing_batch_shapes(hip, golden):
     """Train steps at alternating batch shapes (2 x 8200, 3 x 6100, each twice in a row so that the sequences of BOTH shapes are captured,
     then interleaved) in the benchmarked plan: every replayed sequence -- discriminator chains, generator forward / backward, prepack --

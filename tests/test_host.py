@@ -292,3 +292,26 @@ def test_run_py_config_composition_and_overrides():
     module = run.instantiate(cfg["lightning_module"])
     assert type(module).__name__ == "EBENLightningModule" and module.dynamic_loss_balancing == "ema"
     assert type(module.reconstructive_loss_freq_fn).__name__ == "MultiResolutionSTFTLoss"
+
+
+def test_trainer_precision_selects_the_arithmetic_plan():
+    """vibravox configs/trainer/ddp.yaml:23-25: the reference's knob for the step's arithmetic is ``trainer.precision``.  run.py hands it
+    to ``EBENLightningModule.set_precision``: ``bf16-mixed`` is the plan bench.py measures (BASELINE config 2), the default stays the
+    reference's fp32."""
+    import run
+    from vibravox_amd.lightning_modules.eben import DISC_MATH_PLANS, EBENLightningModule
+
+    cfg = run.compose(["lightning_module=eben"])
+    assert cfg["trainer"]["precision"] == "32-true"
+    module = run.instantiate(cfg["lightning_module"]).set_precision(cfg["trainer"]["precision"])
+    assert (module.disc_math, module.gen_backward_math, module.stft_math) == ("f32", "f32", None)
+    cfg = run.compose(["lightning_module=eben", "trainer.precision=bf16-mixed"])
+    module = run.instantiate(cfg["lightning_module"]).set_precision(cfg["trainer"]["precision"])
+    assert (module.disc_math, module.gen_backward_math, module.stft_math) == ("bf16_bl", "bf16", "folded_x3")
+    assert module.disc_math in DISC_MATH_PLANS and DISC_MATH_PLANS[module.disc_math]["layout"] == "bl"
+    for alias, plan in (("bf16", "bf16-mixed"), (32, "32-true"), ("32-split", "32-split")):
+        assert module.set_precision(alias).precision == plan
+    assert module.disc_math == "bf16x6" and module.gen_backward_math == "f32" and module.stft_math == "folded_x6"
+    with pytest.raises(ValueError):
+        module.set_precision("fp8")
+    assert all(p[0] in DISC_MATH_PLANS for p in EBENLightningModule.PRECISION_PLANS.values())

@@ -23,6 +23,9 @@ import torch
 import torch.distributed as dist
 
 
+_comm_streams = {}   # device -> the ordering stream of the gradient exchanges
+
+
 class _Bucket:
     def __init__(self, params: List[torch.nn.Parameter], device, dtype):
         self.params = params
@@ -50,10 +53,18 @@ class GradSync:
         dev, dtype = self.params[0].device, self.params[0].dtype
         self.on_gpu = dev.type == "cuda"
         if self.on_gpu:
-            # no stream of its own: a fifth stream would share a hardware queue with the main stream or a compute chain
-            # (see ops.aux_stream); the exchange is issued after the work of the side stream it rides on
+            # The stream the exchanges are ORDERED on (torch's process group runs the collective on a stream of its own, behind whatever
+            # stream is current at the call): a stream that carries nothing else, shared by the GradSyncs of the process.  With the six
+            # hardware queues of a data-parallel rank (_env.py) it no longer has to ride on the side stream (generator weight
+            # gradients, pre-packing), whose queued work an exchange then waited for; EBEN_COMM_STREAM=side restores that.
+            import os
             from . import ops
-            self.comm_stream = ops.aux_stream(2, dev)
+            if os.environ.get("EBEN_COMM_STREAM", "own") == "side":
+                self.comm_stream = ops.aux_stream(2, dev)
+            else:
+                if _comm_streams.get(dev) is None:
+                    _comm_streams[dev] = torch.cuda.Stream(device=dev)
+                self.comm_stream = _comm_streams[dev]
         else:
             self.comm_stream = None
         self.overlap = overlap

@@ -490,8 +490,12 @@ class DiscriminatorEngineBL(DiscriminatorEngine):
                                                                for lay in self.chains[i].layers for p in lay.params() if p is not None)
                     jobs_sig = tuple((k, (g.hi.data_ptr() if isinstance(g, Planes) else g.data_ptr()), x.hi.data_ptr(), x.lo.data_ptr()) for k, g, x in res[i][1])
                     sig = (half, s["inputs"][i].data_ptr(), res[i][0].hi.data_ptr(), jobs_sig, self._chain_sig(self.chains[i], -1), sink_sig)
-                    pend[i] = self._graphs["dw"][i].run(sig, lambda i=i: self.chains[i].weight_grads(res[i][1], s["inputs"][i], res[i][0], half, sink),
-                                                        torch.cuda.current_stream())
+                    dw_body = lambda i=i: self.chains[i].weight_grads(res[i][1], s["inputs"][i], res[i][0], half, sink)
+                    # A replay rewrites the gradients of the previous replay in place, and without a sink those tensors BECOME ``.grad``
+                    # (inject_grads): while a parameter still holds a gradient (accumulation over steps, zero_grad(set_to_none=False), a
+                    # caller that does not zero) the launches run eagerly into fresh tensors, as gen_engine._deferrable has it.
+                    held = sink is None and any(p.grad is not None for lay in self.chains[i].layers for p in lay.params() if p is not None)
+                    pend[i] = dw_body() if held else self._graphs["dw"][i].run(sig, dw_body, torch.cuda.current_stream())
                     if self._sink is not None:
                         self._sink.mark_ready([p for lay in self.chains[i].layers for p in lay.params() if p is not None and p.requires_grad])
             self._pending = (pend, s, res)   # keeps the saved activations and the stacked gradients alive until the kernels have run

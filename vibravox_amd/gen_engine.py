@@ -534,9 +534,16 @@ class GeneratorEngine:
         return tuple(parts)
 
     def forward_train(self, x: torch.Tensor):
-        """``forward(x, True)``, replayed as a graph once the sequence has settled."""
+        """``forward(x, True)``, replayed as a graph once the sequence has settled.
+
+        A replay REWRITES the outputs and saved activations of the previous replay in place.  Plain PyTorch semantics -- two
+        grad-enabled forwards, then a backward through both -- therefore need a guard: every call gets a serial number; while the
+        latest replayed forward has not been differentiated (and its autograd node is still alive) the next forward runs eagerly on
+        fresh tensors, and ``backward_train`` refuses saved state whose serial is no longer the graph's (a second backward with
+        ``retain_graph`` after a newer replay) instead of returning gradients of the wrong forward."""
         self._fwd_replayed = False
-        if not self._graphs_usable():
+        self._serial = getattr(self, "_serial", 0) + 1
+        if not self._graphs_usable() or self._replay_outstanding():
             return self.forward(x, True)
         ops.join_prepack()
         ev = getattr(self, "_prepacked", None)
@@ -547,7 +554,24 @@ class GeneratorEngine:
         buf.copy_(x)
         out = self._fwd_graph.run(self._fwd_sig(buf), lambda: self.forward(buf, True), None)
         self._fwd_replayed = self._fwd_graph.graph is not None
+        if self._fwd_replayed:
+            self._graph_serial = self._serial   # whose forward the graph's buffers hold
         return out
+
+    def _replay_outstanding(self) -> bool:
+        """The graph's buffers hold a forward that an autograd node still alive has not been differentiated through."""
+        ref = getattr(self, "_outstanding", None)
+        if ref is None:
+            return False
+        if ref() is None:
+            self._outstanding = None
+            return False
+        return True
+
+    def _note_ctx(self, ctx) -> None:
+        import weakref
+        ctx.serial = self._serial
+        self._outstanding = weakref.ref(ctx) if self._fwd_replayed else None
 
     def _deferrable(self) -> bool:
         """Weight gradients of the whole core go through ``weight_grads_on_side_stream().join()``'s assignment (no gradient held, no
@@ -598,14 +622,19 @@ class GeneratorEngine:
         return assign
 
     @torch.no_grad()
-    def backward_train(self, saved, g_pre: torch.Tensor) -> None:
+    def backward_train(self, saved, g_pre: torch.Tensor, serial: Optional[int] = None) -> None:
         """``backward(saved, g_pre)``; behind a replayed forward and inside ``ops.weight_grads_on_side_stream()``: per segment (decoder
         block / latent convs / encoder block) the input-gradient launches as one graph on the current stream and the segment's
         weight-gradient launches as one graph on the side stream behind it -- the weight gradients of segment k run beside the
         input-gradient chain of segment k + 1, as the launch-by-launch schedule has them.  Results are assigned by the context's
         ``join()``.  ([MI355X] as two graphs -- the whole chain, then all weight gradients -- the step went 12.0 -> 12.5 ms: the chain
         alone fills a fraction of the GPU.)"""
-        if not (self._graphs_usable() and getattr(self, "_fwd_replayed", False) and saved is self._fwd_graph.out[2] and self._deferrable()):
+        from_graph = self._fwd_graph.out is not None and saved is self._fwd_graph.out[2]
+        if from_graph and serial is not None and serial != getattr(self, "_graph_serial", None):
+            raise RuntimeError("EBEN generator engine: this forward's saved activations were rewritten by a later replayed forward (backward "
+                               "through an old graph after a new training forward); set EBEN_GEN_GRAPHS=0 for that pattern")
+        self._outstanding = None   # differentiated: the next forward may replay over these buffers
+        if not (self._graphs_usable() and getattr(self, "_fwd_replayed", False) and from_graph and self._deferrable()):
             return self.backward(saved, g_pre)
         gbuf = self._static_buf("g", g_pre)
         gbuf.copy_(g_pre)
@@ -662,6 +691,7 @@ class _CoreFn(torch.autograd.Function):
     def forward(ctx, x, engine, *params):
         pre, first_bands, saved = engine.forward_train(x)
         ctx.engine, ctx.saved = engine, saved
+        engine._note_ctx(ctx)
         # fresh tensor objects: behind a replayed forward `pre` is the SAME object every step, and autograd writes this call's history
         # into what it is handed
         pre, first_bands = pre.detach(), first_bands.detach()
@@ -670,7 +700,7 @@ class _CoreFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_pre, _g_fb):
-        ctx.engine.backward_train(ctx.saved, g_pre)
+        ctx.engine.backward_train(ctx.saved, g_pre, getattr(ctx, "serial", None))
         return (None, None) + (None,) * (len(ctx.needs_input_grad) - 2)
 
 

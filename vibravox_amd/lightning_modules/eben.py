@@ -168,6 +168,28 @@ class EBENLightningModule(BaseSELightningModule):
     #: None leaves the loss module's own setting (exact fp32, folded); "bf16x3" goes with the bf16 step of BASELINE config 2
     stft_math: Optional[str] = os.environ.get("EBEN_STEP_STFT_MATH") or None
 
+    #: ``trainer.precision`` (vibravox configs/trainer/ddp.yaml:23-25, Lightning's names) -> (disc_math, gen_backward_math, stft_math).
+    #: "32-true" is the reference's arithmetic (exact fp32 products), "bf16-mixed" the plan BASELINE config 2 names and bench.py
+    #: measures (bf16 MFMA operands, fp32 accumulate / parameters / optimiser state), "32-split" fp32-grade arithmetic on the bf16
+    #: matrix pipe (six bf16 piece products per fp32 product).
+    PRECISION_PLANS = {
+        "32-true": ("f32", "f32", None),
+        "bf16-mixed": ("bf16_bl", "bf16", "folded_x3"),
+        "32-split": ("bf16x6", "f32", "folded_x6"),
+    }
+    _PRECISION_ALIASES = {"32": "32-true", "fp32": "32-true", "f32": "32-true", "bf16": "bf16-mixed", "bf16-true": "bf16-mixed",
+                          "16-mixed": "bf16-mixed", "bf16x6": "32-split"}
+
+    def set_precision(self, precision) -> "EBENLightningModule":
+        """Selects the step's arithmetic plan from the trainer's ``precision`` key (``run.py`` passes ``trainer.precision`` here)."""
+        key = str(precision).strip().lower()
+        key = self._PRECISION_ALIASES.get(key, key)
+        if key not in self.PRECISION_PLANS:
+            raise ValueError(f"precision must be one of {sorted(self.PRECISION_PLANS)} (or {sorted(self._PRECISION_ALIASES)}), got {precision!r}")
+        self.disc_math, self.gen_backward_math, self.stft_math = self.PRECISION_PLANS[key]
+        self.precision = key
+        return self
+
     def _engine_usable(self, batch) -> bool:
         from ..disc_engine import DiscriminatorEngine
         from ..torch_modules.losses.feature_loss import FeatureLossForDiscriminatorMelganMultiScales

@@ -415,10 +415,13 @@ def graphs_pending() -> int:
     return n
 
 
-#: replay the collective-free launch sequences as graphs in multi-rank runs too (default off: the captures -- a device-wide synchronisation
-#: and an allocator flush in the first steps, next to RCCL traffic -- have only met a single-rank process group on hardware,
-#: ``bench.py --force-ddp``)
-DDP_GRAPHS = os.environ.get("EBEN_DDP_GRAPHS", "0") != "0"
+#: Multi-rank runs replay the collective-free launch sequences as graphs like a single-GPU run does (every graph holds the launches of ONE
+#: stream between two joins; the all-reduces are issued outside them, from ``GradSync.mark_ready`` / ``finish``).  The captures happen in
+#: the first steps, in the same program order on every rank (SPMD: the signatures settle in the same step everywhere), each with
+#: ``capture_error_mode="thread_local"`` so that the process group's watchdog thread may go on querying its events; a capture's device-wide
+#: synchronisation merely waits for the exchange in flight, which every rank has issued before it reaches the capture.  Without the graphs a
+#: rank enqueues ~11 ms of host work per ~12 ms step.  ``EBEN_DDP_GRAPHS=0`` is the escape hatch (eager launches).
+DDP_GRAPHS = os.environ.get("EBEN_DDP_GRAPHS", "1") != "0"
 
 
 def graphs_captured() -> int:
@@ -445,8 +448,7 @@ class ReplayedPrepack:
 
     @staticmethod
     def _multi_rank() -> bool:
-        """Eager launches in data-parallel runs: the capture (device-wide synchronisation, cache flush) would run next to RCCL's
-        in-flight exchanges on the communication stream; the replay only saves host time, of which a multi-rank step has spare."""
+        """True when a multi-rank run asked for eager launches (``EBEN_DDP_GRAPHS=0``, see ``DDP_GRAPHS``)."""
         if DDP_GRAPHS:
             return False
         d = torch.distributed
@@ -494,21 +496,32 @@ class ReplayedChain:
     would serve parallel branches from extra hardware queues, see ``aux_stream``); events between chains stay outside."""
 
     enabled = os.environ.get("EBEN_CHAIN_GRAPHS", "1") != "0"
+    #: graphs kept per chain, least recently used first out.  A run whose signature alternates -- variable clip lengths, a validation
+    #: shape between train steps, ``update_discriminator_ratio < 1`` toggling ``want_param_grads`` -- replays each variant from its own
+    #: graph instead of paying a capture (device-wide synchronisation, tens of ms) at every other change.  Each graph keeps its pool
+    #: (the tensors its body allocates) for as long as it is cached.
+    KEEP = int(os.environ.get("EBEN_CHAIN_GRAPHS_KEEP", "4"))
+    _generation = [0]
 
     def __init__(self):
         self.graph, self.sig, self.rounds, self.out = None, None, 0, None
-        self.captures = 0   # how many times this chain has been captured: names the generation of the tensors in ``out``
+        self.captures = 0   # names the generation of the tensors in ``out`` (unique per capture, restored on a cache hit)
+        self._cache = {}    # signature -> (graph, out, generation), insertion order = recency
         _replayed.add(self)
 
     def run(self, sig, fn, stream_):
         if not self.enabled or ReplayedPrepack._multi_rank() or _timers_enabled():
             return fn()
+        hit = self._cache.pop(sig, None)
+        if hit is not None:
+            self._cache[sig] = hit   # most recent
+            self.graph, self.out, self.captures = hit
+            self.sig = sig
+            self.graph.replay()
+            return self.out
         if sig != self.sig:
             self.graph, self.sig, self.rounds, self.out = None, sig, 0, None
         self.rounds += 1
-        if self.graph is not None:
-            self.graph.replay()
-            return self.out
         if self.rounds < 2:
             return fn()
         graph = torch.cuda.CUDAGraph()
@@ -523,8 +536,11 @@ class ReplayedChain:
             warnings.warn(f"chain graph capture failed ({exc!r}): staying with eager launches")
             ReplayedChain.enabled = False
             return fn()
-        self.graph, self.out = graph, out
-        self.captures += 1
+        ReplayedChain._generation[0] += 1
+        self.graph, self.out, self.captures = graph, out, ReplayedChain._generation[0]
+        self._cache[sig] = (graph, out, self.captures)
+        while len(self._cache) > max(1, self.KEEP):
+            self._cache.pop(next(iter(self._cache)))
         graph.replay()   # the capture recorded the launches without running them
         return out
 
