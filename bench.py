@@ -187,6 +187,11 @@ def main():
                "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
         sys.exit(subprocess.call(cmd, env=env))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}"
+    # stdout carries ONE line, rank 0's JSON.  RCCL writes its banner and its warnings ("NCCL WARN Missing iommu=pt ...") to file
+    # descriptor 1 from C: from here on fd 1 IS stderr for everything in this process, and the JSON line goes to the saved descriptor.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     from vibravox_amd._env import configure_hw_queues
     hw_queues = configure_hw_queues(world > 1 or args.force_ddp)   # before the first HIP call (vibravox_amd/_env.py)
     assert torch.cuda.is_available(), "bench.py measures the HIP path: no GPU visible"
@@ -492,8 +497,10 @@ def main():
         dist.destroy_process_group()
     import ctypes
     ctypes.CDLL(None).fflush(None)
+    sys.stdout.flush()
     if rank == 0:
-        print(json.dumps(line), flush=True)
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
+    os.close(json_fd)
 
 
 if __name__ == "__main__":

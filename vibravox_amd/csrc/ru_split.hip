@@ -72,6 +72,9 @@ constexpr int RS_DMAX = 9;   // largest dilation the tile strides are laid out f
 
 struct Ru3Args {
   const float* x; const u32x4* wimg; float* y; float* h; float* u;
+  // BL (what the bundle-layout backward reads, ru_bl.hip): xin = lrelu(x) and h as bf16 bundles [item][C / 8][L][8], and one byte per
+  // (bundle, position) with bit e = (u[8 g + e] > 0)
+  u32x4* xb; u32x4* hb; unsigned char* um;
   int B, L, d, ntt, vec;
   float in_slope, out_slope;
 };
@@ -80,7 +83,7 @@ struct Ru3Args {
 // forward: y = xin + lrelu(W_pw . (W_dil (*) xin)), xin = lrelu(x).  Block = NW waves = one item x 32 NW positions x all C = 32 CT
 // channels; a wave owns 32 positions and every row (so that stage 2 finds its whole reduction in the wave's own accumulators).
 // ---------------------------------------------------------------------------------------------------------------------------
-template <int CT, int NW, int NP, int KSC>
+template <int CT, int NW, int NP, int KSC, bool BL = false>
 __global__ __launch_bounds__(NW * 64, (NW == 4 && CT < 4) ? 2 : 1) void ru3_fwd_kernel(const Ru3Args P) {
   constexpr int NT = NW * 64, BN = NW * 32, C = 32 * CT;
   constexpr int XS = BN + 2 * RS_DMAX + 6;          // floats per staged row: BN + 2 d + 3 (alignment shift) fits; multiple of 4
@@ -175,6 +178,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && CT < 4) ? 2 : 1) void ru3_fwd_
 
   const int col = wn * 32 + (lane & 31);
   const float* xb = Xs + (lane >> 5) * 8 * XS + xshift + col;   // this lane's 8 channels of a 16-channel k-step start here
+  const int t = t0 + col;
+  const bool live = t < L;
+  // bundle rows of this item: unit (bundle g, position t) at ubase + g L
+  const long long ubase = (long long)b * (C / 8) * L + t;
 
   // ---- stage 1: h = W_dil (*) xin; k-step ks = tap (ks / KB) x channels 16 (ks % KB) .. + 15 ----
 #pragma nounroll
@@ -195,16 +202,32 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && CT < 4) ? 2 : 1) void ru3_fwd_
 #pragma unroll
         for (int i = 0; i < CT; ++i) a[q][i] = wb[kk * U + (q * CT + i) * 64];
       rs_split8<NP>(v, bq);
+      if constexpr (BL) {
+        // the centre tap's fragment IS the saved input: piece 0 = bf16(xin) of channels 16 cb + 8 (lane >> 5) .. + 7 at this column
+        if (j == 1 && live) P.xb[ubase + (long long)(2 * cb + (lane >> 5)) * L] = bq[0];
+      }
       rs_mma<NP, CT>(a, bq, acc1);
     }
     __syncthreads();
   }
 
-  const int t = t0 + col;
-  const bool live = t < L;
   // stores: one 64-bit base per lane (item, column), 32-bit row offsets
   const long long lbase = (long long)b * C * L + t;
-  if (P.h != nullptr && live) {
+  if constexpr (BL) {
+    // lane holds rows 8 q + 4 (lane >> 5) + e of tile i in registers 4 q + e: one 8-byte half of the unit (bundle 4 i + q, t)
+    if (live) {
+      uint2* __restrict__ hu = reinterpret_cast<uint2*>(P.hb + ubase) + (lane >> 5);
+#pragma unroll
+      for (int i = 0; i < CT; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          uint2 v;
+          v.x = rs_pack_bf16(acc1[i][4 * q], acc1[i][4 * q + 1]);
+          v.y = rs_pack_bf16(acc1[i][4 * q + 2], acc1[i][4 * q + 3]);
+          hu[(long long)(4 * i + q) * L * 2] = v;
+        }
+    }
+  } else if (P.h != nullptr && live) {
     float* __restrict__ hb = P.h + lbase;
 #pragma unroll
     for (int i = 0; i < CT; ++i)
@@ -239,12 +262,40 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && CT < 4) ? 2 : 1) void ru3_fwd_
     if (c2 + 1 < NCH2) __syncthreads();
   }
 
+  if constexpr (BL) {
+    // sign bits of z (= of u): nibble (i, q) of this lane = its four rows of bundle 4 i + q; the other four sit in lane ^ 32
+    unsigned nlo = 0, nhi = 0;
+#pragma unroll
+    for (int i = 0; i < CT; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        unsigned nib = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) nib |= (acc2[i][4 * q + e] > 0.f ? 1u : 0u) << e;
+        if (i < 2) nlo |= nib << (4 * (4 * i + q));
+        else nhi |= nib << (4 * (4 * (i - 2) + q));
+      }
+    const unsigned olo = __shfl_xor(nlo, 32, 64), ohi = CT > 2 ? __shfl_xor(nhi, 32, 64) : 0u;
+    const int hf = lane >> 5;
+    const unsigned l0 = hf ? olo : nlo, l1 = hf ? nlo : olo, h0 = hf ? ohi : nhi, h1 = hf ? nhi : ohi;   // rows 0-3 / 4-7 of every bundle
+    if (live) {
+      unsigned char* __restrict__ ub8 = P.um + ubase;
+#pragma unroll
+      for (int g = 0; g < 4 * CT; g += 2) {   // each half-wave stores every other bundle row
+        const int gg = g + hf;
+        const unsigned w0 = gg < 8 ? l0 : h0, w1 = gg < 8 ? l1 : h1;
+        const int sh = 4 * (gg & 7);
+        ub8[(long long)gg * L] = (unsigned char)(((w0 >> sh) & 15u) | (((w1 >> sh) & 15u) << 4));
+      }
+    }
+  }
+
   // ---- epilogue: y = xin + lrelu(z) (xin from the staged tile) ----
   if (!live) return;
   const float* xc = Xs + xshift + d + col;
   float* __restrict__ yb = P.y + lbase;
   float* __restrict__ ub = P.u + lbase;
-  const bool keep_u = P.u != nullptr;
+  const bool keep_u = !BL && P.u != nullptr;
 #pragma unroll
   for (int i = 0; i < CT; ++i)
 #pragma unroll
@@ -613,10 +664,10 @@ static int rs_pieces(int math) {
   }
 }
 
-template <int CT, int NW, int NP, int KSC>
+template <int CT, int NW, int NP, int KSC, bool BL = false>
 static int launch_ru3_fwd(const Ru3Args& a, hipStream_t st) {
   static bool attr_set = false;
-  auto kern = ru3_fwd_kernel<CT, NW, NP, KSC>;
+  auto kern = ru3_fwd_kernel<CT, NW, NP, KSC, BL>;
   constexpr int XS = NW * 32 + 2 * RS_DMAX + 6;
   const size_t lds = (size_t)2 * KSC * NP * CT * 64 * 16 + sizeof(float) * 32 * CT * XS;
   if (!attr_set) {
