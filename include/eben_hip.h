@@ -78,6 +78,9 @@ typedef struct EbenConv1dDesc {
 } EbenConv1dDesc;
 
 EBEN_API const char* eben_last_error(void);
+/* Bumped whenever a POD structure, an entry point's signature or a table stride changes (2: EbenWnBwdItem.col_perm_k; 3: eben_rubl_*).
+ * eben_version() returns the value the library was built with; bindings compare it with the header they were written against. */
+#define EBEN_ABI_VERSION 3
 EBEN_API int eben_version(void);
 /* fills name with the device's gcnArchName; returns compute-unit count (or negative) */
 EBEN_API int eben_device_info(char* name, size_t name_bytes);
@@ -287,6 +290,24 @@ EBEN_API int eben_ru_bwd_ex(int math, int batch, int channels, int length, int d
 EBEN_API int eben_ru_dw_slabs(int batch, int channels, int length);
 EBEN_API int eben_ru_dw(int math, int batch, int channels, int length, int dilation, const float* gy, const float* u, float out_slope,
                const float* h, const float* gh, const float* x, float in_slope, float* slabs_pw, float* slabs_dil, void* stream);
+
+/* ResidualUnit with what the backward needs AT REST AS bf16 BUNDLES (csrc/ru_bl.hip; the bf16 generator backward of
+ * vibravox/torch_modules/dnn/eben_generator.py:287-316).  Bundle plane of a (batch, C, L) tensor: bf16 [batch][C / 8][L][8] (2 batch C L
+ * bytes); sign plane: [batch][C / 8][L] bytes, bit e = (value of channel 8 g + e > 0).
+ *   eben_rubl_fwd  = eben_ru_fwd_ex (math EBEN_MATH_BF16X6) that writes y (fp32) and, instead of h / u in fp32: xb = bf16(lrelu(x)),
+ *                    hb = bf16(h) as bundle planes and umask = the sign plane of u.
+ *   eben_rubl_bwd  = eben_ru_bwd_ex (math EBEN_MATH_BF16; wimg_bwd = the EBEN_MATH_BF16 image of eben_ru_pack_ex(which = 1)): g_y fp32 in,
+ *                    g_x fp32 out; gzb = bf16(g_y lrelu'(u)) and ghb = bf16(g_h) leave as bundle planes (operands of eben_rubl_dw only).
+ *   eben_rubl_dw   = eben_ru_dw on the four bundle planes: slabs [eben_rubl_dw_slabs(batch, C, L)][C][C] and [..][C][3 C] in
+ *                    eben_ru_dw's layout. */
+EBEN_API int eben_rubl_supported(int channels, int dilation);
+EBEN_API int eben_rubl_fwd(int math, int batch, int channels, int length, int dilation, const float* x, float in_slope, float out_slope,
+                           const float* wimg, float* y, void* xb, void* hb, void* umask, void* stream);
+EBEN_API int eben_rubl_bwd(int batch, int channels, int length, int dilation, const float* gy, const void* umask, float out_slope, const float* x,
+                           float in_slope, const float* post, const float* wimg_bwd, float* gx, void* gzb, void* ghb, void* stream);
+EBEN_API int eben_rubl_dw_slabs(int batch, int channels, int length);
+EBEN_API int eben_rubl_dw(int batch, int channels, int length, int dilation, const void* gzb, const void* hb, const void* ghb, const void* xb,
+                          float* slabs_pw, float* slabs_dil, void* stream);
 
 /* ---- PQMF (vibravox/torch_modules/dsp/pqmf.py:194-213, eben_generator.py:209-211) ---------- */
 /* decimating FIR bank: y[b,k,t] = sum_j w[k*ntaps+j] * x[b,0,t*stride+off0+j], zero outside [0,lx) */

@@ -488,6 +488,126 @@ def test_fused_residual_unit_weight_gradients(hip, channels, dilation, length, b
         assert rel_err(dg, rg.grad) < 2 * tol, (cols, rel_err(dg, rg.grad))
 
 
+def _to_bundles(t: torch.Tensor) -> torch.Tensor:
+    """(batch, C, L) fp32 -> bf16 bundle plane [batch][C / 8][L][8] (RNE), include/eben_hip.h "ResidualUnit ... AT REST AS bf16 BUNDLES"."""
+    b, c, l = t.shape
+    return t.view(b, c // 8, 8, l).permute(0, 1, 3, 2).contiguous().to(torch.bfloat16)
+
+
+def _from_bundles(p: torch.Tensor) -> torch.Tensor:
+    b, cb, l, _ = p.shape
+    return p.float().permute(0, 1, 3, 2).reshape(b, cb * 8, l).contiguous()
+
+
+def _sign_plane(t: torch.Tensor) -> torch.Tensor:
+    b, c, l = t.shape
+    bits = (t.view(b, c // 8, 8, l) > 0).to(torch.int32)
+    w = torch.tensor([1, 2, 4, 8, 16, 32, 64, 128], dtype=torch.int32, device=t.device).view(1, 1, 8, 1)
+    return (bits * w).sum(dim=2).to(torch.uint8).contiguous()
+
+
+@pytest.mark.parametrize("channels,dilation,length,batch,in_slope,post", [
+    (32, 1, 1000, 3, 1.0, False), (32, 3, 517, 2, 0.01, True), (32, 9, 8000, 2, 1.0, False), (64, 9, 300, 3, 0.01, True),
+    (64, 1, 4000, 2, 1.0, False), (128, 3, 1000, 2, 1.0, True), (128, 9, 131, 2, 0.01, False), (32, 9, 20, 1, 1.0, False),
+    (32, 9, 110, 1, 1.0, False), (64, 3, 123, 2, 1.0, False), (128, 9, 999, 2, 1.0, False), (128, 1, 47, 1, 1.0, True),
+    (64, 9, 3996, 2, 1.0, False)])
+def test_bundle_layout_residual_unit(hip, channels, dilation, length, batch, in_slope, post):
+    """The ResidualUnit with its saved tensors at rest as bf16 bundles (csrc/ru_bl.hip; eben_generator.py:287-316 forward and backward):
+      * eben_rubl_fwd: y bit-identical to eben_ru_fwd_ex(EBEN_MATH_BF16X6); the planes it saves are exactly bf16(lrelu(x)), bf16(h) of the
+        fp32 kernel's h and the sign bits of its u;
+      * eben_rubl_bwd: g_x bit-identical to eben_ru_bwd_ex(EBEN_MATH_BF16) (same roundings, same accumulation order) and within its
+        tolerance of fp64 autograd; the planes it writes are bf16(g_y lrelu'(u)) and bf16 of that kernel's g_h;
+      * eben_rubl_dw + eben_wn_bwd: dv / dg of both convs against fp64 autograd at the bf16 tolerance, and against the fp64 contraction of
+        the SAME bf16 operands at fp32 accumulation accuracy (the reduction itself is exact up to summation order).
+    Tile interiors, both reflect folds, windows that overhang the signal, K slabs that end inside a chunk, lengths that are not a
+    multiple of anything."""
+    from vibravox_amd._lib import check, load, ptr, stream
+
+    lib, dev = load(), torch.device("cuda")
+    c = channels
+    assert lib.eben_rubl_supported(c, dilation) == 1
+    vd = formula_tensor(f"rubl/{c}/{dilation}/vd", (c, c, 3), 1 / math.sqrt(3 * c))
+    vp = formula_tensor(f"rubl/{c}/{dilation}/vp", (c, c, 1), 1 / math.sqrt(c))
+    gd = vd.reshape(c, -1).norm(dim=1).reshape(c, 1, 1) * (1 + 0.3 * formula_tensor(f"rubl/{c}/gd", (c, 1, 1)))
+    gp = vp.reshape(c, -1).norm(dim=1).reshape(c, 1, 1) * (1 + 0.3 * formula_tensor(f"rubl/{c}/gp", (c, 1, 1)))
+    x = formula_tensor(f"rubl/{c}/{dilation}/{length}/x", (batch, c, length))
+    gy = formula_tensor(f"rubl/{c}/{dilation}/{length}/gy", (batch, c, length))
+    pt = formula_tensor(f"rubl/{c}/{dilation}/{length}/post", (batch, c, length))
+    # fp64 autograd of the weight-normalised unit
+    rvd, rvp, rgd, rgp = (t.double().requires_grad_(True) for t in (vd, vp, gd, gp))
+    wd = rvd * (rgd / rvd.flatten(1).norm(dim=1).reshape(c, 1, 1))
+    wp_ = rvp * (rgp / rvp.flatten(1).norm(dim=1).reshape(c, 1, 1))
+    xr = x.double().requires_grad_(True)
+    xin = torch.nn.functional.leaky_relu(xr, in_slope)
+    h = torch.nn.functional.conv1d(torch.nn.functional.pad(xin, (dilation, dilation), mode="reflect"), wd, dilation=dilation)
+    h.retain_grad()
+    u = torch.nn.functional.leaky_relu(torch.nn.functional.conv1d(h, wp_), 0.01)
+    ((xin + u) * gy.double()).sum().backward()
+    gx_ref = xr.grad + (pt.double() if post else 0.0)
+
+    xd, gyd, ptd = x.to(dev), gy.to(dev), pt.to(dev)
+    scales = {}
+    for name, v, g, cols in (("d", vd, gd, 3 * c), ("p", vp, gp, c)):
+        vdev, gdev = v.to(dev), g.to(dev)
+        scale, norm = torch.empty(c, device=dev), torch.empty(c, device=dev)
+        check(lib.eben_wn_scale(ptr(gdev), ptr(vdev), c, cols, ptr(scale), ptr(norm), stream()), "wn_scale")
+        scales[name] = (vdev, gdev, scale, norm)
+    img_f = torch.empty(lib.eben_ru_packed_floats_ex(c, 4), dtype=torch.float32, device=dev)
+    img_b = torch.empty(lib.eben_ru_packed_floats_ex(c, 1), dtype=torch.float32, device=dev)
+    check(lib.eben_ru_pack_ex(c, 4, 0, ptr(scales["d"][0]), ptr(scales["d"][2]), ptr(scales["p"][0]), ptr(scales["p"][2]), ptr(img_f), stream()), "ru_pack")
+    check(lib.eben_ru_pack_ex(c, 1, 1, ptr(scales["d"][0]), ptr(scales["d"][2]), ptr(scales["p"][0]), ptr(scales["p"][2]), ptr(img_b), stream()), "ru_pack")
+
+    # ---- forward
+    y0, h0, u0 = torch.empty_like(xd), torch.empty_like(xd), torch.empty_like(xd)
+    check(lib.eben_ru_fwd_ex(4, batch, c, length, dilation, ptr(xd), in_slope, 0.01, ptr(img_f), ptr(y0), ptr(h0), ptr(u0), stream()), "ru_fwd")
+    y1 = torch.full_like(xd, float("nan"))
+    xb = torch.full((batch, c // 8, length, 8), float("nan"), dtype=torch.bfloat16, device=dev)
+    hb = torch.full_like(xb, float("nan"))
+    um = torch.full((batch, c // 8, length), 0xAA, dtype=torch.uint8, device=dev)
+    check(lib.eben_rubl_fwd(4, batch, c, length, dilation, ptr(xd), in_slope, 0.01, ptr(img_f), ptr(y1), xb.data_ptr(), hb.data_ptr(), um.data_ptr(), stream()), "rubl_fwd")
+    torch.cuda.synchronize()
+    assert torch.equal(y0, y1)
+    assert torch.equal(xb, _to_bundles(torch.nn.functional.leaky_relu(xd, in_slope)))
+    assert torch.equal(hb, _to_bundles(h0))
+    assert torch.equal(um, _sign_plane(u0))
+
+    # ---- input gradients
+    gx0, gh0 = torch.empty_like(xd), torch.empty_like(xd)
+    check(lib.eben_ru_bwd_ex(1, batch, c, length, dilation, ptr(gyd), ptr(u0), 0.01, ptr(xd) if in_slope != 1.0 else None, in_slope,
+                             ptr(ptd) if post else None, ptr(img_b), ptr(gx0), ptr(gh0), stream()), "ru_bwd")
+    gx1 = torch.full_like(xd, float("nan"))
+    gzb, ghb = torch.full_like(xb, float("nan")), torch.full_like(xb, float("nan"))
+    check(lib.eben_rubl_bwd(batch, c, length, dilation, ptr(gyd), um.data_ptr(), 0.01, ptr(xd) if in_slope != 1.0 else None, in_slope,
+                            ptr(ptd) if post else None, ptr(img_b), ptr(gx1), gzb.data_ptr(), ghb.data_ptr(), stream()), "rubl_bwd")
+    torch.cuda.synchronize()
+    assert torch.equal(gzb, _to_bundles(gyd * torch.where(u0 > 0, 1.0, 0.01)))
+    assert torch.equal(ghb, _to_bundles(gh0))
+    assert torch.equal(gx0, gx1)
+    assert rel_err(gx1, gx_ref) < RU_TOL[1] and rel_err(_from_bundles(ghb), h.grad) < RU_TOL[1]
+
+    # ---- weight gradients
+    nslab = lib.eben_rubl_dw_slabs(batch, c, length)
+    assert nslab >= batch
+    sp = torch.full((nslab * c * c,), float("nan"), dtype=torch.float32, device=dev)
+    sdil = torch.full((nslab * c * 3 * c,), float("nan"), dtype=torch.float32, device=dev)
+    check(lib.eben_rubl_dw(batch, c, length, dilation, gzb.data_ptr(), hb.data_ptr(), ghb.data_ptr(), xb.data_ptr(), ptr(sp), ptr(sdil), stream()), "rubl_dw")
+    torch.cuda.synchronize()
+    # the contraction of the same bf16 operands in fp64
+    gz64, h64, gh64, x64 = (_from_bundles(t).double().cpu() for t in (gzb, hb, ghb, xb))
+    dwp = torch.einsum("bmt,bct->mc", gz64, h64)
+    xpad = torch.nn.functional.pad(x64, (dilation, dilation), mode="reflect")
+    dwd = torch.stack([torch.einsum("bmt,bct->mc", gh64, xpad[:, :, j * dilation: j * dilation + length]) for j in range(3)], dim=2)
+    got_p = sp.view(nslab, c, c).double().sum(0).cpu()
+    got_d = sdil.view(nslab, c, c, 3).double().sum(0).cpu()
+    assert rel_err(got_p, dwp) < 2e-6 and rel_err(got_d, dwd) < 2e-6, (rel_err(got_p, dwp), rel_err(got_d, dwd))
+    for slabs, cols, key, rv, rg in ((sp, c, "p", rvp, rgp), (sdil, 3 * c, "d", rvd, rgd)):
+        vdev, gdev, _, norm = scales[key]
+        dv, dg = torch.empty_like(vdev), torch.empty_like(gdev)
+        check(lib.eben_wn_bwd(ptr(slabs), nslab, c * cols, c, cols, cols, ptr(gdev), ptr(vdev), ptr(norm), ptr(dg), ptr(dv), None, stream()), "wn_bwd")
+        torch.cuda.synchronize()
+        assert rel_err(dv, rv.grad) < 4e-2 and rel_err(dg, rg.grad) < 4e-2, (cols, rel_err(dv, rv.grad), rel_err(dg, rg.grad))
+
+
 def test_fused_residual_unit_rejects_unsupported_shapes(hip):
     from vibravox_amd._lib import load
 

@@ -37,7 +37,8 @@ def test_library_exports_every_declared_symbol(lib):
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.eben_version() >= 1
+    from vibravox_amd._lib import ABI_VERSION
+    assert lib.eben_version() == ABI_VERSION == int(re.search(r"#define EBEN_ABI_VERSION (\d+)", header).group(1))
 
 
 def test_no_kernel_of_the_library_spills(lib, tmp_path):

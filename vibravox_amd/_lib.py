@@ -137,6 +137,11 @@ SIGNATURES = {
     "eben_ru_bwd_ex": (c_int, [c_int, c_int, c_int, c_int, c_int, _P, _P, c_float, _P, c_float, _P, _P, _P, _P, _P]),
     "eben_ru_dw_slabs": (c_int, [c_int, c_int, c_int]),
     "eben_ru_dw": (c_int, [c_int, c_int, c_int, c_int, c_int, _P, _P, c_float, _P, _P, _P, c_float, _P, _P, _P]),
+    "eben_rubl_supported": (c_int, [c_int, c_int]),
+    "eben_rubl_fwd": (c_int, [c_int, c_int, c_int, c_int, c_int, _P, c_float, c_float, _P, _P, _P, _P, _P, _P]),
+    "eben_rubl_bwd": (c_int, [c_int, c_int, c_int, c_int, _P, _P, c_float, _P, c_float, _P, _P, _P, _P, _P, _P]),
+    "eben_rubl_dw_slabs": (c_int, [c_int, c_int, c_int]),
+    "eben_rubl_dw": (c_int, [c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P]),
     "eben_fir_decimate": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "eben_fir_interp_sum": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "eben_lrelu_fwd": (c_int, [_P, _P, c_size_t, c_float, _P]),
@@ -184,6 +189,10 @@ SIGNATURES = {
 _lib: Optional[ctypes.CDLL] = None
 
 
+#: include/eben_hip.h EBEN_ABI_VERSION this module's structures and signatures were written against
+ABI_VERSION = 3
+
+
 def load(path: Optional[str] = None) -> ctypes.CDLL:
     """dlopen the library and attach the prototypes.  Works without a GPU (symbols only)."""
     global _lib
@@ -200,6 +209,10 @@ def load(path: Optional[str] = None) -> ctypes.CDLL:
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
+    have = lib.eben_version()
+    if have != ABI_VERSION:   # a stale .so (or a caller built against another header) would mis-stride the POD tables
+        raise EbenError(f"{p} reports ABI version {have}, this package binds version {ABI_VERSION} (include/eben_hip.h EBEN_ABI_VERSION): rebuild it "
+                        f"with vibravox_amd/csrc/build.sh")
     if path is None:
         _lib = lib
     return lib

@@ -485,7 +485,7 @@ char* tls_error_buffer() { return g_err; }
 using namespace eben;
 
 extern "C" const char* eben_last_error(void) { return tls_error_buffer(); }
-extern "C" int eben_version(void) { return 1; }
+extern "C" int eben_version(void) { return EBEN_ABI_VERSION; }
 extern "C" int eben_device_info(char* name, size_t name_bytes) {
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);

@@ -727,6 +727,7 @@ int ru3_fwd(int math, int batch, int channels, int length, int dilation, const f
             float* y, float* h, float* u, hipStream_t st) {
   Ru3Args a;
   a.x = x; a.wimg = reinterpret_cast<const u32x4*>(wimg); a.y = y; a.h = h; a.u = u;
+  a.xb = nullptr; a.hb = nullptr; a.um = nullptr;
   a.B = batch; a.L = length; a.d = dilation;
   const int bn = rs_waves(channels) * 32;
   a.ntt = ceil_div(length, bn);
@@ -746,6 +747,25 @@ int ru3_fwd(int math, int batch, int channels, int length, int dilation, const f
     default: EBEN_RU3_FWD(3)
   }
 #undef EBEN_RU3_FWD
+}
+
+// forward that saves for the bundle-layout backward (ru_bl.hip): y fp32, xin / h as bf16 bundles, the sign bits of u
+int ru3_fwd_bl(int math, int batch, int channels, int length, int dilation, const float* x, float in_slope, float out_slope, const float* wimg,
+               float* y, void* xb, void* hb, void* um, hipStream_t st) {
+  Ru3Args a;
+  a.x = x; a.wimg = reinterpret_cast<const u32x4*>(wimg); a.y = y; a.h = nullptr; a.u = nullptr;
+  a.xb = static_cast<u32x4*>(xb); a.hb = static_cast<u32x4*>(hb); a.um = static_cast<unsigned char*>(um);
+  a.B = batch; a.L = length; a.d = dilation;
+  a.ntt = ceil_div(length, 128);
+  a.in_slope = in_slope; a.out_slope = out_slope;
+  a.vec = ((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (length & 3) == 0) ? 1 : 0;
+  if ((long long)a.B * a.ntt > 0x7fffffffLL) return fail(EBEN_EINVAL, "ResidualUnit grid too large");
+  if (rs_pieces(math) != 3) return fail(EBEN_EUNSUPPORTED, "eben_rubl_fwd: the forward computes in EBEN_MATH_BF16X6 (got %d)", math);
+  switch (channels / 32) {
+    case 1: return launch_ru3_fwd<1, 4, 3, 2, true>(a, st);
+    case 2: return launch_ru3_fwd<2, 4, 3, 2, true>(a, st);
+    default: return launch_ru3_fwd<4, 4, 3, 2, true>(a, st);
+  }
 }
 
 int ru3_bwd(int math, int batch, int channels, int length, int dilation, const float* gy, const float* u, float out_slope, const float* x,
@@ -852,4 +872,13 @@ extern "C" int eben_ru_bwd_ex(int math, int batch, int channels, int length, int
   EBEN_REQUIRE(gy && u && wimg_bwd && gx && gh, "null pointer in ru_bwd_ex");
   EBEN_REQUIRE(in_slope == 1.f || x, "x is required to differentiate the fused input activation");
   return ru3_bwd(math, batch, channels, length, dilation, gy, u, out_slope, x, in_slope, post, wimg_bwd, gx, gh, as_stream(stream));
+}
+
+extern "C" int eben_rubl_fwd(int math, int batch, int channels, int length, int dilation, const float* x, float in_slope, float out_slope,
+                             const float* wimg, float* y, void* xb, void* hb, void* umask, void* stream) {
+  EBEN_REQUIRE(ru3_supported(channels, dilation, math), "fused ResidualUnit (split bf16): 32 / 64 / 128 channels, dilation 1..%d (got %d, %d)",
+               RS_DMAX, channels, dilation);
+  EBEN_REQUIRE(batch > 0 && length > 0 && dilation < length, "bad ResidualUnit geometry");
+  EBEN_REQUIRE(x && wimg && y && xb && hb && umask, "null pointer in rubl_fwd");
+  return ru3_fwd_bl(math, batch, channels, length, dilation, x, in_slope, out_slope, wimg, y, xb, hb, umask, as_stream(stream));
 }

@@ -41,6 +41,9 @@ from ._lib import check, load, ptr, stream
 USE_FUSED_RU = os.environ.get("EBEN_RU_FUSED", "1") != "0"
 USE_FUSED_RU_BWD = os.environ.get("EBEN_RU_FUSED_BWD", "1") != "0"
 USE_FUSED_RU_DW = os.environ.get("EBEN_RU_FUSED_DW", "1") != "0"
+#: bf16 generator backward: the units' saved tensors at rest as bf16 bundles + sign bytes, written by the forward, and the bundle-layout
+#: backward / weight-gradient launches (csrc/ru_bl.hip) -- 32 bytes per element and unit instead of 52-56
+USE_RU_BL = os.environ.get("EBEN_RU_BL", "1") != "0"
 USE_GRAPHS = os.environ.get("EBEN_GEN_GRAPHS", "1") != "0"   # training forward / backward sequences replayed as HIP graphs
 #: backward segments (3 decoder blocks, latent convs, 3 encoder blocks) per replayed graph
 BWD_GROUPS = os.environ.get("EBEN_GEN_BWD_GROUPS", "2,2,3")
@@ -284,6 +287,19 @@ class GeneratorEngine:
             _, dd_bwd, pw_d = self._pack(dil, spec_d, b, l, True)
             _, dp_bwd, pw_p = self._pack(pwc, pwc.spec, b, l, True)
         fusable = dil.spec.ksize == 3 and dil.spec.reflect and lib.eben_ru_supported(c, dil.spec.dilation, RU_FWD_MATH) == 1
+        if (train and USE_RU_BL and USE_FUSED_RU and USE_FUSED_RU_BWD and USE_FUSED_RU_DW and fusable and RU_FWD_MATH == ops.MATH_BF16X6
+                and self._ru_bwd_math() == ops.MATH_BF16 and lib.eben_rubl_supported(c, dil.spec.dilation) == 1 and self._ru_bl_params_ok(ru)):
+            # what the bf16 backward reads, written once in the layout its MFMA operands want (csrc/ru_bl.hip)
+            img = self._ru_image(ru)
+            y = torch.empty_like(x)
+            xb = torch.empty((b, c // 8, l, 8), dtype=torch.bfloat16, device=x.device)
+            hb = torch.empty_like(xb)
+            um = torch.empty((b, c // 8, l), dtype=torch.uint8, device=x.device)
+            check(lib.eben_rubl_fwd(RU_FWD_MATH, b, c, l, dil.spec.dilation, ptr(x), float(in_slope), float(pwc.spec.out_slope), ptr(img), ptr(y),
+                                    xb.data_ptr(), hb.data_ptr(), um.data_ptr(), stream()), "rubl_fwd")
+            recs.append((("bl", self._ru_image(ru, 1), xb, hb, um), _ConvRec(dil, spec_d, dd_bwd, x if in_slope != 1.0 else None, None, pw_d.wp_bwd, pw_d.norm),
+                         _ConvRec(pwc, pwc.spec, dp_bwd, None, None, pw_p.wp_bwd, pw_p.norm)))
+            return y
         if USE_FUSED_RU and fusable:
             img = self._ru_image(ru)
             y = torch.empty_like(x)
@@ -421,8 +437,40 @@ class GeneratorEngine:
         self._accumulate((vp, gp, None), res[0])
         self._accumulate((vd, gd, None), res[1])
 
+    @staticmethod
+    def _ru_bl_params_ok(ru) -> bool:
+        """The bundle-layout weight-gradient launch serves weight-normalised, bias-free, trainable convs (every unit of the reference)."""
+        for m in (ru.dilated_conv, ru.pointwise_conv):
+            v, g = _params(m)
+            if g is None or m.bias is not None or not (v.requires_grad and g.requires_grad):
+                return False
+        return True
+
+    def _ru_backward_bl(self, rec, gy, res_post=None):
+        (_, img_b, xb, hb, um), dil, pwc = rec
+        b, c, l = gy.shape
+        gx = torch.empty_like(gy)
+        gzb, ghb = torch.empty_like(xb), torch.empty_like(xb)
+        ins = dil.spec.in_slope
+        check(load().eben_rubl_bwd(b, c, l, dil.spec.dilation, ptr(gy), um.data_ptr(), float(pwc.spec.out_slope), ptr(dil.x) if ins != 1.0 else None,
+                                   float(ins), ptr(res_post), ptr(img_b), ptr(gx), gzb.data_ptr(), ghb.data_ptr(), stream()), "rubl_bwd")
+        if not ops._skip_weight_grads[0]:
+            if self._dwq is not None:
+                self._dwq.append(("rubl", dil, pwc, gzb, hb, ghb, xb))
+            else:
+                (vd, gd), (vp, gp) = _params(dil.m), _params(pwc.m)
+                res = ops.weight_grads_ru_bl(dil.spec.dilation, gzb, hb, ghb, xb, (vp, gp, pwc.norm), (vd, gd, dil.norm))
+                if res is False:
+                    raise RuntimeError("bundle-layout ResidualUnit: the two convs' weight gradients are routed differently (one of them holds a gradient "
+                                       "or a hook the other does not); set EBEN_RU_BL=0 for this pattern")
+                self._accumulate((vp, gp, None), res[0])
+                self._accumulate((vd, gd, None), res[1])
+        return gx
+
     def _ru_backward(self, rec, gy, res_post=None):
         fused, dil, pwc = rec
+        if fused is not None and fused[0] == "bl":
+            return self._ru_backward_bl(rec, gy, res_post)
         if fused is not None:   # one launch: g_h and g_x = (g_y + fold(dilated^T g_h)) * lrelu'(x) + skip gradient
             b, c, l = gy.shape
             gx, gh = torch.empty_like(gy), torch.empty_like(gy)
@@ -603,6 +651,13 @@ class GeneratorEngine:
                     v, g = _params(rec.m)
                     grads = ops.weight_grads(rec.d, dy, rec.y, rec.x, v, g, rec.m.bias, rec.norm)
                     assign.extend((p, t) for p, t in zip((v, g, rec.m.bias), grads) if p is not None and t is not None)
+                elif item[0] == "rubl":
+                    _, dil, pwc, gzb, hb, ghb, xb = item
+                    (vd, gd), (vp, gp) = _params(dil.m), _params(pwc.m)
+                    res = ops.weight_grads_ru_bl(dil.spec.dilation, gzb, hb, ghb, xb, (vp, gp, pwc.norm), (vd, gd, dil.norm))
+                    assert res is not False
+                    assign.extend(zip((vp, gp), res[0][:2]))
+                    assign.extend(zip((vd, gd), res[1][:2]))
                 else:
                     _, dil, pwc, gy, gh, bm = item
                     (vd, gd), (vp, gp) = _params(dil.m), _params(pwc.m)

@@ -772,6 +772,41 @@ def weight_grads_ru(math: int, dilation: int, gy: torch.Tensor, u: torch.Tensor,
     return outs_p, outs_d
 
 
+def weight_grads_ru_bl(dilation: int, gzb: torch.Tensor, hb: torch.Tensor, ghb: torch.Tensor, xb: torch.Tensor, pw_params, dil_params):
+    """``weight_grads_ru`` on the four bf16 bundle planes of a unit (``eben_rubl_dw``, csrc/ru_bl.hip): g_z and g_h as written by
+    ``eben_rubl_bwd``, h and xin as saved by ``eben_rubl_fwd`` -- planes of shape (batch, C / 8, L, 8)."""
+    lib = load()
+    (vp, gp, np_), (vd, gd, nd) = pw_params, dil_params
+    route_p, route_d = _wg_route(vp, gp, None), _wg_route(vd, gd, None)
+    if route_p[0] != route_d[0] or (route_p[1] is None) != (route_d[1] is None):
+        return False
+    use_side = route_p[0]
+    b, cb, l, _ = gzb.shape
+    c = 8 * cb
+    nslab = lib.eben_rubl_dw_slabs(b, c, l)
+    slabs_p = torch.empty(nslab * c * c, dtype=torch.float32, device=gzb.device)
+    slabs_d = torch.empty(nslab * c * 3 * c, dtype=torch.float32, device=gzb.device)
+    job_p, outs_p = _wg_job(slabs_p, nslab, c, vp, gp, None, np_, route_p[1], gzb.device)
+    job_d, outs_d = _wg_job(slabs_d, nslab, 3 * c, vd, gd, None, nd, route_d[1], gzb.device)
+    if use_side:
+        side = _side_stream(gzb.device, deal=True)
+        side.wait_stream(torch.cuda.current_stream(gzb.device))
+        st = side.cuda_stream
+    else:
+        st = stream()
+    check(lib.eben_rubl_dw(b, c, l, dilation, gzb.data_ptr(), hb.data_ptr(), ghb.data_ptr(), xb.data_ptr(), ptr(slabs_p), ptr(slabs_d), st), "rubl_dw")
+    if use_side:
+        _side["keep"].append((gzb, hb, ghb, xb, np_, nd, slabs_p, slabs_d))
+        _wg_defer(job_p, outs_p, vp, gp, None, route_p[1])
+        _wg_defer(job_d, outs_d, vd, gd, None, route_d[1])
+        return (None, None, None), (None, None, None)
+    if _wn_collect[0] is not None:
+        _wn_collect[0].extend((job_p, job_d))
+    else:
+        wn_bwd_multi([job_p, job_d])
+    return outs_p, outs_d
+
+
 class _ConvLayerFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, v, g, bias, spec: ConvSpec, cache):
