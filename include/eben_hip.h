@@ -194,6 +194,18 @@ EBEN_API int eben_bl_conv1d_fwd(const EbenConv1dDesc* d, const void* x_hi, const
 EBEN_API int eben_bl_conv1d_bwd_dx(const EbenConv1dDesc* d, const void* g_hi, const float* wp_bwd, const void* act_hi, const void* act_lo,
                           float mask_slope, int seg, const int* seg_map, int fm_rows, int ref_row_offset, const float* fm_sums,
                           float fm_gs, void* dx_hi, void* dx_lo /* nullable */, void* stream);
+
+/* "Phases as rows": the input gradient of a strided bundle-layout Conv1d (stride 4..8, dilation 1) as ONE stride-1 Conv1d from the
+ * Cout channels of dy to stride x Cin rows (phase, channel), stored depth-to-space (csrc/tapconv.hip; MelGAN layers 1-4,
+ * vibravox/torch_modules/dnn/melgan_discriminator.py:97-130).  eben_bl_dx_pr_desc writes the descriptor of that primed layer (or returns
+ * EBEN_EUNSUPPORTED); eben_bl_dx_pr_weights writes its weights (c_out' x c_in' / groups' x ksize' floats, weight-norm scale folded in), to be
+ * packed as the primed layer's FORWARD image with eben_conv1d_pack(primed, w_primed, NULL, image, NULL); eben_bl_conv1d_bwd_dx_pr is
+ * eben_bl_conv1d_bwd_dx on that image -- same operands, same epilogue, same results up to the order of the fp32 accumulation. */
+EBEN_API int eben_bl_dx_pr_desc(const EbenConv1dDesc* d, EbenConv1dDesc* primed);
+EBEN_API int eben_bl_dx_pr_weights(const EbenConv1dDesc* d, const float* v, const float* scale, float* w_primed, void* stream);
+EBEN_API int eben_bl_conv1d_bwd_dx_pr(const EbenConv1dDesc* d, const void* g_hi, const float* wp_primed_fwd, const void* act_hi, const void* act_lo,
+                                      float mask_slope, int seg, const int* seg_map, int fm_rows, int ref_row_offset, const float* fm_sums,
+                                      float fm_gs, void* dx_hi, void* dx_lo, void* stream);
 /* Weight (+ bias) gradient with both operands in the bundle layout (csrc/bl_dw.hip): the reduction runs along (batch, time) on
  * v_mfma_f32_32x32x16_bf16, both operand tiles arrive in LDS by buffer_load ... lds (descriptor bounds = the zero padding) and are
  * transposed on read -- no packing pre-pass, no conversion.  Slabs [nslab][c_out][row_stride] as eben_conv1d_bwd_dw's, except that

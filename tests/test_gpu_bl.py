@@ -360,6 +360,87 @@ def test_bundle_conv_input_gradient(hip, name):
         assert rel_err(got, dx32) < 1e-4
 
 
+PR_LAYERS = {
+    **{k: MID_LAYERS[k] for k in ("melgan_l1_dense", "melgan_l2")},
+    # lengths that are not a multiple of the stride (the last positions exist for some phases only), one more / one fewer output than S q
+    "melgan_l1_ragged": (dict(c_in=16, c_out=64, ksize=41, stride=4, pad_l=20, pad_r=20, groups=4, out_slope=0.2), 4, 2103, False),
+    "melgan_l2_ragged": (dict(c_in=64, c_out=256, ksize=41, stride=4, pad_l=20, pad_r=20, groups=4, out_slope=0.2), 2, 1097, True),
+    "stride8_k16": (dict(c_in=8, c_out=64, ksize=16, stride=8, pad_l=7, pad_r=7, groups=1, out_slope=0.2), 2, 1001, True),
+    "stride4_g2": (dict(c_in=32, c_out=128, ksize=23, stride=4, pad_l=11, pad_r=11, groups=2, out_slope=0.2), 2, 777, True),
+}
+
+
+@pytest.mark.parametrize("name", list(PR_LAYERS))
+def test_bundle_conv_input_gradient_phases_as_rows(hip, name):
+    """eben_bl_conv1d_bwd_dx_pr: the input gradient of a strided layer as ONE stride-1 contraction whose rows are (phase, channel), stored
+    depth-to-space (melgan_discriminator.py:97-130 backward).  Same operands and epilogue as eben_bl_conv1d_bwd_dx (mask from the saved
+    embedding, feature-matching term on the first rows): against float64 on the MFMA operands and against the phase-scatter kernel."""
+    from vibravox_amd import ops
+    from vibravox_amd._lib import EbenConv1dDesc, check
+    from vibravox_amd.disc_engine_bl import Planes
+
+    kw, rows2, length, _ = PR_LAYERS[name]
+    spec = ops.ConvSpec(**kw)
+    wshape = spec.weight_shape()
+    v = formula_tensor(f"blpr/{name}/v", wshape, 1 / math.sqrt(wshape[1] * wshape[2])).to(DEV)
+    scale = (1 + 0.3 * formula_tensor(f"blpr/{name}/s", (wshape[0],))).to(DEV)
+    half = rows2 // 2
+    rows4 = 4 * half
+    lin = ops.ConvSpec(**{**kw, "out_slope": 1.0})
+    l_out = spec.out_len(length)
+    g = formula_tensor(f"blpr/{name}/g", (rows4, spec.c_out, l_out)).to(DEV)
+    gp = planes_of(g, lo=False)
+    act = planes_of(formula_tensor(f"blpr/{name}/act", (rows2, spec.c_in, length)))
+    a = act.to_f32()
+    sums = torch.tensor([2.5, 7.0], device=DEV)
+    fm_gs = 0.41
+    seg_map = (ctypes.c_int * 4)(0, 0, 0, 1)
+    d = ops.conv_desc(lin, rows4, length, ops.MATH_BF16 | BL)
+    dq = EbenConv1dDesc()
+    assert hip.eben_bl_dx_pr_desc(ctypes.byref(d), ctypes.byref(dq)) == 0
+    assert (dq.c_in, dq.c_out, dq.stride, dq.l_in, dq.l_out) == (spec.c_out, spec.stride * spec.c_in, 1, l_out, -(-length // spec.stride))
+    wq = torch.empty(dq.c_out * (dq.c_in // dq.groups) * dq.ksize, dtype=torch.float32, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    check(hip.eben_bl_dx_pr_weights(ctypes.byref(d), v.data_ptr(), scale.data_ptr(), wq.data_ptr(), st), "bl_dx_pr_weights")
+    img = torch.empty(hip.eben_conv1d_packed_floats(ctypes.byref(dq), 0), dtype=torch.float32, device=DEV)
+    ops.conv1d_pack(dq, wq, None, img, None)
+    dx = Planes(rows4, spec.c_in, length, DEV)
+    dx.hi.fill_(float("nan")); dx.lo.fill_(float("nan"))
+    check(hip.eben_bl_conv1d_bwd_dx_pr(ctypes.byref(d), gp.hi.data_ptr(), img.data_ptr(), act.hi.data_ptr(), act.lo.data_ptr(), 0.2, half, seg_map, half, half,
+                                       sums.data_ptr(), fm_gs, dx.hi.data_ptr(), dx.lo.data_ptr(), st), "bl_conv1d_bwd_dx_pr")
+    w = (v * scale.reshape(-1, 1, 1))
+    base = F.conv_transpose1d(bf16_hi(g).double(), bf16_hi(w).double(), stride=spec.stride, padding=spec.pad_l, dilation=spec.dilation, groups=spec.groups,
+                              output_padding=length - ((l_out - 1) * spec.stride - 2 * spec.pad_l + spec.dilation * (spec.ksize - 1) + 1))
+    ad = a.double()
+    base[:half] += fm_gs * (torch.sign(ad[:half] - ad[half:]) / 7.0 - 2.5 * torch.sign(ad[:half]) / 49.0)
+    a_hi = act.hi.permute(0, 1, 3, 2).reshape(rows2, spec.c_in, length).double()
+    mask_rows = torch.cat((a_hi[:half], a_hi[:half], a_hi[:half], a_hi[half:]), dim=0)
+    want = base * torch.where(mask_rows > 0, 1.0, 0.2)
+    got = dx.to_f32()
+    assert rel_err(got, want) < 3e-5, rel_err(got, want)
+    # the phase-scatter kernel on the same operands: same products, another order of the fp32 accumulation
+    wp = _pack(hip, d, v, scale, 1)
+    dx1 = Planes(rows4, spec.c_in, length, DEV)
+    check(hip.eben_bl_conv1d_bwd_dx(ctypes.byref(d), gp.hi.data_ptr(), wp.data_ptr(), act.hi.data_ptr(), act.lo.data_ptr(), 0.2, half, seg_map, half, half,
+                                    sums.data_ptr(), fm_gs, dx1.hi.data_ptr(), dx1.lo.data_ptr(), st), "bl_conv1d_bwd_dx")
+    assert rel_err(got, dx1.to_f32()) < 2e-5
+
+
+def test_phases_as_rows_declines_what_it_does_not_cover(hip):
+    from vibravox_amd import ops
+    from vibravox_amd._lib import EbenConv1dDesc
+
+    dq = EbenConv1dDesc()
+    for kw in (dict(c_in=96, c_out=192, ksize=7, stride=2, dilation=2, pad_l=3, pad_r=3, groups=4),     # dilated
+               dict(c_in=768, c_out=768, ksize=5, stride=1, pad_l=2, pad_r=2, groups=4),                # not strided
+               dict(c_in=12, c_out=64, ksize=41, stride=4, pad_l=20, pad_r=20, groups=4),               # channels not in bundles
+               dict(c_in=256, c_out=1024, ksize=41, stride=4, pad_l=20, pad_r=20, groups=4)):           # full row tiles either way: phase-scatter is faster
+        d = ops.conv_desc(ops.ConvSpec(**kw), 4, 400, ops.MATH_BF16 | BL)
+        assert hip.eben_bl_dx_pr_desc(ctypes.byref(d), ctypes.byref(dq)) != 0
+    d = ops.conv_desc(ops.ConvSpec(c_in=64, c_out=256, ksize=41, stride=4, pad_l=20, pad_r=20, groups=4), 4, 400, ops.MATH_BF16)   # fp32 at rest
+    assert hip.eben_bl_dx_pr_desc(ctypes.byref(d), ctypes.byref(dq)) != 0
+
+
 @pytest.mark.parametrize("name", list(MID_LAYERS))
 def test_bundle_conv_weight_gradient(hip, name):
     """dW / dbias from bundle planes (bl_dw.hip: reduction along time, LDS-DMA tiles, transposing reads) against float64 on the bf16

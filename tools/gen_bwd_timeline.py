@@ -3,7 +3,8 @@ stream): start, duration, stream, kernel -- where the 3 ms of the step's generat
 import os, sys, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import bench
-from vibravox_amd import ops
+from vibravox_amd import ops, gen_engine
+gen_engine.USE_GRAPHS = False
 dev = torch.device("cuda", 0)
 mod = bench.build_module(dev, 1234)
 batch = bench.synthetic_batch(32, 32000, 1234, dev)

@@ -6,12 +6,17 @@ mod = bench.build_module(dev, 1234)
 batch = bench.synthetic_batch(32, 32000, 1234, dev)
 gen = mod.generator
 x = gen.cut_to_valid_length(batch["audio_body_conducted"])
+from vibravox_amd import ops, gen_engine
+gen_engine.USE_GRAPHS = False   # launch by launch: the profiler shows kernels, not a graph replay
+math = ops.MATH_F32 if os.environ.get("GEN_BWD_MATH", "bf16") == "f32" else ops.MATH_BF16   # the training forward saves what THIS backward reads
 for _ in range(3):
-    y, b = gen(x)
+    with ops.backward_math(math):
+        y, b = gen(x)
 torch.cuda.synchronize()
 from torch.profiler import profile, ProfilerActivity
 with profile(activities=[ProfilerActivity.CUDA]) as prof:
-    y, b = gen(x)
+    with ops.backward_math(math):
+        y, b = gen(x)
     torch.cuda.synchronize()
 evs = [e for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA]
 evs.sort(key=lambda e: e.time_range.start)

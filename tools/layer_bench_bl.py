@@ -117,9 +117,11 @@ def main():
             d4 = ops.conv_desc(lay.spec_lin, r4, cur.length, lay.math_dx)
             g = Planes.from_f32(torch.randn(r4, sp.c_out, d.l_out, device=dev), lo=False)
             gp = Planes(r4, sp.c_in, cur.length, dev, lo=False)
-            wpb = lay.packed(1, r4, cur.length)
-            t_b = time_ms(lambda: check(lib.eben_bl_conv1d_bwd_dx(ctypes.byref(d4), g.hi.data_ptr(), ptr(wpb), xin.hi.data_ptr(), xin.lo.data_ptr(), 0.2, half, seg_map,
-                                                                  half, half, ptr(sums), 0.1, gp.hi.data_ptr(), None, st)), a.iters)
+            pr = lay.pr_desc(r4, cur.length) is not None   # strided MelGAN layers: the phases-as-rows form (as the engine launches it)
+            wpb = lay.packed(2 if pr else 1, r4, cur.length)
+            dx_fn = lib.eben_bl_conv1d_bwd_dx_pr if pr else lib.eben_bl_conv1d_bwd_dx
+            t_b = time_ms(lambda: check(dx_fn(ctypes.byref(d4), g.hi.data_ptr(), ptr(wpb), xin.hi.data_ptr(), xin.lo.data_ptr(), 0.2, half, seg_map,
+                                              half, half, ptr(sums), 0.1, gp.hi.data_ptr(), None, st)), a.iters)
             t_w = time_ms(lambda: ch.weight_grads([(i, g, xin)], x_in, None, half), a.iters)
             wshape = sp.weight_shape()
             wel = wshape[0] * wshape[1] * wshape[2]

@@ -111,6 +111,9 @@ SIGNATURES = {
     "eben_bl_to_f32": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P]),
     "eben_bl_conv1d_fwd": (c_int, [_D, _P, _P, _P, _P, _P, _P, _P]),
     "eben_bl_conv1d_bwd_dx": (c_int, [_D, _P, _P, _P, _P, c_float, c_int, POINTER(c_int), c_int, c_int, _P, c_float, _P, _P, _P]),
+    "eben_bl_dx_pr_desc": (c_int, [_D, _D]),
+    "eben_bl_dx_pr_weights": (c_int, [_D, _P, _P, _P, _P]),
+    "eben_bl_conv1d_bwd_dx_pr": (c_int, [_D, _P, _P, _P, _P, c_float, c_int, POINTER(c_int), c_int, c_int, _P, c_float, _P, _P, _P]),
     "eben_bl_conv1d_bwd_dw_workspace": (c_size_t, [_D, POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
     "eben_bl_conv1d_bwd_dw": (c_int, [_D, _P, _P, c_int, _P, c_size_t, _P]),
     "eben_bl_head_fwd": (c_int, [POINTER(EbenBlHeadJob), c_int, c_int, _P]),

@@ -903,6 +903,126 @@ static int bwd_dx_batched(const EbenConv1dDesc* d, const float* g, const float* 
 }
 
 // ---- bundle layout (EBEN_LAYOUT_BL): the discriminator layers between the chain heads and the logits ------------------------------
+// Input gradient of a STRIDED Conv1d as "phases as rows" (melgan_discriminator.py:97-118: k 41, stride 4, 4 groups).  The phase-scatter
+// form (tap3 mode 1) runs one stride-1 sub-convolution per output phase: `stride` blocks stage the same window of dy, each with a
+// quarter of the taps, and a layer with few channels per group (16 -> 64: four input channels per group) fills an eighth of its MFMA
+// rows.  Written for all phases at once,
+//     dx[c, S q + ph] = sum_{co, u} W[co, c, ph + pad - S u] dy[co, q + u],
+// the input gradient IS a stride-1 Conv1d from the Cout channels of dy to S Cin output rows (ph, c) with taps u = umin .. umax (11 for
+// k 41 / S 4) whose result is stored depth-to-space: MelGAN L1 / L2 become grouped 64 -> 64 / 256 -> 256 k 11 convolutions, dy staged
+// once, full row tiles.  The primed weights W'[(ph, c)][co][u] are a gather of the layer's weights (pr_weights_kernel), packed as an
+// ordinary forward image of the primed layer; tap3's bundle epilogue maps logical bundle -> (physical bundle, phase) (Tap3Args.pr_*).
+namespace eben {
+struct PrGeom { int ok, S, umin, kq, Lq, fold, cbg; };
+
+static int pr_floordiv(int a, int b) { int q = a / b; if ((a % b != 0) && ((a < 0) != (b < 0))) --q; return q; }
+
+static PrGeom pr_geometry(const Canon& c, Canon* cp) {
+  PrGeom g{};
+  static const int min_s = getenv("EBEN_PR_MIN_STRIDE") ? atoi(getenv("EBEN_PR_MIN_STRIDE")) : 4;
+  if (!c.bl || c.np != 1 || c.reflect || c.d != 1 || c.s < 2 || c.s < min_s || c.s > 8 || c.k <= c.s || c.pl > c.k - 1) return g;
+  const int Cg = c.Cin / c.g;
+  if ((c.Cin & 7) || (c.Cout & 7)) return g;
+  g.S = c.s;
+  g.umin = -pr_floordiv(c.k - 1 - c.pl, c.s);             // ceil((pad - (k - 1)) / S): phase 0, last tap
+  const int umax = pr_floordiv(c.s - 1 + c.pl, c.s);      // phase S - 1, tap 0
+  g.kq = umax - g.umin + 1;
+  g.Lq = ceil_div(c.Lin, c.s);
+  g.fold = (Cg & 7) != 0;                                  // groups that do not start on bundles: one dense (block-diagonal) contraction
+  g.cbg = g.fold ? c.Cin / 8 : Cg / 8;
+  Canon q = c;
+  q.Cin = c.Cout; q.Cout = c.s * c.Cin; q.Lin = c.Lout; q.Lout = g.Lq;
+  q.k = g.kq; q.s = 1; q.d = 1; q.g = g.fold ? 1 : c.g;
+  q.pl = -g.umin;
+  q.pr = g.Lq - c.Lout + g.kq - 1 - q.pl;
+  if (q.pl < 0 || q.pr < 0) return g;
+  q.reflect = 0; q.xsplit_dir = -1;
+  // [MI355X, 128 rows] MelGAN L1 / L2 (4 / 16 channels per group: 64 primed rows per group) 0.336 / 0.310 -> 0.239 / 0.210 ms; L3 / L4 (64 /
+  // 256 channels per group: 256 / 1024 primed rows, full row tiles in either form) 0.414 / 0.412 -> 0.531 / 0.524: the form is for the layers
+  // whose phases leave row tiles empty
+  static const int max_rows = getenv("EBEN_PR_MAX_ROWS") ? atoi(getenv("EBEN_PR_MAX_ROWS")) : 64;
+  if (q.Cout / q.g > max_rows) return g;
+  if (!tap3_applicable(q, 0)) return g;
+  if (cp) *cp = q;
+  g.ok = 1;
+  return g;
+}
+
+// W'[(g, ph, c)][co][ui] (groups kept) or [(ph, ci)][co][ui] (folded, zero across groups) = scale[co] v[co][c][ph + pad - S (ui + umin)]
+__global__ __launch_bounds__(256) void pr_weights_kernel(const float* __restrict__ v, const float* __restrict__ scale, float* __restrict__ wq,
+                                                          int Cin, int Cout, int G, int k, int S, int pad, int umin, int kq, int fold) {
+  const int Cg = Cin / G, Mg = Cout / G;
+  const int cin_q = fold ? Cout : Mg;                      // input channels per group of the primed layer
+  const long long total = (long long)S * Cin * cin_q * kq;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int ui = (int)(i % kq);
+    long long r = i / kq;
+    const int cq = (int)(r % cin_q);
+    const int row = (int)(r / cin_q);
+    int ph, ci, co;
+    if (fold) { ph = row / Cin; ci = row - ph * Cin; co = cq; }
+    else { const int g = row / (S * Cg), rr = row - g * S * Cg; ph = rr / Cg; ci = g * Cg + (rr - ph * Cg); co = g * Mg + cq; }
+    const int j = ph + pad - S * (ui + umin);
+    float w = 0.f;
+    if (j >= 0 && j < k && co / Mg == ci / Cg) w = v[((long long)co * Cg + (ci % Cg)) * k + j] * (scale ? scale[co] : 1.f);
+    wq[i] = w;
+  }
+}
+
+static void pr_desc_from_canon(const EbenConv1dDesc* d, const Canon& q, EbenConv1dDesc* o) {
+  *o = *d;
+  o->c_in = q.Cin; o->c_out = q.Cout; o->l_in = q.Lin; o->l_out = q.Lout; o->ksize = q.k; o->stride = 1; o->dilation = 1; o->groups = q.g;
+  o->pad_l = q.pl; o->pad_r = q.pr; o->pad_mode = EBEN_PAD_ZERO; o->transposed = 0; o->in_slope = 1.f; o->out_slope = 1.f;
+}
+}  // namespace eben
+
+extern "C" int eben_bl_dx_pr_desc(const EbenConv1dDesc* d, EbenConv1dDesc* primed) {
+  Canon c, q;
+  int rc = canon_from_desc(d, &c);
+  if (rc) return rc;
+  if (d->transposed || !pr_geometry(c, &q).ok) return fail(EBEN_EUNSUPPORTED, "eben_bl_dx_pr_desc: the layer's input gradient has no phases-as-rows form");
+  EBEN_REQUIRE(primed != nullptr, "null output descriptor");
+  pr_desc_from_canon(d, q, primed);
+  return EBEN_OK;
+}
+
+extern "C" int eben_bl_dx_pr_weights(const EbenConv1dDesc* d, const float* v, const float* scale, float* w_primed, void* stream) {
+  Canon c, q;
+  int rc = canon_from_desc(d, &c);
+  if (rc) return rc;
+  const PrGeom g = d->transposed ? PrGeom{} : pr_geometry(c, &q);
+  if (!g.ok) return fail(EBEN_EUNSUPPORTED, "eben_bl_dx_pr_weights: the layer's input gradient has no phases-as-rows form");
+  EBEN_REQUIRE(v && w_primed, "null pointer in eben_bl_dx_pr_weights");
+  const long long total = (long long)q.Cout * (q.Cin / q.g) * q.k;
+  long long blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(pr_weights_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), v, scale, w_primed, c.Cin, c.Cout, c.g, c.k, c.s, c.pl,
+                     g.umin, g.kq, g.fold);
+  EBEN_CHECK_LAUNCH("pr_weights_kernel");
+  return EBEN_OK;
+}
+
+extern "C" int eben_bl_conv1d_bwd_dx_pr(const EbenConv1dDesc* d, const void* g_hi, const float* wp_primed_fwd, const void* act_hi, const void* act_lo,
+                                        float mask_slope, int seg, const int* seg_map, int fm_rows, int ref_row_offset, const float* fm_sums,
+                                        float fm_gs, void* dx_hi, void* dx_lo, void* stream) {
+  Canon c, q;
+  int rc = canon_from_desc(d, &c);
+  if (rc) return rc;
+  const PrGeom g = d->transposed ? PrGeom{} : pr_geometry(c, &q);
+  if (!g.ok) return fail(EBEN_EUNSUPPORTED, "eben_bl_conv1d_bwd_dx_pr: the layer's input gradient has no phases-as-rows form");
+  EBEN_REQUIRE(g_hi && wp_primed_fwd && dx_hi, "null pointer in eben_bl_conv1d_bwd_dx_pr");
+  EBEN_REQUIRE(seg >= 0 && (seg == 0 || (seg_map && c.B <= 4 * seg)), "bad batch segment map");
+  EBEN_REQUIRE(fm_rows == 0 || (fm_sums && act_hi && act_lo && fm_rows > 0), "feature-matching rows need the sums and both planes of the embedding");
+  TapIO io{};
+  io.in_slope = 1.f; io.wp = wp_primed_fwd; io.out_slope = 1.f; io.res_slope = 1.f;
+  io.res_rows = fm_rows; io.fm_sums = fm_rows > 0 ? fm_sums : nullptr; io.fm_gs = fm_gs;
+  io.emask_slope = mask_slope; io.em_seg = act_hi ? seg : 0;
+  for (int i = 0; i < 4; ++i) io.em_map[i] = (seg > 0 && seg_map) ? seg_map[i] : i;
+  io.xh = g_hi; io.yh = dx_hi; io.yl = dx_lo; io.eh = act_hi; io.el = act_lo; io.bl_ref_off = ref_row_offset;
+  io.pr_S = g.S; io.pr_cbg = g.cbg; io.pr_Ly = c.Lin; io.pr_CBy = c.Cin / 8;
+  return tap3_launch(q, 0, io, 0, as_stream(stream));
+}
+
 extern "C" int eben_bl_conv1d_fwd(const EbenConv1dDesc* d, const void* x_hi, const void* x_lo, const float* wp_fwd, const float* bias,
                                   void* y_hi, void* y_lo, void* stream) {
   Canon c;

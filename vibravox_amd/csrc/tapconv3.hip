@@ -100,6 +100,9 @@ struct Tap3Args {
   uint2* yh; uint2* yl;
   const uint2* eh; const uint2* el;
   int CBx, CBy, bl_ref_off, bl_pad;
+  // phases as rows (TapIO.pr_S): the logical output rows of group g are (phase, channel of the group) and land in the PHYSICAL planes
+  // [row][pr_CB][pr_Ly][8] at bundle g pr_cbg + (logical bundle % pr_cbg), position t pr_S + logical bundle / pr_cbg
+  int pr_S, pr_cbg, pr_Ly, pr_pad;
   unsigned xq, xr;                               // gridDim.x / 8, gridDim.x % 8 (xcd_remap)
   unsigned m_nph, m_ntt, m_B, m_nmt;             // ceil(2^32 / d); valid when id_fast
   int id_fast, pg_n;
@@ -457,7 +460,7 @@ __global__ __launch_bounds__(256, NPW >= 2 ? 1 : 2) void tap3_kernel(const Tap3A
   constexpr bool PREF = BL && FM <= 2;
   uint2 pah[PREF ? FM : 1][4];
   if constexpr (PREF) {
-    if (P.eh != nullptr && !(EBEN_T3_DBG & 32)) {
+    if (P.eh != nullptr && P.pr_S == 0 && !(EBEN_T3_DBG & 32)) {
       const int tq = t0 + wn * 32 + (lane & 31);
       const unsigned loffq = (((unsigned)(tq < nt ? tq : nt - 1) * (unsigned)P.OS + (unsigned)oo) * 2u + (unsigned)(lane >> 5)) * 8u;
       const long long Lrowq = (long long)P.Ly * 16;
@@ -593,9 +596,21 @@ __global__ __launch_bounds__(256, NPW >= 2 ? 1 : 2) void tap3_kernel(const Tap3A
     // uniform too, Mg being a multiple of 8.  (The thin layers are bound by the vector-instruction issue: ~660 VALU instructions per
     // wave around 41 MFMAs, a third of them this epilogue's 64-bit per-lane address arithmetic and per-lane predicates.)
     const int hb = lane >> 5;
-    const unsigned loff = (((unsigned)t * (unsigned)P.OS + (unsigned)oo) * 2u + (unsigned)hb) * 8u;   // bytes inside a bundle row
-    const long long Lrow = (long long)P.Ly * 16;                                                           // bytes per bundle row
-    const long long tile0 = ((long long)((g * P.Mg + m0) >> 3)) * Lrow;                                    // this tile's first bundle row
+    const bool pr = P.pr_S > 0;   // phases as rows (uniform)
+    const unsigned loff = (((unsigned)t * (unsigned)(pr ? P.pr_S : P.OS) + (unsigned)oo) * 2u + (unsigned)hb) * 8u;   // bytes inside a bundle row
+    const long long Lrow = (long long)(pr ? P.pr_Ly : P.Ly) * 16;                                          // bytes per bundle row
+    const long long tile0 = pr ? (long long)(g * P.pr_cbg) * Lrow : ((long long)((g * P.Mg + m0) >> 3)) * Lrow;   // this tile's first bundle row
+    // byte offset of logical bundle q of this tile from tile0 (uniform): its bundle row, in PR mode plus its phase's 16 bytes; prq: the
+    // lane's position t pr_S + phase exists (always, unless the physical length is not a multiple of pr_S)
+    auto qrow = [&](int q) -> long long {
+      if (!pr) return (long long)q * Lrow;
+      const int lb = (m0 >> 3) + q, phs = lb / P.pr_cbg;
+      return (long long)(lb - phs * P.pr_cbg) * Lrow + (long long)phs * 16;
+    };
+    auto qlive = [&](int q) -> bool {
+      if (!pr) return true;
+      return t * P.pr_S + ((m0 >> 3) + q) / P.pr_cbg < P.pr_Ly;
+    };
     const char* ehb = reinterpret_cast<const char*>(P.eh) + (long long)eb * P.CBy * Lrow + tile0;
     const char* elb = reinterpret_cast<const char*>(P.el) + (long long)eb * P.CBy * Lrow + tile0;
     const char* rhb = reinterpret_cast<const char*>(P.eh) + (long long)(b + P.bl_ref_off) * P.CBy * Lrow + tile0;
@@ -616,13 +631,14 @@ __global__ __launch_bounds__(256, NPW >= 2 ? 1 : 2) void tap3_kernel(const Tap3A
 #pragma unroll
       for (int r4 = 0; r4 < 4; ++r4) {
         const int q = 4 * i + r4;
-        const long long row = (long long)(q < quads ? q : 0) * Lrow;   // uniform; a missing quad re-reads the tile's first row
+        long long row = qrow(q < quads ? q : 0);   // uniform; a missing quad re-reads the tile's first row
+        if (pr && !qlive(q < quads ? q : 0)) row = -(long long)loff;   // (per lane) a position past the row's end re-reads the tile's first unit
         {
           const float4 bq = *reinterpret_cast<const float4*>(Bs + i * 32 + 8 * r4 + 4 * hb);
           bz[r4][0] = bq.x; bz[r4][1] = bq.y; bz[r4][2] = bq.z; bz[r4][3] = bq.w;
         }
         if (masked) {
-          if constexpr (PREF) ah[r4] = pah[i][r4];
+          if constexpr (PREF) ah[r4] = pr ? ld2(ehb, row) : pah[i][r4];
           else ah[r4] = ld2(ehb, row);
           if (fmr) { al[r4] = ld2(elb, row); rh[r4] = ld2(rhb, row); rl[r4] = ld2(rlb, row); }
         }
@@ -631,7 +647,8 @@ __global__ __launch_bounds__(256, NPW >= 2 ? 1 : 2) void tap3_kernel(const Tap3A
       for (int r4 = 0; r4 < 4; ++r4) {
         const int q = 4 * i + r4;
         if (q >= quads) continue;   // uniform
-        const long long row = (long long)q * Lrow;
+        const long long row = qrow(q);
+        if (pr && !qlive(q)) continue;   // per lane
         float v[4], a0[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = acc[i][4 * r4 + e] + bz[r4][e];
@@ -1116,6 +1133,7 @@ int tap3_launch(const Canon& c, int dir, const TapIO& io, int reflect, hipStream
   a.x = io.x; a.xmask = io.in_mode ? io.xmask : io.x; a.in_mode = io.in_mode; a.wp = reinterpret_cast<const u32x4*>(io.wp); a.tab = reinterpret_cast<const int*>(io.wp + p.tab_off_floats);
   a.bias = io.bias; a.res = io.res; a.emask = io.emask; a.y = io.y;
   a.xh = a.xl = nullptr; a.yh = a.yl = nullptr; a.eh = a.el = nullptr; a.CBx = a.CBy = a.bl_ref_off = a.bl_pad = 0;
+  a.pr_S = a.pr_cbg = a.pr_Ly = a.pr_pad = 0;
   if (c.bl) {
     if (!io.xh || !io.yh || (p.npx > 1 && !io.xl)) return fail(EBEN_EINVAL, "tap3: null bundle-layout plane");
     a.xh = static_cast<const u32x4*>(io.xh); a.xl = static_cast<const u32x4*>(io.xl);
@@ -1123,6 +1141,10 @@ int tap3_launch(const Canon& c, int dir, const TapIO& io, int reflect, hipStream
     a.eh = static_cast<const uint2*>(io.eh); a.el = static_cast<const uint2*>(io.el);
     a.CBx = p.Cx >> 3; a.CBy = p.Cy >> 3; a.bl_ref_off = io.bl_ref_off;
     a.x = nullptr; a.xmask = nullptr;
+    if (io.pr_S > 0) {
+      if (dir != 0 || p.S != 1 || p.nph != 1) return fail(EBEN_EINVAL, "tap3: phases-as-rows output on a launch that is not a stride-1 gather");
+      a.pr_S = io.pr_S; a.pr_cbg = io.pr_cbg; a.pr_Ly = io.pr_Ly; a.CBy = io.pr_CBy;
+    }
   } else if (io.xh) {
     return fail(EBEN_EINVAL, "tap3: bundle-layout planes on a descriptor without EBEN_LAYOUT_BL");
   }

@@ -41,6 +41,10 @@ from ._lib import check, load, ptr
 from ._lib import stream as _stream  # noqa: E402  (raw handle of the current HIP stream)
 
 
+#: input gradients of the strided MelGAN layers as "phases as rows" (one stride-1 contraction for all output phases, csrc/tapconv.hip)
+USE_DX_PR = os.environ.get("EBEN_DX_PR", "1") != "0"
+
+
 class _Layer:
     """One weight-normalised conv of a sub-discriminator with the packed copies the engine needs."""
 
@@ -58,6 +62,8 @@ class _Layer:
         self.scale = self.norm = None
         self.reuse = False   # inside prepack(): rebuild into the buffers already held (ops._buffer)
         self.keep_scale = False   # the layer's kernels take (v, scale) directly (bundle-layout heads / tails): prepack refreshes the scale
+        self.pr_weights: Dict[tuple, torch.Tensor] = {}   # slot -> primed weights of the phases-as-rows input gradient
+        self._pr_descs: Dict[tuple, object] = {}
 
     def ensure_scale(self) -> None:
         """Weight-norm scale g / ||v|| and norm ||v|| of the current weights (what ``packed`` computes on the way)."""
@@ -104,10 +110,37 @@ class _Layer:
             for old in [k for k in self.packs if k not in self.used] or list(self.packs)[:1]:
                 del self.packs[old]
         d = ops.conv_desc(self.spec, batch, l_in, self.math_fwd if which == 0 else self.math_dx)
+        if which == 2:
+            # "phases as rows" form of the input gradient (include/eben_hip.h, eben_bl_dx_pr_*): the primed stride-1 layer's weights are a
+            # gather of this layer's (scale folded in), packed as that layer's forward image
+            dq = self.pr_desc(batch, l_in)
+            wq = self.pr_weights.get(slot)
+            n_w = dq.c_out * (dq.c_in // dq.groups) * dq.ksize
+            if wq is None or wq.numel() != n_w:
+                wq = self.pr_weights[slot] = torch.empty(n_w, dtype=torch.float32, device=v.device)
+            check(lib.eben_bl_dx_pr_weights(ctypes.byref(d), ptr(v), ptr(self.scale), ptr(wq), _stream()), "bl_dx_pr_weights")
+            wp = ops._buffer(None if hit is None else hit[1], lib.eben_conv1d_packed_floats(ctypes.byref(dq), 0), v, self.reuse)
+            ops.conv1d_pack(dq, wq, None, wp, None)
+            self.packs[slot] = (wkey, wp)
+            return wp
         wp = ops._buffer(None if hit is None else hit[1], lib.eben_conv1d_packed_floats(ctypes.byref(d), which), v, self.reuse)
         ops.conv1d_pack(d, v, self.scale, wp if which == 0 else None, wp if which == 1 else None)
         self.packs[slot] = (wkey, wp)
         return wp
+
+    def pr_desc(self, batch: int, l_in: int):
+        """Descriptor of the primed layer of ``eben_bl_dx_pr_desc`` for this layer's input gradient at (batch, l_in), or None when the
+        input gradient has no such form (cached per shape)."""
+        key = (batch, l_in)
+        if key not in self._pr_descs:
+            from ._lib import EbenConv1dDesc
+            d = ops.conv_desc(self.spec, batch, l_in, self.math_dx)
+            dq = EbenConv1dDesc()
+            ok = USE_DX_PR and (self.math_dx & 0x100) != 0 and load().eben_bl_dx_pr_desc(ctypes.byref(d), ctypes.byref(dq)) == 0
+            if len(self._pr_descs) > 16:
+                self._pr_descs.clear()
+            self._pr_descs[key] = dq if ok else None
+        return self._pr_descs[key]
 
 
 class _Chain:

@@ -171,11 +171,13 @@ class _ChainBL:
                 jobs.append((i, g, x_in))
             d = ops.conv_desc(lay.spec_lin, rows, x_in.length, lay.math_dx)
             gp = Planes(rows, x_in.channels, x_in.length, seeds.device, lo=(i == 1))   # the head's input gradient reads hi + lo
-            wp = lay.packed(1, rows, x_in.length)
+            pr = lay.pr_desc(rows, x_in.length) is not None
+            wp = lay.packed(2 if pr else 1, rows, x_in.length)
             tm = ops.kernel_timer_for(lay.spec, "dx")
             e0 = tm.start() if tm is not None else None
-            check(lib.eben_bl_conv1d_bwd_dx(ctypes.byref(d), _addr(g.hi), ptr(wp), _addr(x_in.hi), _addr(x_in.lo), self.layers[i - 1].spec.out_slope, half,
-                                            seg_map, half, half, fm_sums_addr + 8 * (i - 1), fm_gs, _addr(gp.hi), _addr(gp.lo), st), "bl_conv1d_bwd_dx")
+            dx_fn = lib.eben_bl_conv1d_bwd_dx_pr if pr else lib.eben_bl_conv1d_bwd_dx
+            check(dx_fn(ctypes.byref(d), _addr(g.hi), ptr(wp), _addr(x_in.hi), _addr(x_in.lo), self.layers[i - 1].spec.out_slope, half,
+                        seg_map, half, half, fm_sums_addr + 8 * (i - 1), fm_gs, _addr(gp.hi), _addr(gp.lo), st), "bl_conv1d_bwd_dx")
             if tm is not None:
                 tm.stop(e0, rows)
             g = gp
@@ -321,7 +323,7 @@ class DiscriminatorEngineBL(DiscriminatorEngine):
         """A replayed sequence reads the chain's packed images without passing through ``_Layer.packed``: tell ``prepack`` they are in
         use (it drops the images the last step did not touch)."""
         for lay in ch.layers:
-            lay.used.update(slot for slot in lay.packs if slot[0] == which)
+            lay.used.update(slot for slot in lay.packs if slot[0] == which or (which == 1 and slot[0] == 2))   # 2: phases-as-rows images
 
     @staticmethod
     def _chain_sig(ch: "_ChainBL", which: int):
@@ -331,7 +333,7 @@ class DiscriminatorEngineBL(DiscriminatorEngine):
         for lay in ch.layers:
             v, g, b = lay.params()
             wkey = lay._weights_key()
-            imgs = tuple(sorted((slot, wp.data_ptr(), key == wkey) for slot, (key, wp) in lay.packs.items() if slot[0] == which)) if which >= 0 else ()
+            imgs = tuple(sorted((slot, wp.data_ptr(), key == wkey) for slot, (key, wp) in lay.packs.items() if slot[0] == which or (which == 1 and slot[0] == 2))) if which >= 0 else ()
             out.append((v.data_ptr(), g.data_ptr(), 0 if b is None else b.data_ptr(), 0 if lay.scale is None else lay.scale.data_ptr(),
                         lay.scale_key == wkey, imgs, lay.math_fwd, lay.math_dx, lay.math_dw))
         return tuple(out)
