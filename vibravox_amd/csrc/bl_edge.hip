@@ -14,6 +14,8 @@
 //   feature-matching sums over bundle planes (feature_loss.py:40-47), fp32 <-> bundle conversions (tests, tools).
 #include "common.h"
 
+#include <cstdlib>
+
 namespace eben {
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -224,6 +226,9 @@ __global__ __launch_bounds__(256) void bl_head_dx_kernel(const BlHeadTable T, fl
   }
 }
 
+// ([MI355X] tried: four consecutive positions per thread sharing a window of K + 3 samples per channel -- five ds_read_b128 for 4 K products
+// instead of one ds_read_b32 per product: 109 -> 145 us for the MelGAN head; the one-position form keeps all 240 reads of a thread in flight
+// (251 registers), the windowed one waits for each channel's window in turn.)
 // Weight (+ bias) gradient of a head: slab[z][co][j] = sum over the (batch item, position) pairs of slice z of g[b, co, t] xp[b, ci(co), t - pad + j dil],
 // column K = sum g.  One block = one output bundle x one slice; the 8 (K + 1) per-thread sums meet in a fixed-order block reduction.
 template <int CIN, int OG, int K>
@@ -241,20 +246,38 @@ __global__ __launch_bounds__(256) void bl_head_dw_kernel(const u32x4* __restrict
 #pragma unroll
     for (int j = 0; j <= K; ++j) acc[e][j] = 0.f;
   const int ci0 = (8 * ob) / OG, ci1 = (8 * ob + 7) / OG;   // OG >= 4: at most two input channels feed one bundle
-  for (long long i = lo + threadIdx.x; i < hi; i += 256) {
-    const int b = (int)(i / l_out), t = (int)(i - (long long)b * l_out);
-    float gv[8];
-    bl_unpack8(gh[((long long)b * CB + ob) * l_out + t], gv);
-    const float* xb = x + (long long)b * CIN * l_in;
+  // two (batch item, position) pairs per iteration, every load of both issued before the first product: the loop is a chain of
+  // dependent global round trips at two waves per SIMD (128 accumulators per thread) -- [MI355X] MelGAN head 165 us one pair at a time
+  constexpr int UN = 2;
+  for (long long i0 = lo + threadIdx.x; i0 < hi; i0 += 256 * UN) {
+    u32x4 gu[UN];
+    float x0[UN][K], x1[CIN > 1 ? UN : 1][K];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) acc[e][K] += gv[e];
+    for (int un = 0; un < UN; ++un) {
+      const long long i = i0 + 256 * un;
+      const bool live = i < hi;
+      const long long ic = live ? i : lo;
+      const int b = (int)(ic / l_out), t = (int)(ic - (long long)b * l_out);
+      gu[un] = gh[((long long)b * CB + ob) * l_out + t];
+      if (!live) gu[un] = u32x4{0u, 0u, 0u, 0u};
+      const float* xb = x + (long long)b * CIN * l_in;
 #pragma unroll
-    for (int j = 0; j < K; ++j) {
-      const int u = bl_head_src(t - pad + j * dil, rpad, l_in);
-      const float x0 = u >= 0 ? xb[(long long)ci0 * l_in + u] : 0.f;
-      const float x1 = (u >= 0 && ci1 != ci0) ? xb[(long long)ci1 * l_in + u] : x0;
+      for (int j = 0; j < K; ++j) {
+        const int u = bl_head_src(t - pad + j * dil, rpad, l_in);
+        x0[un][j] = u >= 0 ? xb[(long long)ci0 * l_in + u] : 0.f;
+        if constexpr (CIN > 1) x1[un][j] = (u >= 0 && ci1 != ci0) ? xb[(long long)ci1 * l_in + u] : x0[un][j];
+      }
+    }
 #pragma unroll
-      for (int e = 0; e < 8; ++e) acc[e][j] = fmaf(gv[e], (8 * ob + e) / OG == ci0 ? x0 : x1, acc[e][j]);
+    for (int un = 0; un < UN; ++un) {
+      float gv[8];
+      bl_unpack8(gu[un], gv);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e][K] += gv[e];
+#pragma unroll
+      for (int j = 0; j < K; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e][j] = fmaf(gv[e], (CIN == 1 || (8 * ob + e) / OG == ci0) ? x0[un][j] : x1[CIN > 1 ? un : 0][j], acc[e][j]);
     }
   }
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -615,6 +638,8 @@ extern "C" int eben_bl_tail_dx(const float* seeds, int rows, int channels, int l
   return EBEN_OK;
 }
 
+// split-K slices of a logits layer's weight gradient: ~8 (batch item, position) pairs per thread ([MI355X] 2 pairs per thread, four times
+// the blocks and slabs: 54 -> 80 us per launch)
 static int bl_tail_slabs(long long pairs) {
   long long n = pairs / (256 * 8);
   return (int)(n < 1 ? 1 : (n > 32 ? 32 : n));

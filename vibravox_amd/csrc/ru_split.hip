@@ -23,6 +23,10 @@
 
 namespace eben {
 
+#ifndef EBEN_RU_DBG
+#define EBEN_RU_DBG 0   // scratch builds (results wrong by construction): 1 no y stores, 2 no saved-plane stores, 4 no x loads, 8 no MFMAs
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -64,8 +68,10 @@ __device__ __forceinline__ void rs_mma(const u32x4 (&a)[NP][CT], const u32x4 (&b
 #pragma unroll
     for (int q = 0; q <= lvl; ++q)
 #pragma unroll
-      for (int i = 0; i < CT; ++i)
-        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[q][i]), __builtin_bit_cast(bf16x8, b[lvl - q]), acc[i], 0, 0, 0);
+      for (int i = 0; i < CT; ++i) {
+        if (EBEN_RU_DBG & 8) acc[i][0] += __builtin_bit_cast(float, a[q][i][0] ^ b[lvl - q][i & 3]);
+        else acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[q][i]), __builtin_bit_cast(bf16x8, b[lvl - q]), acc[i], 0, 0, 0);
+      }
 }
 
 constexpr int RS_DMAX = 9;   // largest dilation the tile strides are laid out for (EBEN: 1, 3, 9)
@@ -126,7 +132,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && CT < 4) ? 2 : 1) void ru3_fwd_
   const bool interior = P.vec && q0 >= 0 && qa + XS <= L;
   if (interior) {
     constexpr int x4 = XS >> 2, tot4 = C * x4;
-    for (int base = 0; base < tot4; base += 4 * NT) {
+    for (int base = 0; base < ((EBEN_RU_DBG & 4) ? 4 * NT : tot4); base += 4 * NT) {
       f32x4 v[4];
       int sl[4];
 #pragma unroll
@@ -204,7 +210,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && CT < 4) ? 2 : 1) void ru3_fwd_
       rs_split8<NP>(v, bq);
       if constexpr (BL) {
         // the centre tap's fragment IS the saved input: piece 0 = bf16(xin) of channels 16 cb + 8 (lane >> 5) .. + 7 at this column
-        if (j == 1 && live) P.xb[ubase + (long long)(2 * cb + (lane >> 5)) * L] = bq[0];
+        if (j == 1 && live && (!(EBEN_RU_DBG & 2) || bq[0][0] == 0x12345u)) P.xb[ubase + (long long)(2 * cb + (lane >> 5)) * L] = bq[0];
       }
       rs_mma<NP, CT>(a, bq, acc1);
     }
@@ -224,7 +230,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && CT < 4) ? 2 : 1) void ru3_fwd_
           uint2 v;
           v.x = rs_pack_bf16(acc1[i][4 * q], acc1[i][4 * q + 1]);
           v.y = rs_pack_bf16(acc1[i][4 * q + 2], acc1[i][4 * q + 3]);
-          hu[(long long)(4 * i + q) * L * 2] = v;
+          if (!(EBEN_RU_DBG & 2) || v.x == 0x12345u) hu[(long long)(4 * i + q) * L * 2] = v;
         }
     }
   } else if (P.h != nullptr && live) {
@@ -304,7 +310,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && CT < 4) ? 2 : 1) void ru3_fwd_
       const unsigned off = m * (unsigned)L;
       const float uu = lrelu(acc2[i][r], P.out_slope);
       if (keep_u) ub[off] = uu;
-      yb[off] = xc[m * XS] + uu;
+      if (!(EBEN_RU_DBG & 1) || uu == 12345.f) yb[off] = xc[m * XS] + uu;
     }
 }
 
