@@ -942,46 +942,68 @@ struct Pack3Args {
   int mode, J0, off0, nt, dstep, OS, S, ps_pad, k, d, kstep, Ly;
   int Cin_g, Cout_g, PLEN, CSTRIDE, nxbuf, dense, NPW, KSC;
   long long w_tile, w_phase, wunits;
+  // host-side arithmetic of the unit decomposition: ceil(2^32 / d) per divisor (0: d == 1), the tap geometry of every phase
+  unsigned m_nmt, m_fm, m_npw, m_cp, m_coutg;
+  float r_wphase, r_wtile, r_wchu;
+  struct PGp { int J, k0; unsigned m_kscc; int pad; } pg[8];
 };
 
+// One thread = one 16-byte unit of the image (every unit in flight at once: the eight weights of a unit are eight scattered loads).
+// The unit index is decomposed with 32-bit multiply-high divisions by host-side magic numbers (the image of the largest layer has
+// 2^21 units; round 3's form used 64-bit divisions, ~150 instructions each, and searched the phase geometry per unit) and the per-phase
+// tap geometry comes from a table in the arguments.
+__device__ __forceinline__ unsigned p3_div(unsigned n, unsigned d, unsigned magic) {   // n / d for n * d < 2^32 (small operands)
+  return magic ? __umulhi(n, magic) : n;                                                // magic 0: d == 1
+}
+__device__ __forceinline__ unsigned p3_divf(unsigned n, unsigned d, float rd) {          // n / d for n < 2^24: fp32 estimate + one correction
+  unsigned q = (unsigned)((float)n * rd);
+  const int r = (int)(n - q * d);
+  return r < 0 ? q - 1u : ((unsigned)r >= d ? q + 1u : q);
+}
 __device__ __forceinline__ void pack3_body(const Pack3Args& P, unsigned bid, unsigned nblk) {
-  const long long total = P.wunits + (long long)P.tab_phase * P.nph;
-  for (long long i = (long long)bid * 256 + threadIdx.x; i < total; i += (long long)nblk * 256) {
-    if (i < P.wunits) {
-      long long r = i;
-      const int ph = (int)(r / P.w_phase); r -= (long long)ph * P.w_phase;
-      const int tile = (int)(r / P.w_tile); r -= (long long)tile * P.w_tile;
-      const int g = tile / P.nmt, mt = tile - g * P.nmt;
-      const int ch = (int)(r / P.WCHU);
-      const int e = (int)(r - (long long)ch * P.WCHU);
-      const int ks = e / (64 * P.FM * P.NPW);
-      const int piece = (e / (64 * P.FM)) % P.NPW;
-      const int fm = (e / 64) % P.FM;
-      const int lane = e & 63;
-      const PhaseGeom q = phase_geom(P.mode, ph, P.J0, P.off0, P.nt, P.dstep, P.OS, P.ps_pad, P.k, P.d, P.kstep, P.Ly);
-      const int s = ch * P.KSC + ks;
-      const int KS_CC = q.J * P.CP;
+  const unsigned total = (unsigned)P.wunits + (unsigned)(P.tab_phase * P.nph);
+  for (unsigned i = bid * 256u + threadIdx.x; i < total; i += nblk * 256u) {
+    if (i < (unsigned)P.wunits) {
+      unsigned r = i;
+      const unsigned ph = p3_divf(r, (unsigned)P.w_phase, P.r_wphase); r -= ph * (unsigned)P.w_phase;
+      const unsigned tile = p3_divf(r, (unsigned)P.w_tile, P.r_wtile); r -= tile * (unsigned)P.w_tile;
+      const unsigned g = p3_div(tile, (unsigned)P.nmt, P.m_nmt), mt = tile - g * (unsigned)P.nmt;
+      const unsigned ch = p3_divf(r, (unsigned)P.WCHU, P.r_wchu);
+      const unsigned e = r - ch * (unsigned)P.WCHU;
+      const unsigned e64 = e >> 6, lane = e & 63u;
+      const unsigned kp = p3_div(e64, (unsigned)P.FM, P.m_fm), fm = e64 - kp * (unsigned)P.FM;       // kp = ks * NPW + piece
+      const unsigned ks = p3_div(kp, (unsigned)P.NPW, P.m_npw), piece = kp - ks * (unsigned)P.NPW;
+      int qJ, qk0;
+      unsigned m_kscc;
+      if (ph < 8u) { qJ = P.pg[ph].J; qk0 = P.pg[ph].k0; m_kscc = P.pg[ph].m_kscc; }
+      else {   // strides beyond the table (none in EBEN)
+        const PhaseGeom q = phase_geom(P.mode, (int)ph, P.J0, P.off0, P.nt, P.dstep, P.OS, P.ps_pad, P.k, P.d, P.kstep, P.Ly);
+        qJ = q.J; qk0 = q.k0;
+        const unsigned dd = (unsigned)(qJ * P.CP);
+        m_kscc = dd <= 1u ? 0u : (unsigned)((0x100000000ull + dd - 1) / dd);
+      }
+      const int s = (int)(ch * (unsigned)P.KSC + ks);
+      const int KS_CC = qJ * P.CP;
       float v[8];
       {
         // all eight weight loads are issued unconditionally (clamped index), the padding is a select afterwards
-        const bool live = q.J > 0 && s < P.ncc * KS_CC;
-        const int sc = live ? s : 0;
-        const int KSd = KS_CC > 0 ? KS_CC : 1;
-        const int cc = sc / KSd, rem = sc - cc * KSd;
-        const int j = rem / P.CP, cp = rem - j * P.CP;
-        const int m = mt * P.BM + fm * 32 + (lane & 31);
-        const int kk = q.k0 + j * P.kstep;
+        const bool live = qJ > 0 && s < P.ncc * KS_CC;
+        const unsigned sc = live ? (unsigned)s : 0u;
+        const unsigned cc = KS_CC > 0 ? p3_div(sc, (unsigned)KS_CC, m_kscc) : 0u, rem = sc - cc * (unsigned)KS_CC;
+        const unsigned j = p3_div(rem, (unsigned)P.CP, P.m_cp), cp = rem - j * (unsigned)P.CP;
+        const int m = (int)(mt * (unsigned)P.BM + fm * 32u + (lane & 31u));
+        const int kk = qk0 + (int)j * P.kstep;
         float sc8[8];
         bool ok[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-          const int chan = cc * P.CI_T + 16 * cp + 8 * (lane >> 5) + u;
+          const int chan = (int)(cc * (unsigned)P.CI_T + 16u * cp + 8u * (lane >> 5)) + u;
           ok[u] = live && chan < P.Cg && m < P.Mg && (P.mode == 0 || kk < P.k);
-          const int co = P.mode == 0 ? g * P.Cout_g + m : g * P.Cout_g + chan;   // mode 1: reduction channel = conv output channel
+          const int co = P.mode == 0 ? (int)g * P.Cout_g + m : (int)g * P.Cout_g + chan;   // mode 1: reduction channel = conv output channel
           // conv input channel within its group; dense form (g == 0, channels counted over all groups): zero across groups
-          const int ci = (P.mode == 0 ? chan : m) - (P.dense ? (co / P.Cout_g) * P.Cin_g : 0);
+          const int ci = (P.mode == 0 ? chan : m) - (P.dense ? (int)p3_div((unsigned)(co < 0 ? 0 : co), (unsigned)P.Cout_g, P.m_coutg) * P.Cin_g : 0);
           ok[u] = ok[u] && ci >= 0 && ci < P.Cin_g;
-          const long long idx = ((long long)co * P.Cin_g + ci) * P.k + (P.mode == 0 ? j : kk);
+          const long long idx = ((long long)co * P.Cin_g + ci) * P.k + (P.mode == 0 ? (int)j : kk);
           v[u] = P.w[ok[u] ? idx : 0];
           sc8[u] = P.scale ? P.scale[ok[u] ? co : 0] : 1.f;
         }
@@ -989,7 +1011,7 @@ __device__ __forceinline__ void pack3_body(const Pack3Args& P, unsigned bid, uns
         for (int u = 0; u < 8; ++u) v[u] = ok[u] ? v[u] * sc8[u] : 0.f;
       }
       u32x4 o;
-      for (int qq = 0;; ++qq) {   // piece `piece` of the split w = p0 + p1 + ..: p_q = bf16(w - p0 - .. - p(q-1))
+      for (unsigned qq = 0;; ++qq) {   // piece `piece` of the split w = p0 + p1 + ..: p_q = bf16(w - p0 - .. - p(q-1))
         o[0] = pack_bf16(v[0], v[1]); o[1] = pack_bf16(v[2], v[3]); o[2] = pack_bf16(v[4], v[5]); o[3] = pack_bf16(v[6], v[7]);
         if (qq == piece) break;
 #pragma unroll
@@ -1000,9 +1022,9 @@ __device__ __forceinline__ void pack3_body(const Pack3Args& P, unsigned bid, uns
       }
       reinterpret_cast<u32x4*>(P.wp)[i] = o;
     } else {
-      const long long r = i - P.wunits;
-      const int ph = (int)(r / P.tab_phase);
-      const int s = (int)(r - (long long)ph * P.tab_phase);
+      const int r = (int)(i - (unsigned)P.wunits);
+      const int ph = r / P.tab_phase;
+      const int s = r - ph * P.tab_phase;
       const PhaseGeom q = phase_geom(P.mode, ph, P.J0, P.off0, P.nt, P.dstep, P.OS, P.ps_pad, P.k, P.d, P.kstep, P.Ly);
       const int KS_CC = q.J * P.CP;
       int o = 0;
@@ -1091,6 +1113,20 @@ static int tap3_pack_args(const Canon& c, int dir, const float* w, const float* 
   long long blocks = (a.wunits + (long long)p.tab_phase * p.nph + 255) / 256;
   if (blocks > 8192) blocks = 8192;
   if (blocks < 1) blocks = 1;
+  {
+    // p3_divf needs n < 2^24 (the largest image of EBEN, MelGAN L3 / L4, has 1.3 M units); p3_div: operands < 2^16 x 2^16
+    const long long nmax = a.wunits + (long long)p.tab_phase * p.nph;
+    if (nmax >= (1 << 24)) return fail(EBEN_EUNSUPPORTED, "tap3_pack: an image of %lld units is beyond the pack kernel's unit arithmetic", nmax);
+    auto magic = [](long long d) { return d <= 1 ? 0u : (unsigned)((0x100000000ull + (unsigned long long)d - 1) / (unsigned long long)d); };
+    a.r_wphase = 1.0f / (float)a.w_phase; a.r_wtile = 1.0f / (float)a.w_tile; a.m_nmt = magic(p.nmt); a.r_wchu = 1.0f / (float)p.WCHU; a.m_fm = magic(p.FM);
+    a.m_npw = magic(p.npw); a.m_cp = magic(p.CP); a.m_coutg = magic(c.Cout / c.g);
+    for (int ph = 0; ph < 8; ++ph) {
+      a.pg[ph].J = 0; a.pg[ph].k0 = 0; a.pg[ph].m_kscc = 0; a.pg[ph].pad = 0;
+      if (ph >= p.nph) continue;
+      const PhaseGeom q = phase_geom(p.mode, ph, p.J, p.off0, p.nt, p.dstep, p.OS, p.ps_pad, c.k, c.d, p.kstep, p.Ly);
+      a.pg[ph].J = q.J; a.pg[ph].k0 = q.k0; a.pg[ph].m_kscc = magic((long long)q.J * p.CP);
+    }
+  }
   *out = a;
   *blocks_out = (unsigned)blocks;
   return EBEN_OK;
@@ -1116,7 +1152,7 @@ int tap3_pack_multi(const Canon* cs, const int* dirs, const float* const* ws, co
       unsigned blocks;
       const int rc = tap3_pack_args(cs[base + j], dirs[base + j], ws[base + j], scales[base + j], wps[base + j], &T.job[j], &blocks);
       if (rc) return rc;
-      if (blocks > 512) blocks = 512;   // many jobs share the launch: the grid-stride loop takes the rest
+      { static const unsigned cap = getenv("EBEN_PACK3_CAP") ? (unsigned)atoi(getenv("EBEN_PACK3_CAP")) : 512u; if (blocks > cap) blocks = cap; }   // many jobs share the launch: the grid-stride loop takes the rest
       T.first[j + 1] = T.first[j] + blocks;
     }
     hipLaunchKernelGGL(pack3_multi_kernel, dim3(T.first[T.n]), dim3(256), 0, st, T);
