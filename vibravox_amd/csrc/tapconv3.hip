@@ -1040,6 +1040,110 @@ __device__ __forceinline__ void pack3_body(const Pack3Args& P, unsigned bid, uns
   }
 }
 
+// ---- coalescing form for the big images (MelGAN L3-L5, PQMF-band L5 / L6: ~10^6 weights each, 4/5 of a step's packed bytes) ----------
+// In pack3_body a unit's eight weights are eight loads k (gather-strided) or Cin_g k (phase-scatter) floats apart, and the lanes of a wave
+// sit on 32 different rows: every load instruction touches 64 cache lines for 256 useful bytes, every line is asked for ~30 times
+// ([MI355X] ~100 us per 10^7-weight image, 0.6 TB/s).  Here a block stages the sub-block of w its units come from -- 32 rows x 16
+// reduction channels x all k taps, which is 16 k (mode 0) or 32 k (mode 1) CONTIGUOUS floats per row / channel -- in LDS with coalesced
+// loads, then emits the units of every (phase, tap): LDS reads at an odd row stride (conflict-free), 1 KB contiguous per wave store.
+// Item = (group, row tile, 32-row sub-tile fm, channel chunk cc, channel pair cp).  The padding k-steps behind the last real one of a
+// (phase, tile) are zero-filled by the item that owns the last channel pair.  Not for the dense (block-diagonal) images.
+__device__ __forceinline__ void pack3_tables(const Pack3Args& P);
+__global__ __launch_bounds__(256) void pack3c_kernel(const Pack3Args P) {
+  extern __shared__ float p3c[];
+  if (blockIdx.x == gridDim.x - 1) pack3_tables(P);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int k = P.k;
+  const int NCP = P.ncc * P.CP;                       // 16-channel columns of the reduction
+  int item = blockIdx.x;
+  const int col = item % NCP; item /= NCP;
+  const int fm = item % P.FM; item /= P.FM;
+  const int mt = item % P.nmt;
+  const int g = item / P.nmt;
+  const int cc = col / P.CP, cp = col - cc * P.CP;
+  const int m0 = mt * P.BM + fm * 32;                 // first row of the sub-tile (within the group)
+  const int c0 = cc * P.CI_T + 16 * cp;               // first reduction channel (within the group)
+  const int nrow = P.Mg - m0 < 32 ? P.Mg - m0 : 32;   // rows / channels that exist
+  const int nch = P.Cg - c0 < 16 ? P.Cg - c0 : 16;
+  // mode 0: LDS[row r][c k + j] = w[g Cout_g + m0 + r][c0 + c][j]        (row = conv output channel, 16 k contiguous floats)
+  // mode 1: LDS[chan c][r k + j] = w[g Cout_g + c0 + c][m0 + r][j]        (row of the image = conv INPUT channel; 32 k contiguous floats)
+  const int RS = (P.mode == 0 ? 16 : 32) * k | 1;
+  if (nrow > 0 && nch > 0) {
+    const int nlines = P.mode == 0 ? nrow : nch;
+    const int run = (P.mode == 0 ? nch : nrow) * k;
+    for (int ln = wave; ln < nlines; ln += 4) {
+      const long long src = P.mode == 0 ? ((long long)(g * P.Cout_g + m0 + ln) * P.Cin_g + c0) * k
+                                        : ((long long)(g * P.Cout_g + c0 + ln) * P.Cin_g + m0) * k;
+      const float sc = P.scale ? P.scale[g * P.Cout_g + (P.mode == 0 ? m0 : c0) + ln] : 1.f;
+      for (int i = lane; i < run; i += 64) p3c[ln * RS + i] = P.w[src + i] * sc;
+    }
+  }
+  __syncthreads();
+  const int r = lane & 31, h = lane >> 5;
+  const bool row_ok = r < nrow;
+  u32x4* img = reinterpret_cast<u32x4*>(P.wp);
+  const long long tile = (long long)g * P.nmt + mt;
+  const bool last_col = col == NCP - 1;
+  for (int ph = 0; ph < P.nph; ++ph) {
+    int qJ, qk0;
+    if (ph < 8) { qJ = P.pg[ph].J; qk0 = P.pg[ph].k0; }
+    else { const PhaseGeom q = phase_geom(P.mode, ph, P.J0, P.off0, P.nt, P.dstep, P.OS, P.ps_pad, P.k, P.d, P.kstep, P.Ly); qJ = q.J; qk0 = q.k0; }
+    const int KS_CC = qJ * P.CP, KS_all = P.ncc * KS_CC;
+    const long long base = (long long)ph * P.w_phase + tile * P.w_tile;
+    for (int j = wave; j < qJ; j += 4) {
+      const int tap = P.mode == 0 ? j : qk0 + j * P.kstep;
+      const int s = cc * KS_CC + j * P.CP + cp;
+      const int ch = s / P.KSC, ks = s - ch * P.KSC;
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int c = 8 * h + u;
+        const bool ok = row_ok && c < nch && tap < k;
+        const int idx = P.mode == 0 ? r * RS + c * k + tap : c * RS + r * k + tap;
+        v[u] = ok ? p3c[idx] : 0.f;
+      }
+      for (int piece = 0; piece < P.NPW; ++piece) {
+        u32x4 o;
+        o[0] = pack_bf16(v[0], v[1]); o[1] = pack_bf16(v[2], v[3]); o[2] = pack_bf16(v[4], v[5]); o[3] = pack_bf16(v[6], v[7]);
+        img[base + (long long)ch * P.WCHU + ((ks * P.NPW + piece) * P.FM + fm) * 64 + lane] = o;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          v[2 * u] -= __builtin_bit_cast(float, o[u] << 16);
+          v[2 * u + 1] -= __builtin_bit_cast(float, o[u] & 0xffff0000u);
+        }
+      }
+    }
+    if (last_col) {   // the k-steps of the last chunk that stand for nothing
+      for (int s = KS_all + wave; s < P.NCH * P.KSC; s += 4) {
+        const int ch = s / P.KSC, ks = s - ch * P.KSC;
+        for (int piece = 0; piece < P.NPW; ++piece)
+          img[base + (long long)ch * P.WCHU + ((ks * P.NPW + piece) * P.FM + fm) * 64 + lane] = u32x4{0u, 0u, 0u, 0u};
+      }
+    }
+  }
+}
+
+// the k-step tables (LDS offset of every k-step's B fragment): a few hundred integers per phase, written by the last block
+__device__ __forceinline__ void pack3_tables(const Pack3Args& P) {
+  const int tabs = P.tab_phase * P.nph;
+  for (int r = threadIdx.x; r < tabs; r += 256) {
+    const int ph = r / P.tab_phase;
+    const int s = r - ph * P.tab_phase;
+    const PhaseGeom q = phase_geom(P.mode, ph, P.J0, P.off0, P.nt, P.dstep, P.OS, P.ps_pad, P.k, P.d, P.kstep, P.Ly);
+    const int KS_CC = q.J * P.CP;
+    int o = 0;
+    if (q.J > 0 && s < P.ncc * KS_CC) {
+      const int cc = s / KS_CC, rem = s - cc * KS_CC;
+      const int j = rem / P.CP, cp = rem - j * P.CP;
+      const int rel = q.off0 + j * P.dstep - q.minoff;
+      const int dd = rel / P.S, pp = rel - dd * P.S;
+      o = (P.nxbuf > 1 ? (cc % P.nxbuf) * P.CI_B * P.CSTRIDE : 0) + 2 * cp * P.CSTRIDE + pp * P.PLEN + dd;
+    }
+    reinterpret_cast<int*>(P.wp)[P.wunits * 4 + r] = o;
+  }
+}
+
 __global__ __launch_bounds__(256) void pack3_kernel(const Pack3Args P) { pack3_body(P, blockIdx.x, gridDim.x); }
 
 // several layers' images in one launch (eben_conv1d_pack_multi): block -> job by the prefix sums of the jobs' block counts
@@ -1132,11 +1236,32 @@ static int tap3_pack_args(const Canon& c, int dir, const float* w, const float* 
   return EBEN_OK;
 }
 
+// big, not block-diagonal images go through the coalescing kernel (+ a tables launch); returns 1 when it took the job
+static int tap3_pack_coalesced(const Pack3Args& a, hipStream_t st, int* rc) {
+  static const long long min_w = getenv("EBEN_PACK3C_MIN") ? atoll(getenv("EBEN_PACK3C_MIN")) : 200000;   // weights; 0 = never
+  *rc = EBEN_OK;
+  const long long weights = (long long)a.G * a.Cout_g * a.Cin_g * a.k;
+  const size_t lds = sizeof(float) * (size_t)(a.mode == 0 ? 32 : 16) * (size_t)(((a.mode == 0 ? 16 : 32) * a.k) | 1);
+  if (min_w <= 0 || a.dense || weights < min_w || lds > 150 * 1024 || a.nph > 8) return 0;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pack3c_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) { *rc = hip_fail(e, "hipFuncSetAttribute(pack3c)"); return 1; }
+    attr_set = true;
+  }
+  const long long items = (long long)a.G * a.nmt * a.FM * a.ncc * a.CP;
+  hipLaunchKernelGGL(pack3c_kernel, dim3((unsigned)items), dim3(256), lds, st, a);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) *rc = hip_fail(e, "pack3c_kernel");
+  return 1;
+}
+
 int tap3_pack(const Canon& c, int dir, const float* w, const float* scale, float* wp, hipStream_t st) {
   Pack3Args a;
   unsigned blocks;
-  const int rc = tap3_pack_args(c, dir, w, scale, wp, &a, &blocks);
+  int rc = tap3_pack_args(c, dir, w, scale, wp, &a, &blocks);
   if (rc) return rc;
+  if (tap3_pack_coalesced(a, st, &rc)) return rc;
   hipLaunchKernelGGL(pack3_kernel, dim3(blocks), dim3(256), 0, st, a);
   EBEN_CHECK_LAUNCH("pack3_kernel");
   return EBEN_OK;
@@ -1150,8 +1275,13 @@ int tap3_pack_multi(const Canon* cs, const int* dirs, const float* const* ws, co
     T.first[0] = 0;
     for (int j = 0; j < T.n; ++j) {
       unsigned blocks;
-      const int rc = tap3_pack_args(cs[base + j], dirs[base + j], ws[base + j], scales[base + j], wps[base + j], &T.job[j], &blocks);
+      int rc = tap3_pack_args(cs[base + j], dirs[base + j], ws[base + j], scales[base + j], wps[base + j], &T.job[j], &blocks);
       if (rc) return rc;
+      if (tap3_pack_coalesced(T.job[j], st, &rc)) {   // a big image: its own launches; an empty slot in this table
+        if (rc) return rc;
+        T.job[j].wunits = 0; T.job[j].tab_phase = 0;
+        blocks = 1;
+      }
       { static const unsigned cap = getenv("EBEN_PACK3_CAP") ? (unsigned)atoi(getenv("EBEN_PACK3_CAP")) : 512u; if (blocks > cap) blocks = cap; }   // many jobs share the launch: the grid-stride loop takes the rest
       T.first[j + 1] = T.first[j] + blocks;
     }
