@@ -467,9 +467,12 @@ static int rubl_env(const char* name, int dflt) {
   return s ? atoi(s) : dflt;
 }
 
-// K slab length: a multiple of 64; ~512 positions at 32 / 64 channels, half an item at 128 (the slabs are C x 4 C floats each)
+// K slab length: a multiple of 64; ~1024 positions at 32 channels, ~512 at 64, half an item at 128 (the slabs are C x 4 C floats each: what
+// the weight-gradient launch writes and the slab sum reads back.  [MI355X, same box] step 10.4 ms at 512 / 512 / 512, 10.2 at 1024 / 512 / 512
+// -- the launch alone is 2 us slower, the slab sum behind the generator's last weight gradients 8 MB lighter per unit; 1024 at 64 channels
+// or 4096 at 32: no further gain / slower)
 static int rubl_seg(int channels, int length) {
-  static const int t32 = rubl_env("EBEN_RUBL_SEG32", 512), t64 = rubl_env("EBEN_RUBL_SEG64", 512), t128 = rubl_env("EBEN_RUBL_SEG128", 512);
+  static const int t32 = rubl_env("EBEN_RUBL_SEG32", 1024), t64 = rubl_env("EBEN_RUBL_SEG64", 512), t128 = rubl_env("EBEN_RUBL_SEG128", 512);
   const int target = channels == 32 ? t32 : channels == 64 ? t64 : t128;
   const int nseg = ceil_div(length, target > 64 ? target : 64);
   return round_up(ceil_div(length, nseg), 64);
@@ -526,7 +529,7 @@ extern "C" int eben_rubl_dw(int batch, int channels, int length, int dilation, c
   a.B = batch; a.L = length; a.d = dilation;
   a.seg = rubl_seg(channels, length); a.nseg = ceil_div(length, a.seg);
   hipStream_t st = as_stream(stream);
-  static const int rt64 = rubl_env("EBEN_RUBL_RT64", 1), bkt128 = rubl_env("EBEN_RUBL_BKT128", 32), rt128 = rubl_env("EBEN_RUBL_RT128", 1);
+  static const int rt64 = rubl_env("EBEN_RUBL_RT64", 1), bkt128 = rubl_env("EBEN_RUBL_BKT128", 64), rt128 = rubl_env("EBEN_RUBL_RT128", 1);
   switch (channels / 32) {
     case 1: return launch_rubl_dw<1, 1, 64>(a, st);
     case 2: return rt64 == 2 ? launch_rubl_dw<2, 2, 64>(a, st) : launch_rubl_dw<2, 1, 64>(a, st);
