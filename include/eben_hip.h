@@ -375,6 +375,13 @@ EBEN_API int eben_hinge_fwd(const float* x, size_t n, float target, float* out, 
  * lambdas[i] = clamp(1 / (old[i] + 1e-4), 0, 1e4);  backprop[0] = sum_i *losses[i] * lambdas[i]   (torch's operation order and
  * roundings; norms / losses: n <= 8 device scalars), and the lambda-weighted sum of n tensors out = sum_i weights[i] * tensors[i]
  * (weights on the device) that seeds the generator backward. */
+/* The norms ||dL_i / d(last_conv.weight)|| of the dynamic loss balancing (vibravox/lightning_modules/eben.py:222-229) for n <= 4 losses in
+ * one pass, from the seeds s_i = dL_i / d(bands): dW_i = sum s_i (1 - bands^2) (*) reflect_pad(pre), bands = tanh(last_conv(pre) + lift)
+ * (eben_generator.py:159-166, 203-208; built for that layer: 32 -> 4, k 3, reflect padding 1).  seeds: HOST array of n device pointers to
+ * (batch, 4, length) tensors; norms: n floats on the device; workspace: eben_last_conv_norms_workspace(batch) bytes.  Fixed-order sums. */
+EBEN_API size_t eben_last_conv_norms_workspace(int batch);
+EBEN_API int eben_last_conv_norms(const void* const* seeds, int n, const float* bands, const float* pre, int batch, int c_in, int c_out, int length,
+                                  int ksize, int pad, float* workspace, size_t ws_bytes, float* norms, void* stream);
 EBEN_API int eben_balance(const void* const* norms, const void* const* losses, int n, float* old, int init, int ema, float beta,
                  float one_minus_beta, float* lambdas, float* backprop, void* stream);
 EBEN_API int eben_weighted_sum(const void* const* tensors, const float* weights, int n, size_t numel, float* out, void* stream);

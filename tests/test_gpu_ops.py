@@ -903,6 +903,38 @@ def test_grouped_gemm_on_split_bf16_operands(hip, g, m, k, n, mathmode, tol):
     assert lib.eben_gemm_fwd(0, g, m, k, n, ptr(xd), ptr(wp), ptr(y), stream()) != 0   # exact fp32 is not a mode of this kernel
 
 
+@pytest.mark.parametrize("batch,length,n", [(3, 1000, 3), (2, 8000, 3), (1, 257, 1), (2, 2047, 4), (4, 37, 2)])
+def test_last_conv_gradient_norms_in_one_pass(hip, batch, length, n):
+    """ops.last_conv_grad_norms (eben_last_conv_norms): the balancing norms ||dL_i / d last_conv.weight|| (eben.py:222-229) from the seeds
+    dL_i / d bands in one pass -- against autograd through tanh_lift + the HIP conv, and against float64: position ranges that end inside a
+    chunk, a clip shorter than one chunk, 1..4 losses."""
+    from vibravox_amd import ops
+    from vibravox_amd.torch_modules.utils import HipConv1d
+
+    dev = torch.device("cuda")
+    conv = HipConv1d(32, 4, 3, padding="same", bias=False, padding_mode="reflect", weight_norm=False).to(dev)
+    with torch.no_grad():
+        conv.weight.copy_(formula_tensor("lcn/w", (4, 32, 3), 0.2))
+    pre = formula_tensor(f"lcn/{batch}/{length}/pre", (batch, 32, length)).to(dev)
+    lift = formula_tensor(f"lcn/{batch}/{length}/lift", (batch, 2, length)).to(dev)
+    seeds = [formula_tensor(f"lcn/{batch}/{length}/s{i}", (batch, 4, length), 10.0 ** (i - 1)).to(dev) for i in range(n)]
+    bands = ops.tanh_lift(conv(pre), lift)
+    want = [torch.norm(torch.autograd.grad(bands, conv.weight, grad_outputs=s, retain_graph=True)[0]) for s in seeds]
+    got = ops.last_conv_grad_norms(seeds, bands, pre, conv)
+    assert got is not None and len(got) == n
+    # float64: dW = sum s (1 - bands^2) (*) reflect_pad(pre)
+    bd, pd = bands.detach().double().cpu(), torch.nn.functional.pad(pre.double().cpu(), (1, 1), mode="reflect")
+    for i in range(n):
+        g = seeds[i].double().cpu() * (1 - bd * bd)
+        dw = torch.stack([torch.einsum("bot,bct->oc", g, pd[:, :, j:j + length]) for j in range(3)], dim=2)
+        ref = float(dw.norm())
+        assert abs(float(got[i]) - ref) <= 2e-5 * ref, (i, float(got[i]), ref)
+        assert abs(float(want[i]) - ref) <= 1e-4 * ref
+    # a conv the kernel is not built for: the caller falls back to autograd
+    other = HipConv1d(32, 4, 5, padding="same", bias=False, padding_mode="reflect", weight_norm=False).to(dev)
+    assert ops.last_conv_grad_norms(seeds, bands, pre, other) is None
+
+
 @pytest.mark.parametrize("mode,first", [("ema", True), ("ema", False), ("simple", False)])
 def test_fused_balancing_matches_the_torch_arithmetic_bit_for_bit(hip, mode, first):
     """eben_balance + eben_weighted_sum == the one-element torch kernels of EBENLightningModule._update_lambdas and the weighted seed

@@ -166,6 +166,8 @@ SIGNATURES = {
     "eben_hinge_fwd_multi": (c_int, [POINTER(c_void_p), POINTER(c_int64), POINTER(c_float), c_int, _P, _P]),
     "eben_disc_losses": (c_int, [_P, c_int, c_float, _P, c_int, _P, _P]),
     "eben_stft_loss_total": (c_int, [POINTER(c_void_p), POINTER(c_float), c_int, c_int, _P, _P]),
+    "eben_last_conv_norms_workspace": (c_size_t, [c_int]),
+    "eben_last_conv_norms": (c_int, [POINTER(c_void_p), c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_size_t, _P, _P]),
     "eben_balance": (c_int, [POINTER(c_void_p), POINTER(c_void_p), c_int, _P, c_int, c_int, c_float, c_float, _P, _P, _P]),
     "eben_weighted_sum": (c_int, [POINTER(c_void_p), _P, c_int, c_size_t, _P, _P]),
     "eben_hinge_bwd": (c_int, [_P, c_size_t, c_float, _P, c_float, _P, _P]),

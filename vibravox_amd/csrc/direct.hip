@@ -713,6 +713,139 @@ __global__ __launch_bounds__(256) void weighted_sum_kernel(const WsumTable T, co
     out[j] = acc;
   }
 }
+// ---- the balancing norms in one pass (vibravox/lightning_modules/eben.py:222-229) ----------------------------------------------------------
+// dynamically_balance_losses differentiates every atomic loss down to `generator.last_conv.weight` and takes the norm of that gradient.
+// With the seeds s_i = dL_i / d(bands) at hand (the engine step), that is, for the plain k-tap reflect-padded last conv and the tanh
+// recomposition bands = tanh(last_conv(pre) + lift) (eben_generator.py:159-166, 203-208):
+//     dW_i[co][ci][j] = sum_{b,t} s_i[b,co,t] (1 - bands[b,co,t]^2) pre[b, ci, reflect(t + j - pad)],      norm_i = ||dW_i||_2 .
+// Through autograd this is, per loss, a tanh-backward launch, a weight-gradient launch (+ its slab sum) and torch.norm's kernels --
+// ~15 tiny dependent launches between the discriminators' input gradients and the generator backward; here the n losses share ONE pass
+// over `pre`: partial sums per (item, position range) in fixed order, then one block that finishes the sums and the norms.
+constexpr int LCN_T = 256;        // positions per staged chunk
+constexpr int LCN_MAXN = 4;       // losses per call
+constexpr int LCN_SPLIT = 8;      // position ranges per item
+struct LcnArgs {
+  const float* seeds[LCN_MAXN]; const float* bands; const float* pre; float* partial;
+  int n, B, Cin, Cout, L, k, pad, per;   // per: positions per block (a multiple of LCN_T)
+};
+template <int CIN, int COUT, int K>
+__global__ __launch_bounds__(256) void lcn_partial_kernel(const LcnArgs P) {
+  constexpr int COLS = CIN * K, XS = LCN_T + K - 1;
+  static_assert(COLS <= 128, "one column per thread of a half block");
+  extern __shared__ float lcn_smem[];
+  float* xs = lcn_smem;                         // [CIN][XS]: pre at positions t0 - pad .. (reflected)
+  float* gs = lcn_smem + CIN * XS;              // [n COUT][LCN_T]: s_i (1 - bands^2)
+  const int b = blockIdx.y, sp = blockIdx.x;
+  const int tid = threadIdx.x, col = tid & 127, th = tid >> 7;
+  const int ci = col / K, j = col - ci * K;
+  const int R = P.n * COUT;
+  float acc[LCN_MAXN * COUT];
+#pragma unroll
+  for (int r = 0; r < LCN_MAXN * COUT; ++r) acc[r] = 0.f;
+  const int lo = sp * P.per, hi = lo + P.per < P.L ? lo + P.per : P.L;
+  for (int t0 = lo; t0 < hi; t0 += LCN_T) {
+    __syncthreads();
+    for (int i = tid; i < CIN * XS; i += 256) {
+      const int c = i / XS, r = i - c * XS;
+      int q = t0 - P.pad + r;
+      q = q < 0 ? -q : q;
+      q = q >= P.L ? 2 * (P.L - 1) - q : q;
+      xs[i] = (q >= 0 && q < P.L) ? P.pre[((long long)b * CIN + c) * P.L + q] : 0.f;
+    }
+    for (int i = tid; i < R * LCN_T; i += 256) {
+      const int r = i / LCN_T, t = t0 + (i - r * LCN_T);
+      const int si = r / COUT, co = r - si * COUT;
+      float g = 0.f;
+      if (t < hi) {
+        const long long o = ((long long)b * COUT + co) * P.L + t;
+        const float y = P.bands[o];
+        g = P.seeds[si][o] * (1.f - y * y);
+      }
+      gs[i] = g;
+    }
+    __syncthreads();
+    if (col < COLS) {
+      const float* xr = xs + ci * XS + j;
+#pragma unroll 4
+      for (int t = th * (LCN_T / 2); t < (th + 1) * (LCN_T / 2); ++t) {
+        const float xv = xr[t];
+#pragma unroll
+        for (int r = 0; r < LCN_MAXN * COUT; ++r)
+          if (r < R) acc[r] = fmaf(gs[r * LCN_T + t], xv, acc[r]);
+      }
+    }
+  }
+  // the two time halves meet in LDS in a fixed order; slab [block][row][column]
+  __syncthreads();
+  float* red = lcn_smem;                        // [R][COLS] of the second half
+  if (th == 1 && col < COLS)
+    for (int r = 0; r < R; ++r) red[r * COLS + col] = acc[r];
+  __syncthreads();
+  if (th == 0 && col < COLS) {
+    float* out = P.partial + ((long long)b * gridDim.x + sp) * (LCN_MAXN * COUT * COLS);
+    for (int r = 0; r < R; ++r) out[r * COLS + col] = acc[r] + red[r * COLS + col];
+  }
+}
+// sums the slabs in a fixed order: block = 64 gradient entries x 4 slab residues (a thread's 64-odd loads are independent and unrolled:
+// one block of 1024 threads walking all the slabs alone took ~250 us of dependent round trips), then the squares of the block's entries
+__global__ __launch_bounds__(256) void lcn_sum_kernel(const float* __restrict__ partial, int nslab, int total, int slab_stride, float* __restrict__ dw) {
+  __shared__ float red[4][64];
+  const int tid = threadIdx.x, l = tid & 63, zp = tid >> 6;
+  const int idx = blockIdx.x * 64 + l;
+  float s = 0.f;
+  if (idx < total) {
+    int z = zp;
+    for (; z + 28 < nslab; z += 32) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = partial[(long long)(z + 4 * u) * slab_stride + idx];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; z < nslab; z += 4) s += partial[(long long)z * slab_stride + idx];
+  }
+  red[zp][l] = s;
+  __syncthreads();
+  if (zp == 0 && idx < total) dw[idx] = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
+}
+// norm_i = sqrt(sum of squares of the per_loss entries of dW_i), one wave per loss
+__global__ __launch_bounds__(256) void lcn_norm_kernel(const float* __restrict__ dw, int n, int per_loss, float* __restrict__ norms) {
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  if (w >= n) return;
+  float s = 0.f;
+  for (int i = l; i < per_loss; i += 64) { const float v = dw[w * per_loss + i]; s = fmaf(v, v, s); }
+  s = wave_sum(s);
+  if (l == 0) norms[w] = sqrtf(s);
+}
+
+extern "C" size_t eben_last_conv_norms_workspace(int batch) {
+  return batch > 0 ? sizeof(float) * ((size_t)batch * LCN_SPLIT + 1) * LCN_MAXN * 4 * 96 : 0;   // the slabs + the summed gradients
+}
+
+extern "C" int eben_last_conv_norms(const void* const* seeds, int n, const float* bands, const float* pre, int batch, int c_in, int c_out, int length,
+                                    int ksize, int pad, float* workspace, size_t ws_bytes, float* norms, void* stream) {
+  EBEN_REQUIRE(seeds && bands && pre && workspace && norms && n >= 1 && n <= LCN_MAXN && batch > 0 && length > 0, "bad arguments to eben_last_conv_norms");
+  if (c_in != 32 || c_out != 4 || ksize != 3 || pad != 1 || length < 2)
+    return fail(EBEN_EUNSUPPORTED, "eben_last_conv_norms: built for EBEN's last conv (32 -> 4, k 3, reflect padding 1), got %d -> %d k %d pad %d", c_in, c_out, ksize, pad);
+  EBEN_REQUIRE(ws_bytes >= eben_last_conv_norms_workspace(batch), "eben_last_conv_norms: workspace too small");
+  LcnArgs a;
+  for (int i = 0; i < LCN_MAXN; ++i) a.seeds[i] = i < n ? static_cast<const float*>(seeds[i]) : nullptr;
+  for (int i = 0; i < n; ++i) EBEN_REQUIRE(a.seeds[i] != nullptr, "null seed %d", i);
+  a.bands = bands; a.pre = pre; a.partial = workspace;
+  a.n = n; a.B = batch; a.Cin = c_in; a.Cout = c_out; a.L = length; a.k = ksize; a.pad = pad;
+  a.per = round_up(ceil_div(length, LCN_SPLIT), LCN_T);
+  const int nsp = ceil_div(length, a.per);
+  const size_t lds = sizeof(float) * ((size_t)32 * (LCN_T + 2) + (size_t)LCN_MAXN * 4 * LCN_T);
+  hipStream_t st = as_stream(stream);
+  hipLaunchKernelGGL((lcn_partial_kernel<32, 4, 3>), dim3(nsp, batch), dim3(256), lds, st, a);
+  EBEN_CHECK_LAUNCH("lcn_partial_kernel");
+  float* dw = workspace + (size_t)batch * LCN_SPLIT * LCN_MAXN * 4 * 96;
+  hipLaunchKernelGGL(lcn_sum_kernel, dim3(ceil_div(n * 4 * 96, 64)), dim3(256), 0, st, workspace, nsp * batch, n * 4 * 96, LCN_MAXN * 4 * 96, dw);
+  hipLaunchKernelGGL(lcn_norm_kernel, dim3(1), dim3(256), 0, st, dw, n, 4 * 96, norms);
+  EBEN_CHECK_LAUNCH("lcn_norm_kernel");
+  return EBEN_OK;
+}
+
 extern "C" int eben_balance(const void* const* norms, const void* const* losses, int n, float* old, int init, int ema, float beta,
                             float one_minus_beta, float* lambdas, float* backprop, void* stream) {
   EBEN_REQUIRE(norms && losses && old && lambdas && backprop && n > 0 && n <= BAL_MAX, "balance: 1..%d losses", BAL_MAX);

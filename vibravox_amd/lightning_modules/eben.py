@@ -287,8 +287,13 @@ class EBENLightningModule(BaseSELightningModule):
                 seeds.append(adv_b + torch.autograd.grad(enhanced_speech, bands, grad_outputs=adv_a, retain_graph=True)[0])
             else:
                 seeds.append(own[key])
-        with ops.input_grads_disabled():   # only last_conv's weight gradient is wanted: its input gradient would be computed and dropped
-            atomic_norms = [torch.norm(torch.autograd.grad(bands, leaf, grad_outputs=s, retain_graph=True)[0]).detach() for s in seeds]
+        atomic_norms = None
+        pre = getattr(self.generator, "_last_pre", None)
+        if self.fused_norms and pre is not None and pre.shape[0] == bands.shape[0] and pre.shape[2] == bands.shape[2]:
+            atomic_norms = ops.last_conv_grad_norms(seeds, bands, pre, self.generator.last_conv)   # one pass for the three losses
+        if atomic_norms is None:
+            with ops.input_grads_disabled():   # only last_conv's weight gradient is wanted: its input gradient would be computed and dropped
+                atomic_norms = [torch.norm(torch.autograd.grad(bands, leaf, grad_outputs=s, retain_graph=True)[0]).detach() for s in seeds]
         if self.fused_balancing and len(seeds) <= 8 and atomic_norms[0].is_cuda:
             lambdas, backprop_loss_generator = self._update_lambdas_fused(atomic_norms, [loss.detach() for loss in losses.values()])
             seed = ops.weighted_sum(seeds, self._bal["lam"])
@@ -508,6 +513,10 @@ class EBENLightningModule(BaseSELightningModule):
     #: the engine step's balancing arithmetic (EMA, lambdas, backprop loss, weighted seed) as two launches (`eben_balance`,
     #: `eben_weighted_sum`) instead of ~35 one-element torch kernels in front of the generator backward; same values bit for bit
     fused_balancing: bool = os.environ.get("EBEN_FUSED_BALANCING", "1") != "0"
+
+    #: the balancing norms ||dL_i / d last_conv.weight|| of the engine step from the seeds in one pass (`eben_last_conv_norms`) instead of
+    #: a tanh-backward + weight-gradient + norm chain per loss through autograd; same values up to the order of the fp32 sums
+    fused_norms: bool = os.environ.get("EBEN_FUSED_NORMS", "1") != "0"
 
     def _update_lambdas_fused(self, atomic_norms, losses):
         """``_update_lambdas`` + the backprop loss on the device in one launch; the state stays readable as ``atomic_norms_old``."""

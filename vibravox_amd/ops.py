@@ -1068,6 +1068,27 @@ class _FeatureLossFn(torch.autograd.Function):
         return (None, None, *da, *([None] * n))
 
 
+def last_conv_grad_norms(seeds: Sequence[torch.Tensor], bands: torch.Tensor, pre: torch.Tensor, conv) -> Optional[List[torch.Tensor]]:
+    """||d L_i / d conv.weight|| for the seeds s_i = d L_i / d bands of the balancing losses in one pass over ``pre`` (``eben_last_conv_norms``:
+    bands = tanh(conv(pre) + lift), eben.py:222-229 / eben_generator.py:159-166, 203-208); None when ``conv`` is not the layer that kernel is
+    built for (then the caller differentiates through autograd).  Returns 0-dim views of one device vector."""
+    sp = getattr(conv, "spec", None)
+    if (sp is None or getattr(conv, "weight_norm", True) or conv.bias is not None or not (1 <= len(seeds) <= 4)
+            or (sp.c_in, sp.c_out, sp.ksize, sp.stride, sp.dilation, sp.groups, sp.pad_l, sp.pad_r) != (32, 4, 3, 1, 1, 1, 1, 1) or not sp.reflect
+            or sp.in_slope != 1.0 or sp.out_slope != 1.0 or pre.dtype is not torch.float32 or not pre.is_cuda):
+        return None
+    b, _, l = pre.shape
+    lib = load()
+    ts = [t.contiguous() for t in seeds]
+    bands_c, pre_c = bands.detach().contiguous(), pre.detach().contiguous()
+    nbytes = lib.eben_last_conv_norms_workspace(b)
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=pre.device)
+    out = torch.empty(len(ts), dtype=torch.float32, device=pre.device)
+    check(lib.eben_last_conv_norms(_ptr_array(ts), len(ts), ptr(bands_c), ptr(pre_c), b, sp.c_in, sp.c_out, l, sp.ksize, sp.pad_l, ptr(ws), nbytes, ptr(out),
+                                   stream()), "last_conv_norms")
+    return [out[i] for i in range(len(ts))]
+
+
 def weighted_sum(tensors: Sequence[torch.Tensor], weights: torch.Tensor) -> torch.Tensor:
     """sum_i weights[i] * tensors[i] (weights: device vector), torch's order and roundings, one launch (``eben_weighted_sum``)."""
     ts = [t.contiguous() for t in tensors]

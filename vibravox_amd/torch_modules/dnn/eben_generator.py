@@ -123,6 +123,9 @@ class EBENGenerator(nn.Module, PyTorchModelHubMixin):
             from ... import gen_engine
 
             x, first_bands = gen_engine.core(self, cut_audio)
+            # the input of last_conv of the latest forward: the train step's balancing takes the three loss-gradient norms at
+            # last_conv.weight in one pass over it (ops.last_conv_grad_norms) instead of three autograd passes
+            object.__setattr__(self, "_last_pre", x.detach() if torch.is_grad_enabled() else None)
             x = self.last_conv(x)
             enhanced_speech_decomposed = ops.tanh_lift(x, first_bands)
             return self.pqmf.synthesis_sum(enhanced_speech_decomposed), enhanced_speech_decomposed
