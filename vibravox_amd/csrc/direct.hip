@@ -723,7 +723,7 @@ __global__ __launch_bounds__(256) void weighted_sum_kernel(const WsumTable T, co
 // over `pre`: partial sums per (item, position range) in fixed order, then one block that finishes the sums and the norms.
 constexpr int LCN_T = 256;        // positions per staged chunk
 constexpr int LCN_MAXN = 4;       // losses per call
-constexpr int LCN_SPLIT = 8;      // position ranges per item
+constexpr int LCN_SPLIT = 64;     // position ranges per item, at most (one staged chunk per block: the staging loads are what a block waits for)
 struct LcnArgs {
   const float* seeds[LCN_MAXN]; const float* bands; const float* pre; float* partial;
   int n, B, Cin, Cout, L, k, pad, per;   // per: positions per block (a multiple of LCN_T)
@@ -745,33 +745,56 @@ __global__ __launch_bounds__(256) void lcn_partial_kernel(const LcnArgs P) {
   const int lo = sp * P.per, hi = lo + P.per < P.L ? lo + P.per : P.L;
   for (int t0 = lo; t0 < hi; t0 += LCN_T) {
     __syncthreads();
-    for (int i = tid; i < CIN * XS; i += 256) {
-      const int c = i / XS, r = i - c * XS;
-      int q = t0 - P.pad + r;
-      q = q < 0 ? -q : q;
-      q = q >= P.L ? 2 * (P.L - 1) - q : q;
-      xs[i] = (q >= 0 && q < P.L) ? P.pre[((long long)b * CIN + c) * P.L + q] : 0.f;
-    }
-    for (int i = tid; i < R * LCN_T; i += 256) {
-      const int r = i / LCN_T, t = t0 + (i - r * LCN_T);
-      const int si = r / COUT, co = r - si * COUT;
-      float g = 0.f;
-      if (t < hi) {
-        const long long o = ((long long)b * COUT + co) * P.L + t;
-        const float y = P.bands[o];
-        g = P.seeds[si][o] * (1.f - y * y);
+    // loads in batches of eight with clamped addresses (a load inside its bounds check is issued and waited for one at a time)
+    for (int i0 = tid; i0 < CIN * XS; i0 += 8 * 256) {
+      float v[8];
+      bool ok[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + 256 * u;
+        const int ic = i < CIN * XS ? i : 0;
+        const int c = ic / XS, r = ic - c * XS;
+        int q = t0 - P.pad + r;
+        q = q < 0 ? -q : q;
+        q = q >= P.L ? 2 * (P.L - 1) - q : q;
+        ok[u] = i < CIN * XS && q >= 0 && q < P.L;
+        v[u] = P.pre[((long long)b * CIN + c) * P.L + (ok[u] ? q : 0)];
       }
-      gs[i] = g;
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (i0 + 256 * u < CIN * XS) xs[i0 + 256 * u] = ok[u] ? v[u] : 0.f;
+    }
+    for (int i0 = tid; i0 < R * LCN_T; i0 += 4 * 256) {
+      float sv[4], yv[4];
+      bool ok[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + 256 * u;
+        const int ic = i < R * LCN_T ? i : 0;
+        const int r = ic / LCN_T, t = t0 + (ic - r * LCN_T);
+        const int si = r / COUT, co = r - si * COUT;
+        ok[u] = i < R * LCN_T && t < hi;
+        const long long o = ((long long)b * COUT + co) * P.L + (ok[u] ? t : lo);
+        yv[u] = P.bands[o];
+        sv[u] = P.seeds[si][o];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (i0 + 256 * u < R * LCN_T) gs[i0 + 256 * u] = ok[u] ? sv[u] * (1.f - yv[u] * yv[u]) : 0.f;
     }
     __syncthreads();
     if (col < COLS) {
       const float* xr = xs + ci * XS + j;
-#pragma unroll 4
-      for (int t = th * (LCN_T / 2); t < (th + 1) * (LCN_T / 2); ++t) {
-        const float xv = xr[t];
+      // four positions per step: the gradient rows are read as float4 (wave-uniform addresses: LDS broadcasts), 16 LDS reads per 48 FMAs
+#pragma unroll 2
+      for (int t = th * (LCN_T / 2); t < (th + 1) * (LCN_T / 2); t += 4) {
+        const float x0 = xr[t], x1 = xr[t + 1], x2 = xr[t + 2], x3 = xr[t + 3];
 #pragma unroll
         for (int r = 0; r < LCN_MAXN * COUT; ++r)
-          if (r < R) acc[r] = fmaf(gs[r * LCN_T + t], xv, acc[r]);
+          if (r < R) {
+            const f32x4 g4 = *reinterpret_cast<const f32x4*>(gs + r * LCN_T + t);
+            acc[r] = fmaf(g4[3], x3, fmaf(g4[2], x2, fmaf(g4[1], x1, fmaf(g4[0], x0, acc[r]))));
+          }
       }
     }
   }
@@ -833,7 +856,7 @@ extern "C" int eben_last_conv_norms(const void* const* seeds, int n, const float
   for (int i = 0; i < n; ++i) EBEN_REQUIRE(a.seeds[i] != nullptr, "null seed %d", i);
   a.bands = bands; a.pre = pre; a.partial = workspace;
   a.n = n; a.B = batch; a.Cin = c_in; a.Cout = c_out; a.L = length; a.k = ksize; a.pad = pad;
-  a.per = round_up(ceil_div(length, LCN_SPLIT), LCN_T);
+  a.per = round_up(ceil_div(length, LCN_SPLIT), LCN_T);   // >= one chunk; 8000 positions: 32 blocks of one chunk per item
   const int nsp = ceil_div(length, a.per);
   const size_t lds = sizeof(float) * ((size_t)32 * (LCN_T + 2) + (size_t)LCN_MAXN * 4 * LCN_T);
   hipStream_t st = as_stream(stream);
