@@ -516,6 +516,37 @@ def test_bucketed_grad_sync_path_on_gpu_matches_plain_step(hip, golden):
             assert torch.allclose(a, b, rtol=0, atol=1e-6), k
         for (k, a), (_, b) in zip(plain.discriminator.state_dict().items(), synced.discriminator.state_dict().items()):
             assert torch.allclose(a, b, rtol=0, atol=1e-6), k
+        del plain, synced, gs, ds
+
+        # the benchmarked plan (bf16 bundle layout, MRSTFT, every launch sequence replayed as a graph -- on by default next to a process
+        # group): the rank of a data-parallel job as bench.py builds it, against the plain step of the same plan, long enough for the
+        # sequences to be captured; the gradients land in the bucket views the graphs were captured on
+        from vibravox_amd import ops
+
+        def run(with_group):
+            mod, _, _ = make_module(golden, use_mrstft=True)
+            mod.set_precision("bf16-mixed")
+            syncs = None
+            if with_group:
+                g_opt, d_opt = mod.optimizers()
+                syncs = (GradSync(mod.generator.parameters()), GradSync(mod.discriminator.parameters()))
+                g_w, d_w = BucketedZeroGrad(g_opt, syncs[0]), BucketedZeroGrad(d_opt, syncs[1])
+                mod._optimizers = [g_w, d_w]
+                mod.grad_sync = {id(g_w): syncs[0], id(d_w): syncs[1]}
+            for i in range(6):
+                mod.training_step({"audio_body_conducted": formula_audio(f"ddp/{i}/bc", 2, 8200).to(DEV), "audio_airborne": formula_audio(f"ddp/{i}/air", 2, 8200).to(DEV)})
+            torch.cuda.synchronize()
+            out = {f"G.{k}": v.clone() for k, v in mod.generator.state_dict().items()}
+            out.update({f"D.{k}": v.clone() for k, v in mod.discriminator.state_dict().items()})
+            return out, ops.graphs_captured(), syncs
+
+        assert ops.DDP_GRAPHS
+        a, _, _ = run(False)
+        b, n_graphs, syncs = run(True)
+        assert n_graphs >= 22, n_graphs
+        assert all(sy.launched >= 6 * len(sy.buckets) for sy in syncs)
+        worst = max(float((a[k] - b[k]).abs().max()) for k in a)
+        assert worst <= 1e-6, worst
     finally:
         dist.destroy_process_group()
 
