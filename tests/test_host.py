@@ -316,3 +316,21 @@ def test_trainer_precision_selects_the_arithmetic_plan():
     with pytest.raises(ValueError):
         module.set_precision("fp8")
     assert all(p[0] in DISC_MATH_PLANS for p in EBENLightningModule.PRECISION_PLANS.values())
+
+
+def test_bundle_layout_engine_falls_back_for_heads_it_has_no_kernel_for():
+    """DiscriminatorEBENMultiScales at the reference's class default q = 3 (eben_discriminator.py:18: heads 3 -> 24) under the benchmarked
+    plan: the bundle-layout engine's chain-edge kernels are built for the configured heads, so the engine of the same arithmetic plan on
+    fp32 tensors at rest is constructed instead (with a warning) -- not an EBEN_EUNSUPPORTED on the first training forward."""
+    from vibravox_amd.disc_engine import DiscriminatorEngine
+    from vibravox_amd.disc_engine_bl import DiscriminatorEngineBL
+    from vibravox_amd.lightning_modules.eben import DISC_MATH_PLANS
+    from vibravox_amd.torch_modules.dnn.eben_discriminator import DiscriminatorEBENMultiScales
+
+    plan = DISC_MATH_PLANS["bf16_bl"]
+    d4, d3 = DiscriminatorEBENMultiScales(q=4, min_channels=24), DiscriminatorEBENMultiScales(q=3, min_channels=24)
+    assert DiscriminatorEngineBL.unsupported(d4) is None and type(DiscriminatorEngine(d4, plan)) is DiscriminatorEngineBL
+    assert "3 -> 24" in DiscriminatorEngineBL.unsupported(d3)
+    with pytest.warns(UserWarning, match="fp32 tensors at rest"):
+        eng = DiscriminatorEngine(d3, plan)
+    assert type(eng) is DiscriminatorEngine and eng.math is plan   # the step does not rebuild it every call

@@ -370,7 +370,14 @@ class DiscriminatorEngine:
         if cls is DiscriminatorEngine and isinstance(math, dict) and math.get("layout") == "bl":
             from .disc_engine_bl import DiscriminatorEngineBL   # embeddings / gradients at rest as bf16 bundles
 
-            return super().__new__(DiscriminatorEngineBL)
+            why = DiscriminatorEngineBL.unsupported(disc)
+            if why is None:
+                return super().__new__(DiscriminatorEngineBL)
+            # e.g. DiscriminatorEBENMultiScales at the reference's class default q = 3 (heads 3 -> 24): the chain-edge kernels are built for
+            # the configured shapes (csrc/bl_edge.hip bl_head_shape).  The same arithmetic plan on fp32 tensors at rest covers every shape.
+            import warnings
+
+            warnings.warn(f"bundle-layout discriminator engine: {why}; running the same plan on fp32 tensors at rest ('bf16')")
         return super().__new__(cls)
 
     def __init__(self, disc, math=ops.MATH_F32):

@@ -284,6 +284,23 @@ class _ChainBL:
 class DiscriminatorEngineBL(DiscriminatorEngine):
     """``DiscriminatorEngine`` over bundle-layout tensors (selected by ``math = {..., "layout": "bl"}``)."""
 
+    @staticmethod
+    def unsupported(disc) -> Optional[str]:
+        """Why this discriminator cannot run in the bundle layout (None: it can): the chain heads / logits layers have dedicated kernels
+        built for EBEN's configured shapes (4 -> 24 k 3 and 1 -> 16 k 15 heads, C -> 1 k <= 8 logits layers)."""
+        for m in list(disc.pqmf_discriminators) + [disc.melgan_discriminator]:
+            convs = [sub for part in m.discriminator for sub in (part if isinstance(part, torch.nn.Sequential) else [part]) if hasattr(sub, "spec")]
+            if len(convs) < 3:
+                return "a sub-discriminator with fewer than three conv layers"
+            head, tail = convs[0].spec, convs[-1].spec
+            if (head.c_in, head.c_out, head.ksize) not in ((4, 24, 3), (1, 16, 15)) or head.groups != head.c_in or head.stride != 1:
+                return f"no head kernel for {head.c_in} -> {head.c_out}, k {head.ksize}"
+            if not (tail.c_out == 1 and tail.groups == 1 and tail.stride == 1 and tail.dilation == 1 and tail.ksize <= 8 and tail.c_in % 8 == 0):
+                return f"no logits kernel for {tail.c_in} -> {tail.c_out}, k {tail.ksize}"
+            if any(c.spec.c_in % 8 or c.spec.c_out % 8 for c in convs[1:-1]):
+                return "mid-layer channels that are not whole bundles of 8"
+        return None
+
     def __init__(self, disc, math):
         self.disc = disc
         self.q = disc.q
