@@ -56,12 +56,12 @@ def build_module(device, batch_seed):
 
 
 def pmc_family(math):
-    """Roofline records with HBM traffic from this round's rocprofv3 PMC passes (tools/pmc_family_bl.sh -> profiles/r03_pmc_family.json:
+    """Roofline records with HBM traffic from this round's rocprofv3 PMC passes (tools/pmc_family_bl.sh -> profiles/rNN_pmc_family.json, the latest round's:
     FETCH_SIZE / WRITE_SIZE / TCC hit + miss in separate passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950): the
     roofline kernel (MelGAN L4 forward), its weight gradient and one PQMF-band mid layer, each launched alone at the step's row
     counts.  Empty for the plans the passes were not taken in."""
-    path = os.path.join(ROOT, "profiles", "r03_pmc_family.json")
-    if math != "bf16_bl" or not os.path.exists(path):
+    path = next((q for q in (os.path.join(ROOT, "profiles", f"r{n:02d}_pmc_family.json") for n in range(9, 2, -1)) if os.path.exists(q)), None)
+    if math != "bf16_bl" or path is None:
         return []
     with open(path) as f:
         return json.load(f)

@@ -1,0 +1,20 @@
+# Round-4 measurement set (bench default = bundle-layout plan): bench line (CPU baseline first, fp32 legs), rocprofv3 --kernel-trace --stats of the
+# same command, overlap timeline, per-layer mixed-roofline table, phase times, ResidualUnit table, PQMF kernels, generator timelines, host
+# enqueue times, the single-rank RCCL line, BASELINE config 4, counter traffic.  Usage: bash tools/measure_round_r04.sh <tag> <commit>
+R=${GRAFT_REPO_ROOT:-/root/repo}; T=${1:-r04}; C=${2:-unknown}; O=$R/gpurun_out; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
+python $R/bench.py > $O/${T}_bench.json 2> $O/${T}_bench.err; tail -2 $O/${T}_bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/${T}_s -o p -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-f32-leg > $O/${T}_stats_bench.json 2> $O/${T}_stats.err
+cp "$(find $O/${T}_s -name '*kernel_stats.csv' | head -1)" $O/${T}_rocprofv3_kernel_stats.csv; rm -rf $O/${T}_s
+bash $R/tools/timeline_bl.sh bf16_bl $T
+python $R/tools/layer_bench_bl.py --iters 20 > $O/${T}_layers_bl.txt 2>&1
+EBEN_DISC_MATH=bf16_bl python $R/tools/phase_times.py > $O/${T}_phases.txt 2>&1
+python $R/tools/ru_bench.py > $O/${T}_ru_bench.txt 2>&1
+python $R/tools/pqmf_bench.py > $O/${T}_pqmf.txt 2>&1
+python $R/tools/gen_fwd_timeline.py > $O/${T}_gen_fwd_timeline.txt 2>&1
+python $R/tools/gen_bwd_timeline.py > $O/${T}_gen_bwd_timeline.txt 2>&1
+python $R/tools/host_times.py > $O/${T}_host_times.txt 2>&1
+python $R/bench.py --force-ddp --no-cpu-baseline --no-f32-leg > $O/${T}_force_ddp.json 2> $O/${T}_force_ddp.err
+python $R/bench.py --workload noisybwe --no-cpu-baseline --no-f32-leg > $O/${T}_noisybwe.json 2> $O/${T}_noisybwe.err
+bash $R/tools/pmc_family_bl.sh $T $C
+python $R/tools/hbm_kernels.py $O/${T}_rocprofv3_kernel_stats.csv > $O/${T}_hbm_kernels.txt 2>&1
+ls $O | grep ${T}_
