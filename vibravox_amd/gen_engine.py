@@ -735,7 +735,11 @@ class GeneratorEngine:
             if sink is None:
                 ops._side["assign"].extend((p, t) for p, t in assign if p.requires_grad)
             else:
-                ops._side["sunk"].extend(p for p, _ in assign)   # join() reports them to the sink once the side stream is joined
+                # data-parallel: this group's gradients sit in their bucket views once the side stream has run the launches above -- report
+                # them from THAT stream now (GradSync.mark_ready records its event on the current stream), so that a bucket filled by
+                # an early group is exchanged underneath the later groups' input-gradient chain instead of behind join()
+                with torch.cuda.stream(side):
+                    sink.mark_ready([p for p, _ in assign])
 
 
 class _CoreFn(torch.autograd.Function):
