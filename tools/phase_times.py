@@ -10,6 +10,8 @@ mod.stft_math = "folded" if mod.disc_math == "f32" else "folded_x3"
 if os.environ.get("NO_RECON", "0") == "1":   # the discriminator phases alone: how long the chains take with nothing beside them
     mod.reconstructive_loss_freq_fn = None
     mod.reconstructive_loss_temp_fn = None
+if os.environ.get("NO_D_UPDATE", "0") == "1":   # no discriminator weight gradients / Adam: what the generator backward costs with the GPU to itself
+    mod.update_discriminator_ratio = 0
 batch = bench.synthetic_batch(32, 32000, 1234, dev)
 for _ in range(8):
     mod.training_step(batch)
