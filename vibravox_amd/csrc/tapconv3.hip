@@ -68,7 +68,12 @@ __device__ unsigned long long t3_stamp[T3_STAMP_ROWS * 16];
 // k-steps (of 16 reduction elements) per weight chunk; split weights (NPW pieces per weight, EBEN_MATH_BF16X3 / X6): a k-step carries
 // NPW times the weight bytes and 3 / 6 times the MFMAs
 __host__ __device__ constexpr int t3_ksc(int npw, int fm = 4) { return npw == 1 ? (fm <= 2 ? EBEN_T3_KSC : EBEN_T3_KSC_BIGFM) : 2; }
-__host__ __device__ constexpr int t3_ring(int npw, int fm) { return t3_ksc(npw, fm) * npw * fm <= 8 ? EBEN_T3_RING_SMALL : EBEN_T3_RING_BIG; }
+#ifndef EBEN_T3_RING_SPLIT
+#define EBEN_T3_RING_SPLIT 2   // slots of the split-weight (fp32 tensors at rest, NPW >= 2) launches: the generator's six-product convs
+#endif
+__host__ __device__ constexpr int t3_ring(int npw, int fm, bool bl = false) {
+  return (!bl && npw >= 2) ? EBEN_T3_RING_SPLIT : t3_ksc(npw, fm) * npw * fm <= 8 ? EBEN_T3_RING_SMALL : EBEN_T3_RING_BIG;
+}
 // 16 zero bytes in device memory: where the lanes of an input-tile LDS-DMA piece that fall into the zero padding read from
 __device__ u32x4 t3_zero_unit = {0u, 0u, 0u, 0u};
 
@@ -126,7 +131,7 @@ __global__ __launch_bounds__(256, NPW >= 2 ? 1 : 2) void tap3_kernel(const Tap3A
   constexpr bool SP = NPX > 1;
   constexpr int NPM = NPW > NPX ? NPW : NPX;
   constexpr int WCHU = KSC * NPW * FM * 64;       // 16-byte units per weight chunk
-  constexpr int RING = t3_ring(NPW, FM), DIST = RING - 1;
+  constexpr int RING = t3_ring(NPW, FM, BL), DIST = RING - 1;
   constexpr int WU = (WCHU + NT - 1) / NT;        // LDS-DMA instructions per thread and chunk
   static_assert(WCHU % 64 == 0, "weight chunk must split into whole wave pieces");
   static_assert(DIST >= 1 && DIST <= 3, "ring depth");
@@ -880,7 +885,7 @@ static void make_plan3(const Canon& c, int dir, Tap3Plan* p) {
   static const int lds_budget1 = env_int3("EBEN_TAP3_LDS_KB", 48) * 1024;
   static const int lds_budget_split = env_int3("EBEN_TAP3_SPLIT_LDS_KB", 150) * 1024;   // split weights: one MFMA-bound block per CU
   static const int lds_budget_x3 = env_int3("EBEN_TAP3_X3_LDS_KB", 64) * 1024;
-  const int wbytes = t3_ring(p->npw, p->FM) * p->WCHU * 16;
+  const int wbytes = t3_ring(p->npw, p->FM, c.bl != 0) * p->WCHU * 16;
   const int Cg2 = round_up(p->Cg, 16);
   // input tiles inside `lds_budget` bytes per block (weights included); a three-buffer scheme may go up to `big`
   auto size_tiles = [&](int lds_budget, int big) -> bool {
