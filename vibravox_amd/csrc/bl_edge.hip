@@ -461,7 +461,20 @@ __global__ __launch_bounds__(256) void bl_fm_partial_kernel(const BlFmTable T, f
   const long long b0 = (long long)blockIdx.x * per;
   const long long b1 = b0 + per < n ? b0 + per : n;
   float s1 = 0.f, s2 = 0.f;
-  for (long long i = b0 + threadIdx.x; i < b1; i += 256) {
+  // two units per iteration, the eight 16-byte loads issued before the first use (four per iteration reached 4.2 TB/s of the 1.6 GB)
+  long long i = b0 + threadIdx.x;
+  for (; i + 256 < b1; i += 512) {
+    const u32x4 ah0 = hi[i], al0 = lo[i], rh0 = hi[i + n], rl0 = lo[i + n];
+    const u32x4 ah1 = hi[i + 256], al1 = lo[i + 256], rh1 = hi[i + 256 + n], rl1 = lo[i + 256 + n];
+    float a[8], l[8], r[8], q[8];
+    bl_unpack8(ah0, a); bl_unpack8(al0, l); bl_unpack8(rh0, r); bl_unpack8(rl0, q);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const float av = a[e] + l[e], rv = r[e] + q[e]; s1 += fabsf(av - rv); s2 += fabsf(av); }
+    bl_unpack8(ah1, a); bl_unpack8(al1, l); bl_unpack8(rh1, r); bl_unpack8(rl1, q);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const float av = a[e] + l[e], rv = r[e] + q[e]; s1 += fabsf(av - rv); s2 += fabsf(av); }
+  }
+  for (; i < b1; i += 256) {
     float a[8], r[8];
     bl_load8(hi, lo, i, a);
     bl_load8(hi, lo, i + n, r);
