@@ -52,6 +52,14 @@ class Planes:
         self.hi = torch.empty((rows, channels // 8, length, 8), dtype=torch.bfloat16, device=device)
         self.lo = torch.empty_like(self.hi) if lo else None
 
+    def rows_slice(self, r0: int, r1: int) -> "Planes":
+        """Rows [r0, r1) of the same storage (the leading dimension: still contiguous)."""
+        v = Planes.__new__(Planes)
+        v.rows, v.channels, v.length = r1 - r0, self.channels, self.length
+        v.hi = self.hi[r0:r1]
+        v.lo = None if self.lo is None else self.lo[r0:r1]
+        return v
+
     def to_f32(self) -> torch.Tensor:
         """(rows, channels, length) fp32 = hi + lo (tests / tools)."""
         out = torch.empty((self.rows, self.channels, self.length), dtype=torch.float32, device=self.hi.device)
@@ -113,7 +121,18 @@ class _ChainBL:
         return l_in + 2 * self.pad + 2 * sp.pad_l - sp.dilation * (sp.ksize - 1)
 
     # ---- forward: layers 1 .. n-1 from the head's output ------------------------------------------------------------------------
-    def forward_body(self, act0: Planes):
+    def out_shapes(self, l0: int):
+        """(channels, length) of every embedding behind the head's output of length l0, and the logits' length."""
+        shapes, cur = [], l0
+        for lay in self.layers[1:-1]:
+            cur = lay.spec.out_len(cur)
+            shapes.append((lay.spec.c_out, cur))
+        sp = self.layers[-1].spec
+        return shapes, cur + sp.pad_l + sp.pad_r - (sp.ksize - 1)
+
+    def forward_body(self, act0: Planes, outs: Optional[List[Planes]] = None, logits_out: Optional[torch.Tensor] = None):
+        """The layers behind the head on the rows of ``act0``; ``outs`` / ``logits_out``: write into these (row views of the full batch's
+        planes: the two halves of the batch run as two launches sequences) instead of allocating."""
         lib = load()
         acts = [act0]
         rows = act0.rows
@@ -122,7 +141,7 @@ class _ChainBL:
         for i in range(1, n - 1):
             lay = self.layers[i]
             d = ops.conv_desc(lay.spec, rows, cur.length, lay.math_fwd)
-            y = Planes(rows, lay.spec.c_out, d.l_out, act0.hi.device)
+            y = outs[i - 1] if outs is not None else Planes(rows, lay.spec.c_out, d.l_out, act0.hi.device)
             _, _, bias = lay.params()
             wp = lay.packed(0, rows, cur.length)
             tm = ops.kernel_timer_for(lay.spec, "fwd")
@@ -139,7 +158,7 @@ class _ChainBL:
         v, _, bias = tail.params()
         tail.ensure_scale()
         l_out = cur.length + sp.pad_l + sp.pad_r - (sp.ksize - 1)
-        logits = torch.empty((rows, 1, l_out), dtype=torch.float32, device=act0.hi.device)
+        logits = logits_out if logits_out is not None else torch.empty((rows, 1, l_out), dtype=torch.float32, device=act0.hi.device)
         check(lib.eben_bl_tail_fwd(_addr(cur.hi), _addr(cur.lo), rows, cur.channels, cur.length, sp.ksize, sp.pad_l, ptr(v.detach()), ptr(tail.scale),
                                    ptr(bias.detach()) if bias is not None else None, sp.out_slope, ptr(logits), _stream()), "bl_tail_fwd")
         return acts, logits
@@ -356,8 +375,82 @@ class DiscriminatorEngineBL(DiscriminatorEngine):
         return tuple(out)
 
     # ---- forward ---------------------------------------------------------------------------------------------------------------
+    def _split_planes(self, st: dict, half: int):
+        """Planes of every embedding / the logits of the full 2B-row batch, allocated once per shape: with the forward split into its
+        reference and enhanced halves two launch sequences write into them (row views)."""
+        if "planes" not in st:
+            dev = st["wav"].device
+            planes, logits = [], []
+            for i, ch in enumerate(self.chains):
+                shapes, l_logits = ch.out_shapes(st["act0"][i].length)
+                planes.append([Planes(2 * half, c, l, dev) for c, l in shapes])
+                logits.append(torch.empty((2 * half, 1, l_logits), dtype=torch.float32, device=dev))
+            st["planes"], st["logits"] = planes, logits
+        return st["planes"], st["logits"]
+
+    def _forward_rows(self, st: dict, half: int, r0: int, r1: int, fm: bool, key: str):
+        """Heads + chain bodies of batch rows [r0, r1) on the chains' streams (not joined).  fm: the feature-matching sums of each chain's
+        embedding pairs behind its layers (the second of the two halves)."""
+        lib = load()
+        sub, wav, act0 = st["sub"], st["wav"], st["act0"]
+        planes, logits = self._split_planes(st, half)
+        n = len(self.chains)
+        nrows = r1 - r0
+        fm_first = [sum(len(c.layers) - 1 for c in self.chains[:i]) for i in range(n)]
+        fm_sums = st["fm_sums"]
+        head_done = [None]
+
+        def body(i):
+            a0 = act0[i].rows_slice(r0, r1)
+            self.chains[i].forward_body(a0, [p.rows_slice(r0, r1) for p in planes[i]], logits[i][r0:r1])
+            if fm:
+                acts = [act0[i]] + planes[i]
+                k = len(acts)
+                ptrs = (ctypes.c_void_p * (2 * k))()
+                units = (ctypes.c_int64 * k)()
+                for j, pl in enumerate(acts):
+                    ptrs[2 * j], ptrs[2 * j + 1] = _addr(pl.hi), _addr(pl.lo)
+                    units[j] = half * (pl.channels // 8) * pl.length
+                ws_bytes = lib.eben_bl_fm_sums_workspace(k)
+                ws = torch.empty(max(1, (ws_bytes + 3) // 4), dtype=torch.float32, device=acts[0].hi.device)
+                check(lib.eben_bl_fm_sums(ptrs, units, k, ptr(ws), ws_bytes, ptr(fm_sums[2 * fm_first[i]:]), _stream()), "bl_fm_sums")
+            return True
+
+        def run(i):
+            ch = self.chains[i]
+            if i == n - 1:
+                jobs = (EbenBlHeadJob * 1)(ch.head_job(wav[r0:r1], wav.shape[2], act0[i].rows_slice(r0, r1)))
+                check(lib.eben_bl_head_fwd(jobs, 1, nrows, _stream()), "bl_head_fwd")
+            elif i == 0:
+                jobs = (EbenBlHeadJob * (n - 1))(*[self.chains[k].head_job(sub[r0:r1], sub.shape[2], act0[k].rows_slice(r0, r1)) for k in range(n - 1)])
+                check(lib.eben_bl_head_fwd(jobs, n - 1, nrows, _stream()), "bl_head_fwd")
+                head_done[0] = torch.cuda.Event()
+                head_done[0].record()
+            else:
+                torch.cuda.current_stream().wait_event(head_done[0])
+            sig = (r0, r1, fm, act0[i].hi.data_ptr(), act0[i].lo.data_ptr(), act0[i].length, fm_sums.data_ptr(), planes[i][0].hi.data_ptr(),
+                   self._chain_sig(ch, 0))
+            self._graphs[key][i].run(sig, lambda: body(i), torch.cuda.current_stream())
+            self._mark_used(ch, 0)
+            return [act0[i]] + planes[i], logits[i]
+
+        return self._launch_on_streams(run, forward=True, order=[n - 1] + list(range(n - 1)))
+
+    @torch.no_grad()
     def forward_reference(self, bands_ref, audio_ref):
-        raise ops._lib.EbenError("the bundle-layout engine runs the two halves of the batch in one pass (split_discriminator_forward = False)")
+        """The reference half of the batch (rows B .. 2B: it does not depend on the generator) on the chains' streams, to run underneath
+        the generator forward -- a chain of latency-bound launches that leaves most of the GPU idle.  ``forward`` then runs the enhanced
+        half only."""
+        half = bands_ref.shape[0]
+        st = self._static_for(half, bands_ref, audio_ref)
+        st["sub"][half:].copy_(bands_ref[:, -self.q:, :])
+        st["wav"][half:].copy_(audio_ref)
+        if "fwd_ref" not in self._graphs:
+            n = len(self.chains)
+            self._graphs["fwd_ref"] = [ops.ReplayedChain() for _ in range(n)]
+            self._graphs["fwd_enh"] = [ops.ReplayedChain() for _ in range(n)]
+        self._forward_rows(st, half, half, 2 * half, False, "fwd_ref")
+        self._ref_done = (half, st)
 
     @torch.no_grad()
     def forward(self, bands, audio, bands_ref, audio_ref, join: bool = True):
@@ -365,6 +458,17 @@ class DiscriminatorEngineBL(DiscriminatorEngine):
         half = bands.shape[0]
         st = self._static_for(half, bands, audio)
         sub, wav, inputs, act0 = st["sub"], st["wav"], st["inputs"], st["act0"]
+        pre = getattr(self, "_ref_done", None)
+        self._ref_done = None
+        if pre is not None and pre[0] == half and pre[1] is st:
+            # the reference rows are on their way (forward_reference): the enhanced rows + the feature-matching sums behind them
+            sub[:half].copy_(bands[:, -self.q:, :])
+            wav[:half].copy_(audio)
+            res = self._forward_rows(st, half, 0, half, True, "fwd_enh")
+            if join:
+                self._join_streams()
+            self._state = dict(half=half, acts=[r[0] for r in res], logits=[r[1] for r in res], inputs=inputs, bands_shape=tuple(bands.shape), static=st)
+            return self._state
         sub[:half].copy_(bands[:, -self.q:, :])
         sub[half:].copy_(bands_ref[:, -self.q:, :])
         wav[:half].copy_(audio)

@@ -335,10 +335,11 @@ class EBENLightningModule(BaseSELightningModule):
                 engine.prepack()   # next step's discriminator images, under the next generator forward
         return {"corrupted": corrupted_speech, "enhanced": enhanced_speech.detach(), "reference": reference_speech}
 
-    #: run the discriminators on the reference half of the batch underneath the generator forward.  Measured neutral
-    #: (25.8 vs 25.8 ms/step: the generator forward slows by what the discriminator phase gains -- the step is bound by
-    #: total kernel work, not by idle units), so off by default: one 2B-row launch per layer is the simpler schedule.
-    split_discriminator_forward: bool = os.environ.get("EBEN_SPLIT_D_FWD", "0") != "0"
+    #: run the discriminators on the reference half of the batch underneath the generator forward (it does not depend on the generator).
+    #: Round 1 (fp32 discriminators): neutral, 25.8 vs 25.8 ms/step.  Round 4 (bundle-layout plan, generator forward a chain of latency-bound
+    #: launches): [MI355X, same box, interleaved] 10.25 -> 10.05 ms/step -- the generator forward phase lengthens by 0.7 ms (1.47 -> 2.19: its
+    #: launches share the CUs), the discriminator forward phase shortens by 0.8 (2.26 -> 1.49).  On by default.
+    split_discriminator_forward: bool = os.environ.get("EBEN_SPLIT_D_FWD", "1") != "0"
 
     #: rebuild the packed weight images right after each optimiser step, on the side stream (off the critical path)
     prepack_weights: bool = os.environ.get("EBEN_PREPACK", "1") != "0"
