@@ -367,6 +367,12 @@ PR_LAYERS = {
     "melgan_l2_ragged": (dict(c_in=64, c_out=256, ksize=41, stride=4, pad_l=20, pad_r=20, groups=4, out_slope=0.2), 2, 1097, True),
     "stride8_k16": (dict(c_in=8, c_out=64, ksize=16, stride=8, pad_l=7, pad_r=7, groups=1, out_slope=0.2), 2, 1001, True),
     "stride4_g2": (dict(c_in=32, c_out=128, ksize=23, stride=4, pad_l=11, pad_r=11, groups=2, out_slope=0.2), 2, 777, True),
+    # stride 2 and dilated (the PQMF-band layers): taken only under EBEN_PR_MIN_STRIDE=2 EBEN_PR_MAX_DIL=3 EBEN_PR_MAX_ROWS=256 (off by
+    # default -- see DESIGN 11.2); skipped otherwise
+    "pqmf_l1_d1_dense": MID_LAYERS["pqmf_l1_d1_dense"],
+    "pqmf_l3_d2": MID_LAYERS["pqmf_l3_d2"],
+    "pqmf_l2_d3_dense": MID_LAYERS["pqmf_l2_d3_dense"],
+    "pqmf_l4_d3": (dict(c_in=192, c_out=384, ksize=7, stride=2, dilation=3, pad_l=3, pad_r=3, groups=4, out_slope=0.2), 2, 517, True),
 }
 
 
@@ -397,6 +403,8 @@ def test_bundle_conv_input_gradient_phases_as_rows(hip, name):
     seg_map = (ctypes.c_int * 4)(0, 0, 0, 1)
     d = ops.conv_desc(lin, rows4, length, ops.MATH_BF16 | BL)
     dq = EbenConv1dDesc()
+    if hip.eben_bl_dx_pr_desc(ctypes.byref(d), ctypes.byref(dq)) != 0 and (spec.stride < 4 or spec.dilation > 1):
+        pytest.skip("stride-2 / dilated layers take the phases-as-rows form only under EBEN_PR_MIN_STRIDE=2 EBEN_PR_MAX_DIL=3")
     assert hip.eben_bl_dx_pr_desc(ctypes.byref(d), ctypes.byref(dq)) == 0
     assert (dq.c_in, dq.c_out, dq.stride, dq.l_in, dq.l_out) == (spec.c_out, spec.stride * spec.c_in, 1, l_out, -(-length // spec.stride))
     wq = torch.empty(dq.c_out * (dq.c_in // dq.groups) * dq.ksize, dtype=torch.float32, device=DEV)

@@ -920,11 +920,13 @@ static int pr_floordiv(int a, int b) { int q = a / b; if ((a % b != 0) && ((a < 
 static PrGeom pr_geometry(const Canon& c, Canon* cp) {
   PrGeom g{};
   static const int min_s = getenv("EBEN_PR_MIN_STRIDE") ? atoi(getenv("EBEN_PR_MIN_STRIDE")) : 4;
-  if (!c.bl || c.np != 1 || c.reflect || c.d != 1 || c.s < 2 || c.s < min_s || c.s > 8 || c.k <= c.s || c.pl > c.k - 1) return g;
+  static const int max_d = getenv("EBEN_PR_MAX_DIL") ? atoi(getenv("EBEN_PR_MAX_DIL")) : 1;
+  if (!c.bl || c.np != 1 || c.reflect || c.d > max_d || c.s < 2 || c.s < min_s || c.s > 8 || (c.k - 1) * c.d + 1 <= c.s || c.pl > (c.k - 1) * c.d) return g;
   const int Cg = c.Cin / c.g;
   if ((c.Cin & 7) || (c.Cout & 7)) return g;
   g.S = c.s;
-  g.umin = -pr_floordiv(c.k - 1 - c.pl, c.s);             // ceil((pad - (k - 1)) / S): phase 0, last tap
+  // dilation d: tap j sits at offset j d, i.e. W' is nonzero where ph + pad - S u is a multiple of d inside [0, (k - 1) d]
+  g.umin = -pr_floordiv((c.k - 1) * c.d - c.pl, c.s);     // ceil((pad - (k - 1) d) / S): phase 0, last tap
   const int umax = pr_floordiv(c.s - 1 + c.pl, c.s);      // phase S - 1, tap 0
   g.kq = umax - g.umin + 1;
   g.Lq = ceil_div(c.Lin, c.s);
@@ -950,7 +952,7 @@ static PrGeom pr_geometry(const Canon& c, Canon* cp) {
 
 // W'[(g, ph, c)][co][ui] (groups kept) or [(ph, ci)][co][ui] (folded, zero across groups) = scale[co] v[co][c][ph + pad - S (ui + umin)]
 __global__ __launch_bounds__(256) void pr_weights_kernel(const float* __restrict__ v, const float* __restrict__ scale, float* __restrict__ wq,
-                                                          int Cin, int Cout, int G, int k, int S, int pad, int umin, int kq, int fold) {
+                                                          int Cin, int Cout, int G, int k, int S, int pad, int umin, int kq, int fold, int dil) {
   const int Cg = Cin / G, Mg = Cout / G;
   const int cin_q = fold ? Cout : Mg;                      // input channels per group of the primed layer
   const long long total = (long long)S * Cin * cin_q * kq;
@@ -962,9 +964,10 @@ __global__ __launch_bounds__(256) void pr_weights_kernel(const float* __restrict
     int ph, ci, co;
     if (fold) { ph = row / Cin; ci = row - ph * Cin; co = cq; }
     else { const int g = row / (S * Cg), rr = row - g * S * Cg; ph = rr / Cg; ci = g * Cg + (rr - ph * Cg); co = g * Mg + cq; }
-    const int j = ph + pad - S * (ui + umin);
+    const int off = ph + pad - S * (ui + umin);              // = j dil for the tap this entry stands for, if any
+    const int j = off / dil;
     float w = 0.f;
-    if (j >= 0 && j < k && co / Mg == ci / Cg) w = v[((long long)co * Cg + (ci % Cg)) * k + j] * (scale ? scale[co] : 1.f);
+    if (off >= 0 && j * dil == off && j < k && co / Mg == ci / Cg) w = v[((long long)co * Cg + (ci % Cg)) * k + j] * (scale ? scale[co] : 1.f);
     wq[i] = w;
   }
 }
@@ -997,7 +1000,7 @@ extern "C" int eben_bl_dx_pr_weights(const EbenConv1dDesc* d, const float* v, co
   long long blocks = (total + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(pr_weights_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), v, scale, w_primed, c.Cin, c.Cout, c.g, c.k, c.s, c.pl,
-                     g.umin, g.kq, g.fold);
+                     g.umin, g.kq, g.fold, c.d);
   EBEN_CHECK_LAUNCH("pr_weights_kernel");
   return EBEN_OK;
 }
