@@ -31,6 +31,8 @@ from ._lib import stream as _stream
 from .disc_engine import DiscriminatorEngine, _Layer
 
 BL = 0x100   # EBEN_LAYOUT_BL
+#: split forward (forward_reference): also run MelGAN's reference half underneath the generator forward (default: MelGAN whole, behind it)
+SPLIT_MELGAN = __import__("os").environ.get("EBEN_SPLIT_MELGAN", "0") != "0"
 
 
 def _addr(t: Optional[torch.Tensor]) -> Optional[int]:
@@ -400,9 +402,20 @@ class DiscriminatorEngineBL(DiscriminatorEngine):
         fm_sums = st["fm_sums"]
         head_done = [None]
 
+        # MelGAN (the last chain) keeps ONE 2B-row launch per layer, behind the generator: its heavy layers fill the machine exactly once at
+        # 64 rows (512 blocks = two per CU) and lose a third of their rate as two 32-row launches ([MI355X] L4 forward alone 0.35 -> 0.29 of
+        # the bf16 peak); the thin PQMF-band chains are what gains from running beside the generator forward
+        whole_last = not SPLIT_MELGAN
+
+        def rng(i):
+            if whole_last and i == n - 1:
+                return (0, 2 * half) if fm else None
+            return r0, r1
+
         def body(i):
-            a0 = act0[i].rows_slice(r0, r1)
-            self.chains[i].forward_body(a0, [p.rows_slice(r0, r1) for p in planes[i]], logits[i][r0:r1])
+            q0, q1 = rng(i)
+            a0 = act0[i].rows_slice(q0, q1)
+            self.chains[i].forward_body(a0, [p.rows_slice(q0, q1) for p in planes[i]], logits[i][q0:q1])
             if fm:
                 acts = [act0[i]] + planes[i]
                 k = len(acts)
@@ -418,9 +431,12 @@ class DiscriminatorEngineBL(DiscriminatorEngine):
 
         def run(i):
             ch = self.chains[i]
+            if rng(i) is None:   # MelGAN in the reference pass: nothing yet
+                return [act0[i]] + planes[i], logits[i]
             if i == n - 1:
-                jobs = (EbenBlHeadJob * 1)(ch.head_job(wav[r0:r1], wav.shape[2], act0[i].rows_slice(r0, r1)))
-                check(lib.eben_bl_head_fwd(jobs, 1, nrows, _stream()), "bl_head_fwd")
+                q0, q1 = rng(i)
+                jobs = (EbenBlHeadJob * 1)(ch.head_job(wav[q0:q1], wav.shape[2], act0[i].rows_slice(q0, q1)))
+                check(lib.eben_bl_head_fwd(jobs, 1, q1 - q0, _stream()), "bl_head_fwd")
             elif i == 0:
                 jobs = (EbenBlHeadJob * (n - 1))(*[self.chains[k].head_job(sub[r0:r1], sub.shape[2], act0[k].rows_slice(r0, r1)) for k in range(n - 1)])
                 check(lib.eben_bl_head_fwd(jobs, n - 1, nrows, _stream()), "bl_head_fwd")
@@ -428,7 +444,7 @@ class DiscriminatorEngineBL(DiscriminatorEngine):
                 head_done[0].record()
             else:
                 torch.cuda.current_stream().wait_event(head_done[0])
-            sig = (r0, r1, fm, act0[i].hi.data_ptr(), act0[i].lo.data_ptr(), act0[i].length, fm_sums.data_ptr(), planes[i][0].hi.data_ptr(),
+            sig = (rng(i), fm, act0[i].hi.data_ptr(), act0[i].lo.data_ptr(), act0[i].length, fm_sums.data_ptr(), planes[i][0].hi.data_ptr(),
                    self._chain_sig(ch, 0))
             self._graphs[key][i].run(sig, lambda: body(i), torch.cuda.current_stream())
             self._mark_used(ch, 0)
