@@ -257,6 +257,71 @@ def test_bf16_math_forward_and_batched_input_gradient(hip, name):
         assert rel_err(dv, wr2.grad) < 1e-4
 
 
+GC_CASES = {
+    # the generator's eight non-residual convs (eben_generator.py:241-312) with the MFMA B operand loaded straight from the fp32 rows
+    # (gen_conv.hip, kernel generation 5): name -> (ConvSpec kwargs, batch, length, bias, residual)
+    "enc_s2": (dict(c_in=32, c_out=64, ksize=4, stride=2, pad_l=1, pad_r=1, reflect=True), 3, 1000, False, False),
+    "enc_s4": (dict(c_in=64, c_out=128, ksize=8, stride=4, pad_l=3, pad_r=3, reflect=True), 2, 1001, False, False),
+    "enc_s8": (dict(c_in=128, c_out=256, ksize=16, stride=8, pad_l=7, pad_r=7, reflect=True), 2, 999, False, False),
+    "enc_s8_act_bias": (dict(c_in=128, c_out=256, ksize=16, stride=8, pad_l=7, pad_r=7, reflect=True, in_slope=0.01, out_slope=0.2), 2, 1500, True, False),
+    "latent_down": (dict(c_in=256, c_out=64, ksize=7, pad_l=3, pad_r=3, reflect=True, in_slope=0.01, out_slope=0.01), 3, 125, False, False),
+    "latent_up": (dict(c_in=64, c_out=256, ksize=7, pad_l=3, pad_r=3, reflect=True, out_slope=0.01), 3, 125, False, False),
+    "latent_zero_pad_res": (dict(c_in=64, c_out=64, ksize=5, pad_l=2, pad_r=2, out_slope=0.01), 2, 300, True, True),
+    "dec_s8": (dict(c_in=256, c_out=128, ksize=16, stride=8, pad_l=4, transposed=True, out_slope=0.01), 2, 125, False, False),
+    "dec_s4": (dict(c_in=128, c_out=64, ksize=8, stride=4, pad_l=2, transposed=True, out_slope=0.01), 2, 999, False, False),
+    "dec_s2": (dict(c_in=64, c_out=32, ksize=4, stride=2, pad_l=1, transposed=True, out_slope=0.01), 2, 3996 // 4, False, False),
+    "dec_s2_bias_res": (dict(c_in=64, c_out=32, ksize=4, stride=2, pad_l=1, transposed=True, in_slope=0.01, out_slope=0.01), 2, 517, True, True),
+    "dec_s4_bias_res": (dict(c_in=32, c_out=16, ksize=8, stride=4, pad_l=2, transposed=True), 1, 70, True, True),
+    "dec_s8_bias_res": (dict(c_in=16, c_out=8, ksize=16, stride=8, pad_l=4, transposed=True), 1, 33, True, True),
+    "short_rows": (dict(c_in=16, c_out=32, ksize=8, stride=4, pad_l=3, pad_r=3, reflect=True), 5, 9, False, False),   # every tile at both ends of the row
+    "one_column": (dict(c_in=16, c_out=32, ksize=7, pad_l=3, pad_r=3), 2, 1, True, False),
+}
+
+
+@pytest.mark.parametrize("name", list(GC_CASES))
+def test_generator_direct_operand_convs(hip, name):
+    """gen_conv.hip (EBEN_MATH_BF16X6 forward of the generator's strided / transposed / latent convs): fp32-grade against the fp64 conv
+    of the exact operands -- 3e-5 is the bound of the fp32 kernels, the split products land at ~1e-6."""
+    import ctypes
+
+    from vibravox_amd import ops
+    from vibravox_amd._lib import check, load, ptr, stream
+
+    lib = load()
+    kw, batch, length, has_bias, has_res = GC_CASES[name]
+    spec = ops.ConvSpec(**kw)
+    wshape = spec.weight_shape()
+    v = formula_tensor(f"gc/{name}/w", wshape, 1 / math.sqrt(wshape[1] * wshape[2]))
+    g = formula_tensor(f"gc/{name}/g", (wshape[0], 1, 1)).abs() + 0.5
+    bias = formula_tensor(f"gc/{name}/b", (spec.c_out,), 0.1) if has_bias else None
+    x = formula_tensor(f"gc/{name}/x", (batch, spec.c_in, length))
+    l_out = spec.out_len(length)
+    res = formula_tensor(f"gc/{name}/r", (batch, spec.c_out, l_out)) if has_res else None
+    okw = {k: val for k, val in kw.items() if k not in ("c_in", "c_out", "ksize")}
+    exact = O.conv_layer(x.double(), v.double(), g.double(), None if bias is None else bias.double(), **okw)
+    if res is not None:
+        exact = exact + torch.nn.functional.leaky_relu(res.double(), 0.3)
+    dev = torch.device("cuda")
+    d = ops.conv_desc(spec, batch, length, ops.MATH_BF16X6)
+    assert lib.eben_conv1d_kernel_generation(ctypes.byref(d), 0) == 5
+    vd, gd, xd = v.to(dev), g.to(dev), x.to(dev)
+    scale = torch.empty(wshape[0], dtype=torch.float32, device=dev)
+    norm = torch.empty_like(scale)
+    check(lib.eben_wn_scale(ptr(gd), ptr(vd), wshape[0], wshape[1] * wshape[2], ptr(scale), ptr(norm), stream()), "wn_scale")
+    wp = torch.full((lib.eben_conv1d_packed_floats(ctypes.byref(d), 0),), float("nan"), dtype=torch.float32, device=dev)
+    check(lib.eben_conv1d_pack(ctypes.byref(d), ptr(vd), ptr(scale), ptr(wp), None, stream()), "pack")
+    y = torch.full((batch, spec.c_out, l_out), float("nan"), dtype=torch.float32, device=dev)
+    bd = None if bias is None else bias.to(dev)
+    if res is None:
+        check(lib.eben_conv1d_fwd(ctypes.byref(d), ptr(xd), ptr(wp), ptr(bd), None, ptr(y), stream()), "fwd")
+    else:
+        rd = res.to(dev)
+        check(lib.eben_conv1d_fwd_res(ctypes.byref(d), ptr(xd), ptr(wp), ptr(bd), ptr(rd), 0.3, ptr(y), stream()), "fwd_res")
+    torch.cuda.synchronize()
+    assert torch.isfinite(wp).all()
+    assert rel_err(y, exact) < 3e-6
+
+
 @pytest.mark.parametrize("math_name", ["bf16x6", "bf16x3"])
 @pytest.mark.parametrize("name", [n for n, c in BF16_CASES.items() if c[2][0] == 4])
 def test_split_bf16_math_forward_and_batched_input_gradient(hip, name, math_name):

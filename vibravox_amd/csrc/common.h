@@ -149,6 +149,13 @@ int tap3_pack(const Canon& c, int dir, const float* w, const float* scale, float
 int tap3_pack_multi(const Canon* cs, const int* dirs, const float* const* ws, const float* const* scales, float* const* wps, int n, hipStream_t st);
 int tap3_launch(const Canon& c, int dir, const TapIO& io, int reflect, hipStream_t st);
 
+// the generator's strided / transposed / latent convs with the MFMA B operand loaded straight from the fp32 rows (gen_conv.hip): forward
+// launches only (kernel generation 5 of eben_conv1d_kernel_generation)
+int gc_applicable(const Canon& c, int dir);
+size_t gc_packed_floats(const Canon& c, int dir);
+int gc_pack(const Canon& c, int dir, const float* w, const float* scale, float* wp, hipStream_t st);
+int gc_launch(const Canon& c, int dir, const TapIO& io, hipStream_t st);
+
 // direct (VALU) tap-conv for layers with a handful of output channels per group (thinconv.hip)
 int thin_applicable(const Canon& c, int dir);
 size_t thin_packed_floats(const Canon& c, int dir);

@@ -679,6 +679,7 @@ extern "C" size_t eben_conv1d_packed_floats(const EbenConv1dDesc* d, int which) 
   TapPlan p;
   // which: 0 = the layer's forward, 1 = the layer's input gradient
   const int dir = d->transposed ? 1 - which : which;
+  if (which == 0 && gc_applicable(c, dir)) return gc_packed_floats(c, dir);
   const int gen = tap_generation(c, dir);
   if (gen == 2) return tap2_packed_floats(c, dir);
   if (gen == 3) return thin_packed_floats(c, dir);
@@ -690,6 +691,7 @@ extern "C" size_t eben_conv1d_packed_floats(const EbenConv1dDesc* d, int which) 
 extern "C" int eben_conv1d_kernel_generation(const EbenConv1dDesc* d, int which) {
   Canon c;
   if (canon_from_desc(d, &c) != EBEN_OK) return 0;
+  if (which == 0 && gc_applicable(c, d->transposed ? 1 : 0)) return 5;
   return tap_generation(c, d->transposed ? 1 - which : which);
 }
 
@@ -702,6 +704,10 @@ extern "C" int eben_conv1d_pack(const EbenConv1dDesc* d, const float* v, const f
     float* dst = which == 0 ? wp_fwd : wp_bwd;
     if (!dst) continue;
     const int dir = d->transposed ? 1 - which : which;
+    if (which == 0 && gc_applicable(c, dir)) {
+      if ((rc = gc_pack(c, dir, v, scale, dst, as_stream(stream)))) return rc;
+      continue;
+    }
     const int gen = tap_generation(c, dir);
     if (gen != 1) {
       rc = gen == 2 ? tap2_pack(c, dir, v, scale, dst, as_stream(stream))
@@ -743,7 +749,7 @@ extern "C" int eben_conv1d_pack_multi(const EbenPackJob* jobs, int n, void* stre
       float* dst = which == 0 ? jb.wp_fwd : jb.wp_bwd;
       if (!dst) continue;
       const int dir = jb.desc.transposed ? 1 - which : which;
-      if (tap_generation(c, dir) == 4) {
+      if (!(which == 0 && gc_applicable(c, dir)) && tap_generation(c, dir) == 4) {
         if (m == CAP && (rc = flush())) return rc;
         cs[m] = c; dirs[m] = dir; ws[m] = jb.v; scs[m] = jb.scale; wps[m] = dst;
         ++m;
@@ -774,6 +780,7 @@ static int conv1d_fwd_impl(const EbenConv1dDesc* d, const float* x, const float*
   io.x = x; io.in_mode = 0; io.in_slope = d->in_slope; io.wp = wp_fwd; io.bias = bias;
   io.res = residual; io.res_slope = res_slope; io.emask = nullptr; io.emask_slope = 1.f;
   io.out_slope = d->out_slope; io.y = y; io.accumulate = 0;
+  if (gc_applicable(c, d->transposed ? 1 : 0)) return gc_launch(c, d->transposed ? 1 : 0, io, as_stream(stream));
   const int fgen = tap_generation(c, d->transposed ? 1 : 0);
   if (fgen == 2) return tap2_launch(c, d->transposed ? 1 : 0, io, c.reflect && !d->transposed, as_stream(stream));
   if (fgen == 3) return thin_launch(c, d->transposed ? 1 : 0, io, c.reflect && !d->transposed, as_stream(stream));

@@ -67,7 +67,18 @@ __device__ unsigned long long t3_stamp[T3_STAMP_ROWS * 16];
 #endif
 // k-steps (of 16 reduction elements) per weight chunk; split weights (NPW pieces per weight, EBEN_MATH_BF16X3 / X6): a k-step carries
 // NPW times the weight bytes and 3 / 6 times the MFMAs
-__host__ __device__ constexpr int t3_ksc(int npw, int fm = 4) { return npw == 1 ? (fm <= 2 ? EBEN_T3_KSC : EBEN_T3_KSC_BIGFM) : 2; }
+#ifndef EBEN_T3_KSC_X6_FM1
+#define EBEN_T3_KSC_X6_FM1 2   // six-product launches (the generator's forward convs), 32-row tiles
+#endif
+#ifndef EBEN_T3_KSC_X6_FM2
+#define EBEN_T3_KSC_X6_FM2 2   // ... 64-row tiles
+#endif
+#ifndef EBEN_T3_SPLIT_OCC2
+#define EBEN_T3_SPLIT_OCC2 0   // 1: register budget of two blocks per CU for the split-weight launches with <= 64-row tiles
+#endif
+__host__ __device__ constexpr int t3_ksc(int npw, int fm = 4) {
+  return npw == 1 ? (fm <= 2 ? EBEN_T3_KSC : EBEN_T3_KSC_BIGFM) : npw == 3 ? (fm == 1 ? EBEN_T3_KSC_X6_FM1 : fm == 2 ? EBEN_T3_KSC_X6_FM2 : 2) : 2;
+}
 #ifndef EBEN_T3_RING_SPLIT
 #define EBEN_T3_RING_SPLIT 2   // slots of the split-weight (fp32 tensors at rest, NPW >= 2) launches: the generator's six-product convs
 #endif
@@ -126,7 +137,7 @@ struct Tap3Args {
 // halves of the output units (lanes 0-31 channels +0..3, lanes 32-63 channels +4..7 of a bundle: a wave stores 512 contiguous
 // bytes per row quad) and reads the mask / feature-matching operands the same way.
 template <int FM, int XRB, bool IM = false, int NPW = 1, int NPX = 1, bool BL = false>
-__global__ __launch_bounds__(256, NPW >= 2 ? 1 : 2) void tap3_kernel(const Tap3Args P) {
+__global__ __launch_bounds__(256, NPW >= 2 ? ((EBEN_T3_SPLIT_OCC2 && FM <= 2) ? 2 : 1) : 2) void tap3_kernel(const Tap3Args P) {
   constexpr int NT = 256, BN = 128, BM = FM * 32, KSC = t3_ksc(NPW, FM);
   constexpr bool SP = NPX > 1;
   constexpr int NPM = NPW > NPX ? NPW : NPX;

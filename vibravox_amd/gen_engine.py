@@ -152,7 +152,7 @@ class GeneratorEngine:
         d, d_bwd, pw = self._pack(m, spec, b, l_in, train)
         y = torch.empty((b, spec.c_out, d.l_out), dtype=torch.float32, device=x.device)
         route = None
-        if not spec.transposed and self._s2d_wanted(spec, CONV_FWD_MATH) and lib.eben_conv1d_kernel_generation(ctypes.byref(d), 0) != 4:
+        if not spec.transposed and self._s2d_wanted(spec, CONV_FWD_MATH) and lib.eben_conv1d_kernel_generation(ctypes.byref(d), 0) not in (4, 5):
             kq = spec.ksize // spec.stride
             l_q = d.l_out + kq - 1
             route = self._s2d_route(m, spec, b, l_q, kq, CONV_FWD_MATH, spec.c_in, spec.c_out, spec.in_slope, spec.out_slope, pw.scale)
