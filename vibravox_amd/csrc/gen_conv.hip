@@ -80,7 +80,7 @@ __device__ __forceinline__ void gc_split(const float (&v)[8], u32x4 (&pc)[NP]) {
 
 template <int FORM, int RT, int CT, int NP>
 __global__ __launch_bounds__(256, 2) void gc_kernel(const GcArgs P) {
-  constexpr int KC = 8 / RT;                  // k-steps per weight chunk
+  constexpr int KC = (RT == 2 && CT == 2) ? 2 : 8 / RT;   // k-steps per weight chunk (64 x 64 wave tiles: the samples of 4 k-steps in flight beside 64 accumulator registers spill)
   constexpr int RTU = KC * NP * 64;           // units of one row tile's chunk (contiguous in the image)
   constexpr int SLOT = RT * RTU;              // units per LDS slot
   __shared__ __attribute__((aligned(16))) u32x4 Ws[2 * SLOT];
@@ -113,18 +113,26 @@ __global__ __launch_bounds__(256, 2) void gc_kernel(const GcArgs P) {
   // wait for the DMA issued after it
   constexpr int WPT = SLOT / 256;             // units per thread and chunk
   typedef const __attribute__((address_space(1))) char* gptr_t;   // global address space: a laundered integer must not come back as a flat pointer
-  static_assert(RTU % 256 == 0, "a row tile's chunk is a whole number of block-wide pieces");
+  static_assert(SLOT % 256 == 0, "a slot is a whole number of block-wide pieces");
   u32x4 wreg[WPT];
   auto load_w = [&](int ch) {
     if (EBEN_GC_DBG & 4) return;
 #pragma unroll
     for (int p = 0; p < WPT; ++p) {
-      // unit p 256 + tid of the slot: row tile (p 256) / RTU, then the chunk's units as they lie in the image -- a wave-uniform base
-      // plus the thread id (scalar base + 32-bit lane offset: one address register for all the loads)
-      const u32x4* base = wsrc + (long long)((p * 256) / RTU) * P.w_rt + (long long)ch * RTU + (p * 256) % RTU;
-      unsigned long long a = reinterpret_cast<unsigned long long>(base);
-      asm volatile("" : "+s"(a));
-      wreg[p] = *reinterpret_cast<const __attribute__((address_space(1))) u32x4*>(reinterpret_cast<gptr_t>(a) + (unsigned)tid * 16u);
+      // unit p 256 + tid of the slot: row tile idx / RTU, then the chunk's units as they lie in the image -- a wave-uniform base (scalar
+      // register pair) plus a 32-bit per-thread offset: one address register for all the loads
+      if constexpr (RTU % 256 == 0) {
+        const u32x4* base = wsrc + (long long)((p * 256) / RTU) * P.w_rt + (long long)ch * RTU + (p * 256) % RTU;
+        unsigned long long a = reinterpret_cast<unsigned long long>(base);
+        asm volatile("" : "+s"(a));
+        wreg[p] = *reinterpret_cast<const __attribute__((address_space(1))) u32x4*>(reinterpret_cast<gptr_t>(a) + (unsigned)tid * 16u);
+      } else {   // a block-wide piece straddles two row tiles: the tile is part of the thread's offset
+        const int idx = p * 256 + tid;
+        const unsigned off = (unsigned)((idx / RTU) * (int)P.w_rt + idx % RTU) * 16u;
+        unsigned long long a = reinterpret_cast<unsigned long long>(wsrc + (long long)ch * RTU);
+        asm volatile("" : "+s"(a));
+        wreg[p] = *reinterpret_cast<const __attribute__((address_space(1))) u32x4*>(reinterpret_cast<gptr_t>(a) + off);
+      }
     }
   };
   auto store_w = [&](int ch) {
