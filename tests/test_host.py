@@ -103,6 +103,19 @@ def test_kernel_family_selection_without_gpu(lib):
     assert gen(logits, 0) == 1                                           # single-output-channel reduction
     ru = EbenConv1dDesc(32, 64, 64, 4000, 4000, 3, 1, 9, 1, 9, 9, 1, 0, 0.01, 1.0)
     assert gen(ru, 0) == 2 and gen(ru, 1) == 2
+    # the generator's strided / transposed / latent convs under the forward's fp32-grade math: their own kernel (gen_conv.hip, 5) for the
+    # forward, the general tap-conv for the input gradient; the image is sized by the same plan
+    X6 = 4
+    enc3 = EbenConv1dDesc(32, 128, 256, 999, 125, 16, 8, 1, 1, 7, 7, 1, 0, 1.0, 1.0, X6)
+    dec2 = EbenConv1dDesc(32, 128, 64, 999, 3996, 8, 4, 1, 1, 2, 0, 0, 1, 1.0, 0.01, X6)
+    lat1 = EbenConv1dDesc(32, 256, 64, 125, 125, 7, 1, 1, 1, 3, 3, 1, 0, 0.01, 0.01, X6)
+    for dsc in (enc3, dec2, lat1):
+        assert gen(dsc, 0) == 5 and gen(dsc, 1) != 5
+    # [half][32-row tile][k-step, padded to 8][piece][lane] of 16-byte units
+    assert lib.eben_conv1d_packed_floats(ctypes.byref(enc3), 0) == 1 * 8 * 128 * 3 * 64 * 4
+    assert lib.eben_conv1d_packed_floats(ctypes.byref(dec2), 0) == 2 * 4 * 16 * 3 * 64 * 4
+    grouped = EbenConv1dDesc(32, 128, 256, 999, 125, 16, 8, 1, 4, 7, 7, 1, 0, 1.0, 1.0, X6)
+    assert gen(grouped, 0) != 5                                          # groups stay with the tap-conv
     nslab, rs = ctypes.c_int(0), ctypes.c_int(0)
     assert lib.eben_conv1d_bwd_dw_workspace(ctypes.byref(melgan_l4), ctypes.byref(nslab), ctypes.byref(rs)) > 4 * 1024 * (256 * 41 + 1)
     assert rs.value == 256 * 41 + 1
