@@ -127,7 +127,8 @@ EBEN_API int eben_conv1d_pack_multi(const EbenPackJob* jobs, int n, void* stream
 /* which tap-conv kernel generation serves the forward (which=0) / input-gradient (which=1) pass of
  * this layer: 1 = tapconv.hip (16x16x4 tiles, any shape), 2 = tapconv2.hip (32x32x2 tiles, LDS-DMA
  * weight stream; deep reductions), 3 = thinconv.hip (VALU), 4 = tapconv3.hip (bf16 operands), 5 = gen_conv.hip (forward only: the
- * generator's strided / transposed / latent convs under EBEN_MATH_BF16X6, eben_generator.py:241-312).  The packed layouts differ;
+ * generator's strided / transposed / latent convs under EBEN_MATH_BF16X6, eben_generator.py:241-312), 6 = bigtap.hip (bundle layout only: the
+ * long reductions of melgan_discriminator.py:119-145 / eben_discriminator.py:118-140 as persistent whole-panel blocks).  The packed layouts differ;
  * pack / fwd / bwd_dx agree by construction. */
 EBEN_API int eben_conv1d_kernel_generation(const EbenConv1dDesc* d, int which);
 /* pack v (optionally scaled per dim-0 row: weight-norm) into the MFMA-friendly layouts */

@@ -300,7 +300,8 @@ def test_bundle_conv_forward(hip, name, math_name):
     wp32 = _pack(hip, d32, v, scale, 0)
     y32 = torch.empty((rows, spec.c_out, d.l_out), dtype=torch.float32, device=DEV)
     check(hip.eben_conv1d_fwd(ctypes.byref(d32), x.data_ptr(), wp32.data_ptr(), bias.data_ptr(), None, y32.data_ptr(), st), "conv1d_fwd")
-    if same:
+    # bundle-layout launches served by the persistent whole-panel kernel (generation 6) sum the channel chunks in another order
+    if same and hip.eben_conv1d_kernel_generation(ctypes.byref(d), 0) == hip.eben_conv1d_kernel_generation(ctypes.byref(d32), 0):
         hi = y.hi.permute(0, 1, 3, 2).reshape(rows, spec.c_out, d.l_out).float()
         assert torch.equal(hi, bf16_hi(y32))
         assert torch.equal(got, bf16_hi(y32) + bf16_hi(y32 - bf16_hi(y32)))
@@ -349,7 +350,7 @@ def test_bundle_conv_input_gradient(hip, name):
     dx32 = torch.empty((rows4, spec.c_in, length), dtype=torch.float32, device=DEV)
     check(hip.eben_conv1d_bwd_dx_fm(ctypes.byref(d32), g.data_ptr(), wp32.data_ptr(), a[half:].contiguous().data_ptr(), half, sums.data_ptr(), fm_gs, a.data_ptr(), 0.2,
                                     half, seg_map, dx32.data_ptr(), st), "conv1d_bwd_dx_fm")
-    if same and hip.eben_conv1d_kernel_generation(ctypes.byref(d32), 1) == 4:
+    if same and hip.eben_conv1d_kernel_generation(ctypes.byref(d32), 1) == 4 and hip.eben_conv1d_kernel_generation(ctypes.byref(d), 1) == 4:
         # same launch plan, same operands: the accumulators agree bit for bit; the epilogue's feature-matching arithmetic may be
         # contracted differently by the compiler in the two kernels (one ulp of fp32), so: hi + lo within 2^-15 of the fp32 output
         # everywhere, and identical on all but a handful of elements

@@ -144,6 +144,7 @@ int tap2_launch(const Canon& c, int dir, const TapIO& io, int reflect, hipStream
 
 // bf16-operand form of the second generation (tapconv3.hip): 32x32x16 bf16 MFMA, fp32 accumulate / storage
 int tap3_applicable(const Canon& c, int dir);
+int tap3_is_big(const Canon& c, int dir);
 size_t tap3_packed_floats(const Canon& c, int dir);
 int tap3_pack(const Canon& c, int dir, const float* w, const float* scale, float* wp, hipStream_t st);
 int tap3_pack_multi(const Canon* cs, const int* dirs, const float* const* ws, const float* const* scales, float* const* wps, int n, hipStream_t st);

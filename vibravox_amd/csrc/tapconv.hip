@@ -692,7 +692,9 @@ extern "C" int eben_conv1d_kernel_generation(const EbenConv1dDesc* d, int which)
   Canon c;
   if (canon_from_desc(d, &c) != EBEN_OK) return 0;
   if (which == 0 && gc_applicable(c, d->transposed ? 1 : 0)) return 5;
-  return tap_generation(c, d->transposed ? 1 - which : which);
+  const int dir = d->transposed ? 1 - which : which;
+  const int gen = tap_generation(c, dir);
+  return gen == 4 && tap3_is_big(c, dir) ? 6 : gen;
 }
 
 extern "C" int eben_conv1d_pack(const EbenConv1dDesc* d, const float* v, const float* scale, float* wp_fwd, float* wp_bwd, void* stream) {

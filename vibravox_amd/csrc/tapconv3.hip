@@ -16,6 +16,7 @@
 //   * the per-layer k-step table (scalar cache), phase geometry, double / triple-buffered input tiles and the
 //     epilogue are the second generation's.
 #include "common.h"
+#include "tap3.h"
 
 #include <cstdlib>
 
@@ -25,7 +26,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
   const f32x2 v = {a, b};
@@ -93,37 +93,6 @@ template <int N> __device__ __forceinline__ void t3_wait_vm() {   // s_waitcnt v
   __builtin_amdgcn_s_waitcnt((N & 15) | ((N >> 4) << 14) | 0x70);
 }
 
-struct Tap3Args {
-  const float* x; const float* xmask; const u32x4* wp; const int* tab;
-  const float* bias; const float* res; const float* emask; float* y;
-  int B, G, Cg, Mg, Cx, Cy, Lx, Ly;
-  int S, OS, dstep, J0, mode, off0, nt, nph;
-  int ps_pad, ps_k, ps_d, ps_kstep;
-  int reflect, accumulate, in_mode;   // in_mode 1: the input is multiplied by lrelu'(xmask) as it is staged (autograd's mask-on-load)
-  int res_rows, em_seg, em_map[4];
-  const float* fm_sums; float fm_gs;
-  float in_slope, out_slope, res_slope, emask_slope;
-  int CI_T, CI_B, CP, ncc, PLEN, CSTRIDE, nxb;   // CI_T channels = CI_B bundles per input tile; CP = CI_B / 2 k-steps per tap
-  unsigned s_magic;
-  int ntt, nmt, tab_phase;
-  long long w_tile, w_phase;                     // in 16-byte units
-  // host-side arithmetic of the block prologue (integer divisions are ~40 instructions each on the device, the 64-bit one
-  // behind span_magic ~150): the block-id decomposition by multiply-high, and the per-phase tap geometry for up to 8 phases
-  // bundle layout (BL: bf16 [batch][channels / 8][length][8] planes hi = bf16(v), lo = bf16(v - hi); template flag BL): the input
-  // planes (xl: split input, NPX = 2), the output planes (yl nullable), the saved activation the epilogue reads its mask /
-  // feature-matching operands from (eh / el; the reference rows of a feature-matching pair start bl_ref_off batch rows further)
-  const u32x4* xh; const u32x4* xl;
-  uint2* yh; uint2* yl;
-  const uint2* eh; const uint2* el;
-  int CBx, CBy, bl_ref_off, bl_pad;
-  // phases as rows (TapIO.pr_S): the logical output rows of group g are (phase, channel of the group) and land in the PHYSICAL planes
-  // [row][pr_CB][pr_Ly][8] at bundle g pr_cbg + (logical bundle % pr_cbg), position t pr_S + logical bundle / pr_cbg
-  int pr_S, pr_cbg, pr_Ly, pr_pad;
-  unsigned xq, xr;                               // gridDim.x / 8, gridDim.x % 8 (xcd_remap)
-  unsigned m_nph, m_ntt, m_B, m_nmt;             // ceil(2^32 / d); valid when id_fast
-  int id_fast, pg_n;
-  struct PG { int J, off0, minoff, nt, oo, span; unsigned span_magic; int pad; } pg[8];
-};
 
 // NPX / NPW: pieces per operand.  The input operand is staged as NPX bf16 tiles, piece q = bf16(x - p0 - .. - p(q-1)) (every
 // residual exact in fp32), the weights arrive as NPW pieces from the pack kernel, and a k-step issues the piece products
@@ -789,23 +758,81 @@ __global__ __launch_bounds__(256, NPW >= 2 ? ((EBEN_T3_SPLIT_OCC2 && FM <= 2) ? 
 // ---------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------
-struct Tap3Plan {
-  int ok;
-  int mode, G, Cg, Mg, S, OS, dstep, kstep, nph, J, Lx, Ly, Cx, Cy, off0, nt, ps_pad;
-  int FM, BM, BN, WCHU;
-  int dense;   // groups folded into ONE block-diagonal contraction (layers with a handful of channels per group)
-  int npw, npx, KSC;   // pieces per weight / per input element (tap3_kernel), k-steps per weight chunk
-  int CI_T, CI_B, CP, ncc, PLEN, CSTRIDE, nxbuf, XRB;
-  int nmt, ntt, NCH, tab_phase;
-  long long w_tile, w_phase, tab_off_floats;
-  size_t packed_floats, lds_bytes;
-};
 
 static int gcd3(int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a; }
 
 static int env_int3(const char* name, int dflt) {
   const char* s = getenv(name);
   return s ? atoi(s) : dflt;
+}
+
+// tap4_kernel (bigtap.hip) for the long reductions of the bundle layout: whole weight panels (up to 256 rows) per block, four waves with
+// TM x TN MFMA tiles each, the input of one channel chunk (CI_T channels, all stride phases, BN columns + halo) double-buffered, the
+// weights in a ring of RING chunks of KSC k-steps.  Needs: groups of whole 16-channel k-steps, an even number of channel chunks (the
+// k-step table alternates two input buffers and a block runs tile after tile), channel chunks of at least (RING + 1) weight chunks (the
+// DMA of an input tile is covered by the wait for the weight chunk issued after it).
+static bool plan_big(const Canon& c, int dir, int Jmin, Tap3Plan* p) {
+  static const int enabled = env_int3("EBEN_BIG", 1);
+  static const int min_ks = env_int3("EBEN_BIG_MIN_KS", 100);     // MFMA k-steps of one output tile (x 3 for hi + lo operands)
+  static const int min_ks_dx = env_int3("EBEN_BIG_MIN_KS_DX", 100);
+  // [MI355X] the phase-scatter input gradients of the STRIDED layers (one output phase per tile: 8-byte stores 64 bytes apart, the mask
+  // read the same way) lose here against tap3's many small blocks -- MelGAN L3 / L4 0.416 / 0.402 -> 0.506 / 0.444 ms: the epilogue's
+  // partial lines are what a block per CU cannot hide; they stay with tap3 until they run phases-as-rows
+  static const int strided_dx = env_int3("EBEN_BIG_STRIDED_DX", 0);
+  if (!enabled || !c.bl || p->dense || c.reflect) return false;
+  if (dir == 1 && p->OS > 1 && !strided_dx) return false;
+  if (p->npw != p->npx || p->npw > 2 || p->nph > 8 || (p->Cg & 15) || (p->Mg & 31)) return false;
+  const long long ks_total = (long long)(p->Cg / 16) * p->J * (p->npw == 2 ? 3 : 1);
+  if (ks_total < (dir == 0 ? min_ks : min_ks_dx)) return false;
+  int WM, WN, TM, TN;
+  if (p->Mg % 256 == 0) { WM = 2; WN = 2; TM = 4; TN = 2; }
+  else if (p->Mg % 192 == 0) { WM = 2; WN = 2; TM = 3; TN = 2; }
+  else if (p->Mg == 128) { WM = 2; WN = 2; TM = 2; TN = 2; }
+  else if (p->Mg == 96) { WM = 1; WN = 4; TM = 3; TN = p->npw == 1 ? 2 : 1; }
+  else if (p->Mg == 64) { WM = 1; WN = 4; TM = 2; TN = 2; }
+  else return false;
+  if (p->npw == 2 && !(WM == 2 && TN == 2 && TM >= 3)) return false;   // instantiated: 192- and 256-row panels
+  const int KSC = p->npw == 1 ? 4 : 2, RING = 3;
+  p->BM = WM * TM * 32; p->FM = WM * TM; p->BN = WN * TN * 32;
+  p->KSC = KSC;
+  p->WCHU = KSC * p->npw * p->FM * 64;
+  p->nmt = p->Mg / p->BM;
+  p->ntt = ceil_div(p->nt, p->BN);
+  const int adstep = p->dstep >= 0 ? p->dstep : -p->dstep;
+  const int maxd = ((p->J - 1) * adstep) / p->S + 1;
+  p->PLEN = p->BN + maxd + 1;
+  p->CSTRIDE = p->S * p->PLEN;
+  const int wbytes = RING * p->WCHU * 16;
+  int best = 0;
+  for (int ct = 16; ct <= p->Cg / 2; ct += 16) {
+    if (p->Cg % ct) continue;
+    const int ncc = p->Cg / ct;
+    if (ncc & 1) continue;
+    if (Jmin * (ct / 16) < (RING + 1) * KSC) continue;
+    const int ppt = ceil_div((ct / 8) * p->CSTRIDE, 64);
+    if (ppt < 4 || ceil_div(ppt, 4) > 8) continue;
+    if ((size_t)wbytes + (size_t)2 * p->npw * ppt * 64 * 16 + 2048 > 160 * 1024) continue;
+    best = ct;
+    break;
+  }
+  if (!best) return false;
+  p->CI_T = best; p->CI_B = best / 8; p->CP = best / 16; p->ncc = p->Cg / best; p->nxbuf = 2; p->XRB = 0;
+  p->PPT = ceil_div(p->CI_B * p->CSTRIDE, 64);
+  p->XT = p->PPT * 64;
+  p->xbuf_stride = p->npw * p->XT;
+  const int KSmax = p->ncc * p->J * p->CP;
+  p->NCH = ceil_div(KSmax, KSC);
+  if (p->NCH < RING) return false;
+  p->tab_phase = p->NCH * KSC;
+  p->w_tile = (long long)p->NCH * p->WCHU;
+  p->w_phase = p->w_tile * p->nmt * p->G;
+  p->tab_off_floats = p->w_phase * p->nph * 4;
+  p->packed_floats = (size_t)p->tab_off_floats + (size_t)p->tab_phase * p->nph;
+  p->lds_bytes = (size_t)wbytes + (size_t)2 * p->npw * p->XT * 16 + 2048;
+  p->WM = WM; p->WN = WN; p->TM = TM; p->TN = TN; p->RING = RING;
+  p->big = 1;
+  p->ok = 1;
+  return true;
 }
 
 static void make_plan3(const Canon& c, int dir, Tap3Plan* p) {
@@ -858,6 +885,8 @@ static void make_plan3(const Canon& c, int dir, Tap3Plan* p) {
   // reduction of at least two weight chunks
   if (!enabled || p->Cg < min_c || p->Mg < min_m || p->nph > 64 || (long long)round_up(p->Cg, 16) * p->J < min_k) return;
   const int Jmin = dir == 0 ? p->J : (c.k / p->kstep > 0 ? c.k / p->kstep : 1);
+  p->big = 0; p->WM = p->WN = p->TM = p->TN = p->RING = p->XT = p->PPT = 0;
+  if (plan_big(c, dir, Jmin, p)) return;
 
   const int cand[4] = {128, 96, 64, 32};
   const double eff[4] = {1.0, 0.9, 0.8, 0.5};
@@ -939,6 +968,7 @@ static void make_plan3(const Canon& c, int dir, Tap3Plan* p) {
   if (!sized) return;
   p->CI_B = p->CI_T / 8;
   p->CP = p->CI_T / 16;
+  p->xbuf_stride = p->CI_B * p->CSTRIDE;
   const int KSmax = p->ncc * p->J * p->CP;
   p->NCH = ceil_div(KSmax, p->KSC);
   p->tab_phase = p->NCH * p->KSC;
@@ -956,7 +986,7 @@ struct Pack3Args {
   const float* w; const float* scale; float* wp;
   int G, Cg, Mg, nmt, BM, FM, WCHU, CI_T, CI_B, CP, ncc, NCH, nph, tab_phase;
   int mode, J0, off0, nt, dstep, OS, S, ps_pad, k, d, kstep, Ly;
-  int Cin_g, Cout_g, PLEN, CSTRIDE, nxbuf, dense, NPW, KSC;
+  int Cin_g, Cout_g, PLEN, CSTRIDE, nxbuf, dense, NPW, KSC, xbuf_stride;
   long long w_tile, w_phase, wunits;
   // host-side arithmetic of the unit decomposition: ceil(2^32 / d) per divisor (0: d == 1), the tap geometry of every phase
   unsigned m_nmt, m_fm, m_npw, m_cp, m_coutg;
@@ -1049,7 +1079,7 @@ __device__ __forceinline__ void pack3_body(const Pack3Args& P, unsigned bid, uns
         const int j = rem / P.CP, cp = rem - j * P.CP;
         const int rel = q.off0 + j * P.dstep - q.minoff;
         const int dd = rel / P.S, pp = rel - dd * P.S;
-        o = (P.nxbuf > 1 ? (cc % P.nxbuf) * P.CI_B * P.CSTRIDE : 0) + 2 * cp * P.CSTRIDE + pp * P.PLEN + dd;
+        o = (P.nxbuf > 1 ? (cc % P.nxbuf) * P.xbuf_stride : 0) + 2 * cp * P.CSTRIDE + pp * P.PLEN + dd;
       }
       reinterpret_cast<int*>(P.wp)[P.wunits * 4 + r] = o;
     }
@@ -1154,7 +1184,7 @@ __device__ __forceinline__ void pack3_tables(const Pack3Args& P) {
       const int j = rem / P.CP, cp = rem - j * P.CP;
       const int rel = q.off0 + j * P.dstep - q.minoff;
       const int dd = rel / P.S, pp = rel - dd * P.S;
-      o = (P.nxbuf > 1 ? (cc % P.nxbuf) * P.CI_B * P.CSTRIDE : 0) + 2 * cp * P.CSTRIDE + pp * P.PLEN + dd;
+      o = (P.nxbuf > 1 ? (cc % P.nxbuf) * P.xbuf_stride : 0) + 2 * cp * P.CSTRIDE + pp * P.PLEN + dd;
     }
     reinterpret_cast<int*>(P.wp)[P.wunits * 4 + r] = o;
   }
@@ -1211,6 +1241,12 @@ int tap3_applicable(const Canon& c, int dir) {
   return p.ok;
 }
 
+int tap3_is_big(const Canon& c, int dir) {   // served by tap4_kernel (bigtap.hip): kernel generation 6
+  Tap3Plan p;
+  make_plan3(c, dir, &p);
+  return p.ok && p.big;
+}
+
 size_t tap3_packed_floats(const Canon& c, int dir) {
   Tap3Plan p;
   make_plan3(c, dir, &p);
@@ -1228,7 +1264,7 @@ static int tap3_pack_args(const Canon& c, int dir, const float* w, const float* 
   a.mode = p.mode; a.J0 = p.J; a.off0 = p.off0; a.nt = p.nt; a.dstep = p.dstep; a.OS = p.OS; a.S = p.S; a.ps_pad = p.ps_pad;
   a.k = c.k; a.d = c.d; a.kstep = p.kstep; a.Ly = p.Ly;
   a.Cin_g = c.Cin / c.g; a.Cout_g = c.Cout / c.g; a.PLEN = p.PLEN; a.CSTRIDE = p.CSTRIDE; a.nxbuf = p.nxbuf; a.dense = p.dense;
-  a.NPW = p.npw; a.KSC = p.KSC;
+  a.NPW = p.npw; a.KSC = p.KSC; a.xbuf_stride = p.xbuf_stride;
   a.w_tile = p.w_tile; a.w_phase = p.w_phase; a.wunits = p.w_phase * p.nph;
   long long blocks = (a.wunits + (long long)p.tab_phase * p.nph + 255) / 256;
   if (blocks > 8192) blocks = 8192;
@@ -1343,6 +1379,9 @@ int tap3_launch(const Canon& c, int dir, const TapIO& io, int reflect, hipStream
   a.w_tile = p.w_tile; a.w_phase = p.w_phase;
   const long long nb = (long long)p.ntt * c.B * p.nph * p.nmt * p.G;
   if (nb <= 0 || nb > 0x7fffffffLL) return fail(EBEN_EINVAL, "tap3 grid of %lld blocks", nb);
+  a.big_XT = p.XT; a.big_PPT = p.PPT; a.big_tiles = (int)nb;
+  a.m_cstride = (unsigned)((0x100000000ull + (unsigned)p.CSTRIDE - 1) / (unsigned)p.CSTRIDE);
+  a.m_plen = p.S > 1 ? (unsigned)((0x100000000ull + (unsigned)p.PLEN - 1) / (unsigned)p.PLEN) : 0u;
   a.xq = (unsigned)(nb / 8); a.xr = (unsigned)(nb % 8);
   {
     auto magic = [](int d) { return (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); };
@@ -1365,6 +1404,10 @@ int tap3_launch(const Canon& c, int dir, const TapIO& io, int reflect, hipStream
       a.pg[ph].span_magic = a.pg[ph].span > 0 ? magic(a.pg[ph].span) : 0u;
       a.pg[ph].pad = 0;
     }
+  }
+  if (p.big) {
+    if (p.nph > 8) return fail(EBEN_EUNSUPPORTED, "tap4: more than 8 output phases");
+    return tap4_launch(p, a, st);
   }
 #define EBEN_T3_CASE(FMV)                                                          \
   switch (p.XRB) {                                                                 \
