@@ -366,6 +366,10 @@ PR_LAYERS = {
     # lengths that are not a multiple of the stride (the last positions exist for some phases only), one more / one fewer output than S q
     "melgan_l1_ragged": (dict(c_in=16, c_out=64, ksize=41, stride=4, pad_l=20, pad_r=20, groups=4, out_slope=0.2), 4, 2103, False),
     "melgan_l2_ragged": (dict(c_in=64, c_out=256, ksize=41, stride=4, pad_l=20, pad_r=20, groups=4, out_slope=0.2), 2, 1097, True),
+    # the wide layers: rows ordered (channel bundle, phase, channel in bundle) on the persistent whole-panel kernel (generation 6), whole
+    # 64-byte position groups per lane pair -- lengths that end inside a group of four, one and four row tiles per group
+    "melgan_l3_wide": (dict(c_in=256, c_out=1024, ksize=41, stride=4, pad_l=20, pad_r=20, groups=4, out_slope=0.2), 2, 1030, True),
+    "melgan_l4_wide": (dict(c_in=1024, c_out=1024, ksize=41, stride=4, pad_l=20, pad_r=20, groups=4, out_slope=0.2), 4, 301, True),
     "stride8_k16": (dict(c_in=8, c_out=64, ksize=16, stride=8, pad_l=7, pad_r=7, groups=1, out_slope=0.2), 2, 1001, True),
     "stride4_g2": (dict(c_in=32, c_out=128, ksize=23, stride=4, pad_l=11, pad_r=11, groups=2, out_slope=0.2), 2, 777, True),
     # stride 2 and dilated (the PQMF-band layers): taken only under EBEN_PR_MIN_STRIDE=2 EBEN_PR_MAX_DIL=3 EBEN_PR_MAX_ROWS=256 (off by
@@ -443,7 +447,7 @@ def test_phases_as_rows_declines_what_it_does_not_cover(hip):
     for kw in (dict(c_in=96, c_out=192, ksize=7, stride=2, dilation=2, pad_l=3, pad_r=3, groups=4),     # dilated
                dict(c_in=768, c_out=768, ksize=5, stride=1, pad_l=2, pad_r=2, groups=4),                # not strided
                dict(c_in=12, c_out=64, ksize=41, stride=4, pad_l=20, pad_r=20, groups=4),               # channels not in bundles
-               dict(c_in=256, c_out=1024, ksize=41, stride=4, pad_l=20, pad_r=20, groups=4)):           # full row tiles either way: phase-scatter is faster
+               dict(c_in=256, c_out=1024, ksize=16, stride=8, pad_l=7, pad_r=7, groups=4)):             # wide layers (full row tiles either way) at stride 4 only
         d = ops.conv_desc(ops.ConvSpec(**kw), 4, 400, ops.MATH_BF16 | BL)
         assert hip.eben_bl_dx_pr_desc(ctypes.byref(d), ctypes.byref(dq)) != 0
     d = ops.conv_desc(ops.ConvSpec(c_in=64, c_out=256, ksize=41, stride=4, pad_l=20, pad_r=20, groups=4), 4, 400, ops.MATH_BF16)   # fp32 at rest

@@ -63,6 +63,12 @@ template <int N> __device__ __forceinline__ void t4_wait_vm() {
 }
 __device__ __forceinline__ void t4_barrier() { asm volatile("s_barrier" ::: "memory"); }
 
+// v_permlane32_swap: x's lanes 32-63 <-> y's lanes 0-31
+__device__ __forceinline__ void t4_swap32(unsigned& x, unsigned& y) {
+  const auto r = __builtin_amdgcn_permlane32_swap(x, y, false, false);
+  x = r[0]; y = r[1];
+}
+
 constexpr int T4_MAXP = 8;   // LDS-DMA pieces per wave and input tile piece
 
 struct T4Tile {
@@ -331,6 +337,123 @@ __global__ __launch_bounds__(512) void tap4_kernel(const Tap3Args P) {
       f[0] = __builtin_bit_cast(float, w.x << 16); f[1] = __builtin_bit_cast(float, w.x & 0xffff0000u);
       f[2] = __builtin_bit_cast(float, w.y << 16); f[3] = __builtin_bit_cast(float, w.y & 0xffff0000u);
     };
+    if (P.pr_S > 0) {
+      // ---- phases as rows, rows ordered (channel bundle, phase, channel in bundle), stride 4 (eben_bl_conv1d_bwd_dx_pr): accumulator tile
+      // i of this wave IS bundle cb0 + i of the group at the four phases of the tile's columns -- row quad r4 = phase r4 -- i.e. the
+      // 64 contiguous bytes of positions 4 t .. 4 t + 3.  The MFMA layout gives lane (t, half h) the half units of all four phases; one
+      // v_permlane32_swap per dword turns that into whole units: lane (t, 0) positions 4 t, 4 t + 1, lane (t, 1) positions 4 t + 2,
+      // 4 t + 3 -- 32 contiguous bytes per lane, two 16-byte accesses where the phase-scatter form makes four of 8 bytes 64 bytes apart
+      // (mask and feature-matching operands come in the same way and are swapped back).
+      const long long LrowP = (long long)P.pr_Ly * 16;
+      const int cb0 = (T.mt * BM + wm * TM * 32) >> 5;
+      const long long tileP = (long long)(T.g * P.pr_cbg + cb0) * LrowP;
+      const char* ehp = reinterpret_cast<const char*>(P.eh) + (long long)eb * P.CBy * LrowP + tileP;
+      const char* elp = reinterpret_cast<const char*>(P.el) + (long long)eb * P.CBy * LrowP + tileP;
+      const char* rhp = reinterpret_cast<const char*>(P.eh) + (long long)(b + P.bl_ref_off) * P.CBy * LrowP + tileP;
+      const char* rlp = reinterpret_cast<const char*>(P.el) + (long long)(b + P.bl_ref_off) * P.CBy * LrowP + tileP;
+      char* yhp = reinterpret_cast<char*>(P.yh) + (long long)b * P.CBy * LrowP + tileP;
+      char* ylp = reinterpret_cast<char*>(P.yl) + (long long)b * P.CBy * LrowP + tileP;
+      unsigned poff[TN];
+      bool lv[TN][2];
+#pragma unroll
+      for (int f = 0; f < TN; ++f) {
+        const int t = T.t0 + (wn * TN + f) * 32 + (lane & 31);
+        const int pos0 = 4 * t + 2 * hb;
+        lv[f][0] = t < T.nt && pos0 < P.pr_Ly;
+        lv[f][1] = t < T.nt && pos0 + 1 < P.pr_Ly;
+        poff[f] = (unsigned)(lv[f][0] ? pos0 : 0) * 16u;
+      }
+      // memory layout (two whole units per lane) <-> MFMA layout (four half units per lane)
+      auto to_halves = [&](const u32x4 (&U)[2], uint2 (&H)[4]) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          unsigned x0 = U[j][0], x1 = U[j][1], y0 = U[j][2], y1 = U[j][3];
+          t4_swap32(x0, y0); t4_swap32(x1, y1);
+          H[j].x = x0; H[j].y = x1; H[2 + j].x = y0; H[2 + j].y = y1;
+        }
+      };
+      auto to_units = [&](const uint2 (&H)[4], u32x4 (&U)[2]) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          unsigned x0 = H[j].x, x1 = H[j].y, y0 = H[2 + j].x, y1 = H[2 + j].y;
+          t4_swap32(x0, y0); t4_swap32(x1, y1);
+          U[j] = u32x4{x0, x1, y0, y1};
+        }
+      };
+      auto ldu = [&](const char* base, int i, int f, u32x4 (&U)[2]) {
+        const char* q = base + (long long)i * LrowP + poff[f];
+        U[0] = *reinterpret_cast<const u32x4*>(q);
+        U[1] = *reinterpret_cast<const u32x4*>(q + (lv[f][1] ? 16 : 0));
+      };
+      auto stu = [&](int i, int f, const uint2 (&H)[4], char* base) {
+        u32x4 U[2];
+        to_units(H, U);
+        char* q = base + (long long)i * LrowP + poff[f];
+        if (lv[f][0]) *reinterpret_cast<u32x4*>(q) = U[0];
+        if (lv[f][1]) *reinterpret_cast<u32x4*>(q + 16) = U[1];
+      };
+      auto quad = [&](int i, int f, int r4, bool has_a, bool has_fm, const uint2 (&a_h)[4], const uint2 (&a_l)[4], const uint2 (&r_h)[4], const uint2 (&r_l)[4], uint2& oh_, uint2& ol_) {
+        float v[4], a0[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[i][f][4 * r4 + e];
+        if (has_a) {
+          unpack(a_h[r4], a0);
+          if (has_fm) {
+            float a1[4], r0[4], r1[4];
+            unpack(a_l[r4], a1); unpack(r_h[r4], r0); unpack(r_l[r4], r1);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float av = a0[e] + a1[e], dv = av - (r0[e] + r1[e]);
+              v[e] += fk1 * (float)((dv > 0.f) - (dv < 0.f)) - fk2 * (float)((av > 0.f) - (av < 0.f));
+            }
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] *= dlrelu(a0[e], P.emask_slope);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = lrelu(v[e], P.out_slope);
+        }
+        oh_.x = t4_pack(v[0], v[1]); oh_.y = t4_pack(v[2], v[3]);
+        float hf[4];
+        unpack(oh_, hf);
+        ol_.x = t4_pack(v[0] - hf[0], v[1] - hf[1]); ol_.y = t4_pack(v[2] - hf[2], v[3] - hf[3]);
+      };
+      if (masked && !fmr) {
+        u32x4 AU[TN][TM][2];
+#pragma unroll
+        for (int f = 0; f < TN; ++f)
+#pragma unroll
+          for (int i = 0; i < TM; ++i) ldu(ehp, i, f, AU[f][i]);
+#pragma unroll
+        for (int f = 0; f < TN; ++f)
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            uint2 AH[4], OH[4], OL[4];
+            to_halves(AU[f][i], AH);
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) quad(i, f, r4, true, false, AH, AH, AH, AH, OH[r4], OL[r4]);
+            stu(i, f, OH, yhp);
+            if (P.yl) stu(i, f, OL, ylp);
+          }
+      } else {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int f = 0; f < TN; ++f) {
+            uint2 AH[4], AL[4], RH[4], RL[4], OH[4], OL[4];
+            if (masked) {
+              u32x4 AU[2], LU[2], RHU[2], RLU[2];
+              ldu(ehp, i, f, AU); ldu(elp, i, f, LU); ldu(rhp, i, f, RHU); ldu(rlp, i, f, RLU);
+              to_halves(AU, AH); to_halves(LU, AL); to_halves(RHU, RH); to_halves(RLU, RL);
+            }
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) quad(i, f, r4, masked, masked, AH, AL, RH, RL, OH[r4], OL[r4]);
+            stu(i, f, OH, yhp);
+            if (P.yl) stu(i, f, OL, ylp);
+          }
+      }
+      return;
+    }
     // Loads before stores: with loads and stores both in flight hipcc waits vmcnt(0) for any load result (the two return out of order),
     // i.e. for every store issued so far -- written group by group ((loads, arithmetic, stores) x 8) a tile's epilogue drained its
     // stores eight times (MelGAN L4 input gradients 0.40 -> 0.52 ms).  Forward tiles have no loads: value by value.  Masked tiles: every
@@ -540,7 +663,8 @@ static int launch4(const Tap3Plan& p, const Tap3Args& a, hipStream_t st) {
 }
 
 int tap4_launch(const Tap3Plan& p, const Tap3Args& a, hipStream_t st) {
-  if (a.pr_S > 0 || a.in_mode || !a.xh) return fail(EBEN_EUNSUPPORTED, "tap4: bundle-layout launches without phases-as-rows output only");
+  if (a.in_mode || !a.xh) return fail(EBEN_EUNSUPPORTED, "tap4: bundle-layout launches only");
+  if (a.pr_S > 0 && (a.pr_S != 4 || a.pr_order != 1 || a.bias)) return fail(EBEN_EUNSUPPORTED, "tap4: phases as rows at stride 4 in bundle-major row order only");
   if (!a.id_fast || a.pg_n < a.nph) return fail(EBEN_EUNSUPPORTED, "tap4: grid beyond the tile decomposition's 32-bit arithmetic");
   if (a.bias && (reinterpret_cast<unsigned long long>(a.bias) & 15ull)) return fail(EBEN_EINVAL, "tap4: the bias vector must be 16-byte aligned");
   const int key = ((p.WM * 10 + p.WN) * 10 + p.TM) * 10 + p.TN;

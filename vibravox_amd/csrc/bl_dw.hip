@@ -41,7 +41,7 @@ struct BlDwArgs {
   int B, G, Mg, Cg, MgB, CgB, CBa, CBx, La, Lx;
   int S, d, k, pad, amin;
   int NQW;                       // weight column bundles (CgB * k); bundle NQW is the bias column
-  int has_bias, nnt, nmt, nsplit, nct, nchunks, XR;
+  int has_bias, nnt, nmt, nsplit, nct, nchunks, XR, xneed;   // xneed: units of an X row a chunk reads (64 time steps + the taps' reach)
   int dense, c_in_g, c_out_g, row_stride;
   long long slab_stride;
 };
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256, 2) void bl_dw_kernel(const BlDwArgs P) {
   for (int i = 0; i < AR; ++i) {
     int bundle = g * P.MgB + mt * BMB + wave + 4 * i;
     if (bundle > P.CBa - 1) bundle = P.CBa - 1;
-    arow[i] = (long long)bundle * P.La;
+    arow[i] = mt * BMB + wave + 4 * i < P.MgB ? (long long)bundle * P.La : -1;   // rows past the group's last: zeros (no traffic), never stored
   }
   auto issue = [&](int q, int bsel) {
     const int b = q / P.nct;
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256, 2) void bl_dw_kernel(const BlDwArgs P) {
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
       const int r = wave + 4 * i;
-      if (r < BMB) bl_dma_piece(a_ok ? ab + arow[i] + t0 + lane : zero, __builtin_amdgcn_readfirstlane(dst + (unsigned)(r * TS * 16)));
+      if (r < BMB) bl_dma_piece((a_ok && arow[i] >= 0) ? ab + arow[i] + t0 + lane : zero, __builtin_amdgcn_readfirstlane(dst + (unsigned)(r * TS * 16)));
     }
     const u32x4* xb = P.xh + ((long long)b * P.CBx + (long long)g * P.CgB) * P.Lx;
     for (int xr = wave; xr < xrows; xr += 4) {
@@ -168,8 +168,9 @@ __global__ __launch_bounds__(256, 2) void bl_dw_kernel(const BlDwArgs P) {
 #pragma unroll
       for (int piece = 0; piece < 2; ++piece) {
         // unit u of the row = position (t0 + amin + u) S + p; outside [0, Lx): the zero unit
+        // (units behind the taps' reach are never read: zeros instead of a second kilobyte of the row per chunk)
         const int pos = (t0 + P.amin + piece * 64 + lane) * P.S + p;
-        bl_dma_piece((pos >= 0 && pos < P.Lx) ? row + pos : zero, __builtin_amdgcn_readfirstlane(rdst + (unsigned)(piece * 64 * 16)));
+        bl_dma_piece((pos >= 0 && pos < P.Lx && piece * 64 + lane < P.xneed) ? row + pos : zero, __builtin_amdgcn_readfirstlane(rdst + (unsigned)(piece * 64 * 16)));
       }
     }
   };
@@ -344,6 +345,7 @@ extern "C" int eben_bl_conv1d_bwd_dw(const EbenConv1dDesc* d, const void* dy_hi,
   a.S = c.s; a.d = c.d; a.k = c.k; a.pad = c.pl; a.amin = p.amin; a.NQW = p.NQW; a.has_bias = has_bias ? 1 : 0;
   a.nnt = p.nnt; a.nmt = p.nmt; a.nsplit = p.nsplit; a.nct = p.nct; a.nchunks = p.nchunks; a.XR = p.XR;
   a.dense = p.dense; a.c_in_g = c.Cin / c.g; a.c_out_g = c.Cout / c.g; a.row_stride = p.row_stride; a.slab_stride = p.slab_stride;
+  a.xneed = BLDW_BKT + bldw_floordiv((c.k - 1) * c.d - c.pl, c.s) - p.amin + 1;
   hipStream_t st = as_stream(stream);
   if (p.FM == 2) return p.FN == 4 ? launch_bldw<2, 4>(a, p, st) : p.FN == 2 ? launch_bldw<2, 2>(a, p, st) : launch_bldw<2, 1>(a, p, st);
   return p.FN == 4 ? launch_bldw<1, 4>(a, p, st) : p.FN == 2 ? launch_bldw<1, 2>(a, p, st) : launch_bldw<1, 1>(a, p, st);

@@ -103,7 +103,7 @@ struct TapIO {
   const void* xh; const void* xl; void* yh; void* yl; const void* eh; const void* el; int bl_ref_off;
   // phases as rows (eben_bl_conv1d_bwd_dx_pr): the launch is the stride-1 gather form of a strided conv's input gradient whose output rows
   // are (phase, channel); they are stored depth-to-space into planes of pr_CBy bundles x pr_Ly positions per batch row (pr_cbg bundles per group)
-  int pr_S, pr_cbg, pr_Ly, pr_CBy;
+  int pr_S, pr_cbg, pr_Ly, pr_CBy, pr_order;   // pr_order 1: primed rows (channel bundle, phase, channel in bundle) -- tap4_kernel only
 };
 
 // Tap geometry of one output phase.  mode 0 (gather-strided): every block uses (J0, off0_gs, nt_gs).

@@ -32,7 +32,7 @@ struct Tap3Args {
   int CBx, CBy, bl_ref_off, bl_pad;
   // phases as rows (TapIO.pr_S): the logical output rows of group g are (phase, channel of the group) and land in the PHYSICAL planes
   // [row][pr_CB][pr_Ly][8] at bundle g pr_cbg + (logical bundle % pr_cbg), position t pr_S + logical bundle / pr_cbg
-  int pr_S, pr_cbg, pr_Ly, pr_pad;
+  int pr_S, pr_cbg, pr_Ly, pr_order;   // pr_order 1 (tap4_kernel): logical bundle = physical bundle * pr_S + phase
   unsigned xq, xr;                               // gridDim.x / 8, gridDim.x % 8 (xcd_remap)
   unsigned m_nph, m_ntt, m_B, m_nmt;             // ceil(2^32 / d); valid when id_fast
   int id_fast, pg_n;

@@ -922,7 +922,7 @@ static int bwd_dx_batched(const EbenConv1dDesc* d, const float* g, const float* 
 // once, full row tiles.  The primed weights W'[(ph, c)][co][u] are a gather of the layer's weights (pr_weights_kernel), packed as an
 // ordinary forward image of the primed layer; tap3's bundle epilogue maps logical bundle -> (physical bundle, phase) (Tap3Args.pr_*).
 namespace eben {
-struct PrGeom { int ok, S, umin, kq, Lq, fold, cbg; };
+struct PrGeom { int ok, S, umin, kq, Lq, fold, cbg, order; };   // order 1: rows (channel bundle, phase, channel in bundle) -- tap4_kernel's coalesced depth-to-space epilogue
 
 static int pr_floordiv(int a, int b) { int q = a / b; if ((a % b != 0) && ((a < 0) != (b < 0))) --q; return q; }
 
@@ -952,7 +952,16 @@ static PrGeom pr_geometry(const Canon& c, Canon* cp) {
   // 256 channels per group: 256 / 1024 primed rows, full row tiles in either form) 0.414 / 0.412 -> 0.531 / 0.524: the form is for the layers
   // whose phases leave row tiles empty
   static const int max_rows = getenv("EBEN_PR_MAX_ROWS") ? atoi(getenv("EBEN_PR_MAX_ROWS")) : 64;
-  if (q.Cout / q.g > max_rows) return g;
+  // Wider layers (MelGAN L3 / L4: 256 / 1024 primed rows per group) take the form on tap4_kernel (bigtap.hip) with the rows ordered
+  // (channel bundle, phase, channel in bundle): a 32-row MFMA tile is then ONE bundle at the four phases of a position, i.e. 64
+  // contiguous bytes per column -- the phase-scatter form writes (and reads its mask as) 8-byte pieces 64 bytes apart, which a
+  // block per CU cannot hide ([MI355X] phase-scatter on tap4: 0.416 / 0.402 -> 0.506 / 0.444 ms)
+  static const int big_pr = getenv("EBEN_PR_BIG") ? atoi(getenv("EBEN_PR_BIG")) : 1;
+  g.order = 0;
+  if (q.Cout / q.g > max_rows) {
+    if (!big_pr || g.fold || c.s != 4 || c.d != 1 || !tap3_is_big(q, 0)) return g;
+    g.order = 1;
+  }
   if (!tap3_applicable(q, 0)) return g;
   if (cp) *cp = q;
   g.ok = 1;
@@ -961,7 +970,7 @@ static PrGeom pr_geometry(const Canon& c, Canon* cp) {
 
 // W'[(g, ph, c)][co][ui] (groups kept) or [(ph, ci)][co][ui] (folded, zero across groups) = scale[co] v[co][c][ph + pad - S (ui + umin)]
 __global__ __launch_bounds__(256) void pr_weights_kernel(const float* __restrict__ v, const float* __restrict__ scale, float* __restrict__ wq,
-                                                          int Cin, int Cout, int G, int k, int S, int pad, int umin, int kq, int fold, int dil) {
+                                                          int Cin, int Cout, int G, int k, int S, int pad, int umin, int kq, int fold, int dil, int order) {
   const int Cg = Cin / G, Mg = Cout / G;
   const int cin_q = fold ? Cout : Mg;                      // input channels per group of the primed layer
   const long long total = (long long)S * Cin * cin_q * kq;
@@ -972,7 +981,11 @@ __global__ __launch_bounds__(256) void pr_weights_kernel(const float* __restrict
     const int row = (int)(r / cin_q);
     int ph, ci, co;
     if (fold) { ph = row / Cin; ci = row - ph * Cin; co = cq; }
-    else { const int g = row / (S * Cg), rr = row - g * S * Cg; ph = rr / Cg; ci = g * Cg + (rr - ph * Cg); co = g * Mg + cq; }
+    else if (order == 0) { const int g = row / (S * Cg), rr = row - g * S * Cg; ph = rr / Cg; ci = g * Cg + (rr - ph * Cg); co = g * Mg + cq; }
+    else {   // (group, channel bundle, phase, channel in bundle)
+      const int g = row / (S * Cg), rr = row - g * S * Cg, lb = rr >> 3, cb = lb / S;
+      ph = lb - cb * S; ci = g * Cg + cb * 8 + (rr & 7); co = g * Mg + cq;
+    }
     const int off = ph + pad - S * (ui + umin);              // = j dil for the tap this entry stands for, if any
     const int j = off / dil;
     float w = 0.f;
@@ -1009,7 +1022,7 @@ extern "C" int eben_bl_dx_pr_weights(const EbenConv1dDesc* d, const float* v, co
   long long blocks = (total + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(pr_weights_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), v, scale, w_primed, c.Cin, c.Cout, c.g, c.k, c.s, c.pl,
-                     g.umin, g.kq, g.fold, c.d);
+                     g.umin, g.kq, g.fold, c.d, g.order);
   EBEN_CHECK_LAUNCH("pr_weights_kernel");
   return EBEN_OK;
 }
@@ -1031,7 +1044,7 @@ extern "C" int eben_bl_conv1d_bwd_dx_pr(const EbenConv1dDesc* d, const void* g_h
   io.emask_slope = mask_slope; io.em_seg = act_hi ? seg : 0;
   for (int i = 0; i < 4; ++i) io.em_map[i] = (seg > 0 && seg_map) ? seg_map[i] : i;
   io.xh = g_hi; io.yh = dx_hi; io.yl = dx_lo; io.eh = act_hi; io.el = act_lo; io.bl_ref_off = ref_row_offset;
-  io.pr_S = g.S; io.pr_cbg = g.cbg; io.pr_Ly = c.Lin; io.pr_CBy = c.Cin / 8;
+  io.pr_S = g.S; io.pr_cbg = g.cbg; io.pr_Ly = c.Lin; io.pr_CBy = c.Cin / 8; io.pr_order = g.order;
   return tap3_launch(q, 0, io, 0, as_stream(stream));
 }
 

@@ -1351,7 +1351,7 @@ int tap3_launch(const Canon& c, int dir, const TapIO& io, int reflect, hipStream
   a.x = io.x; a.xmask = io.in_mode ? io.xmask : io.x; a.in_mode = io.in_mode; a.wp = reinterpret_cast<const u32x4*>(io.wp); a.tab = reinterpret_cast<const int*>(io.wp + p.tab_off_floats);
   a.bias = io.bias; a.res = io.res; a.emask = io.emask; a.y = io.y;
   a.xh = a.xl = nullptr; a.yh = a.yl = nullptr; a.eh = a.el = nullptr; a.CBx = a.CBy = a.bl_ref_off = a.bl_pad = 0;
-  a.pr_S = a.pr_cbg = a.pr_Ly = a.pr_pad = 0;
+  a.pr_S = a.pr_cbg = a.pr_Ly = a.pr_order = 0;
   if (c.bl) {
     if (!io.xh || !io.yh || (p.npx > 1 && !io.xl)) return fail(EBEN_EINVAL, "tap3: null bundle-layout plane");
     a.xh = static_cast<const u32x4*>(io.xh); a.xl = static_cast<const u32x4*>(io.xl);
@@ -1361,7 +1361,8 @@ int tap3_launch(const Canon& c, int dir, const TapIO& io, int reflect, hipStream
     a.x = nullptr; a.xmask = nullptr;
     if (io.pr_S > 0) {
       if (dir != 0 || p.S != 1 || p.nph != 1) return fail(EBEN_EINVAL, "tap3: phases-as-rows output on a launch that is not a stride-1 gather");
-      a.pr_S = io.pr_S; a.pr_cbg = io.pr_cbg; a.pr_Ly = io.pr_Ly; a.CBy = io.pr_CBy;
+      a.pr_S = io.pr_S; a.pr_cbg = io.pr_cbg; a.pr_Ly = io.pr_Ly; a.CBy = io.pr_CBy; a.pr_order = io.pr_order;
+      if ((io.pr_order != 0) != (p.big != 0)) return fail(EBEN_EINVAL, "tap3: phases-as-rows order %d on a launch plan that is%s tap4's", io.pr_order, p.big ? "" : " not");
     }
   } else if (io.xh) {
     return fail(EBEN_EINVAL, "tap3: bundle-layout planes on a descriptor without EBEN_LAYOUT_BL");
