@@ -957,11 +957,8 @@ static PrGeom pr_geometry(const Canon& c, Canon* cp) {
   // contiguous bytes per column -- the phase-scatter form writes (and reads its mask as) 8-byte pieces 64 bytes apart, which a
   // block per CU cannot hide ([MI355X] phase-scatter on tap4: 0.416 / 0.402 -> 0.506 / 0.444 ms)
   static const int big_pr = getenv("EBEN_PR_BIG") ? atoi(getenv("EBEN_PR_BIG")) : 1;
-  g.order = 0;
-  if (q.Cout / q.g > max_rows) {
-    if (!big_pr || g.fold || c.s != 4 || c.d != 1 || !tap3_is_big(q, 0)) return g;
-    g.order = 1;
-  }
+  g.order = (big_pr && c.s == 4 && c.d == 1 && tap3_is_big(q, 0)) ? 1 : 0;
+  if (q.Cout / q.g > max_rows && !g.order) return g;
   if (!tap3_applicable(q, 0)) return g;
   if (cp) *cp = q;
   g.ok = 1;
@@ -980,7 +977,8 @@ __global__ __launch_bounds__(256) void pr_weights_kernel(const float* __restrict
     const int cq = (int)(r % cin_q);
     const int row = (int)(r / cin_q);
     int ph, ci, co;
-    if (fold) { ph = row / Cin; ci = row - ph * Cin; co = cq; }
+    if (fold && order) { const int lb = row >> 3, cb = lb / S; ph = lb - cb * S; ci = cb * 8 + (row & 7); co = cq; }
+    else if (fold) { ph = row / Cin; ci = row - ph * Cin; co = cq; }
     else if (order == 0) { const int g = row / (S * Cg), rr = row - g * S * Cg; ph = rr / Cg; ci = g * Cg + (rr - ph * Cg); co = g * Mg + cq; }
     else {   // (group, channel bundle, phase, channel in bundle)
       const int g = row / (S * Cg), rr = row - g * S * Cg, lb = rr >> 3, cb = lb / S;

@@ -773,66 +773,89 @@ static int env_int3(const char* name, int dflt) {
 // DMA of an input tile is covered by the wait for the weight chunk issued after it).
 static bool plan_big(const Canon& c, int dir, int Jmin, Tap3Plan* p) {
   static const int enabled = env_int3("EBEN_BIG", 1);
-  static const int min_ks = env_int3("EBEN_BIG_MIN_KS", 100);     // MFMA k-steps of one output tile (x 3 for hi + lo operands)
-  static const int min_ks_dx = env_int3("EBEN_BIG_MIN_KS_DX", 100);
-  // [MI355X] the phase-scatter input gradients of the STRIDED layers (one output phase per tile: 8-byte stores 64 bytes apart, the mask
+  // thin layers too (EBEN_BIG_THIN): panels that end inside a row tile, groups padded to whole k-steps, all channels in ONE input tile
+  // that alternates between the two buffers from tile to tile -- HBM-bound streams for which a producer wave per SIMD keeps the next
+  // tile in flight while the consumers multiply and store
+  // [MI355X, 64 / 128 rows] measured and NOT kept as the default: PQMF-band L1-L4 forward 0.040 -> 0.041-0.048 ms, their phase-scatter
+  // input gradients 0.053-0.087 -> 0.093-0.126, MelGAN L1 / L2 phases-as-rows 0.232 / 0.212 -> 0.223 / 0.220 -- these launches are not
+  // streams waiting for bytes: padded to 64 rows x whole k-steps (and block-diagonal over the groups where a group is narrower than
+  // a bundle) they carry 2-4x their MFMAs, and four consumer waves per CU issue them slower than tap3's eight to twenty
+  static const int thin = env_int3("EBEN_BIG_THIN", 0);
+  static const int min_ks = env_int3("EBEN_BIG_MIN_KS", thin ? 0 : 100);     // MFMA k-steps of one output tile (x 3 for hi + lo operands)
+  static const int min_ks_dx = env_int3("EBEN_BIG_MIN_KS_DX", thin ? 0 : 100);
+  // [MI355X] the phase-scatter input gradients of the stride-4 layers (one output phase per tile: 8-byte stores 64 bytes apart, the mask
   // read the same way) lose here against tap3's many small blocks -- MelGAN L3 / L4 0.416 / 0.402 -> 0.506 / 0.444 ms: the epilogue's
-  // partial lines are what a block per CU cannot hide; they stay with tap3 until they run phases-as-rows
-  static const int strided_dx = env_int3("EBEN_BIG_STRIDED_DX", 0);
-  if (!enabled || !c.bl || p->dense || c.reflect) return false;
-  if (dir == 1 && p->OS > 1 && !strided_dx) return false;
-  if (p->npw != p->npx || p->npw > 2 || p->nph > 8 || (p->Cg & 15) || (p->Mg & 31)) return false;
-  const long long ks_total = (long long)(p->Cg / 16) * p->J * (p->npw == 2 ? 3 : 1);
+  // partial lines are what a block per CU cannot hide; they run phases-as-rows (eben_bl_conv1d_bwd_dx_pr) or stay with tap3
+  static const int strided_dx = env_int3("EBEN_BIG_STRIDED_DX", thin ? 2 : 0);   // largest output stride taken in phase-scatter form
+  if (!enabled || !c.bl || c.reflect) return false;
+  if (p->dense && !thin) return false;
+  if (dir == 1 && p->OS > 1 && p->OS > strided_dx) return false;
+  if (p->npw != p->npx || p->npw > 2 || p->nph > 8 || (p->Cg & 7) || (p->Mg & 7)) return false;
+  if (!thin && ((p->Cg & 15) || (p->Mg & 31))) return false;
+  const int CgP = round_up(p->Cg, 16);
+  const long long ks_total = (long long)(CgP / 16) * p->J * (p->npw == 2 ? 3 : 1);
   if (ks_total < (dir == 0 ? min_ks : min_ks_dx)) return false;
-  int WM, WN, TM, TN;
-  if (p->Mg % 256 == 0) { WM = 2; WN = 2; TM = 4; TN = 2; }
-  else if (p->Mg % 192 == 0) { WM = 2; WN = 2; TM = 3; TN = 2; }
-  else if (p->Mg == 128) { WM = 2; WN = 2; TM = 2; TN = 2; }
-  else if (p->Mg == 96) { WM = 1; WN = 4; TM = 3; TN = p->npw == 1 ? 2 : 1; }
-  else if (p->Mg == 64) { WM = 1; WN = 4; TM = 2; TN = 2; }
-  else return false;
-  if (p->npw == 2 && !(WM == 2 && TN == 2 && TM >= 3)) return false;   // instantiated: 192- and 256-row panels
+  int BM;
+  if (p->Mg % 256 == 0) BM = 256;
+  else if (p->Mg % 192 == 0) BM = 192;
+  else if (p->Mg % 128 == 0) BM = 128;
+  else if (p->Mg <= 64) BM = 64;
+  else if (p->Mg <= 96) BM = 96;
+  else if (p->Mg <= 128) BM = 128;
+  else if (p->Mg <= 192) BM = 192;
+  else BM = 256;
+  if (!thin && p->Mg % BM) return false;
+  const int WM = BM >= 128 ? 2 : 1, WN = 4 / WM, TM = BM / (32 * WM);
   const int KSC = p->npw == 1 ? 4 : 2, RING = 3;
-  p->BM = WM * TM * 32; p->FM = WM * TM; p->BN = WN * TN * 32;
-  p->KSC = KSC;
-  p->WCHU = KSC * p->npw * p->FM * 64;
-  p->nmt = p->Mg / p->BM;
-  p->ntt = ceil_div(p->nt, p->BN);
   const int adstep = p->dstep >= 0 ? p->dstep : -p->dstep;
   const int maxd = ((p->J - 1) * adstep) / p->S + 1;
-  p->PLEN = p->BN + maxd + 1;
-  p->CSTRIDE = p->S * p->PLEN;
-  const int wbytes = RING * p->WCHU * 16;
-  int best = 0;
-  for (int ct = 16; ct <= p->Cg / 2; ct += 16) {
-    if (p->Cg % ct) continue;
-    const int ncc = p->Cg / ct;
-    if (ncc & 1) continue;
-    if (Jmin * (ct / 16) < (RING + 1) * KSC) continue;
-    const int ppt = ceil_div((ct / 8) * p->CSTRIDE, 64);
-    if (ppt < 4 || ceil_div(ppt, 4) > 8) continue;
-    if ((size_t)wbytes + (size_t)2 * p->npw * ppt * 64 * 16 + 2048 > 160 * 1024) continue;
-    best = ct;
-    break;
+  for (int TN = 2; TN >= 1; --TN) {
+    if (TN == 1 && WN != 4) break;               // instantiated: 128- or 256-column tiles for the four-wave-wide grids, 128 otherwise
+    p->BM = BM; p->FM = WM * TM; p->BN = WN * TN * 32;
+    p->KSC = KSC;
+    p->WCHU = KSC * p->npw * p->FM * 64;
+    p->nmt = ceil_div(p->Mg, p->BM);
+    p->ntt = ceil_div(p->nt, p->BN);
+    p->PLEN = p->BN + maxd + 1;
+    p->CSTRIDE = p->S * p->PLEN;
+    const int wbytes = RING * p->WCHU * 16;
+    int best = 0, best_ncc = 0;
+    auto fits = [&](int ct, int ncc) {
+      const int ppt = ceil_div((ct / 8) * p->CSTRIDE, 64);
+      if (ppt < 4 || ceil_div(ppt, 4) > 12) return false;
+      return (size_t)wbytes + (size_t)2 * p->npw * ppt * 64 * 16 + 2048 <= 160 * 1024;
+    };
+    // all channels in one tile where that fits (thin layers) ...
+    if (thin && fits(CgP, 1) && ceil_div(Jmin * (CgP / 16), KSC) >= RING) { best = CgP; best_ncc = 1; }
+    // ... else an even number of chunks of at least RING + 1 weight chunks each
+    for (int ct = 16; !best && ct <= p->Cg / 2; ct += 16) {
+      if (p->Cg % ct) continue;
+      const int ncc = p->Cg / ct;
+      if (ncc & 1) continue;
+      if (Jmin * (ct / 16) < (RING + 1) * KSC) continue;
+      if (!fits(ct, ncc)) continue;
+      best = ct; best_ncc = ncc;
+    }
+    if (!best) continue;
+    p->CI_T = best; p->CI_B = best / 8; p->CP = best / 16; p->ncc = best_ncc; p->nxbuf = 2; p->XRB = 0;
+    p->PPT = ceil_div(p->CI_B * p->CSTRIDE, 64);
+    p->XT = p->PPT * 64;
+    p->xbuf_stride = p->npw * p->XT;
+    const int KSmax = p->ncc * p->J * p->CP;
+    p->NCH = ceil_div(KSmax, KSC);
+    if (p->NCH < RING) continue;
+    p->tab_phase = p->NCH * KSC;
+    p->w_tile = (long long)p->NCH * p->WCHU;
+    p->w_phase = p->w_tile * p->nmt * p->G;
+    p->tab_off_floats = p->w_phase * p->nph * 4;
+    p->packed_floats = (size_t)p->tab_off_floats + (size_t)p->tab_phase * p->nph;
+    p->lds_bytes = (size_t)wbytes + (size_t)2 * p->npw * p->XT * 16 + 2048;
+    p->WM = WM; p->WN = WN; p->TM = TM; p->TN = TN; p->RING = RING;
+    p->big = 1;
+    p->ok = 1;
+    return true;
   }
-  if (!best) return false;
-  p->CI_T = best; p->CI_B = best / 8; p->CP = best / 16; p->ncc = p->Cg / best; p->nxbuf = 2; p->XRB = 0;
-  p->PPT = ceil_div(p->CI_B * p->CSTRIDE, 64);
-  p->XT = p->PPT * 64;
-  p->xbuf_stride = p->npw * p->XT;
-  const int KSmax = p->ncc * p->J * p->CP;
-  p->NCH = ceil_div(KSmax, KSC);
-  if (p->NCH < RING) return false;
-  p->tab_phase = p->NCH * KSC;
-  p->w_tile = (long long)p->NCH * p->WCHU;
-  p->w_phase = p->w_tile * p->nmt * p->G;
-  p->tab_off_floats = p->w_phase * p->nph * 4;
-  p->packed_floats = (size_t)p->tab_off_floats + (size_t)p->tab_phase * p->nph;
-  p->lds_bytes = (size_t)wbytes + (size_t)2 * p->npw * p->XT * 16 + 2048;
-  p->WM = WM; p->WN = WN; p->TM = TM; p->TN = TN; p->RING = RING;
-  p->big = 1;
-  p->ok = 1;
-  return true;
+  return false;
 }
 
 static void make_plan3(const Canon& c, int dir, Tap3Plan* p) {
