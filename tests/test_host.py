@@ -328,6 +328,8 @@ def test_trainer_precision_selects_the_arithmetic_plan():
     assert module.disc_math == "bf16x6" and module.gen_backward_math == "f32" and module.stft_math == "folded_x6"
     with pytest.raises(ValueError):
         module.set_precision("fp8")
+    with pytest.raises(ValueError):
+        module.set_precision("16-mixed")      # Lightning's fp16 AMP: not silently mapped onto the bf16 plan
     assert all(p[0] in DISC_MATH_PLANS for p in EBENLightningModule.PRECISION_PLANS.values())
 
 

@@ -904,6 +904,7 @@ extern "C" int eben_last_conv_norms(const void* const* seeds, int n, const float
   EBEN_CHECK_LAUNCH("lcn_partial_kernel");
   float* dw = workspace + (size_t)batch * LCN_SPLIT * LCN_MAXN * 4 * 96;
   hipLaunchKernelGGL(lcn_sum_kernel, dim3(ceil_div(n * 4 * 96, 64)), dim3(256), 0, st, workspace, nsp * batch, n * 4 * 96, LCN_MAXN * 4 * 96, dw);
+  EBEN_CHECK_LAUNCH("lcn_sum_kernel");
   hipLaunchKernelGGL(lcn_norm_kernel, dim3(1), dim3(256), 0, st, dw, n, 4 * 96, norms);
   EBEN_CHECK_LAUNCH("lcn_norm_kernel");
   return EBEN_OK;

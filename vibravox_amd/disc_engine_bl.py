@@ -459,6 +459,9 @@ class DiscriminatorEngineBL(DiscriminatorEngine):
         half only."""
         half = bands_ref.shape[0]
         st = self._static_for(half, bands_ref, audio_ref)
+        # the planes are static per shape: every consumer of the previous step's embeddings (stacked input gradients, weight gradients)
+        # must have been joined before they are rewritten
+        assert not getattr(self, "_pending", None), "forward_reference while the previous step's discriminator work is still pending (join it first)"
         st["sub"][half:].copy_(bands_ref[:, -self.q:, :])
         st["wav"][half:].copy_(audio_ref)
         if "fwd_ref" not in self._graphs:

@@ -288,7 +288,7 @@ class GeneratorEngine:
             _, dp_bwd, pw_p = self._pack(pwc, pwc.spec, b, l, True)
         fusable = dil.spec.ksize == 3 and dil.spec.reflect and lib.eben_ru_supported(c, dil.spec.dilation, RU_FWD_MATH) == 1
         if (train and USE_RU_BL and USE_FUSED_RU and USE_FUSED_RU_BWD and USE_FUSED_RU_DW and fusable and RU_FWD_MATH == ops.MATH_BF16X6
-                and self._ru_bwd_math() == ops.MATH_BF16 and lib.eben_rubl_supported(c, dil.spec.dilation) == 1 and self._ru_bl_params_ok(ru)):
+                and self._ru_bwd_math() == ops.MATH_BF16 and lib.eben_rubl_supported(c, dil.spec.dilation) == 1 and self._ru_bl_params_ok(ru, l)):
             # what the bf16 backward reads, written once in the layout its MFMA operands want (csrc/ru_bl.hip)
             img = self._ru_image(ru)
             y = torch.empty_like(x)
@@ -438,13 +438,18 @@ class GeneratorEngine:
         self._accumulate((vd, gd, None), res[1])
 
     @staticmethod
-    def _ru_bl_params_ok(ru) -> bool:
-        """The bundle-layout weight-gradient launch serves weight-normalised, bias-free, trainable convs (every unit of the reference)."""
+    def _ru_bl_params_ok(ru, length: int) -> bool:
+        """The bundle-layout weight-gradient launch serves weight-normalised, bias-free, trainable convs (every unit of the reference) whose
+        gradients take the SAME route (both or neither hold a gradient / carry a hook: the unit's two weight gradients are one launch) on
+        rows longer than the dilation (the kernels' reflect window); anything else keeps the fp32-at-rest path, which can fall back conv
+        by conv -- the bundle path saves only bf16 planes and cannot."""
+        keys = []
         for m in (ru.dilated_conv, ru.pointwise_conv):
             v, g = _params(m)
             if g is None or m.bias is not None or not (v.requires_grad and g.requires_grad):
                 return False
-        return True
+            keys.append((v.grad is None and g.grad is None, ops._no_grad_hooks(v) and ops._no_grad_hooks(g)))
+        return keys[0] == keys[1] and ru.dilated_conv.spec.dilation < length
 
     def _ru_backward_bl(self, rec, gy, res_post=None):
         (_, img_b, xb, hb, um), dil, pwc = rec

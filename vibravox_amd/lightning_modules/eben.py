@@ -178,15 +178,31 @@ class EBENLightningModule(BaseSELightningModule):
         "32-split": ("bf16x6", "f32", "folded_x6"),
     }
     _PRECISION_ALIASES = {"32": "32-true", "fp32": "32-true", "f32": "32-true", "bf16": "bf16-mixed", "bf16-true": "bf16-mixed",
-                          "16-mixed": "bf16-mixed", "bf16x6": "32-split"}
+                          "bf16x6": "32-split"}
 
     def set_precision(self, precision) -> "EBENLightningModule":
         """Selects the step's arithmetic plan from the trainer's ``precision`` key (``run.py`` passes ``trainer.precision`` here)."""
         key = str(precision).strip().lower()
+        if key in ("16-mixed", "16", "fp16", "16-true"):
+            # Lightning's fp16 AMP: no such plan here (the MFMA operands are bf16; mapping it silently would misreport the arithmetic)
+            raise ValueError(f"precision {precision!r} (fp16) is not offered: use 'bf16-mixed', '32-split' or '32-true'")
         key = self._PRECISION_ALIASES.get(key, key)
         if key not in self.PRECISION_PLANS:
             raise ValueError(f"precision must be one of {sorted(self.PRECISION_PLANS)} (or {sorted(self._PRECISION_ALIASES)}), got {precision!r}")
-        self.disc_math, self.gen_backward_math, self.stft_math = self.PRECISION_PLANS[key]
+        overridden = [v for v in ("EBEN_DISC_MATH", "EBEN_GEN_BWD_MATH", "EBEN_STEP_STFT_MATH") if os.environ.get(v)]
+        if overridden:
+            import warnings
+            warnings.warn(f"trainer.precision={key!r} overrides {', '.join(overridden)} (set by the environment)", stacklevel=2)
+        self.disc_math, self.gen_backward_math, stft = self.PRECISION_PLANS[key]
+        # "32-true": the loss module's OWN arithmetic again (the step writes stft_math into the module when it is not None: a module that
+        # ran a bf16-mixed step must not keep folded_x3 while the step reports the reference's exact fp32)
+        loss = getattr(self, "reconstructive_loss_freq_fn", None)
+        if loss is not None and hasattr(loss, "stft_math"):
+            if not hasattr(self, "_loss_stft_math0"):
+                self._loss_stft_math0 = loss.stft_math
+            if stft is None:
+                loss.stft_math = self._loss_stft_math0
+        self.stft_math = stft
         self.precision = key
         return self
 
@@ -238,9 +254,11 @@ class EBENLightningModule(BaseSELightningModule):
         self._mark("start")
         with torch.no_grad():
             bands_ref = self.generator.pqmf.forward(reference_speech, "analysis")
-        if self.split_discriminator_forward:
+        if self.split_discriminator_forward and (type(engine).__name__ == "DiscriminatorEngineBL" or self._split_forward_forced):
             # the reference half of the discriminator batch does not depend on the generator: it runs on the chains'
-            # streams underneath the generator forward (a chain of small launches that leaves most of the GPU idle)
+            # streams underneath the generator forward (a chain of small launches that leaves most of the GPU idle).
+            # Measured for the bundle-layout engine only (0.2 ms of a 10 ms step); the fp32-at-rest engines keep the
+            # one-piece forward unless EBEN_SPLIT_D_FWD=1 asks for it.
             engine.forward_reference(bands_ref, reference_speech)
         with ops.backward_math({"f32": ops.MATH_F32, "bf16": ops.MATH_BF16}[self.gen_backward_math]):
             enhanced_speech, bands = self.generator(corrupted_speech)
@@ -340,6 +358,7 @@ class EBENLightningModule(BaseSELightningModule):
     #: launches): [MI355X, same box, interleaved] 10.25 -> 10.05 ms/step -- the generator forward phase lengthens by 0.7 ms (1.47 -> 2.19: its
     #: launches share the CUs), the discriminator forward phase shortens by 0.8 (2.26 -> 1.49).  On by default.
     split_discriminator_forward: bool = os.environ.get("EBEN_SPLIT_D_FWD", "1") != "0"
+    _split_forward_forced: bool = os.environ.get("EBEN_SPLIT_D_FWD") == "1"
 
     #: rebuild the packed weight images right after each optimiser step, on the side stream (off the critical path)
     prepack_weights: bool = os.environ.get("EBEN_PREPACK", "1") != "0"

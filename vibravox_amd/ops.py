@@ -499,7 +499,8 @@ class ReplayedChain:
     #: graphs kept per chain, least recently used first out.  A run whose signature alternates -- variable clip lengths, a validation
     #: shape between train steps, ``update_discriminator_ratio < 1`` toggling ``want_param_grads`` -- replays each variant from its own
     #: graph instead of paying a capture (device-wide synchronisation, tens of ms) at every other change.  Each graph keeps its pool
-    #: (the tensors its body allocates) for as long as it is cached.
+    #: (the tensors its body allocates) for as long as it is cached: with KEEP variants alive a chain pins up to KEEP times its
+    #: activation memory (~22 chains per step; config 2: ~1.5 GB per variant in total) -- lower it for runs over many clip lengths.
     KEEP = int(os.environ.get("EBEN_CHAIN_GRAPHS_KEEP", "4"))
     _generation = [0]
 
@@ -507,6 +508,7 @@ class ReplayedChain:
         self.graph, self.sig, self.rounds, self.out = None, None, 0, None
         self.captures = 0   # names the generation of the tensors in ``out`` (unique per capture, restored on a cache hit)
         self._cache = {}    # signature -> (graph, out, generation), insertion order = recency
+        self._seen = {}     # signature -> eager rounds so far (signatures that strictly alternate still reach their second round)
         _replayed.add(self)
 
     def run(self, sig, fn, stream_):
@@ -520,8 +522,11 @@ class ReplayedChain:
             self.graph.replay()
             return self.out
         if sig != self.sig:
-            self.graph, self.sig, self.rounds, self.out = None, sig, 0, None
-        self.rounds += 1
+            self.graph, self.sig, self.out = None, sig, None
+        self.rounds = self._seen.get(sig, 0) + 1
+        self._seen[sig] = self.rounds
+        while len(self._seen) > 4 * max(1, self.KEEP):   # bounded: forget the oldest signatures' counts
+            self._seen.pop(next(iter(self._seen)))
         if self.rounds < 2:
             return fn()
         graph = torch.cuda.CUDAGraph()
@@ -539,6 +544,7 @@ class ReplayedChain:
         ReplayedChain._generation[0] += 1
         self.graph, self.out, self.captures = graph, out, ReplayedChain._generation[0]
         self._cache[sig] = (graph, out, self.captures)
+        self._seen.pop(sig, None)
         while len(self._cache) > max(1, self.KEEP):
             self._cache.pop(next(iter(self._cache)))
         graph.replay()   # the capture recorded the launches without running them
