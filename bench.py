@@ -55,6 +55,22 @@ def build_module(device, batch_seed):
     return mod
 
 
+def profile_average(fragment):
+    """Average duration of the kernel whose name contains `fragment` in the latest committed rocprofv3 --kernel-trace --stats summary."""
+    import csv
+    path = next((q for q in (os.path.join(ROOT, "profiles", f"r{n:02d}_rocprofv3_kernel_stats.csv") for n in range(9, 0, -1)) if os.path.exists(q)), None)
+    if path is None:
+        return None
+    try:
+        for r in csv.DictReader(open(path)):
+            if fragment in r["Name"]:
+                return {"file": os.path.relpath(path, ROOT), "calls": int(r["Calls"]), "avg_ms": round(float(r["AverageNs"]) / 1e6, 4),
+                        "min_ms": round(float(r["MinNs"]) / 1e6, 4)}
+    except Exception:
+        return None
+    return None
+
+
 def pmc_family(math):
     """Roofline records with HBM traffic from this round's rocprofv3 PMC passes (tools/pmc_family_bl.sh -> profiles/rNN_pmc_family.json, the latest round's:
     FETCH_SIZE / WRITE_SIZE / TCC hit + miss in separate passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950): the
@@ -427,11 +443,19 @@ def main():
         stft_desc = {"folded_x6": "fp32-grade (three bf16 pieces per operand)",
                      "folded_x3": "hi + lo bf16 operands (three MFMAs per product, ~2^-17; the generator gradient against the fp32 step stays at 5.5e-3)"
                      }.get(stft_math, "fp32 (" + stft_math + ")")
-        kn = ("tap3_kernel<4,*,BL> (v_mfma_f32_32x32x16_bf16, bf16 bundles at rest)" if args.disc_math == "bf16_bl" else
+        kn = ("tap4_kernel<2,2,4,2,1,4,3,2> (bigtap.hip: persistent producer / consumer block per CU, v_mfma_f32_32x32x16_bf16, bf16 bundles at rest)" if args.disc_math == "bf16_bl" else
               "tap3_kernel<4,*> (v_mfma_f32_32x32x16_bf16)" if bf16 else "tap2_kernel<4,4,16> (v_mfma_f32_32x32x2_f32)")
         roof, flops = launch_record(timer, "fwd", kn)
         family = pmc_family(args.disc_math) if (timer.batch or 2 * args.batch) == 64 else []
         roof["traffic"] = next((r["traffic_bytes"] for r in family if r["name"] == "melgan_l4_fwd"), None)
+        # the counters are not collected inside this run (rocprofv3 --pmc passes are separate processes): the figure is the committed profile's
+        roof["traffic_source"] = next((r.get("source") for r in family if r["name"] == "melgan_l4_fwd"), None)
+        roof["launch_ms_note"] = ("HIP events around the launch on its stream, over a second run of the timed steps with the chains launched kernel by "
+                                  "kernel (events cannot sit between the nodes of a replayed graph); `isolated` = the same launch alone; "
+                                  "`profile` = rocprofv3 --kernel-trace average of the graph-replayed step from the committed file")
+        prof = profile_average("tap4_kernel<2, 2, 4, 2, 1" if args.disc_math == "bf16_bl" else "tap3_kernel<4")
+        if prof:
+            roof["profile"] = prof
         if iso_ms:
             roof["isolated"] = {"launch_ms": round(iso_ms, 4), "achieved": round(flops / (iso_ms * 1e-3) / 1e12, 2),
                                 "frac": round(flops / (iso_ms * 1e-3) / 1e12 / peak, 4),

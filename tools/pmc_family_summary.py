@@ -22,7 +22,7 @@ def pick(layer, which, match, blocks=None):
 # (record name, layer, kernel match, blocks or None, description, flops, algorithmic bytes) at 64 rows (forward / weight gradient)
 rows64 = 64
 spec = [
-    ("melgan_l4_fwd", "melgan.4", "tap3_kernelILi4E", 512, "MelGAN L4 forward (1024->1024 k41 s4 g4, 500->125), 64 rows, bf16 bundles",
+    ("melgan_l4_fwd", "melgan.4", "tap4_kernelILi2ELi2ELi4ELi2ELi1E", 256, "MelGAN L4 forward (1024->1024 k41 s4 g4, 500->125), 64 rows, bf16 bundles",
      2.0 * rows64 * 1024 * 256 * 41 * 125, rows64 * (2 * 1024 * 500 + 4 * 1024 * 125) + 2 * 1024 * 256 * 41),
     ("melgan_l4_dw", "melgan.4", "bl_dw_kernel", None, "MelGAN L4 weight gradient, 64 rows [fake | real] x [enhanced | reference]",
      2.0 * rows64 * 1024 * 256 * 41 * 125, rows64 * 2 * (1024 * 500 + 1024 * 125) + 4 * 1024 * 256 * 41),
@@ -40,7 +40,8 @@ for name, layer, match, blocks, desc, flops, alg in spec:
                 "bound": "mfma" if flops / PEAK >= alg / HBM else "hbm", "flops": flops, "algorithmic_bytes": alg,
                 "traffic_bytes": int(fetch + write), "fetch_bytes_corrected": int(fetch), "write_bytes": int(write),
                 "l2_hit_rate": round(hit / (hit + miss), 4), "roof_us": round(roof * 1e6, 1), "frac_of_mixed_roof": round(roof * 1e6 / us, 3),
-                "achieved_tflops": round(flops / us / 1e6, 1), "achieved_gbs_algorithmic": round(alg / us / 1e3, 1), "commit": commit})
+                "achieved_tflops": round(flops / us / 1e6, 1), "achieved_gbs_algorithmic": round(alg / us / 1e3, 1), "commit": commit,
+                "source": f"profiles/{tag}_pmc_family.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/pmc_family_bl.sh at commit {commit})"})
 json.dump(out, open(os.path.join(O, f"{tag}_pmc_family.json"), "w"), indent=1)
 for r in out:
     print(r["name"], r["launch_us_profiled"], "us  traffic", r["traffic_bytes"] / 1e6, "MB  algorithmic", r["algorithmic_bytes"] / 1e6, "MB  frac", r["frac_of_mixed_roof"])
