@@ -347,7 +347,9 @@ def test_bf16_step_against_fp32_step_at_config2(hip, plan):
     tol = BF16_STEP_TOLERANCES
     # the bf16 step exactly as bench.py runs it: bf16 plan, bf16 generator backward, MRSTFT contractions on hi + lo bf16 operands
     f32, bf = _one_step(make, "f32"), _one_step(make, plan, "bf16", stft_math="folded_x3")
-    assert torch.equal(f32[0], bf[0])   # the generator's forward is exact fp32 in every mode
+    # the generator's forward: fp32-grade six-product arithmetic in the fp32 plans, hi + lo operands (three products, 2^-17 each) in the
+    # bf16 step -- orders of magnitude inside north_star's 1e-5
+    assert float(((f32[0].double() - bf[0].double()) ** 2).mean()) < 1e-8
     for k, v in f32[1].items():
         t = tol["feature_matching_loss"] if "feature_matching" in k else tol["backprop_loss"] if "backprop" in k else tol["loss"]
         assert abs(bf[1][k] - v) <= t * abs(v), (k, v, bf[1][k])
@@ -659,7 +661,8 @@ def test_full_size_step_against_oracle(hip, golden):
         torch.cuda.synchronize()
         enh = out["enhanced"].cpu().double()
         mse = float(((enh - logs["enhanced"].double()) ** 2).mean())
-        assert enh.shape == (32, 1, 31968) and mse < 1e-10, (plan, mse)   # north-star bar: 1e-5
+        # north-star bar: 1e-5; fp32-grade forwards 1e-10, the bf16 plans' three-product ResidualUnits 1e-8
+        assert enh.shape == (32, 1, 31968) and mse < (1e-8 if plan in ("bf16", "bf16_bl") else 1e-10), (plan, mse)
         got = _adam_moments(mod.optimizers())
         g_rel, d_rel = _rel(want[0], got[0]), _rel(want[1], got[1])
         norms = (torch.stack(mod.last_norms).cpu().double() - logs["balancing/norms"].double()).abs() / logs["balancing/norms"].double().abs()

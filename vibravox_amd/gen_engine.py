@@ -52,6 +52,20 @@ BWD_GROUPS = os.environ.get("EBEN_GEN_BWD_GROUPS", "2,2,3")
 # fp32 arithmetic at 6/16 of the fp32 MFMA's cost); "f32" selects the v_mfma_f32_32x32x2_f32 kernels (bisecting aid).
 _RU_MATH = {"f32": ops.MATH_F32, "bf16x6": ops.MATH_BF16X6, "bf16x3": ops.MATH_BF16X3, "bf16": ops.MATH_BF16}
 RU_FWD_MATH = _RU_MATH[os.environ.get("EBEN_RU_FWD_MATH", "bf16x6")]
+# the arithmetic of the ResidualUnit forwards from now on: EBENLightningModule sets "bf16x3" (hi + lo operands, three piece products) at
+# the head of every training step of the bf16-mixed plan and the default for the other plans (the weight images are cached per
+# arithmetic; the prepack behind the optimiser step rebuilds the ones of the step that just ran); a generator that never trained in
+# this process -- from_pretrained inference -- runs RU_FWD_MATH
+_ru_fwd_math = [RU_FWD_MATH]
+
+
+def ru_forward_math() -> int:
+    return _ru_fwd_math[0]
+
+
+def set_ru_forward_math(name=None) -> None:
+    """``None`` restores the default (``EBEN_RU_FWD_MATH``, fp32-grade six-product arithmetic)."""
+    _ru_fwd_math[0] = RU_FWD_MATH if name is None else _RU_MATH[name]
 RU_BWD_F32_MATH = _RU_MATH[os.environ.get("EBEN_RU_BWD_F32_MATH", "bf16x6")]
 # forward of the other conv layers of the core (first / strided / latent / transposed convs): the same fp32-grade split form
 CONV_FWD_MATH = _RU_MATH[os.environ.get("EBEN_GEN_CONV_FWD_MATH", "bf16x6")]
@@ -182,7 +196,7 @@ class GeneratorEngine:
         vd, gd = _params(ru.dilated_conv)
         vp, gp = _params(ru.pointwise_conv)
         e = ops._storage_epoch
-        key = tuple((t.data_ptr(), t._version, e.get(t.data_ptr(), 0)) for t in (vd, gd, vp, gp)) + (e.get(-1, 0),)
+        key = tuple((t.data_ptr(), t._version, e.get(t.data_ptr(), 0)) for t in (vd, gd, vp, gp)) + (e.get(-1, 0), ru_forward_math())
         hit = self._ru_images.get(id(ru))
         bm = self._ru_bwd_math() if which == 1 else None
         if hit is not None and hit["key"] == key and (bm is None or bm in hit["bwd"]):
@@ -199,8 +213,8 @@ class GeneratorEngine:
                 batch["wn"].extend(wn)
             else:
                 ops.wn_scale_multi(wn)
-            img = ops._buffer(None if hit is None else hit["fwd"], lib.eben_ru_packed_floats_ex(c, RU_FWD_MATH), vd, reuse)
-            self._ru_pack(c, RU_FWD_MATH, 0, vd, scales[0], vp, scales[2], img)
+            img = ops._buffer(None if hit is None else hit["fwd"], lib.eben_ru_packed_floats_ex(c, ru_forward_math()), vd, reuse)
+            self._ru_pack(c, ru_forward_math(), 0, vd, scales[0], vp, scales[2], img)
             maths = set(hit["bwd"]) if hit is not None else set()
             old_bwd = hit["bwd"] if hit is not None else {}
             hit = self._ru_images[id(ru)] = {"key": key, "fwd": img, "bwd": {}, "scales": scales}
@@ -250,7 +264,7 @@ class GeneratorEngine:
         def key_of(ru):
             e = ops._storage_epoch
             ts = _params(ru.dilated_conv) + _params(ru.pointwise_conv)
-            return tuple((t.data_ptr(), t._version, e.get(t.data_ptr(), 0)) for t in ts) + (e.get(-1, 0),)
+            return tuple((t.data_ptr(), t._version, e.get(t.data_ptr(), 0)) for t in ts) + (e.get(-1, 0), ru_forward_math())
 
         def body():
             self._ru_batch = {"wn": [], "packs": []}
@@ -286,8 +300,9 @@ class GeneratorEngine:
             spec_d = self._spec(dil, in_slope=in_slope if in_slope != 1.0 else None)
             _, dd_bwd, pw_d = self._pack(dil, spec_d, b, l, True)
             _, dp_bwd, pw_p = self._pack(pwc, pwc.spec, b, l, True)
-        fusable = dil.spec.ksize == 3 and dil.spec.reflect and lib.eben_ru_supported(c, dil.spec.dilation, RU_FWD_MATH) == 1
-        if (train and USE_RU_BL and USE_FUSED_RU and USE_FUSED_RU_BWD and USE_FUSED_RU_DW and fusable and RU_FWD_MATH == ops.MATH_BF16X6
+        fwd_math = ru_forward_math()
+        fusable = dil.spec.ksize == 3 and dil.spec.reflect and lib.eben_ru_supported(c, dil.spec.dilation, fwd_math) == 1
+        if (train and USE_RU_BL and USE_FUSED_RU and USE_FUSED_RU_BWD and USE_FUSED_RU_DW and fusable and fwd_math in (ops.MATH_BF16X6, ops.MATH_BF16X3)
                 and self._ru_bwd_math() == ops.MATH_BF16 and lib.eben_rubl_supported(c, dil.spec.dilation) == 1 and self._ru_bl_params_ok(ru, l)):
             # what the bf16 backward reads, written once in the layout its MFMA operands want (csrc/ru_bl.hip)
             img = self._ru_image(ru)
@@ -295,7 +310,7 @@ class GeneratorEngine:
             xb = torch.empty((b, c // 8, l, 8), dtype=torch.bfloat16, device=x.device)
             hb = torch.empty_like(xb)
             um = torch.empty((b, c // 8, l), dtype=torch.uint8, device=x.device)
-            check(lib.eben_rubl_fwd(RU_FWD_MATH, b, c, l, dil.spec.dilation, ptr(x), float(in_slope), float(pwc.spec.out_slope), ptr(img), ptr(y),
+            check(lib.eben_rubl_fwd(fwd_math, b, c, l, dil.spec.dilation, ptr(x), float(in_slope), float(pwc.spec.out_slope), ptr(img), ptr(y),
                                     xb.data_ptr(), hb.data_ptr(), um.data_ptr(), stream()), "rubl_fwd")
             recs.append((("bl", self._ru_image(ru, 1), xb, hb, um), _ConvRec(dil, spec_d, dd_bwd, x if in_slope != 1.0 else None, None, pw_d.wp_bwd, pw_d.norm),
                          _ConvRec(pwc, pwc.spec, dp_bwd, None, None, pw_p.wp_bwd, pw_p.norm)))
@@ -305,7 +320,7 @@ class GeneratorEngine:
             y = torch.empty_like(x)
             h = torch.empty_like(x) if train else None
             u = torch.empty_like(x) if train else None
-            check(lib.eben_ru_fwd_ex(RU_FWD_MATH, b, c, l, dil.spec.dilation, ptr(x), float(in_slope), float(pwc.spec.out_slope), ptr(img), ptr(y),
+            check(lib.eben_ru_fwd_ex(fwd_math, b, c, l, dil.spec.dilation, ptr(x), float(in_slope), float(pwc.spec.out_slope), ptr(img), ptr(y),
                                      ptr(h), ptr(u), stream()), "ru_fwd")
         else:   # layer by layer (bisecting aid, EBEN_RU_FUSED=0)
             xin = x
@@ -567,7 +582,7 @@ class GeneratorEngine:
                                 for m in part.modules() if isinstance(m, HipConv1d)]
             self._core_units = [ru for blk in list(gen.encoder_blocks) + list(gen.decoder_blocks) for ru in blk.residuals]
         addr = lambda t: 0 if t is None else t.data_ptr()
-        parts = [buf.data_ptr(), tuple(buf.shape), ops._backward_math[0], CONV_FWD_MATH, RU_FWD_MATH]
+        parts = [buf.data_ptr(), tuple(buf.shape), ops._backward_math[0], CONV_FWD_MATH, ru_forward_math()]
         for m in self._core_convs:
             pw = m._packed
             if pw is None or pw.last is None:
@@ -582,7 +597,7 @@ class GeneratorEngine:
                 parts.append(None)
                 continue
             ts = _params(ru.dilated_conv) + _params(ru.pointwise_conv)
-            key = tuple((t.data_ptr(), t._version, e.get(t.data_ptr(), 0)) for t in ts) + (e.get(-1, 0),)
+            key = tuple((t.data_ptr(), t._version, e.get(t.data_ptr(), 0)) for t in ts) + (e.get(-1, 0), ru_forward_math())
             parts.append((hit["fwd"].data_ptr(), tuple((k, hit["bwd"][k].data_ptr()) for k in sorted(hit["bwd"])), hit["scales"].data_ptr(), hit["key"] == key))
         return tuple(parts)
 

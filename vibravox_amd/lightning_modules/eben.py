@@ -260,6 +260,10 @@ class EBENLightningModule(BaseSELightningModule):
             # Measured for the bundle-layout engine only (0.2 ms of a 10 ms step); the fp32-at-rest engines keep the
             # one-piece forward unless EBEN_SPLIT_D_FWD=1 asks for it.
             engine.forward_reference(bands_ref, reference_speech)
+        # bf16-mixed: the ResidualUnit forwards on hi + lo operands (three piece products, 2^-17 each) instead of the fp32-grade six --
+        # the output stays orders of magnitude inside north_star's 1e-5 MSE (tests: < 1e-8 against the oracle at config 2)
+        from .. import gen_engine
+        gen_engine.set_ru_forward_math("bf16x3" if self.gen_backward_math == "bf16" and self.ru_forward_x3 else None)
         with ops.backward_math({"f32": ops.MATH_F32, "bf16": ops.MATH_BF16}[self.gen_backward_math]):
             enhanced_speech, bands = self.generator(corrupted_speech)
         self._mark("generator forward")
@@ -359,6 +363,9 @@ class EBENLightningModule(BaseSELightningModule):
     #: launches share the CUs), the discriminator forward phase shortens by 0.8 (2.26 -> 1.49).  On by default.
     split_discriminator_forward: bool = os.environ.get("EBEN_SPLIT_D_FWD", "1") != "0"
     _split_forward_forced: bool = os.environ.get("EBEN_SPLIT_D_FWD") == "1"
+
+    #: bf16-mixed plan: ResidualUnit forwards with three piece products (EBEN_MATH_BF16X3) instead of six; EBEN_RU_FWD_X3=0 keeps six
+    ru_forward_x3: bool = os.environ.get("EBEN_RU_FWD_X3", "1") != "0" and not os.environ.get("EBEN_RU_FWD_MATH")
 
     #: rebuild the packed weight images right after each optimiser step, on the side stream (off the critical path)
     prepack_weights: bool = os.environ.get("EBEN_PREPACK", "1") != "0"
