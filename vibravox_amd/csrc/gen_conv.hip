@@ -509,7 +509,7 @@ struct GcPlan {
 static void gc_plan(const Canon& c, int dir, GcPlan* p) {
   static const int enabled = gc_env("EBEN_GC", 1);
   memset(p, 0, sizeof(*p));
-  if (!enabled || c.bl || c.np != 3 || c.g != 1 || c.d != 1 || c.xsplit_dir >= 0) return;
+  if (!enabled || c.bl || (c.np != 3 && c.np != 2) || c.g != 1 || c.d != 1 || c.xsplit_dir >= 0) return;   // EBEN_MATH_BF16X6 / EBEN_MATH_BF16X3
   p->np = c.np;
   p->S = c.s; p->k = c.k;
   if (dir == 0) {
@@ -609,7 +609,11 @@ int gc_launch(const Canon& c, int dir, const TapIO& io, hipStream_t st) {
   a.w_rt = (long long)p.KSP * p.np * 64; a.w_half = a.w_rt * p.nrt;
   const unsigned grid = (unsigned)(p.nh * p.nrg * c.B * p.ncb);
   a.xq = grid / 8; a.xr = grid % 8;
-  if (p.form == 0) gc_launch_shape<0, 3>(p, a, grid, st);
+  if (p.np == 2) {   // hi + lo operands, three piece products (the bf16-mixed plan)
+    if (p.form == 0) gc_launch_shape<0, 2>(p, a, grid, st);
+    else if (p.form == 1) gc_launch_shape<1, 2>(p, a, grid, st);
+    else gc_launch_shape<2, 2>(p, a, grid, st);
+  } else if (p.form == 0) gc_launch_shape<0, 3>(p, a, grid, st);
   else if (p.form == 1) gc_launch_shape<1, 3>(p, a, grid, st);
   else gc_launch_shape<2, 3>(p, a, grid, st);
   EBEN_CHECK_LAUNCH("gc_kernel");

@@ -69,6 +69,18 @@ def set_ru_forward_math(name=None) -> None:
 RU_BWD_F32_MATH = _RU_MATH[os.environ.get("EBEN_RU_BWD_F32_MATH", "bf16x6")]
 # forward of the other conv layers of the core (first / strided / latent / transposed convs): the same fp32-grade split form
 CONV_FWD_MATH = _RU_MATH[os.environ.get("EBEN_GEN_CONV_FWD_MATH", "bf16x6")]
+_conv_fwd_math = [CONV_FWD_MATH]   # like _ru_fwd_math: the strided / transposed / latent convs of the generator
+
+
+def conv_forward_math() -> int:
+    return _conv_fwd_math[0]
+
+
+def set_forward_math(name=None) -> None:
+    """Arithmetic of the generator's forward from now on: ``"bf16x3"`` (hi + lo operands: the bf16-mixed plan) or ``None`` = the defaults
+    (``EBEN_RU_FWD_MATH`` / ``EBEN_GEN_CONV_FWD_MATH``: fp32-grade six-product arithmetic)."""
+    set_ru_forward_math(name)
+    _conv_fwd_math[0] = CONV_FWD_MATH if name is None else _RU_MATH[name]
 #: strided convs from this stride up run as space-to-depth + stride-1 tap-conv where the tap-conv does not cover them directly (0: never)
 S2D_MIN_STRIDE = int(os.environ.get("EBEN_GEN_S2D_MIN_STRIDE", "8"))
 
@@ -121,7 +133,7 @@ class GeneratorEngine:
         return s
 
     def _pack(self, m, spec, batch, l_in, train):
-        d = ops.conv_desc(spec, batch, l_in, CONV_FWD_MATH)   # layers the split bf16 tap-conv does not cover run their fp32 kernel
+        d = ops.conv_desc(spec, batch, l_in, conv_forward_math())   # layers the split bf16 tap-conv does not cover run their fp32 kernel
         d_bwd = ops.conv_desc(spec, batch, l_in, ops._backward_math[0])
         v, g = _params(m)
         pw = ops.pack_weights(m.spec, d, v.detach(), None if g is None else g.detach(), m._packed, train, d_bwd)
@@ -166,10 +178,10 @@ class GeneratorEngine:
         d, d_bwd, pw = self._pack(m, spec, b, l_in, train)
         y = torch.empty((b, spec.c_out, d.l_out), dtype=torch.float32, device=x.device)
         route = None
-        if not spec.transposed and self._s2d_wanted(spec, CONV_FWD_MATH) and lib.eben_conv1d_kernel_generation(ctypes.byref(d), 0) not in (4, 5):
+        if not spec.transposed and self._s2d_wanted(spec, conv_forward_math()) and lib.eben_conv1d_kernel_generation(ctypes.byref(d), 0) not in (4, 5):
             kq = spec.ksize // spec.stride
             l_q = d.l_out + kq - 1
-            route = self._s2d_route(m, spec, b, l_q, kq, CONV_FWD_MATH, spec.c_in, spec.c_out, spec.in_slope, spec.out_slope, pw.scale)
+            route = self._s2d_route(m, spec, b, l_q, kq, conv_forward_math(), spec.c_in, spec.c_out, spec.in_slope, spec.out_slope, pw.scale)
         if route is not None:
             xq = torch.empty((b, spec.c_in * spec.stride, l_q), dtype=torch.float32, device=x.device)
             check(lib.eben_space_to_depth(ptr(x), None, 1.0, ptr(xq), b * spec.c_in, l_in, spec.stride, -spec.pad_l, l_q,
@@ -582,7 +594,7 @@ class GeneratorEngine:
                                 for m in part.modules() if isinstance(m, HipConv1d)]
             self._core_units = [ru for blk in list(gen.encoder_blocks) + list(gen.decoder_blocks) for ru in blk.residuals]
         addr = lambda t: 0 if t is None else t.data_ptr()
-        parts = [buf.data_ptr(), tuple(buf.shape), ops._backward_math[0], CONV_FWD_MATH, ru_forward_math()]
+        parts = [buf.data_ptr(), tuple(buf.shape), ops._backward_math[0], conv_forward_math(), ru_forward_math()]
         for m in self._core_convs:
             pw = m._packed
             if pw is None or pw.last is None:

@@ -263,7 +263,7 @@ class EBENLightningModule(BaseSELightningModule):
         # bf16-mixed: the ResidualUnit forwards on hi + lo operands (three piece products, 2^-17 each) instead of the fp32-grade six --
         # the output stays orders of magnitude inside north_star's 1e-5 MSE (tests: < 1e-8 against the oracle at config 2)
         from .. import gen_engine
-        gen_engine.set_ru_forward_math("bf16x3" if self.gen_backward_math == "bf16" and self.ru_forward_x3 else None)
+        gen_engine.set_forward_math("bf16x3" if self.gen_backward_math == "bf16" and self.ru_forward_x3 else None)
         with ops.backward_math({"f32": ops.MATH_F32, "bf16": ops.MATH_BF16}[self.gen_backward_math]):
             enhanced_speech, bands = self.generator(corrupted_speech)
         self._mark("generator forward")
@@ -365,7 +365,8 @@ class EBENLightningModule(BaseSELightningModule):
     _split_forward_forced: bool = os.environ.get("EBEN_SPLIT_D_FWD") == "1"
 
     #: bf16-mixed plan: ResidualUnit forwards with three piece products (EBEN_MATH_BF16X3) instead of six; EBEN_RU_FWD_X3=0 keeps six
-    ru_forward_x3: bool = os.environ.get("EBEN_RU_FWD_X3", "1") != "0" and not os.environ.get("EBEN_RU_FWD_MATH")
+    ru_forward_x3: bool = (os.environ.get("EBEN_RU_FWD_X3", "1") != "0" and not os.environ.get("EBEN_RU_FWD_MATH")
+                           and not os.environ.get("EBEN_GEN_CONV_FWD_MATH"))
 
     #: rebuild the packed weight images right after each optimiser step, on the side stream (off the critical path)
     prepack_weights: bool = os.environ.get("EBEN_PREPACK", "1") != "0"
