@@ -15,7 +15,9 @@ def rows(layer, which):
 
 def pick(layer, which, match, blocks=None):
     c = [r for r in rows(layer, which) if match in r["kernel"] and (blocks is None or int(r["blocks"]) == blocks)]
-    c.sort(key=lambda r: -float(r["us"]))
+    # the layer bench launches forward, input gradient and weight gradient: the forward is the shortest launch of its kernel (the
+    # phases-as-rows input gradient of MelGAN L4 runs the SAME tap4 instantiation over twice the rows), the others match one launch each
+    c.sort(key=lambda r: float(r["us"]) if "tap4" in match else -float(r["us"]))
     return c[0]
 
 

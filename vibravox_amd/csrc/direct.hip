@@ -4,6 +4,8 @@
 // time) float32 rows with coalesced accesses; reductions are two-level and order-deterministic.
 #include "common.h"
 
+#include <cstdlib>
+
 namespace eben {
 
 // ---------------------------------------------------------------------------------------------
@@ -70,6 +72,81 @@ __global__ __launch_bounds__(256) void fir_interp_sum_kernel(const float* __rest
     for (int k = 0; k < bands; ++k) acc = fmaf(ws[k * ntaps + j], ys[k * tile_t + tl], acc);
   }
   x[(long long)b * lx + u] = acc;
+}
+
+// ---- PQMF banks at M = 4, N = 32 (pqmf.py:194-213; every EBEN configuration): the polyphase form on wave shuffles ---------------
+// Analysis: output t of every band reads the 32 samples 4 t + off0 .. + 31 = EIGHT aligned-in-phase quads.  Lane t of a wave loads ONE
+// quad -- the window's last, samples 4 t + off0 + 28 .. + 31: a coalesced 16-byte load, no LDS tile, no barrier -- and gets the seven
+// others from lanes t - 1 .. t - 7 (ds_bpermute: __shfl_up); the first seven lanes of a wave only supply their quads (57 outputs per
+// wave).  All bands from the one window in registers, the taps through the scalar cache, the 32 products of a band accumulated in the
+// order j = 0 .. 31 of the LDS form -- bit-identical results.  ([MI355X] the LDS form: 13 us for 6-8 MB, its 128 ds_read_b32 per
+// output four ways bank-conflicted at stride 4.)
+template <int BANDS>
+__global__ __launch_bounds__(256) void pqmf_analysis_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y, int lx, int ly, int off0) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, b = blockIdx.y;
+  const int t = (blockIdx.x * 4 + wave) * 57 - 7 + lane;
+  const long long q0 = 4LL * t + off0 + 28;
+  const float* xr = x + (long long)b * lx;
+  float xq[4];
+  if (q0 >= 0 && q0 + 3 < lx) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) xq[e] = xr[q0 + e];
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) xq[e] = (q0 + e >= 0 && q0 + e < lx) ? xr[q0 + e] : 0.f;
+  }
+  float win[8][4];   // win[c] = samples 4 t + off0 + 4 c .. + 3
+#pragma unroll
+  for (int c = 0; c < 8; ++c)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) win[c][e] = c == 7 ? xq[e] : __shfl_up(xq[e], 7 - c, 64);
+  if (lane < 7 || t < 0 || t >= ly) return;
+  typedef const __attribute__((address_space(4))) float* cw_t;
+  const cw_t wc = (cw_t)w;
+#pragma unroll
+  for (int k = 0; k < BANDS; ++k) {
+    float acc = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc = fmaf(wc[k * 32 + 4 * c + e], win[c][e], acc);
+    y[((long long)b * BANDS + k) * ly + t] = acc;
+  }
+}
+
+// Synthesis + band sum: outputs u = 4 q + off0 + r, r = 0 .. 3, read y_k[q - i] with the taps j = r + 4 i, i = 0 .. 7: lane q loads its
+// BANDS samples y_k[q] (coalesced), gets y_k[q - 1 .. q - 7] from its neighbours and writes the four outputs as one 16-byte store.
+// Accumulation order of the LDS form (taps ascending, bands inside): bit-identical.
+template <int BANDS>
+__global__ __launch_bounds__(256) void pqmf_synthesis_kernel(const float* __restrict__ y, const float* __restrict__ w, float* __restrict__ x, int lx, int ly, int off0, int qmin) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, b = blockIdx.y;
+  const int q = qmin + (blockIdx.x * 4 + wave) * 57 - 7 + lane;
+  float yq[BANDS];
+#pragma unroll
+  for (int k = 0; k < BANDS; ++k) yq[k] = (q >= 0 && q < ly) ? y[((long long)b * BANDS + k) * ly + q] : 0.f;
+  float win[8][BANDS];   // win[i][k] = y_k[q - i]
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int k = 0; k < BANDS; ++k) win[i][k] = i == 0 ? yq[k] : __shfl_up(yq[k], i, 64);
+  if (lane < 7) return;
+  typedef const __attribute__((address_space(4))) float* cw_t;
+  const cw_t wc = (cw_t)w;
+  const long long u0 = 4LL * q + off0;
+  float out[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int k = 0; k < BANDS; ++k) acc = fmaf(wc[k * 32 + r + 4 * i], win[i][k], acc);
+    out[r] = acc;
+  }
+  float* xr = x + (long long)b * lx;
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    if (u0 + r >= 0 && u0 + r < lx) xr[u0 + r] = out[r];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -541,6 +618,15 @@ extern "C" int eben_fir_decimate(const float* x, const float* w, float* y, int b
                                  int stride, int off0, void* stream) {
   EBEN_REQUIRE(x && w && y && batch > 0 && lx > 0 && ly > 0 && bands > 0 && ntaps > 0 && stride > 0, "bad fir_decimate arguments");
   EBEN_REQUIRE(bands * ntaps <= FIR_MAX_W, "fir bank of %d x %d taps exceeds %d", bands, ntaps, FIR_MAX_W);
+  static const bool shuffles = !(getenv("EBEN_PQMF_SHUFFLE") && atoi(getenv("EBEN_PQMF_SHUFFLE")) == 0);
+  if (shuffles && stride == 4 && ntaps == 32 && (bands == 1 || bands == 2 || bands == 4)) {   // the PQMF banks: polyphase form on wave shuffles
+    const dim3 grid(ceil_div(ly, 4 * 57), batch);
+    if (bands == 1) hipLaunchKernelGGL(pqmf_analysis_kernel<1>, grid, dim3(256), 0, as_stream(stream), x, w, y, lx, ly, off0);
+    else if (bands == 2) hipLaunchKernelGGL(pqmf_analysis_kernel<2>, grid, dim3(256), 0, as_stream(stream), x, w, y, lx, ly, off0);
+    else hipLaunchKernelGGL(pqmf_analysis_kernel<4>, grid, dim3(256), 0, as_stream(stream), x, w, y, lx, ly, off0);
+    EBEN_CHECK_LAUNCH("pqmf_analysis_kernel");
+    return EBEN_OK;
+  }
   const size_t lds = sizeof(float) * (FIR_MAX_W + (size_t)255 * stride + ntaps);
   EBEN_REQUIRE(lds <= 64 * 1024, "fir_decimate stride %d too large", stride);
   hipLaunchKernelGGL(fir_decimate_kernel, dim3(ceil_div(ly, 256), batch), dim3(256), lds, as_stream(stream), x, w, y, lx, ly,
@@ -553,6 +639,18 @@ extern "C" int eben_fir_interp_sum(const float* y, const float* w, float* x, int
                                    int stride, int off0, void* stream) {
   EBEN_REQUIRE(x && w && y && batch > 0 && lx > 0 && ly > 0 && bands > 0 && ntaps > 0 && stride > 0, "bad fir_interp_sum arguments");
   EBEN_REQUIRE(bands * ntaps <= FIR_MAX_W, "fir bank of %d x %d taps exceeds %d", bands, ntaps, FIR_MAX_W);
+  static const bool shuffles = !(getenv("EBEN_PQMF_SHUFFLE") && atoi(getenv("EBEN_PQMF_SHUFFLE")) == 0);
+  if (shuffles && stride == 4 && ntaps == 32 && (bands == 1 || bands == 2 || bands == 4)) {
+    // u - off0 = 4 q + r covers u = 0 .. lx - 1 for q = floor(-off0 / 4) .. floor((lx - 1 - off0) / 4)
+    auto fdiv = [](long long a, long long d) { long long qq = a / d; return (a % d != 0 && ((a < 0) != (d < 0))) ? qq - 1 : qq; };
+    const int qmin = (int)fdiv(-(long long)off0, 4), qmax = (int)fdiv((long long)lx - 1 - off0, 4);
+    const dim3 grid(ceil_div(qmax - qmin + 1, 4 * 57), batch);
+    if (bands == 1) hipLaunchKernelGGL(pqmf_synthesis_kernel<1>, grid, dim3(256), 0, as_stream(stream), y, w, x, lx, ly, off0, qmin);
+    else if (bands == 2) hipLaunchKernelGGL(pqmf_synthesis_kernel<2>, grid, dim3(256), 0, as_stream(stream), y, w, x, lx, ly, off0, qmin);
+    else hipLaunchKernelGGL(pqmf_synthesis_kernel<4>, grid, dim3(256), 0, as_stream(stream), y, w, x, lx, ly, off0, qmin);
+    EBEN_CHECK_LAUNCH("pqmf_synthesis_kernel");
+    return EBEN_OK;
+  }
   const int tile_t = (255 + ntaps - 1) / stride + 3;
   const size_t lds = sizeof(float) * (FIR_MAX_W + (size_t)bands * tile_t);
   EBEN_REQUIRE(lds <= 64 * 1024, "fir_interp_sum tile too large");
