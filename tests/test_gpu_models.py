@@ -200,6 +200,20 @@ def test_two_train_steps_against_reference_replay_golden(hip, golden, fused_adam
         np.testing.assert_allclose(v.double().norm().item(), golden[f"post/D/{k}"][1], rtol=dtol)
 
 
+_MSTEP_ORACLE = []
+
+
+def mstep_oracle(g_sd, d_sd):
+    """Two consecutive default-configuration steps of the CPU oracle on the formula clips mstep0 / mstep1 from the golden weights:
+    six tests compare against this one trajectory, computed once per session (~10 s of CPU each time otherwise)."""
+    if not _MSTEP_ORACLE:
+        trainer = O.OracleTrainer(g_sd, d_sd, p=2, q=4, use_mrstft=True)
+        for i in range(2):
+            bc, air = formula_audio(f"mstep{i}/bc", 2, 8200), formula_audio(f"mstep{i}/air", 2, 8200)
+            _MSTEP_ORACLE.append((bc, air, trainer.step(bc, air)))
+    return _MSTEP_ORACLE
+
+
 @pytest.mark.parametrize("literal,engine,split", [(False, True, False), (False, False, False), (True, False, False), (False, True, True)])
 def test_train_step_with_mrstft_against_oracle(hip, golden, literal, engine, split):
     """Full default configuration (MRSTFT + FM + hinge, EMA balancing).  The MRSTFT term is a
@@ -210,11 +224,8 @@ def test_train_step_with_mrstft_against_oracle(hip, golden, literal, engine, spl
     mod.use_disc_engine = engine
     if split:
         mod.disc_math, mod.stft_math = "bf16x6", "folded_x6"
-    trainer = O.OracleTrainer(g_sd, d_sd, p=2, q=4, use_mrstft=True)
-    for i in range(2):
-        bc, air = formula_audio(f"mstep{i}/bc", 2, 8200), formula_audio(f"mstep{i}/air", 2, 8200)
+    for i, (bc, air, logs) in enumerate(mstep_oracle(g_sd, d_sd)):
         mod.training_step({"audio_body_conducted": bc.to(DEV), "audio_airborne": air.to(DEV)})
-        logs = trainer.step(bc, air)
         for k in ("train/generator/reconstructive_loss_freq", "train/generator/feature_matching_loss", "train/generator/adv_loss_gen",
                   "train/generator/backprop_loss", "train/discriminator/real_loss", "train/discriminator/fake_loss"):
             np.testing.assert_allclose(mod.logged[k].item(), logs[k].item(), rtol=1e-3, err_msg=k)
@@ -694,11 +705,8 @@ def test_benchmarked_plan_two_steps_with_mrstft_against_oracle(hip, golden, plan
              "train/generator/backprop_loss": 5e-2, "train/discriminator/real_loss": 2e-3, "train/discriminator/fake_loss": 2e-3}
     mod, g_sd, d_sd = make_module(golden, use_mrstft=True)
     mod.disc_math, mod.gen_backward_math, mod.stft_math = plan, "bf16", "folded_x3"
-    trainer = O.OracleTrainer(g_sd, d_sd, p=2, q=4, use_mrstft=True)
-    for i in range(2):
-        bc, air = formula_audio(f"mstep{i}/bc", 2, 8200), formula_audio(f"mstep{i}/air", 2, 8200)
+    for i, (bc, air, logs) in enumerate(mstep_oracle(g_sd, d_sd)):
         out = mod.training_step({"audio_body_conducted": bc.to(DEV), "audio_airborne": air.to(DEV)})
-        logs = trainer.step(bc, air)
         if i == 0:
             assert max_abs(out["enhanced"], logs["enhanced"]) < 2e-5
         for k, rtol in table.items():
