@@ -16,10 +16,6 @@ int tap4_launch(const Tap3Plan& p, const Tap3Args& a, hipStream_t st) {
       case 2242: return launch4<2, 2, 4, 2, 1, 4, 3, EBEN_T4_HB>(p, a, st);
       case 2232: return launch4<2, 2, 3, 2, 1, 4, 3, EBEN_T4_HB>(p, a, st);
       case 2222: return launch4<2, 2, 2, 2, 1, 4, 3, EBEN_T4_HB>(p, a, st);
-      case 1422: return launch4<1, 4, 2, 2, 1, 4, 3, EBEN_T4_HB>(p, a, st);
-      case 1432: return launch4<1, 4, 3, 2, 1, 4, 3, EBEN_T4_HB>(p, a, st);
-      case 1421: return launch4<1, 4, 2, 1, 1, 4, 3, EBEN_T4_HB>(p, a, st);
-      case 1431: return launch4<1, 4, 3, 1, 1, 4, 3, EBEN_T4_HB>(p, a, st);
       default: break;
     }
   } else if (p.npw == 2 && p.KSC == 2 && p.RING == 3) {

@@ -10,10 +10,6 @@ int tap4_launch_x3(const Tap3Plan& p, const Tap3Args& a, hipStream_t st) {
     case 2242: return launch4<2, 2, 4, 2, 2, 2, 3, 1>(p, a, st);
     case 2232: return launch4<2, 2, 3, 2, 2, 2, 3, 1>(p, a, st);
     case 2222: return launch4<2, 2, 2, 2, 2, 2, 3, 1>(p, a, st);
-    case 1422: return launch4<1, 4, 2, 2, 2, 2, 3, 1>(p, a, st);
-    case 1432: return launch4<1, 4, 3, 2, 2, 2, 3, 1>(p, a, st);
-    case 1421: return launch4<1, 4, 2, 1, 2, 2, 3, 1>(p, a, st);
-    case 1431: return launch4<1, 4, 3, 1, 2, 2, 3, 1>(p, a, st);
     default: break;
   }
   return fail(EBEN_EUNSUPPORTED, "tap4: no hi + lo instantiation for wave grid %d x %d, wave tile %d x %d", p.WM, p.WN, p.TM, p.TN);

@@ -235,19 +235,10 @@ struct DwPlan {
 static void make_dw_plan(const Canon& c, DwPlan* p) {
   p->G = c.g; p->Cg = c.Cin / c.g; p->Mg = c.Cout / c.g; p->J = c.k;
   p->Ng = p->Cg * c.k; p->row_stride = p->Ng + 1;
-  // Measured on MI355X (tools/layer_bench.py): the weight-gradient kernel is latency-bound, so the
-  // tiles are small and run on 8 waves (half the prefetch registers per thread -> 3-4 waves per SIMD):
-  // 32x256 tiles ran 1.8x faster than 128x128 (1 block per CU) on the big layers.
-  static const int env_big = getenv("EBEN_DW_BIG_CFG") ? atoi(getenv("EBEN_DW_BIG_CFG")) : -1;  // tuning aid
-  if (env_big == 0 && p->Mg > 64) { p->cfg = 0; p->BM = 128; p->BN = 128; }
-  else if (env_big == 2) {  // the 4-wave tiles
-    if (p->Mg > 64 || (p->Mg > 16 && p->Mg <= 32)) { p->cfg = 2; p->BM = 32; p->BN = 256; }
-    else if (p->Mg > 32) { p->cfg = 1; p->BM = 64; p->BN = 128; }
-    else { p->cfg = 3; p->BM = 16; p->BN = 256; }
-  }
-  else if (p->Mg > 32 && p->Mg <= 64) { p->cfg = 5; p->BM = 64; p->BN = 128; }
-  else if (p->Mg > 16) { p->cfg = 4; p->BM = 32; p->BN = 256; }
-  else { p->cfg = 6; p->BM = 16; p->BN = 256; }
+  // The first-generation kernel is the universal fp32 fallback (weight gradients with fewer than 8 columns per row or one input
+  // channel, the logits layers of the fp32-at-rest plans): ONE configuration, 16 x 256 tiles on eight waves.  (Rounds 1-2 chose among
+  // seven tile shapes; the layers those were tuned for run on conv_dw2 / conv_dw3 / bl_dw, profiles/r05_kernel_coverage.txt.)
+  p->cfg = 6; p->BM = 16; p->BN = 256;
   p->nnt = ceil_div(p->row_stride, p->BN);
   p->nmt = ceil_div(p->Mg, p->BM);
   p->nch_max = (p->BN - 1) / c.k + 2;
@@ -805,13 +796,5 @@ extern "C" int eben_conv1d_bwd_dw(const EbenConv1dDesc* d, const float* dy, cons
   a.slab_stride = p.slab_stride;
   const int nb = p.nnt * p.nmt * p.G * p.nsplit;
   hipStream_t st = as_stream(stream);
-  switch (p.cfg) {
-    case 0: return launch_dw_cfg<2, 2, 4, 4>(a, nb, p.lds_bytes, st);
-    case 1: return launch_dw_cfg<1, 4, 4, 2>(a, nb, p.lds_bytes, st);
-    case 2: return launch_dw_cfg<1, 4, 2, 4>(a, nb, p.lds_bytes, st);
-    case 4: return launch_dw_cfg<1, 8, 2, 2>(a, nb, p.lds_bytes, st);
-    case 5: return launch_dw_cfg<2, 4, 2, 2>(a, nb, p.lds_bytes, st);
-    case 6: return launch_dw_cfg<1, 8, 1, 2>(a, nb, p.lds_bytes, st);
-    default: return launch_dw_cfg<1, 4, 1, 4>(a, nb, p.lds_bytes, st);
-  }
+  return launch_dw_cfg<1, 8, 1, 2>(a, nb, p.lds_bytes, st);
 }

@@ -1,22 +1,28 @@
-// bigtap.hip -- tap4_kernel: the MFMA-bound bundle-layout launches of the bf16 tap-conv (MelGAN L3-L5, the wide PQMF-band layers;
-// forward and stacked input gradients) as ONE PERSISTENT 256-thread block per CU (gfx950).
+// tap4_kernel.h -- tap4_kernel: the MFMA-bound bundle-layout launches of the bf16 tap-conv (MelGAN L3-L5, PQMF-band L5 / L6; forward and
+// stacked input gradients) as ONE PERSISTENT 512-thread block per CU (gfx950).  Instantiated in bigtap.hip / bigtap_x3.hip.
 //
 // Same contraction, same packed weight image, same k-step table as tap3_kernel (tapconv3.hip):
 //   y[b, g*Mg+m, t*OS+oo] = epi( sum_{c<Cg} sum_{j<J} W[j,c,m] * x(b, g*Cg+c, t*S + off0 + j*dstep) ),   k-step = one tap x 16 channels.
 // What differs is how a CU is kept busy:
-//   * block tile = ALL rows the weight panel has up to 256 (x 128 or 256 columns), four waves -- one per SIMD -- with 128 x 64 /
-//     96 x 64 / 64 x 64 wave tiles: 0.75-1 LDS fragment read per MFMA (tap3: 1.25), every input tile staged once per panel instead of
-//     once per 128-row tile, half the weight bytes per MFMA of a 128-row tile;
-//   * a block walks a contiguous range of tiles and treats (tile, channel chunk, k-step) as ONE stream: the weight chunks go through a
-//     ring of RING LDS slots by LDS-DMA, DIST = RING - 1 chunks ahead of the chunk being multiplied, across tile boundaries; the input
-//     tile of the next channel chunk (or of the next tile) lands in the other input buffer meanwhile; the bias rows too.  Prologue and
-//     DMA round trips are paid once per block, not once per tile;
-//   * every DMA is inline asm (hipcc does not know of them), every wait on them an explicit counted s_waitcnt vmcnt(N) in front of the
-//     one raw s_barrier per chunk; loads come back in order, so "all but the N youngest" is exactly "the next chunk has landed";
-//   * the last k-step of a chunk is HELD BACK in registers across the barrier: behind the barrier a wave issues the next chunk's first
-//     fragment reads and then has a k-step of MFMAs that needs no LDS while they fly.
+//   * block tile = 256 / 192 / 128 rows x 128 columns on FOUR CONSUMER WAVES (2 x 2, one per SIMD; wave tile 128 / 96 / 64 rows x 64
+//     columns): 0.75-1 LDS fragment read per MFMA (tap3: 1.25), every input tile staged once per panel instead of once per 128-row
+//     tile, half the weight bytes per MFMA of a 128-row tile;
+//   * FOUR PRODUCER WAVES (one beside each consumer on its SIMD) issue every LDS-DMA of the block: an LDS-DMA piece costs the wave that
+//     issues it 60-185 cycles of issue time, which a wave that also multiplies pays in MFMA slots (one-role blocks: 0.49 of peak,
+//     split roles: 0.53);
+//   * a block walks a contiguous range of tiles and treats (tile, channel chunk, k-step) as ONE stream: weight chunks of KSC k-steps go
+//     through a ring of RING LDS slots, DIST = RING - 1 chunks ahead of the chunk being multiplied, across tile boundaries; the input
+//     tile of the next channel chunk (or of the next tile) lands in the other input buffer meanwhile; the bias rows too.  Prologue
+//     and DMA round trips are paid once per block, not once per tile;
+//   * every DMA is inline asm (hipcc does not know of them), every wait on them an explicit counted s_waitcnt vmcnt(N) of the producers in
+//     front of the one raw s_barrier per chunk; loads come back in order, so "all but the N youngest" is exactly "the next chunk has landed";
+//   * the consumers' fragment reads run HB k-steps ahead of the MFMAs (four fragment register sets at HB = 2), one read behind each MFMA,
+//     ONE counted lgkmcnt wait per k-step; the last HB k-steps of a chunk are held in registers across the barrier, so the MFMAs come
+//     first behind it and the next chunk's first reads fly under them.
+// What bounds it [MI355X]: the LDS-DMA path -- ~39 B / clock / CU alone, ~21 B / clock / CU under the consumers' LDS reads -- against the
+// 8 KB of weights per k-step of a 256 x 128 tile: 0.53 of the dense bf16 peak at 2.0 GHz (profiles/r05_l4_waits.txt).
 // The epilogue is tap3_kernel's bundle epilogue (bias through LDS, four rows per lane = one 8-byte half unit, LeakyReLU mask and
-// feature-matching operands read the same way).
+// feature-matching operands read the same way), plus the phases-as-rows form (whole 16-byte units through v_permlane32_swap).
 #pragma once
 #include "common.h"
 #include "tap3.h"
@@ -171,8 +177,6 @@ __global__ __launch_bounds__(512) void tap4_kernel(const Tap3Args P) {
       const unsigned p = P.m_plen ? __umulhi(rr, P.m_plen) : 0u, d = rr - p * (unsigned)P.PLEN;
       rel[k] = bb < (unsigned)P.CI_B ? (int)(d * (unsigned)P.S + p) : -0x40000000;
       rowoff[k] = (int)(bb < (unsigned)P.CI_B ? bb : 0u) * P.Lx;
-      // a single channel chunk may be padded to whole k-steps: bundles past the group's last are zeros (their weights too)
-      if (P.ncc == 1 && (int)bb >= CgB) rel[k] = -0x40000000;
     }
     const u32x4* zunit = &t4_zero_unit;
     asm volatile("" : "+v"(zunit));   // one register pair for the whole kernel instead of a pc-relative address per piece
@@ -193,8 +197,7 @@ __global__ __launch_bounds__(512) void tap4_kernel(const Tap3Args P) {
         }
       });
       if (cc == 0) {   // BM floats = BM / 4 units; the lanes behind them re-read the first: every producer wave, the same bytes
-        const int brows = P.Mg - T.mt * BM < BM ? P.Mg - T.mt * BM : BM;   // rows of this tile that exist (a multiple of 8)
-        const float* bsrc = P.bias ? P.bias + (long long)T.g * P.Mg + T.mt * BM + 4 * (4 * lane < brows ? lane : 0) : reinterpret_cast<const float*>(zunit);
+        const float* bsrc = P.bias ? P.bias + (long long)T.g * P.Mg + T.mt * BM + 4 * (4 * lane < BM ? lane : 0) : reinterpret_cast<const float*>(zunit);
         t4_dma(bsrc, bs_byte + (unsigned)(par * 1024));
       }
     };
@@ -223,9 +226,8 @@ __global__ __launch_bounds__(512) void tap4_kernel(const Tap3Args P) {
       if (p_dst == p_dst_end) p_dst -= (unsigned)(RING * WCHU * 16);
       if (++p_ch == NCH) { p_ch = 0; p_src = P.wp + nxt.wsrc; }
     };
-    // input buffer of (tile i, channel chunk cc): (cc) & 1 for an even number of chunks per tile (what the k-step table says), the tile's
-    // parity for the single-chunk layers (the table says buffer 0; the consumers add the parity)
-    const bool one_cc = P.ncc == 1;
+    // input buffer of (tile i, channel chunk cc): cc & 1 -- the plan keeps an even number of chunks per tile, which is what the k-step
+    // table says
     x_tile(cur, 0, 0, 0);
     t4_static_for<0, DIST>([&](auto) { w_chunk(); });
     t4_wait_vm<(DIST - 1) * WU>();               // chunk 0 and the first input tile (asked for first) have landed
@@ -242,7 +244,7 @@ __global__ __launch_bounds__(512) void tap4_kernel(const Tap3Args P) {
           // it is needed DIST + 1 chunks later at the earliest (the plan keeps channel chunks that long), i.e. it is older than the
           // weight chunk whose landing the consumers are let go on
           if (in_cc < P.ncc) x_tile(cur, in_cc, in_cc & 1, 0);
-          else if ((unsigned)(tile_i + 1) < count) x_tile(nxt, 0, one_cc ? (tile_i + 1) & 1 : 0, (tile_i + 1) & 1);
+          else if ((unsigned)(tile_i + 1) < count) x_tile(nxt, 0, 0, (tile_i + 1) & 1);
           ++in_cc;
           in_ch = in_cc <= P.ncc ? ((in_cc - 1) * cur.kscc) / KSC + 1 : 0x7fffffff;
         }
@@ -299,9 +301,7 @@ __global__ __launch_bounds__(512) void tap4_kernel(const Tap3Args P) {
   };
   auto no_hook = [](auto) {};
 
-  unsigned xlane = xs_byte + (unsigned)(((lane >> 5) * P.CSTRIDE + wn * TN * 32 + (lane & 31)) * 16);
-  const unsigned xflip = P.ncc == 1 ? (unsigned)(NP * XT * 16) : 0u;   // single-chunk layers: the tiles alternate between the two input buffers
-  unsigned xpar = 0;
+  const unsigned xlane = xs_byte + (unsigned)(((lane >> 5) * P.CSTRIDE + wn * TN * 32 + (lane & 31)) * 16);
   const unsigned wlane = ws_byte + (unsigned)((wm * TM * 64 + lane) * 16);
   int cslot = 0;
   auto rd_one = [&](int ks, Frag& F, auto rc) {   // read r of a k-step's NRD: the B fragments first
@@ -329,6 +329,10 @@ __global__ __launch_bounds__(512) void tap4_kernel(const Tap3Args P) {
     fk1 = P.fm_gs / s2; fk2 = P.fm_gs * s1 / (s2 * s2);
   }
   auto epilogue = [&](const T4Tile& T, int par) {
+    // (the lane id passes through an empty asm: hipcc otherwise hoists the epilogue's per-lane offsets and predicates out of the tile
+    // loop, where they live through the reduction beside 224 accumulator / fragment registers -- and spill)
+    int lane = tid & 63;
+    asm volatile("" : "+v"(lane));
     const int hb = lane >> 5;
     const int b = T.b;
     const int es = P.em_seg > 0 ? (int)(b >= P.em_seg) + (int)(b >= 2 * P.em_seg) + (int)(b >= 3 * P.em_seg) : 0;
@@ -480,9 +484,7 @@ __global__ __launch_bounds__(512) void tap4_kernel(const Tap3Args P) {
       loffs[f] = (((unsigned)(lives[f] ? t : 0) * (unsigned)P.OS + (unsigned)T.oo) * 2u + (unsigned)hb) * 8u;   // bytes inside a bundle row
     }
     auto ld2 = [&](const char* base, long long row, int f) { return *reinterpret_cast<const uint2*>(base + row + loffs[f]); };
-    const int quads = (P.Mg - m0w + 7) >> 3;   // bundle rows of this wave's tile that exist (uniform; a panel may end inside a tile)
     auto finish = [&](int f, int i, int r4, float (&v)[4]) {   // pack + store one row quad
-      if (4 * i + r4 >= quads) return;
       const long long row = (long long)(4 * i + r4) * Lrow;
       uint2 h;
       h.x = t4_pack(v[0], v[1]); h.y = t4_pack(v[2], v[3]);
@@ -521,7 +523,7 @@ __global__ __launch_bounds__(512) void tap4_kernel(const Tap3Args P) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int r4 = 0; r4 < 4; ++r4) ah[f][i][r4] = ld2(ehb, (long long)(4 * i + r4 < quads ? 4 * i + r4 : 0) * Lrow, f);
+          for (int r4 = 0; r4 < 4; ++r4) ah[f][i][r4] = ld2(ehb, (long long)(4 * i + r4) * Lrow, f);
 #pragma unroll
       for (int f = 0; f < TN; ++f)
 #pragma unroll
@@ -543,7 +545,7 @@ __global__ __launch_bounds__(512) void tap4_kernel(const Tap3Args P) {
         for (int f = 0; f < TN; ++f)
 #pragma unroll
           for (int r4 = 0; r4 < 4; ++r4) {
-            const long long row = (long long)(4 * i + r4 < quads ? 4 * i + r4 : 0) * Lrow;
+            const long long row = (long long)(4 * i + r4) * Lrow;
             ah[f][r4] = ld2(ehb, row, f); al[f][r4] = ld2(elb, row, f); rh[f][r4] = ld2(rhb, row, f); rl[f][r4] = ld2(rlb, row, f);
           }
 #pragma unroll
@@ -626,10 +628,6 @@ __global__ __launch_bounds__(512) void tap4_kernel(const Tap3Args P) {
 #pragma unroll
             for (int ks = 0; ks < KSC; ++ks) te[ks] = tn[ks] << 4;
             cslot = cslot + 1 == RING ? 0 : cslot + 1;
-            if (ch == NCH - 1 && xflip) {   // the next chunk is the next tile's first
-              xlane = xpar ? xlane - xflip : xlane + xflip;
-              xpar ^= 1u;
-            }
             __builtin_amdgcn_sched_barrier(0);
           }
           if constexpr (IL) {

@@ -363,36 +363,11 @@ struct TapPlan {
   size_t packed_floats;
 };
 
-static const int kCfgBM[8] = {128, 64, 32, 16, 32, 16, 128, 64};
-static const int kCfgBN[8] = {128, 128, 256, 256, 128, 128, 128, 128};
-
-static void choose_tile(int Mg, int nt_max, int* cfg) {
-  // largest BM with <= 12.5 % padding waste, else the least wasteful
-  const int cand[4] = {128, 64, 32, 16};
-  // up to a third of padded rows is accepted for the thin layers (M <= 96: one 64- or 128-row tile
-  // instead of three 16- / 32-row tiles that each restage the same input: PQMF-disc L3 fwd 0.092 ->
-  // 0.059 ms, L4 dX 0.210 -> 0.098 ms); for M = 192 the three exact 64-row tiles stay faster.
-  static const double env_waste = getenv("EBEN_TAP_WASTE") ? atof(getenv("EBEN_TAP_WASTE")) : 0.0;  // tuning aid
-  const double max_waste = env_waste > 0 ? env_waste : (Mg <= 96 ? 1.34 : 1.125);
-  int best = -1;
-  double best_waste = 1e9;
-  for (int i = 0; i < 4; ++i) {
-    const double waste = (double)round_up(Mg, cand[i]) / Mg;
-    if (waste <= max_waste) { best = i; break; }
-    if (waste < best_waste - 1e-9) { best_waste = waste; best = i; }
-  }
-  static const int env_cfg = getenv("EBEN_TAP_BIG_CFG") ? atoi(getenv("EBEN_TAP_BIG_CFG")) : -1;  // tuning aid
-  if (best == 0 && env_cfg >= 0) best = env_cfg;
-  // 8-wave blocks for the two big tiles: same LDS footprint, half the accumulators per wave, up to
-  // 4 waves per SIMD -- measured +5..14 % on the MelGAN / PQMF top layers (profiles/r01_layer_bench_ab*.txt)
-  static const int env_w8 = getenv("EBEN_TAP_WAVES8") ? atoi(getenv("EBEN_TAP_WAVES8")) : 3;  // tuning aid
-  if (best == 0 && (env_w8 & 1)) best = 6;  // 128x128 on 8 waves
-  if (best == 1 && (env_w8 & 2)) best = 7;  // 64x128 on 8 waves
-  int c = best;  // 0:128x128 1:64x128 2:32x256 3:16x256
-  if (c == 2 && nt_max <= 128) c = 4;
-  if (c == 3 && nt_max <= 128) c = 5;
-  *cfg = c;
-}
+// The first-generation kernel is the library's UNIVERSAL fp32 fallback: the shapes no later family takes (one-channel inputs with long
+// taps such as the dense STFT form, odd row counts).  One configuration serves them all: 16 x 256 tiles on four waves.  (Rounds 1-2 chose
+// among eight tile shapes here; every layer those were tuned for now runs on tapconv2 / tapconv3 / gen_conv / thinconv, and none of
+// the other seven was launched by the GPU suite or the bench any more: profiles/r05_kernel_coverage.txt.)
+constexpr int kTapBM = 16, kTapBN = 256;
 
 // dir 0: canonical forward direction (GS); dir 1: canonical input-gradient direction (PS).
 // For PS with reflect padding the output domain is the padded one (caller folds afterwards).
@@ -416,11 +391,8 @@ static void make_plan(const Canon& c, int dir, TapPlan* p) {
     p->ps_pad = c.reflect ? 0 : c.pl;
     p->off0 = 0; p->nt = ceil_div(p->Ly, c.s);
   }
-  choose_tile(p->Mg, p->nt, &p->cfg);
-  // a 128-row grid that gives every CU at most one block (the 125-sample layers): halve the tile so
-  // that two blocks overlap per CU (MelGAN L4/L5 fwd +5..8 %; with >= 512 blocks 128 rows stay faster)
-  if (p->cfg == 6 && (long long)ceil_div(p->nt, 128) * c.B * p->nph * ceil_div(p->Mg, 128) * p->G <= 256) p->cfg = 7;
-  p->BM = kCfgBM[p->cfg]; p->BN = kCfgBN[p->cfg];
+  p->cfg = 3;
+  p->BM = kTapBM; p->BN = kTapBN;
   p->Mp = round_up(p->Mg, p->BM);
   p->nmt = p->Mp / p->BM;
   p->ntt = ceil_div(p->nt, p->BN);
@@ -555,16 +527,7 @@ static int launch_tap(const Canon& c, const TapPlan& p, const TapIO& io, int ref
   a.phase_stride = p.phase_stride;
   const long long nb = (long long)p.ntt * c.B * p.nph * p.nmt * p.G;
   if (nb <= 0 || nb > 0x7fffffffLL) return fail(EBEN_EINVAL, "tapconv grid of %lld blocks", nb);
-  switch (p.cfg) {
-    case 0: return launch_cfg<2, 2, 4, 4>(a, (int)nb, p.lds_bytes, st);
-    case 1: return launch_cfg<1, 4, 4, 2>(a, (int)nb, p.lds_bytes, st);
-    case 2: return launch_cfg<1, 4, 2, 4>(a, (int)nb, p.lds_bytes, st);
-    case 3: return launch_cfg<1, 4, 1, 4>(a, (int)nb, p.lds_bytes, st);
-    case 4: return launch_cfg<1, 4, 2, 2>(a, (int)nb, p.lds_bytes, st);
-    case 6: return launch_cfg<2, 4, 4, 2>(a, (int)nb, p.lds_bytes, st);
-    case 7: return launch_cfg<2, 4, 2, 2>(a, (int)nb, p.lds_bytes, st);
-    default: return launch_cfg<1, 4, 1, 2>(a, (int)nb, p.lds_bytes, st);
-  }
+  return launch_cfg<1, 4, 1, 4>(a, (int)nb, p.lds_bytes, st);
 }
 
 // Single-output-channel convolution (the logits layers: 1024->1 and 768->1, k=3): a channel

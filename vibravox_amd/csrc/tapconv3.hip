@@ -773,46 +773,36 @@ static int env_int3(const char* name, int dflt) {
 // DMA of an input tile is covered by the wait for the weight chunk issued after it).
 static bool plan_big(const Canon& c, int dir, int Jmin, Tap3Plan* p) {
   static const int enabled = env_int3("EBEN_BIG", 1);
-  // thin layers too (EBEN_BIG_THIN): panels that end inside a row tile, groups padded to whole k-steps, all channels in ONE input tile
-  // that alternates between the two buffers from tile to tile -- HBM-bound streams for which a producer wave per SIMD keeps the next
-  // tile in flight while the consumers multiply and store
-  // [MI355X, 64 / 128 rows] measured and NOT kept as the default: PQMF-band L1-L4 forward 0.040 -> 0.041-0.048 ms, their phase-scatter
-  // input gradients 0.053-0.087 -> 0.093-0.126, MelGAN L1 / L2 phases-as-rows 0.232 / 0.212 -> 0.223 / 0.220 -- these launches are not
-  // streams waiting for bytes: padded to 64 rows x whole k-steps (and block-diagonal over the groups where a group is narrower than
-  // a bundle) they carry 2-4x their MFMAs, and four consumer waves per CU issue them slower than tap3's eight to twenty
-  static const int thin = env_int3("EBEN_BIG_THIN", 0);
-  static const int min_ks = env_int3("EBEN_BIG_MIN_KS", thin ? 0 : 100);     // MFMA k-steps of one output tile (x 3 for hi + lo operands)
-  static const int min_ks_dx = env_int3("EBEN_BIG_MIN_KS_DX", thin ? 0 : 100);
+  // The thin layers stay with tap3_kernel.  [MI355X, 64 / 128 rows] measured and NOT kept, twice: (i) streamed weights, all channels in
+  // one input tile alternating between two buffers: PQMF-band L1-L4 forward 0.040 -> 0.041-0.048 ms, their phase-scatter input
+  // gradients 0.053-0.087 -> 0.093-0.126, MelGAN L1 / L2 phases-as-rows 0.232 / 0.212 -> 0.223 / 0.220; (ii) the whole weight image of
+  // a panel RESIDENT in LDS (25-90 KB, loaded once per block instead of once per tile, one barrier per tile): MelGAN L1 / L2 forward
+  // 0.067 / 0.067 -> 0.072 / 0.076, phases-as-rows 0.233 / 0.211 -> 0.214 / 0.218, PQMF-band L1-L4 input gradients 0.052-0.087 ->
+  // 0.076-0.124.  These launches are not streams waiting for weight bytes: padded to 64 rows x whole k-steps they carry 2-4x their
+  // MFMAs, and their epilogue (mask and feature-matching operands in, 8-byte pieces out) is what one consumer wave per SIMD cannot
+  // hide -- tap3's eight to twenty waves per CU overlap it across blocks.
+  static const int min_ks = env_int3("EBEN_BIG_MIN_KS", 100);     // MFMA k-steps of one output tile (x 3 for hi + lo operands)
+  static const int min_ks_dx = env_int3("EBEN_BIG_MIN_KS_DX", 100);
   // [MI355X] the phase-scatter input gradients of the stride-4 layers (one output phase per tile: 8-byte stores 64 bytes apart, the mask
   // read the same way) lose here against tap3's many small blocks -- MelGAN L3 / L4 0.416 / 0.402 -> 0.506 / 0.444 ms: the epilogue's
   // partial lines are what a block per CU cannot hide; they run phases-as-rows (eben_bl_conv1d_bwd_dx_pr) or stay with tap3
-  static const int strided_dx = env_int3("EBEN_BIG_STRIDED_DX", thin ? 2 : 0);   // largest output stride taken in phase-scatter form
+  static const int strided_dx = env_int3("EBEN_BIG_STRIDED_DX", 0);   // largest output stride taken in phase-scatter form
   if (!enabled || !c.bl || c.reflect) return false;
-  if (p->dense && !thin) return false;
+  if (p->dense) return false;
   if (dir == 1 && p->OS > 1 && p->OS > strided_dx) return false;
-  if (p->npw != p->npx || p->npw > 2 || p->nph > 8 || (p->Cg & 7) || (p->Mg & 7)) return false;
-  if (!thin && ((p->Cg & 15) || (p->Mg & 31))) return false;
-  const int CgP = round_up(p->Cg, 16);
-  const long long ks_total = (long long)(CgP / 16) * p->J * (p->npw == 2 ? 3 : 1);
+  if (p->npw != p->npx || p->npw > 2 || p->nph > 8 || (p->Cg & 15) || (p->Mg & 63)) return false;
+  const long long ks_total = (long long)(p->Cg / 16) * p->J * (p->npw == 2 ? 3 : 1);
   if (ks_total < (dir == 0 ? min_ks : min_ks_dx)) return false;
-  int BM;
-  if (p->Mg % 256 == 0) BM = 256;
-  else if (p->Mg % 192 == 0) BM = 192;
-  else if (p->Mg % 128 == 0) BM = 128;
-  else if (p->Mg <= 64) BM = 64;
-  else if (p->Mg <= 96) BM = 96;
-  else if (p->Mg <= 128) BM = 128;
-  else if (p->Mg <= 192) BM = 192;
-  else BM = 256;
-  if (!thin && p->Mg % BM) return false;
-  const int WM = BM >= 128 ? 2 : 1, WN = 4 / WM, TM = BM / (32 * WM);
+  // whole row tiles of 256, 192 or 128 rows on a 2 x 2 wave grid, 128 columns
+  const int BM = p->Mg % 256 == 0 ? 256 : p->Mg % 192 == 0 ? 192 : 128;
+  if (p->Mg % BM) return false;
+  const int WM = 2, WN = 2, TM = BM / 64;
   // ([MI355X] a ring of two slots -- 105 KB instead of 137 KB per block, room for a small block of another stream beside it: MelGAN L4
   // forward 0.141 -> 0.145 ms alone, 0.15-0.18 -> 0.19 in the step, step 9.73 -> 9.81 ms: three it stays)
   const int KSC = p->npw == 1 ? 4 : 2, RING = 3;
   const int adstep = p->dstep >= 0 ? p->dstep : -p->dstep;
   const int maxd = ((p->J - 1) * adstep) / p->S + 1;
-  for (int TN = 2; TN >= 1; --TN) {
-    if (TN == 1 && WN != 4) break;               // instantiated: 128- or 256-column tiles for the four-wave-wide grids, 128 otherwise
+  for (int TN = 2; TN == 2; --TN) {
     p->BM = BM; p->FM = WM * TM; p->BN = WN * TN * 32;
     p->KSC = KSC;
     p->WCHU = KSC * p->npw * p->FM * 64;
@@ -827,9 +817,7 @@ static bool plan_big(const Canon& c, int dir, int Jmin, Tap3Plan* p) {
       if (ppt < 4 || ceil_div(ppt, 4) > 12) return false;
       return (size_t)wbytes + (size_t)2 * p->npw * ppt * 64 * 16 + 2048 <= 160 * 1024;
     };
-    // all channels in one tile where that fits (thin layers) ...
-    if (thin && fits(CgP, 1) && ceil_div(Jmin * (CgP / 16), KSC) >= RING) { best = CgP; best_ncc = 1; }
-    // ... else an even number of chunks of at least RING + 1 weight chunks each
+    // an even number of channel chunks (the input tile alternates between two buffers) of at least RING + 1 weight chunks each
     for (int ct = 16; !best && ct <= p->Cg / 2; ct += 16) {
       if (p->Cg % ct) continue;
       const int ncc = p->Cg / ct;
