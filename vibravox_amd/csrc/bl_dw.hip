@@ -31,6 +31,9 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef EBEN_BLDW_DBG
+#define EBEN_BLDW_DBG 0   // scratch-build ablations (wrong results): 1 no A-tile DMA, 2 no X-row DMA, 4 no MFMA, 8 no slab stores
+#endif
 constexpr int BLDW_BKT = 64;    // time steps per K chunk
 constexpr int BLDW_TS = 68;     // A row stride in units (64 + 4: = 4 mod 16)
 constexpr int BLDW_RS = 132;    // X row stride in units (two whole 64-unit LDS-DMA pieces + 4)
@@ -156,10 +159,10 @@ __global__ __launch_bounds__(256, 2) void bl_dw_kernel(const BlDwArgs P) {
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
       const int r = wave + 4 * i;
-      if (r < BMB) bl_dma_piece((a_ok && arow[i] >= 0) ? ab + arow[i] + t0 + lane : zero, __builtin_amdgcn_readfirstlane(dst + (unsigned)(r * TS * 16)));
+      if (r < BMB && !(EBEN_BLDW_DBG & 1)) bl_dma_piece((a_ok && arow[i] >= 0) ? ab + arow[i] + t0 + lane : zero, __builtin_amdgcn_readfirstlane(dst + (unsigned)(r * TS * 16)));
     }
     const u32x4* xb = P.xh + ((long long)b * P.CBx + (long long)g * P.CgB) * P.Lx;
-    for (int xr = wave; xr < xrows; xr += 4) {
+    for (int xr = wave; xr < ((EBEN_BLDW_DBG & 2) ? 0 : xrows); xr += 4) {
       const int cbl = xr / P.S, p = xr - cbl * P.S;
       int cb = cb_lo + cbl;
       if (cb > P.CgB - 1) cb = P.CgB - 1;
@@ -193,7 +196,10 @@ __global__ __launch_bounds__(256, 2) void bl_dw_kernel(const BlDwArgs P) {
 #pragma unroll
       for (int i = 0; i < FM; ++i)
 #pragma unroll
-        for (int f = 0; f < FN; ++f) acc[i][f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[f], acc[i][f], 0, 0, 0);
+        for (int f = 0; f < FN; ++f) {
+          if (EBEN_BLDW_DBG & 4) acc[i][f][0] += __builtin_bit_cast(float, __builtin_bit_cast(u32x4, av[i])[0] ^ __builtin_bit_cast(u32x4, bv[f])[1]);
+          else acc[i][f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[f], acc[i][f], 0, 0, 0);
+        }
     }
     bsel ^= 1;
   }
@@ -225,7 +231,7 @@ __global__ __launch_bounds__(256, 2) void bl_dw_kernel(const BlDwArgs P) {
         const int m = m_base + i * 32 + (r & 3) + 8 * (r >> 2);
         if (m >= P.Mg) continue;
         if (P.dense && cgrp >= 0 && m / P.c_out_g != cgrp) continue;
-        slab[((long long)g * P.Mg + m) * P.row_stride + col] = acc[i][f][r];
+        if (!(EBEN_BLDW_DBG & 8) || acc[i][f][r] == 12345.f) slab[((long long)g * P.Mg + m) * P.row_stride + col] = acc[i][f][r];
       }
   }
 }
@@ -258,6 +264,13 @@ static void make_bldw_plan(const Canon& c, BlDwPlan* p) {
   // [MI355X, 64 rows] MelGAN L1-L5 0.124 / 0.106 / 0.286 / 0.331 / 0.175 -> 0.097 / 0.085 / 0.255 / 0.301 / 0.146 ms; the PQMF-band
   // layers (7 taps, 42-84 column bundles: three 256-column tiles where six 128-column ones covered them as well) lose 10-40 %
   p->FN = (fn_max >= 4 && (c.k >= 16 || p->NQW >= 256)) ? 4 : p->NQW + 1 > 8 ? 2 : 1;
+  // 192-column tiles where 256-column ones leave the second round of block slots mostly empty: MelGAN L4's 328 tiles become 440 on
+  // 512 slots ([MI355X] 0.287 -> 0.263 ms; forced on the other layers it loses 3-10 %: more A-tile bytes per MFMA)
+  static const int fn3 = getenv("EBEN_BLDW_FN3") ? atoi(getenv("EBEN_BLDW_FN3")) : 1;
+  if (fn3 && p->FN == 4) {
+    const int t4 = ceil_div(p->NQW + 1, 32) * ceil_div(p->Mg, 64 * p->FM) * p->G, t3 = ceil_div(p->NQW + 1, 24) * ceil_div(p->Mg, 64 * p->FM) * p->G;
+    if (fn3 == 2 || (t4 <= 512 && t4 > 256 && t3 <= 512)) p->FN = 3;
+  }
   const int BNQ = 8 * p->FN;
   p->nmt = ceil_div(p->Mg, 64 * p->FM);
   p->nnt = ceil_div(p->NQW + 1, BNQ);
@@ -347,6 +360,6 @@ extern "C" int eben_bl_conv1d_bwd_dw(const EbenConv1dDesc* d, const void* dy_hi,
   a.dense = p.dense; a.c_in_g = c.Cin / c.g; a.c_out_g = c.Cout / c.g; a.row_stride = p.row_stride; a.slab_stride = p.slab_stride;
   a.xneed = BLDW_BKT + bldw_floordiv((c.k - 1) * c.d - c.pl, c.s) - p.amin + 1;
   hipStream_t st = as_stream(stream);
-  if (p.FM == 2) return p.FN == 4 ? launch_bldw<2, 4>(a, p, st) : p.FN == 2 ? launch_bldw<2, 2>(a, p, st) : launch_bldw<2, 1>(a, p, st);
-  return p.FN == 4 ? launch_bldw<1, 4>(a, p, st) : p.FN == 2 ? launch_bldw<1, 2>(a, p, st) : launch_bldw<1, 1>(a, p, st);
+  if (p.FM == 2) return p.FN == 4 ? launch_bldw<2, 4>(a, p, st) : p.FN == 3 ? launch_bldw<2, 3>(a, p, st) : p.FN == 2 ? launch_bldw<2, 2>(a, p, st) : launch_bldw<2, 1>(a, p, st);
+  return p.FN == 4 ? launch_bldw<1, 4>(a, p, st) : p.FN == 3 ? launch_bldw<1, 3>(a, p, st) : p.FN == 2 ? launch_bldw<1, 2>(a, p, st) : launch_bldw<1, 1>(a, p, st);
 }

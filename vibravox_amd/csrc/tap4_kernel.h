@@ -37,7 +37,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
 #ifndef EBEN_T4_DBG
-#define EBEN_T4_DBG 0   // scratch-build ablations (wrong results): 1 no weight stream, 2 no input stream, 4 no barrier, 8 no MFMA, 16 no epilogue stores
+#define EBEN_T4_DBG 0   // scratch-build ablations (wrong results): 1 no weight stream, 2 no input stream, 4 no barrier, 8 no MFMA, 16 no epilogue stores, 32 no mask / feature-matching loads
 #endif
 #ifndef EBEN_T4_HB
 #define EBEN_T4_HB 2    // k-steps the fragment reads run ahead of the MFMAs (single-piece launches)
@@ -338,7 +338,7 @@ __global__ __launch_bounds__(512) void tap4_kernel(const Tap3Args P) {
     const int es = P.em_seg > 0 ? (int)(b >= P.em_seg) + (int)(b >= 2 * P.em_seg) + (int)(b >= 3 * P.em_seg) : 0;
     const int eb = P.em_seg > 0 ? P.em_map[es] * P.em_seg + (b - es * P.em_seg) : b;
     const bool fmr = P.fm_sums != nullptr && P.res_rows > 0 && b < P.res_rows;
-    const bool masked = P.eh != nullptr;
+    const bool masked = P.eh != nullptr && !(EBEN_T4_DBG & 32);
     const long long Lrow = (long long)P.Ly * 16;                                                    // bytes per bundle row
     const int m0w = T.mt * BM + wm * TM * 32;
     const long long tile0 = ((long long)((T.g * P.Mg + m0w) >> 3)) * Lrow;                         // this wave's first bundle row
@@ -405,6 +405,7 @@ __global__ __launch_bounds__(512) void tap4_kernel(const Tap3Args P) {
         u32x4 U[2];
         to_units(H, U);
         char* q = base + (long long)i * LrowP + poff[f];
+        if ((EBEN_T4_DBG & 16) && U[0][0] != 0x12345u) return;
         if (lv[f][0]) *reinterpret_cast<u32x4*>(q) = U[0];
         if (lv[f][1]) *reinterpret_cast<u32x4*>(q + 16) = U[1];
       };

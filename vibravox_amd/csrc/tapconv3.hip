@@ -786,6 +786,12 @@ static bool plan_big(const Canon& c, int dir, int Jmin, Tap3Plan* p) {
   // [MI355X] the phase-scatter input gradients of the stride-4 layers (one output phase per tile: 8-byte stores 64 bytes apart, the mask
   // read the same way) lose here against tap3's many small blocks -- MelGAN L3 / L4 0.416 / 0.402 -> 0.506 / 0.444 ms: the epilogue's
   // partial lines are what a block per CU cannot hide; they run phases-as-rows (eben_bl_conv1d_bwd_dx_pr) or stay with tap3
+  // [MI355X] the input gradients' epilogue is what tap4 hides worst (one consumer wave per SIMD): without its mask / feature-matching loads
+  // MelGAN L3 / L4 / L5 dX run 0.376 / 0.375 / 0.149 -> 0.297 / 0.286 / 0.136 ms (scratch build EBEN_T4_DBG=32).  Measured and NOT kept: the
+  // mask tile (hi plane under the output tile, 64 KB) staged through LDS by the producers during the reduction, with a ring of two
+  // weight slots and 16-32-channel input tiles to make room -- 0.382 / 0.372 / 0.151 -> 0.411 / 0.394 / 0.157: the rows with a
+  // feature-matching term (a quarter, four operands per value, one load batch per 32-row tile) are the larger part of the exposed
+  // latency, and the smaller ring + 4.5 % more LDS-DMA bytes cost more than the masked rows gain.
   static const int strided_dx = env_int3("EBEN_BIG_STRIDED_DX", 0);   // largest output stride taken in phase-scatter form
   if (!enabled || !c.bl || c.reflect) return false;
   if (p->dense) return false;
