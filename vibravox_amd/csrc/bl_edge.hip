@@ -248,6 +248,7 @@ __global__ __launch_bounds__(256) void bl_head_dw_kernel(const u32x4* __restrict
   const int ci0 = (8 * ob) / OG, ci1 = (8 * ob + 7) / OG;   // OG >= 4: at most two input channels feed one bundle
   // two (batch item, position) pairs per iteration, every load of both issued before the first product: the loop is a chain of
   // dependent global round trips at two waves per SIMD (128 accumulators per thread) -- [MI355X] MelGAN head 165 us one pair at a time
+  // ([MI355X] four / eight pairs per iteration for the 3-tap heads: 36.7 -> 37.0 / 39.6 us -- not what they wait for)
   constexpr int UN = 2;
   for (long long i0 = lo + threadIdx.x; i0 < hi; i0 += 256 * UN) {
     u32x4 gu[UN];
@@ -651,10 +652,82 @@ extern "C" int eben_bl_tail_dx(const float* seeds, int rows, int channels, int l
   return EBEN_OK;
 }
 
+// The same for k = K taps known at compile time (every logits layer of the reference: K = 3), UN (batch item, position) pairs per
+// iteration with all 2 K UN unit loads issued before the first product: the loop above is a chain of dependent global round trips
+// (~10 per thread, six loads each) -- [MI355X] kernel time 768 -> 1, L 250: 37.8 -> 20.6 us; 1024 -> 1, L 125: 43.1 -> 16.2 us.  Same sums in the same order per thread.
+template <int K, int UN>
+__global__ __launch_bounds__(256) void bl_tail_dw_k_kernel(const float* __restrict__ seeds, const u32x4* __restrict__ xh, const u32x4* __restrict__ xl,
+                                                           int rows, int CB, int L, int pad, int l_out, int nslab, float* __restrict__ slabs) {
+  __shared__ float red[4][8 * K + 1];
+  const int cb = blockIdx.x, z = blockIdx.y, br = blockIdx.z;
+  const long long total = (long long)rows * l_out;
+  const long long per = (total + nslab - 1) / nslab;
+  const long long lo = (long long)z * per, hi = lo + per < total ? lo + per : total;
+  const float* sd = seeds + (long long)br * total;
+  float acc[8][K], sb = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e)
+#pragma unroll
+    for (int j = 0; j < K; ++j) acc[e][j] = 0.f;
+  for (long long i0 = lo + threadIdx.x; i0 < hi; i0 += 256 * UN) {
+    u32x4 uh[UN][K], ul[UN][K];
+    float sq[UN][K], sv[UN];
+#pragma unroll
+    for (int un = 0; un < UN; ++un) {
+      const long long i = i0 + 256 * un;
+      const bool live = i < hi;
+      const long long ic = live ? i : lo;
+      const int b = (int)(ic / l_out), t = (int)(ic - (long long)b * l_out);
+      const float s = live ? sd[ic] : 0.f;
+      sv[un] = s;
+      const long long row = ((long long)(br * rows + b) * CB + cb) * L;
+#pragma unroll
+      for (int j = 0; j < K; ++j) {
+        const int q = t - pad + j;
+        const int qc = q < 0 ? 0 : (q >= L ? L - 1 : q);
+        uh[un][j] = xh[row + qc];
+        ul[un][j] = xl ? xl[row + qc] : u32x4{0u, 0u, 0u, 0u};
+        sq[un][j] = q == qc ? s : 0.f;
+      }
+    }
+#pragma unroll
+    for (int un = 0; un < UN; ++un) {
+      sb += sv[un];
+#pragma unroll
+      for (int j = 0; j < K; ++j) {
+        float f[8], l[8];
+        bl_unpack8(uh[un][j], f);
+        bl_unpack8(ul[un][j], l);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e][j] = fmaf(sq[un][j], f[e] + l[e], acc[e][j]);
+      }
+    }
+  }
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int e = 0; e < 8; ++e)
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      const float s = wave_sum(acc[e][j]);
+      if (lane == 0) red[w][e * K + j] = s;
+    }
+  sb = wave_sum(sb);
+  if (lane == 0) red[w][8 * K] = sb;
+  __syncthreads();
+  const long long rs = (long long)CB * 8 * K + 1;
+  float* out = slabs + ((long long)br * nslab + z) * rs;
+  for (int i = threadIdx.x; i < 8 * K + 1; i += 256) {
+    const float s = red[0][i] + red[1][i] + red[2][i] + red[3][i];
+    if (i == 8 * K) { if (cb == 0) out[rs - 1] = s; }
+    else out[(long long)(cb * 8 + i / K) * K + i % K] = s;
+  }
+}
+
 // split-K slices of a logits layer's weight gradient: ~8 (batch item, position) pairs per thread ([MI355X] 2 pairs per thread, four times
 // the blocks and slabs: 54 -> 80 us per launch)
 static int bl_tail_slabs(long long pairs) {
-  long long n = pairs / (256 * 8);
+  static const int per_thread = getenv("EBEN_TAIL_DW_PAIRS") ? atoi(getenv("EBEN_TAIL_DW_PAIRS")) : 8;
+  long long n = pairs / (256 * (per_thread > 0 ? per_thread : 8));
   return (int)(n < 1 ? 1 : (n > 32 ? 32 : n));
 }
 extern "C" size_t eben_bl_tail_dw_workspace(int rows, int channels, int length, int ksize, int nbranch, int* nslab, int* row_stride) {
@@ -673,6 +746,15 @@ extern "C" int eben_bl_tail_dw(const float* seeds, const void* x_hi, const void*
   const int l_out = length + 2 * pad - (ksize - 1);
   int ns = 0;
   if (ws_bytes < eben_bl_tail_dw_workspace(rows, channels, l_out, ksize, nbranch, &ns, nullptr)) return fail(EBEN_EWORKSPACE, "bl_tail_dw workspace too small");
+  static const int un = getenv("EBEN_TAIL_DW_UN") ? atoi(getenv("EBEN_TAIL_DW_UN")) : 4;
+  if (ksize == 3 && un > 1) {
+    if (un >= 4) hipLaunchKernelGGL((bl_tail_dw_k_kernel<3, 4>), dim3(channels / 8, ns, nbranch), dim3(256), 0, as_stream(stream), seeds, static_cast<const u32x4*>(x_hi),
+                                    static_cast<const u32x4*>(x_lo), rows, channels / 8, length, pad, l_out, ns, slabs);
+    else hipLaunchKernelGGL((bl_tail_dw_k_kernel<3, 2>), dim3(channels / 8, ns, nbranch), dim3(256), 0, as_stream(stream), seeds, static_cast<const u32x4*>(x_hi),
+                            static_cast<const u32x4*>(x_lo), rows, channels / 8, length, pad, l_out, ns, slabs);
+    EBEN_CHECK_LAUNCH("bl_tail_dw_k_kernel");
+    return EBEN_OK;
+  }
   hipLaunchKernelGGL(bl_tail_dw_kernel, dim3(channels / 8, ns, nbranch), dim3(256), 0, as_stream(stream), seeds, static_cast<const u32x4*>(x_hi),
                      static_cast<const u32x4*>(x_lo), rows, channels / 8, length, ksize, pad, l_out, ns, slabs);
   EBEN_CHECK_LAUNCH("bl_tail_dw_kernel");
