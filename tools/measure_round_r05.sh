@@ -1,4 +1,4 @@
-# Round-4 measurement set (bench default = bundle-layout plan): bench line (CPU baseline first, fp32 legs), rocprofv3 --kernel-trace --stats of the
+# Round measurement set (bench default = bundle-layout plan): bench line (CPU baseline first, fp32 legs), rocprofv3 --kernel-trace --stats of the
 # same command, overlap timeline, per-layer mixed-roofline table, phase times, ResidualUnit table, PQMF kernels, generator timelines, host
 # enqueue times, the single-rank RCCL line, BASELINE config 4, counter traffic.  Usage: bash tools/measure_round_r05.sh <tag> <commit>
 R=${GRAFT_REPO_ROOT:-/root/repo}; T=${1:-r05}; C=${2:-unknown}; O=$R/gpurun_out; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
