@@ -9,6 +9,8 @@ x = gen.cut_to_valid_length(batch["audio_body_conducted"])
 from vibravox_amd import ops, gen_engine
 gen_engine.USE_GRAPHS = False   # launch by launch: the profiler shows kernels, not a graph replay
 math = ops.MATH_F32 if os.environ.get("GEN_BWD_MATH", "bf16") == "f32" else ops.MATH_BF16   # the training forward saves what THIS backward reads
+# the forward arithmetic of the benchmarked step: hi + lo operands (three products) with the bf16 backward
+gen_engine.set_forward_math("bf16x3" if math == ops.MATH_BF16 and mod.ru_forward_x3 else None)
 for _ in range(3):
     with ops.backward_math(math):
         y, b = gen(x)

@@ -22,7 +22,10 @@ acc = {}
 order = []
 SYNC = os.environ.get("SYNC_EACH_STEP", "0") == "1"
 runs = []
+PRE_SLEEP = int(float(os.environ.get("PRE_SLEEP_CYCLES", "0")))   # a GPU-side delay in front of every step: the host gets that far ahead
 for _ in range(N):
+    if PRE_SLEEP:
+        torch.cuda._sleep(PRE_SLEEP)
     mod.phase_events = []
     mod.training_step(batch)
     if SYNC:
