@@ -240,6 +240,8 @@ MID_LAYERS = {
     "melgan_l2": (dict(c_in=64, c_out=256, ksize=41, stride=4, pad_l=20, pad_r=20, groups=4, out_slope=0.2), 4, 1100, True),
     "melgan_l4_like": (dict(c_in=512, c_out=512, ksize=41, stride=4, pad_l=20, pad_r=20, groups=4, out_slope=0.2), 4, 500, True),
     "melgan_l5_like": (dict(c_in=512, c_out=512, ksize=5, stride=1, pad_l=2, pad_r=2, groups=1, out_slope=0.2), 4, 125, True),
+    # 192 rows and 192 channels per group, nine taps: the 192-row tile of the persistent kernel (bigtap.hip) in both directions and both arithmetics
+    "wide_192rows_k9": (dict(c_in=768, c_out=768, ksize=9, stride=1, pad_l=4, pad_r=4, groups=4, out_slope=0.2), 4, 140, False),
     # ragged edges: clips shorter than one tile, one position past a tile boundary, a single pair of rows, an odd half batch
     "ragged_short_dense": (dict(c_in=24, c_out=48, ksize=7, stride=2, dilation=2, pad_l=3, pad_r=3, groups=4, out_slope=0.2), 2, 37, False),
     "ragged_tile_plus_one": (dict(c_in=96, c_out=192, ksize=7, stride=2, dilation=1, pad_l=3, pad_r=3, groups=4, out_slope=0.2), 6, 263, True),
