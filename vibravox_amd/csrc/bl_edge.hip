@@ -226,6 +226,103 @@ __global__ __launch_bounds__(256) void bl_head_dx_kernel(const BlHeadTable T, fl
   }
 }
 
+// The one-channel head at dilation 1 (MelGAN: 1 -> 16, k 15), TWO consecutive positions per thread: the two outputs share a window of
+// K + 1 staged samples per output channel, read as (K + 1) / 2 aligned ds_read_b64 (lane t reads floats 2 t .. of the row: contiguous over
+// the wave) instead of 2 K ds_read_b32 -- the one-position form is bound by its 240 LDS reads per output.  The next channel's window is
+// asked for before the current channel's products (two window register sets).  Same products in the same order per output as above.
+template <int OG, int K>
+__global__ __launch_bounds__(256) void bl_head_dx2_kernel(const BlHeadTable T, float* __restrict__ dx) {
+  static_assert(K % 2 == 1, "the window of two positions, K + 1 samples, is a whole number of 8-byte reads");
+  constexpr int COUT = OG, CB = COUT / 8, NW = (K + 1) / 2;
+  extern __shared__ __attribute__((aligned(16))) float gt2[];   // [COUT][TL], TL even
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  typedef const __attribute__((address_space(3))) f32x2_t* lds_f2;
+  const int l_in = T.job[0].l_in;
+  const int b = blockIdx.y;
+  const int u0 = blockIdx.x * 512;
+  const int ua = u0 + 2 * (int)threadIdx.x;
+  float acc[2] = {0.f, 0.f};
+  for (int jb = 0; jb < T.n; ++jb) {
+    const BlHeadJob& J = T.job[jb];
+    const int P = J.rpad, span = K - 1, TL = 512 + span;
+    const int tlo = u0 + P + J.pad - span;
+    __syncthreads();
+    for (int i = threadIdx.x; i < CB * TL; i += 256) {
+      const int cb = i / TL, r = i - cb * TL, t = tlo + r;
+      float f[8];
+      if (t >= 0 && t < J.l_out) bl_load8(J.yh, J.yl, ((long long)b * CB + cb) * J.l_out + t, f);
+      else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = 0.f;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) gt2[(8 * cb + e) * TL + r] = f[e];
+    }
+    __syncthreads();
+    cfloat_t v = (cfloat_t)J.v;
+    cfloat_t sc = (cfloat_t)J.scale;
+    if (ua < l_in) {
+      // window of output channel co: W[i] = g[co][tlo + 2 t + i], i = 0 .. K; output q (0, 1) takes tap j from W[K - 1 - j + q]
+      const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) float*)gt2 + (unsigned)(2 * threadIdx.x) * 4u;
+      f32x2_t wa[NW], wb[NW];
+#pragma unroll
+      for (int i = 0; i < NW; ++i) wa[i] = ((lds_f2)(size_t)base)[i];
+      float a0 = 0.f, a1 = 0.f;
+      auto channel = [&](int co, const f32x2_t (&w)[NW]) {
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+          const int i0 = K - 1 - j, i1 = K - j;
+          const float wj = v[co * K + j];
+          s0 = fmaf(wj, w[i0 >> 1][i0 & 1], s0);
+          s1 = fmaf(wj, w[i1 >> 1][i1 & 1], s1);
+        }
+        const float scl = J.scale ? sc[co] : 1.f;
+        a0 = fmaf(s0, scl, a0);
+        a1 = fmaf(s1, scl, a1);
+      };
+      // channel pairs, NOT unrolled: fully unrolled hipcc hoists all sixteen windows (256 registers, one wave per SIMD)
+#pragma unroll 1
+      for (int co = 0; co < COUT; co += 2) {
+#pragma unroll
+        for (int i = 0; i < NW; ++i) wb[i] = ((lds_f2)(size_t)(base + (unsigned)((co + 1) * TL) * 4u))[i];
+        channel(co, wa);
+        const int nx = co + 2 < COUT ? co + 2 : co;   // the last pair re-reads its own first window (unused)
+#pragma unroll
+        for (int i = 0; i < NW; ++i) wa[i] = ((lds_f2)(size_t)(base + (unsigned)(nx * TL) * 4u))[i];
+        channel(co + 1, wb);
+      }
+      acc[0] += a0;
+      acc[1] += a1;
+      // folded terms of the reflection, as above, for each of the two positions
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int u = ua + q;
+        if (u >= l_in) continue;
+        int pts[2], np = 0;
+        if (u >= 1 && u <= P) pts[np++] = P - u;
+        if (u >= l_in - 1 - P && u <= l_in - 2) pts[np++] = P + 2 * (l_in - 1) - u;
+        for (int qq = 0; qq < np; ++qq)
+          for (int j = 0; j < K; ++j) {
+            const int t = pts[qq] + J.pad - j;
+            if (t < 0 || t >= J.l_out) continue;
+            for (int cb = 0; cb < CB; ++cb) {
+              float gv[8];
+              bl_load8(J.yh, J.yl, ((long long)b * CB + cb) * J.l_out + t, gv);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                const int co = 8 * cb + e;
+                acc[q] += J.v[co * K + j] * (J.scale ? J.scale[co] : 1.f) * gv[e];
+              }
+            }
+          }
+      }
+    }
+  }
+  if (ua < l_in) dx[(long long)b * l_in + ua] = acc[0];
+  if (ua + 1 < l_in) dx[(long long)b * l_in + ua + 1] = acc[1];
+}
+
 // ([MI355X] tried: four consecutive positions per thread sharing a window of K + 3 samples per channel -- five ds_read_b128 for 4 K products
 // instead of one ds_read_b32 per product: 109 -> 145 us for the MelGAN head; the one-position form keeps all 240 reads of a thread in flight
 // (251 registers), the windowed one waits for each channel's window in turn.)
@@ -580,9 +677,18 @@ extern "C" int eben_bl_head_dx(const EbenBlHeadJob* jobs, int njobs, int rows, f
   const size_t lds = sizeof(float) * (size_t)jobs[0].c_out * (256 + span);
   EBEN_REQUIRE(lds <= 64 * 1024, "head input gradient: the gradient tile does not fit");
   const dim3 grid(ceil_div(jobs[0].l_in, 256), rows);
+  static const int two_pos = getenv("EBEN_HEAD_DX2") ? atoi(getenv("EBEN_HEAD_DX2")) : 1;
+  bool unit_dil = true;
+  for (int i = 0; i < njobs; ++i) unit_dil = unit_dil && jobs[i].dilation == 1;
   switch (bl_head_shape(jobs[0])) {
     case 0: hipLaunchKernelGGL((bl_head_dx_kernel<4, 6, 3>), grid, dim3(256), lds, as_stream(stream), T, dx); break;
-    case 1: hipLaunchKernelGGL((bl_head_dx_kernel<1, 16, 15>), grid, dim3(256), lds, as_stream(stream), T, dx); break;
+    case 1:
+      if (two_pos && unit_dil) {
+        hipLaunchKernelGGL((bl_head_dx2_kernel<16, 15>), dim3(ceil_div(jobs[0].l_in, 512), rows), dim3(256), sizeof(float) * 16 * (512 + 14), as_stream(stream), T, dx);
+        EBEN_CHECK_LAUNCH("bl_head_dx2_kernel");
+        return EBEN_OK;
+      }
+      hipLaunchKernelGGL((bl_head_dx_kernel<1, 16, 15>), grid, dim3(256), lds, as_stream(stream), T, dx); break;
     default: return fail(EBEN_EUNSUPPORTED, "chain head %d -> %d, k %d: not one of the built shapes", jobs[0].c_in, jobs[0].c_out, jobs[0].ksize);
   }
   EBEN_CHECK_LAUNCH("bl_head_dx_kernel");
