@@ -18,6 +18,13 @@
 
 namespace eben {
 
+#ifdef EBEN_EDGE_NO_WAVESUM   // scratch ablation (wrong results): what the 8 (K + 1) wave reductions of a block cost
+#define EDGE_WAVE_SUM(x) (x)
+#else
+#define EDGE_WAVE_SUM(x) wave_sum(x)
+#endif
+
+
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2v __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
@@ -383,7 +390,7 @@ __global__ __launch_bounds__(256) void bl_head_dw_kernel(const u32x4* __restrict
   for (int e = 0; e < 8; ++e)
 #pragma unroll
     for (int j = 0; j <= K; ++j) {
-      const float sm = wave_sum(acc[e][j]);
+      const float sm = EDGE_WAVE_SUM(acc[e][j]);
       if (lane == 0) red[w][e * (K + 1) + j] = sm;
     }
   __syncthreads();
@@ -697,8 +704,12 @@ extern "C" int eben_bl_head_dx(const EbenBlHeadJob* jobs, int njobs, int rows, f
 
 // split-K slices of a head's weight gradient: ~2048 (batch item, position) pairs per thread block column
 static int bl_head_slabs(long long pairs) {
-  long long n = pairs / (256 * 24);
-  return (int)(n < 32 ? 32 : (n > 256 ? 256 : n));
+  // [MI355X] 24 pairs per thread put the 3-tap heads on 249 blocks (one per CU, a dozen dependent round trips each): 36.0 -> 21.1 us at 6;
+  // the 15-tap head sits at the cap either way (more, shorter blocks lose to their fixed cost: 82 -> 108 us at 512 slabs)
+  static const int per_thread = getenv("EBEN_HEAD_DW_PAIRS") ? atoi(getenv("EBEN_HEAD_DW_PAIRS")) : 6;
+  static const int cap = getenv("EBEN_HEAD_DW_SLABS") ? atoi(getenv("EBEN_HEAD_DW_SLABS")) : 256;
+  long long n = pairs / (256 * (per_thread > 0 ? per_thread : 24));
+  return (int)(n < 32 ? 32 : (n > cap ? cap : n));
 }
 extern "C" size_t eben_bl_head_dw_workspace(const EbenBlHeadJob* job, int rows, int* nslab, int* row_stride) {
   if (!job || rows <= 0) return 0;

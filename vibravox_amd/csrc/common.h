@@ -54,7 +54,31 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblocks) {
   return start + idx;
 }
 
+// Sum over the wave, every lane receives it: the butterfly v += v[lane ^ 32], ^ 16, ^ 8, ^ 4, ^ 2, ^ 1 -- on the cross-lane VALU paths
+// instead of six ds_bpermute_b32 (__shfl_xor): v_permlane32_swap / v_permlane16_swap pair the halves / the odd and even rows, a DPP
+// row rotation by 8 / 4 / 2 / 1 pairs lane ^ 8 ... lane ^ 1 once the partial sums repeat with that period.  Same pairs, same order:
+// bit-identical to the shuffle form ([MI355X] the 128 reductions of a MelGAN-head weight-gradient block: 24 of the kernel's 86 us).
 __device__ __forceinline__ float wave_sum(float v) {
+  // (inline asm: the swaps exchange lanes BETWEEN their two operands, and handed the same value twice through the builtin hipcc
+  // (ROCm 7.2) takes both results from one register; "+v" on two variables keeps two registers.  s_nop 1 = the two wait states
+  // between a VALU write of an operand and the swap reading it)
+  float a = v, b = v;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  v = a + b;
+  a = v; b = v;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  v = a + b;
+#define EBEN_ROW_ROR_ADD(N)                                                                                                   \
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + (N), 0xf, 0xf, false));
+  EBEN_ROW_ROR_ADD(8)
+  EBEN_ROW_ROR_ADD(4)
+  EBEN_ROW_ROR_ADD(2)
+  EBEN_ROW_ROR_ADD(1)
+#undef EBEN_ROW_ROR_ADD
+  return v;
+}
+// the shuffle form (reference of tests / scratch comparisons)
+__device__ __forceinline__ float wave_sum_shfl(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
