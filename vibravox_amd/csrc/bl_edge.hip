@@ -441,6 +441,72 @@ __global__ __launch_bounds__(1024) void bl_tail_fwd_kernel(const u32x4* __restri
   }
 }
 
+// The same for k = K taps known at compile time: the loop above waits for each (bundle, tap)'s two unit loads in turn -- 18-24 dependent
+// round trips per thread.  Here a bundle's 2 K loads go out together and the next bundle's are in flight while the current one is
+// summed (two register sets, bundle pairs per iteration).  Same products and sums in the same order.
+template <int K>
+__global__ __launch_bounds__(1024) void bl_tail_fwd_k_kernel(const u32x4* __restrict__ xh, const u32x4* __restrict__ xl, int CB, int L, int pad,
+                                                             int l_out, const float* __restrict__ v, const float* __restrict__ scale,
+                                                             const float* __restrict__ bias, float out_slope, float* __restrict__ y) {
+  extern __shared__ __attribute__((aligned(16))) float wt[];   // [CB][K][8] scaled weights, then 16 x 64 partial sums
+  float* part = wt + CB * 8 * K;
+  const float sc = scale ? scale[0] : 1.f;
+  for (int i = threadIdx.x; i < CB * 8 * K; i += 1024) {
+    const int cb = i / (8 * K), r = i - cb * 8 * K, j = r >> 3, e = r & 7;
+    wt[i] = v[(cb * 8 + e) * K + j] * sc;
+  }
+  __syncthreads();
+  const int b = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int t = blockIdx.x * 64 + lane;
+  float acc = 0.f;
+  if (t < l_out) {
+    u32x4 ha[K], la[K], hb[K], lb[K];
+    auto issue = [&](int cb, u32x4 (&h)[K], u32x4 (&l)[K]) {
+      const long long row = ((long long)b * CB + cb) * L;
+#pragma unroll
+      for (int j = 0; j < K; ++j) {
+        const int q = t - pad + j;
+        const int qc = q < 0 ? 0 : (q >= L ? L - 1 : q);
+        h[j] = xh[row + qc];
+        l[j] = xl[row + qc];
+      }
+    };
+    auto sum = [&](int cb, const u32x4 (&h)[K], const u32x4 (&l)[K]) {
+#pragma unroll
+      for (int j = 0; j < K; ++j) {
+        float f[8], g[8];
+        bl_unpack8(h[j], f);
+        bl_unpack8(l[j], g);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] += g[e];
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(wt + (cb * K + j) * 8), w1 = *reinterpret_cast<const f32x4*>(wt + (cb * K + j) * 8 + 4);
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s = fmaf(w0[e], f[e], fmaf(w1[e], f[4 + e], s));
+        const int q = t - pad + j;
+        acc += (q >= 0 && q < L) ? s : 0.f;
+      }
+    };
+    if (w < CB) issue(w, ha, la);
+#pragma unroll 1
+    for (int cb = w; cb < CB; cb += 32) {
+      const bool second = cb + 16 < CB;
+      if (second) issue(cb + 16, hb, lb);
+      sum(cb, ha, la);
+      if (cb + 32 < CB) issue(cb + 32, ha, la);
+      if (second) sum(cb + 16, hb, lb);
+    }
+  }
+  part[w * 64 + lane] = acc;
+  __syncthreads();
+  if (w == 0 && t < l_out) {
+    float s = bias ? bias[0] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += part[i * 64 + lane];
+    y[(long long)b * l_out + t] = lrelu(s, out_slope);
+  }
+}
+
 // input gradient of the logits layer, with the epilogue of the engine's stacked backward:
 //   g[b, c, t] = ( sum_j w[c, j] seed[b, t + pad - j] + (b < fm_rows ? fm term of the embedding : 0) ) * lrelu'(act[map(b), c, t])
 struct BlTailDxArgs {
@@ -745,6 +811,13 @@ extern "C" int eben_bl_tail_fwd(const void* x_hi, const void* x_lo, int batch, i
   EBEN_REQUIRE(l_out > 0, "tail forward: empty output");
   const size_t lds = sizeof(float) * ((size_t)channels * ksize + 16 * 64);
   EBEN_REQUIRE(lds <= 64 * 1024, "tail forward: %d channels x %d taps exceed the weight buffer", channels, ksize);
+  static const int pipelined = getenv("EBEN_TAIL_FWD_K") ? atoi(getenv("EBEN_TAIL_FWD_K")) : 1;
+  if (ksize == 3 && pipelined && x_lo) {
+    hipLaunchKernelGGL((bl_tail_fwd_k_kernel<3>), dim3(ceil_div(l_out, 64), batch), dim3(1024), lds, as_stream(stream), static_cast<const u32x4*>(x_hi),
+                       static_cast<const u32x4*>(x_lo), channels / 8, length, pad, l_out, v, scale, bias, out_slope, y);
+    EBEN_CHECK_LAUNCH("bl_tail_fwd_k_kernel");
+    return EBEN_OK;
+  }
   hipLaunchKernelGGL(bl_tail_fwd_kernel, dim3(ceil_div(l_out, 64), batch), dim3(1024), lds, as_stream(stream), static_cast<const u32x4*>(x_hi),
                      static_cast<const u32x4*>(x_lo), channels / 8, length, ksize, pad, l_out, v, scale, bias, out_slope, y);
   EBEN_CHECK_LAUNCH("bl_tail_fwd_kernel");
