@@ -55,6 +55,8 @@ HEADS = {
     "pqmf_d2": (4, 24, 3, 2, 1, 1, 3, 1003),
     "pqmf_d3": (4, 24, 3, 3, 1, 1, 2, 700),
     "melgan": (1, 16, 15, 1, 0, 7, 2, 2014),
+    "melgan_odd_length": (1, 16, 15, 1, 0, 7, 3, 1535),   # rows that end inside a two-position pair of the input-gradient kernel
+    "melgan_d2": (1, 16, 15, 2, 0, 7, 2, 1200),           # dilation 2: the one-position input-gradient kernel
 }
 
 
@@ -161,16 +163,16 @@ def test_pqmf_heads_as_one_launch_and_summed_input_gradient(hip):
     assert rel_err(dx, xr.grad) < 1e-5
 
 
-@pytest.mark.parametrize("channels,length", [(768, 251), (1024, 125), (96, 33)])
-def test_chain_tail_forward_backward(hip, channels, length):
+@pytest.mark.parametrize("channels,length,k", [(768, 251, 3), (1024, 125, 3), (96, 33, 3), (96, 40, 5)])   # k = 5: the kernels for any tap count
+def test_chain_tail_forward_backward(hip, channels, length, k):
     from vibravox_amd._lib import check
     from vibravox_amd.disc_engine_bl import Planes
 
     half = 2
     rows2, rows4 = 2 * half, 4 * half
-    k, pad = 3, 1
+    pad = k // 2
     st = torch.cuda.current_stream().cuda_stream
-    v = formula_tensor(f"blt/{channels}/v", (1, channels, k), 1 / math.sqrt(channels * k)).to(DEV)
+    v = formula_tensor(f"blt/{channels}/{k}/v", (1, channels, k), 1 / math.sqrt(channels * k)).to(DEV)
     scale = torch.tensor([1.3], device=DEV)
     bias = torch.tensor([0.05], device=DEV)
     act = planes_of(formula_tensor(f"blt/{channels}/x", (rows2, channels, length)))
