@@ -399,6 +399,11 @@ EBEN_API int eben_stft_loss_total(const void* const* sums, const float* inv_coun
  * step, eben.py:99-128 through hinge_loss.py:35-43); the single-term kernel's summation order. */
 EBEN_API int eben_hinge_fwd_multi(const void* const* xs, const int64_t* numel, const float* targets, int n, float* out, void* stream);
 EBEN_API int eben_hinge_bwd(const float* x, size_t n, float target, const float* gout, float scale, float* dx, void* stream);
+/* The stacked seeds of the batched discriminator backward (hinge_loss.py:38-43 differentiated three times; rows [fm | adv | fake | real],
+ * `per` logits each): seeds[0 .. per) = 0, seeds[per ..) = d hinge(enhanced, +1), [2 per ..) = d hinge(enhanced, -1), [3 per ..) =
+ * d hinge(reference, +1), each times gout[0] * scale_x / per -- eben_hinge_bwd's arithmetic, one launch. */
+EBEN_API int eben_hinge_bwd_stacked(const float* enhanced_logits, const float* reference_logits, size_t per, const float* gout, float scale_adv,
+                                    float scale_fake, float scale_real, float* seeds, void* stream);
 /* STFT magnitude losses (auraloss.freq.STFTLoss as configured by multi_stft.yaml; call site
  * vibravox/lightning_modules/eben.py:195-198).  spec_* hold (rows, 2*bins_pad, frames) with re in
  * channels [0,bins) and im in [bins_pad, bins_pad+bins); |.| = sqrt(clamp(re^2+im^2, eps)).

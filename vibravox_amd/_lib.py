@@ -171,6 +171,7 @@ SIGNATURES = {
     "eben_balance": (c_int, [POINTER(c_void_p), POINTER(c_void_p), c_int, _P, c_int, c_int, c_float, c_float, _P, _P, _P]),
     "eben_weighted_sum": (c_int, [POINTER(c_void_p), _P, c_int, c_size_t, _P, _P]),
     "eben_hinge_bwd": (c_int, [_P, c_size_t, c_float, _P, c_float, _P, _P]),
+    "eben_hinge_bwd_stacked": (c_int, [_P, _P, c_size_t, _P, c_float, c_float, c_float, _P, _P]),
     "eben_stft_loss_sums": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_float, _P, c_size_t, _P, _P]),
     "eben_stft_loss_sums_workspace": (c_size_t, [c_int]),
     "eben_stft_loss_bwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_float, _P, _P, c_float, _P, _P]),

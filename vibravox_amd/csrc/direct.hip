@@ -347,6 +347,21 @@ __global__ __launch_bounds__(256) void hinge_bwd_kernel(const float* __restrict_
   const float g = gout[0] * scale / (float)n;
   EBEN_GRID_STRIDE(i, n) dx[i] = (1.f - target * x[i] > 0.f) ? -target * g : 0.f;
 }
+// The four stacked seed blocks of the discriminator engine's backward in one launch: [0 | hinge'(a, +1) | hinge'(a, -1) | hinge'(b, +1)]
+// (rows [fm | adv | fake | real]; a = logits of the enhanced rows, b = of the reference rows; `per` elements each), every block with
+// hinge_bwd_kernel's arithmetic -- a memset and three tiny launches at the head of every input-gradient chain otherwise.
+__global__ __launch_bounds__(256) void hinge_bwd_stacked_kernel(const float* __restrict__ a, const float* __restrict__ b, size_t per,
+                                                                const float* __restrict__ gout, float s0, float s1, float s2, float* __restrict__ seeds) {
+  const float g0 = gout[0] * s0 / (float)per, g1 = gout[0] * s1 / (float)per, g2 = gout[0] * s2 / (float)per;
+  EBEN_GRID_STRIDE(i, 4 * per) {
+    const size_t seg = i / per, j = i - seg * per;
+    float v = 0.f;
+    if (seg == 1) v = (1.f - a[j] > 0.f) ? -g0 : 0.f;
+    else if (seg == 2) v = (1.f + a[j] > 0.f) ? g1 : 0.f;
+    else if (seg == 3) v = (1.f - b[j] > 0.f) ? -g2 : 0.f;
+    seeds[i] = v;
+  }
+}
 __global__ __launch_bounds__(256) void l2_partial_kernel(const float* __restrict__ x, size_t n, float* __restrict__ partial) {
   __shared__ float red[4];
   float s = 0.f;
@@ -1113,6 +1128,15 @@ extern "C" int eben_hinge_bwd(const float* x, size_t n, float target, const floa
   EBEN_REQUIRE(x && gout && dx && n > 0, "bad hinge arguments");
   hipLaunchKernelGGL(hinge_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), x, n, target, gout, scale, dx);
   EBEN_CHECK_LAUNCH("hinge_bwd_kernel");
+  return EBEN_OK;
+}
+
+extern "C" int eben_hinge_bwd_stacked(const float* enhanced_logits, const float* reference_logits, size_t per, const float* gout, float scale_adv,
+                                      float scale_fake, float scale_real, float* seeds, void* stream) {
+  EBEN_REQUIRE(enhanced_logits && reference_logits && gout && seeds && per > 0, "bad stacked hinge arguments");
+  hipLaunchKernelGGL(hinge_bwd_stacked_kernel, dim3(grid_for(4 * per)), dim3(256), 0, as_stream(stream), enhanced_logits, reference_logits, per, gout,
+                     scale_adv, scale_fake, scale_real, seeds);
+  EBEN_CHECK_LAUNCH("hinge_bwd_stacked_kernel");
   return EBEN_OK;
 }
 

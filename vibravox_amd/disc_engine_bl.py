@@ -33,6 +33,8 @@ from .disc_engine import DiscriminatorEngine, _Layer
 BL = 0x100   # EBEN_LAYOUT_BL
 #: split forward (forward_reference): also run MelGAN's reference half underneath the generator forward (default: MelGAN whole, behind it)
 SPLIT_MELGAN = __import__("os").environ.get("EBEN_SPLIT_MELGAN", "0") != "0"
+#: the four stacked seed blocks of a chain's backward from one launch (eben_hinge_bwd_stacked); 0: a memset + three launches
+STACKED_SEEDS = __import__("os").environ.get("EBEN_STACKED_SEEDS", "1") != "0"
 
 
 def _addr(t: Optional[torch.Tensor]) -> Optional[int]:
@@ -574,12 +576,18 @@ class DiscriminatorEngineBL(DiscriminatorEngine):
 
         def body(i):
             lg = s["logits"][i]
-            seeds = torch.zeros((4 * half,) + tuple(lg.shape[1:]), dtype=torch.float32, device=dev)
+            # rows [fm | adv | fake | real]: zeros and the three hinge derivatives (targets +1, -1 on the enhanced rows, +1 on the reference rows)
             per = lg[:half].numel()
-            flat = seeds.reshape(-1)
-            for k2, (rows, target) in enumerate(((lg[:half], 1.0), (lg[:half], -1.0), (lg[half:], 1.0))):
-                check(lib.eben_hinge_bwd(ptr(rows), rows.numel(), target, ptr(one), inv_scales * self.seed_weights[k2], ptr(flat[(k2 + 1) * per:]),
-                                         _stream()), "hinge_bwd")
+            if STACKED_SEEDS:
+                seeds = torch.empty((4 * half,) + tuple(lg.shape[1:]), dtype=torch.float32, device=dev)
+                check(lib.eben_hinge_bwd_stacked(ptr(lg[:half]), ptr(lg[half:]), per, ptr(one), inv_scales * self.seed_weights[0],
+                                                 inv_scales * self.seed_weights[1], inv_scales * self.seed_weights[2], ptr(seeds), _stream()), "hinge_bwd_stacked")
+            else:   # a memset and one launch per seed block (bisecting aid: the same values)
+                seeds = torch.zeros((4 * half,) + tuple(lg.shape[1:]), dtype=torch.float32, device=dev)
+                flat = seeds.reshape(-1)
+                for k2, (rows, target) in enumerate(((lg[:half], 1.0), (lg[:half], -1.0), (lg[half:], 1.0))):
+                    check(lib.eben_hinge_bwd(ptr(rows), rows.numel(), target, ptr(one), inv_scales * self.seed_weights[k2], ptr(flat[(k2 + 1) * per:]),
+                                             _stream()), "hinge_bwd")
             return self.chains[i].backward_body(s["acts"][i], seeds, half, want_param_grads, sums_ptr + 8 * s["fm_first"][i], s["fm_inv"]) + (seeds,)
 
         def run(i):
