@@ -920,7 +920,10 @@ static PrGeom pr_geometry(const Canon& c, Canon* cp) {
   // contiguous bytes per column -- the phase-scatter form writes (and reads its mask as) 8-byte pieces 64 bytes apart, which a
   // block per CU cannot hide ([MI355X] phase-scatter on tap4: 0.416 / 0.402 -> 0.506 / 0.444 ms)
   static const int big_pr = getenv("EBEN_PR_BIG") ? atoi(getenv("EBEN_PR_BIG")) : 1;
-  g.order = (big_pr && c.s == 4 && c.d == 1 && tap3_is_big(q, 0)) ? 1 : 0;
+  // ... and the narrow ones (MelGAN L1 / L2: 64 primed rows per group, tap3_kernel) take the same row order: their mask / feature-matching
+  // operands and results move as whole units too ([MI355X] those loads were 36-43 % of the order-0 launches)
+  static const int small_pr2 = getenv("EBEN_PR2_TAP3") ? atoi(getenv("EBEN_PR2_TAP3")) : 1;
+  g.order = (big_pr && c.s == 4 && c.d == 1 && (tap3_is_big(q, 0) || (small_pr2 && (q.Cout / q.g) % 32 == 0))) ? 1 : 0;
   if (q.Cout / q.g > max_rows && !g.order) return g;
   if (!tap3_applicable(q, 0)) return g;
   if (cp) *cp = q;

@@ -609,6 +609,106 @@ __global__ __launch_bounds__(256, NPW >= 2 ? ((EBEN_T3_SPLIT_OCC2 && FM <= 2) ? 
     };
     auto ld2 = [&](const char* base, long long row) { return *reinterpret_cast<const uint2*>(base + row + loff); };
     const int quads = (P.Mg - m0 + 7) >> 3;   // bundle rows of this tile that exist (uniform)
+    if (pr && P.pr_order == 1) {
+      // ---- phases as rows, rows ordered (channel bundle, phase, channel in bundle), stride 4 (tap4_kernel.h has the same form): accumulator
+      // tile i IS bundle cb0 + i of the group at the four phases of this lane's column -- row quad r4 = phase r4 -- i.e. the 64 contiguous
+      // bytes of positions 4 t .. 4 t + 3.  One v_permlane32_swap per dword turns the lane's four half units into two whole units: lane
+      // (t, 0) positions 4 t, 4 t + 1, lane (t, 1) positions 4 t + 2, 4 t + 3 -- 32 contiguous bytes per lane, where order 0 reads its mask
+      // and writes its result as 8-byte pieces 64 bytes apart.  [MI355X] the mask / feature-matching loads of the order-0 form are 36-43 %
+      // of a MelGAN L1 / L2 input-gradient launch (253 / 233 -> 143 / 148 us without them).
+      const long long LrowP = (long long)P.pr_Ly * 16;
+      const long long tileP = (long long)(g * P.pr_cbg + (m0 >> 5)) * LrowP;
+      const char* ehp = reinterpret_cast<const char*>(P.eh) + (long long)eb * P.CBy * LrowP + tileP;
+      const char* elp = reinterpret_cast<const char*>(P.el) + (long long)eb * P.CBy * LrowP + tileP;
+      const char* rhp = reinterpret_cast<const char*>(P.eh) + (long long)(b + P.bl_ref_off) * P.CBy * LrowP + tileP;
+      const char* rlp = reinterpret_cast<const char*>(P.el) + (long long)(b + P.bl_ref_off) * P.CBy * LrowP + tileP;
+      char* yhp = reinterpret_cast<char*>(P.yh) + (long long)b * P.CBy * LrowP + tileP;
+      char* ylp = reinterpret_cast<char*>(P.yl) + (long long)b * P.CBy * LrowP + tileP;
+      const int pos0 = 4 * t + 2 * hb;
+      const bool lv0 = pos0 < P.pr_Ly, lv1 = pos0 + 1 < P.pr_Ly;
+      const unsigned poff = (unsigned)(lv0 ? pos0 : 0) * 16u;
+      auto swap32 = [](unsigned& x, unsigned& y) {
+        const auto r = __builtin_amdgcn_permlane32_swap(x, y, false, false);
+        x = r[0]; y = r[1];
+      };
+      // memory layout (two whole units per lane) <-> MFMA layout (four half units per lane)
+      auto to_halves = [&](const u32x4 (&U)[2], uint2 (&H)[4]) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          unsigned x0 = U[j][0], x1 = U[j][1], y0 = U[j][2], y1 = U[j][3];
+          swap32(x0, y0); swap32(x1, y1);
+          H[j].x = x0; H[j].y = x1; H[2 + j].x = y0; H[2 + j].y = y1;
+        }
+      };
+      auto to_units = [&](const uint2 (&H)[4], u32x4 (&U)[2]) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          unsigned x0 = H[j].x, x1 = H[j].y, y0 = H[2 + j].x, y1 = H[2 + j].y;
+          swap32(x0, y0); swap32(x1, y1);
+          U[j] = u32x4{x0, x1, y0, y1};
+        }
+      };
+      auto ldu = [&](const char* base, int i, u32x4 (&U)[2]) {
+        const char* q = base + (long long)i * LrowP + poff;
+        U[0] = *reinterpret_cast<const u32x4*>(q);
+        U[1] = *reinterpret_cast<const u32x4*>(q + (lv1 ? 16 : 0));
+      };
+      auto stu = [&](int i, const uint2 (&H)[4], char* base) {
+        u32x4 U[2];
+        to_units(H, U);
+        char* q = base + (long long)i * LrowP + poff;
+        if ((EBEN_T3_DBG & 128) && U[0][0] != 0x12345u) return;
+        if (lv0) *reinterpret_cast<u32x4*>(q) = U[0];
+        if (lv1) *reinterpret_cast<u32x4*>(q + 16) = U[1];
+      };
+      const int tiles = (P.Mg - m0 + 31) >> 5;   // 32-row tiles of this block that exist (uniform; Mg is a multiple of 32 here)
+      u32x4 AU[FM][2];
+      if (masked && !fmr) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i) ldu(ehp, i < tiles ? i : 0, AU[i]);
+      }
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        if (i >= tiles) continue;
+        uint2 AH[4], AL[4], RH[4], RL[4], OH[4], OL[4];
+        if (masked && !fmr) to_halves(AU[i], AH);
+        else if (masked) {
+          u32x4 A2[2], L2[2], RH2[2], RL2[2];
+          ldu(ehp, i, A2); ldu(elp, i, L2); ldu(rhp, i, RH2); ldu(rlp, i, RL2);
+          to_halves(A2, AH); to_halves(L2, AL); to_halves(RH2, RH); to_halves(RL2, RL);
+        }
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          float v[4], a0[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = acc[i][4 * r4 + e];
+          if (masked) {
+            unpack(AH[r4], a0);
+            if (fmr) {
+              float a1[4], r0[4], r1[4];
+              unpack(AL[r4], a1); unpack(RH[r4], r0); unpack(RL[r4], r1);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float av = a0[e] + a1[e], dv = av - (r0[e] + r1[e]);
+                v[e] += fk1 * (float)((dv > 0.f) - (dv < 0.f)) - fk2 * (float)((av > 0.f) - (av < 0.f));
+              }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= dlrelu(a0[e], P.emask_slope);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = lrelu(v[e], P.out_slope);
+          }
+          OH[r4].x = pack_bf16(v[0], v[1]); OH[r4].y = pack_bf16(v[2], v[3]);
+          float hf[4];
+          unpack(OH[r4], hf);
+          OL[r4].x = pack_bf16(v[0] - hf[0], v[1] - hf[1]); OL[r4].y = pack_bf16(v[2] - hf[2], v[3] - hf[3]);
+        }
+        stu(i, OH, yhp);
+        if (P.yl) stu(i, OL, ylp);
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
       uint2 ah[4], al[4], rh[4], rl[4];
@@ -1381,7 +1481,8 @@ int tap3_launch(const Canon& c, int dir, const TapIO& io, int reflect, hipStream
     if (io.pr_S > 0) {
       if (dir != 0 || p.S != 1 || p.nph != 1) return fail(EBEN_EINVAL, "tap3: phases-as-rows output on a launch that is not a stride-1 gather");
       a.pr_S = io.pr_S; a.pr_cbg = io.pr_cbg; a.pr_Ly = io.pr_Ly; a.CBy = io.pr_CBy; a.pr_order = io.pr_order;
-      if ((io.pr_order != 0) != (p.big != 0)) return fail(EBEN_EINVAL, "tap3: phases-as-rows order %d on a launch plan that is%s tap4's", io.pr_order, p.big ? "" : " not");
+      if (p.big && io.pr_order != 1) return fail(EBEN_EINVAL, "tap3: phases-as-rows order %d on a launch plan that is tap4's", io.pr_order);
+      if (io.pr_order == 1 && (io.pr_S != 4 || (p.Mg & 31) || !c.bl)) return fail(EBEN_EINVAL, "tap3: bundle-major phases as rows need stride 4 and whole 32-row tiles");
     }
   } else if (io.xh) {
     return fail(EBEN_EINVAL, "tap3: bundle-layout planes on a descriptor without EBEN_LAYOUT_BL");
