@@ -376,8 +376,8 @@ PR_LAYERS = {
     "melgan_l4_wide": (dict(c_in=1024, c_out=1024, ksize=41, stride=4, pad_l=20, pad_r=20, groups=4, out_slope=0.2), 4, 301, True),
     "stride8_k16": (dict(c_in=8, c_out=64, ksize=16, stride=8, pad_l=7, pad_r=7, groups=1, out_slope=0.2), 2, 1001, True),
     "stride4_g2": (dict(c_in=32, c_out=128, ksize=23, stride=4, pad_l=11, pad_r=11, groups=2, out_slope=0.2), 2, 777, True),
-    # stride 2 and dilated (the PQMF-band layers): taken only under EBEN_PR_MIN_STRIDE=2 EBEN_PR_MAX_DIL=3 EBEN_PR_MAX_ROWS=256 (off by
-    # default -- see DESIGN 11.2); skipped otherwise
+    # stride 2 (the PQMF-band layers): bundle-major rows, two bundles per 32-row tile, up to dilation 2 (EBEN_PR2_S2_MAX_DIL); an odd
+    # bundle count (l3: 48 primed rows) ends inside a tile; dilation 3 is declined and skipped here
     "pqmf_l1_d1_dense": MID_LAYERS["pqmf_l1_d1_dense"],
     "pqmf_l3_d2": MID_LAYERS["pqmf_l3_d2"],
     "pqmf_l2_d3_dense": MID_LAYERS["pqmf_l2_d3_dense"],
@@ -448,7 +448,7 @@ def test_phases_as_rows_declines_what_it_does_not_cover(hip):
     from vibravox_amd._lib import EbenConv1dDesc
 
     dq = EbenConv1dDesc()
-    for kw in (dict(c_in=96, c_out=192, ksize=7, stride=2, dilation=2, pad_l=3, pad_r=3, groups=4),     # dilated
+    for kw in (dict(c_in=96, c_out=192, ksize=7, stride=2, dilation=3, pad_l=3, pad_r=3, groups=4),     # dilation 3 (10 primed taps for 4 + 3)
                dict(c_in=768, c_out=768, ksize=5, stride=1, pad_l=2, pad_r=2, groups=4),                # not strided
                dict(c_in=12, c_out=64, ksize=41, stride=4, pad_l=20, pad_r=20, groups=4),               # channels not in bundles
                dict(c_in=256, c_out=1024, ksize=16, stride=8, pad_l=7, pad_r=7, groups=4)):             # wide layers (full row tiles either way) at stride 4 only

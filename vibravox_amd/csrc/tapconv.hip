@@ -893,7 +893,14 @@ static PrGeom pr_geometry(const Canon& c, Canon* cp) {
   PrGeom g{};
   static const int min_s = getenv("EBEN_PR_MIN_STRIDE") ? atoi(getenv("EBEN_PR_MIN_STRIDE")) : 4;
   static const int max_d = getenv("EBEN_PR_MAX_DIL") ? atoi(getenv("EBEN_PR_MAX_DIL")) : 1;
-  if (!c.bl || c.np != 1 || c.reflect || c.d > max_d || c.s < 2 || c.s < min_s || c.s > 8 || (c.k - 1) * c.d + 1 <= c.s || c.pl > (c.k - 1) * c.d) return g;
+  // stride 2 (the PQMF-band layers) in bundle-major row order on tap3_kernel, up to this dilation (0: off).  [MI355X, 128 rows] the five
+  // stride-2 input gradients of a chain at dilation 1: 0.063 / 0.070 / 0.055 / 0.062 / 0.070 -> 0.053 / 0.052 / 0.045 / 0.046 / 0.064 ms,
+  // at dilation 2 (7 primed taps for 4 + 3): 0.071 / 0.085 / 0.064 / 0.077 / 0.089 -> 0.061 / 0.063 / 0.050 / 0.057 / 0.085; at dilation
+  // 3 (10 primed taps) the extra products cost what the whole-unit epilogue saves: 0.057 / 0.066 / 0.054 / 0.063 / 0.071 -> 0.064 /
+  // 0.069 / 0.054 / 0.065 / 0.070
+  static const int s2_max_d = getenv("EBEN_PR2_S2_MAX_DIL") ? atoi(getenv("EBEN_PR2_S2_MAX_DIL")) : 2;
+  const bool s2 = c.s == 2 && c.d <= s2_max_d;
+  if (!c.bl || c.np != 1 || c.reflect || (c.d > max_d && !s2) || c.s < 2 || (c.s < min_s && !s2) || c.s > 8 || (c.k - 1) * c.d + 1 <= c.s || c.pl > (c.k - 1) * c.d) return g;
   const int Cg = c.Cin / c.g;
   if ((c.Cin & 7) || (c.Cout & 7)) return g;
   g.S = c.s;
@@ -924,6 +931,10 @@ static PrGeom pr_geometry(const Canon& c, Canon* cp) {
   // operands and results move as whole units too ([MI355X] those loads were 36-43 % of the order-0 launches)
   static const int small_pr2 = getenv("EBEN_PR2_TAP3") ? atoi(getenv("EBEN_PR2_TAP3")) : 1;
   g.order = (big_pr && c.s == 4 && c.d == 1 && (tap3_is_big(q, 0) || (small_pr2 && (q.Cout / q.g) % 32 == 0))) ? 1 : 0;
+  if (s2) {   // two bundles per 32-row tile: whole bundles at both phases, tap3_kernel only
+    if (tap3_is_big(q, 0) || (q.Cout / q.g) % 16 != 0) return g;
+    g.order = 1;
+  }
   if (q.Cout / q.g > max_rows && !g.order) return g;
   if (!tap3_applicable(q, 0)) return g;
   if (cp) *cp = q;

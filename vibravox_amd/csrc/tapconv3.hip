@@ -616,17 +616,22 @@ __global__ __launch_bounds__(256, NPW >= 2 ? ((EBEN_T3_SPLIT_OCC2 && FM <= 2) ? 
       // (t, 0) positions 4 t, 4 t + 1, lane (t, 1) positions 4 t + 2, 4 t + 3 -- 32 contiguous bytes per lane, where order 0 reads its mask
       // and writes its result as 8-byte pieces 64 bytes apart.  [MI355X] the mask / feature-matching loads of the order-0 form are 36-43 %
       // of a MelGAN L1 / L2 input-gradient launch (253 / 233 -> 143 / 148 us without them).
+      // Stride 2: a 32-row tile is TWO bundles at the two phases; the swap leaves lane (t, 0) with bundle 2 i at positions 2 t, 2 t + 1
+      // and lane (t, 1) with bundle 2 i + 1 at the same positions.
+      const bool s4 = P.pr_S == 4;
+      const int tile0i = m0 >> 5;
       const long long LrowP = (long long)P.pr_Ly * 16;
-      const long long tileP = (long long)(g * P.pr_cbg + (m0 >> 5)) * LrowP;
+      const long long tileP = (long long)(g * P.pr_cbg) * LrowP;
       const char* ehp = reinterpret_cast<const char*>(P.eh) + (long long)eb * P.CBy * LrowP + tileP;
       const char* elp = reinterpret_cast<const char*>(P.el) + (long long)eb * P.CBy * LrowP + tileP;
       const char* rhp = reinterpret_cast<const char*>(P.eh) + (long long)(b + P.bl_ref_off) * P.CBy * LrowP + tileP;
       const char* rlp = reinterpret_cast<const char*>(P.el) + (long long)(b + P.bl_ref_off) * P.CBy * LrowP + tileP;
       char* yhp = reinterpret_cast<char*>(P.yh) + (long long)b * P.CBy * LrowP + tileP;
       char* ylp = reinterpret_cast<char*>(P.yl) + (long long)b * P.CBy * LrowP + tileP;
-      const int pos0 = 4 * t + 2 * hb;
+      const int pos0 = s4 ? 4 * t + 2 * hb : 2 * t;
       const bool lv0 = pos0 < P.pr_Ly, lv1 = pos0 + 1 < P.pr_Ly;
       const unsigned poff = (unsigned)(lv0 ? pos0 : 0) * 16u;
+      auto bund = [&](int i) { return s4 ? tile0i + i : 2 * (tile0i + i) + hb; };   // this lane's physical bundle (within the group) of tile i
       auto swap32 = [](unsigned& x, unsigned& y) {
         const auto r = __builtin_amdgcn_permlane32_swap(x, y, false, false);
         x = r[0]; y = r[1];
@@ -649,15 +654,18 @@ __global__ __launch_bounds__(256, NPW >= 2 ? ((EBEN_T3_SPLIT_OCC2 && FM <= 2) ? 
         }
       };
       auto ldu = [&](const char* base, int i, u32x4 (&U)[2]) {
-        const char* q = base + (long long)i * LrowP + poff;
+        const int bd = bund(i);
+        const char* q = base + (long long)(bd < P.pr_cbg ? bd : 0) * LrowP + poff;   // a bundle past the group's last (stride 2, odd count): re-read, never stored
         U[0] = *reinterpret_cast<const u32x4*>(q);
         U[1] = *reinterpret_cast<const u32x4*>(q + (lv1 ? 16 : 0));
       };
       auto stu = [&](int i, const uint2 (&H)[4], char* base) {
         u32x4 U[2];
         to_units(H, U);
-        char* q = base + (long long)i * LrowP + poff;
+        const int bd = bund(i);
+        char* q = base + (long long)bd * LrowP + poff;
         if ((EBEN_T3_DBG & 128) && U[0][0] != 0x12345u) return;
+        if (bd >= P.pr_cbg) return;
         if (lv0) *reinterpret_cast<u32x4*>(q) = U[0];
         if (lv1) *reinterpret_cast<u32x4*>(q + 16) = U[1];
       };
@@ -1482,7 +1490,8 @@ int tap3_launch(const Canon& c, int dir, const TapIO& io, int reflect, hipStream
       if (dir != 0 || p.S != 1 || p.nph != 1) return fail(EBEN_EINVAL, "tap3: phases-as-rows output on a launch that is not a stride-1 gather");
       a.pr_S = io.pr_S; a.pr_cbg = io.pr_cbg; a.pr_Ly = io.pr_Ly; a.CBy = io.pr_CBy; a.pr_order = io.pr_order;
       if (p.big && io.pr_order != 1) return fail(EBEN_EINVAL, "tap3: phases-as-rows order %d on a launch plan that is tap4's", io.pr_order);
-      if (io.pr_order == 1 && (io.pr_S != 4 || (p.Mg & 31) || !c.bl)) return fail(EBEN_EINVAL, "tap3: bundle-major phases as rows need stride 4 and whole 32-row tiles");
+      if (io.pr_order == 1 && ((io.pr_S != 4 && io.pr_S != 2) || (io.pr_S == 4 && (p.Mg & 31)) || (p.Mg & 15) || !c.bl || (p.big && io.pr_S != 4)))
+        return fail(EBEN_EINVAL, "tap3: bundle-major phases as rows need stride 4 (whole 32-row tiles) or 2 (whole 16-row bundles)");
     }
   } else if (io.xh) {
     return fail(EBEN_EINVAL, "tap3: bundle-layout planes on a descriptor without EBEN_LAYOUT_BL");
