@@ -198,9 +198,12 @@ EBEN_API int eben_bl_conv1d_bwd_dx(const EbenConv1dDesc* d, const void* g_hi, co
                           float mask_slope, int seg, const int* seg_map, int fm_rows, int ref_row_offset, const float* fm_sums,
                           float fm_gs, void* dx_hi, void* dx_lo /* nullable */, void* stream);
 
-/* "Phases as rows": the input gradient of a strided bundle-layout Conv1d (stride 4..8, dilation 1) as ONE stride-1 Conv1d from the
- * Cout channels of dy to stride x Cin rows (phase, channel), stored depth-to-space (csrc/tapconv.hip; MelGAN layers 1-4,
- * vibravox/torch_modules/dnn/melgan_discriminator.py:97-130).  eben_bl_dx_pr_desc writes the descriptor of that primed layer (or returns
+/* "Phases as rows": the input gradient of a strided bundle-layout Conv1d (stride 4..8 at dilation 1; stride 2 up to dilation 2) as ONE
+ * stride-1 Conv1d from the Cout channels of dy to stride x Cin rows, stored depth-to-space (csrc/tapconv.hip; MelGAN layers 1-4,
+ * vibravox/torch_modules/dnn/melgan_discriminator.py:97-130, and the stride-2 layers of the PQMF-band discriminators,
+ * eben_discriminator.py:86-130).  Rows are (phase, channel) or, at strides 4 and 2, (channel bundle, phase, channel in bundle): a 32-row
+ * MFMA tile is then whole 16-byte units at consecutive positions, and mask, feature-matching operands and results move 32 contiguous
+ * bytes per lane.  eben_bl_dx_pr_desc writes the descriptor of that primed layer (or returns
  * EBEN_EUNSUPPORTED); eben_bl_dx_pr_weights writes its weights (c_out' x c_in' / groups' x ksize' floats, weight-norm scale folded in), to be
  * packed as the primed layer's FORWARD image with eben_conv1d_pack(primed, w_primed, NULL, image, NULL); eben_bl_conv1d_bwd_dx_pr is
  * eben_bl_conv1d_bwd_dx on that image -- same operands, same epilogue, same results up to the order of the fp32 accumulation. */
