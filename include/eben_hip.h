@@ -212,6 +212,15 @@ EBEN_API int eben_bl_dx_pr_weights(const EbenConv1dDesc* d, const float* v, cons
 EBEN_API int eben_bl_conv1d_bwd_dx_pr(const EbenConv1dDesc* d, const void* g_hi, const float* wp_primed_fwd, const void* act_hi, const void* act_lo,
                                       float mask_slope, int seg, const int* seg_map, int fm_rows, int ref_row_offset, const float* fm_sums,
                                       float fm_gs, void* dx_hi, void* dx_lo, void* stream);
+/* eben_bl_conv1d_bwd_dx / eben_bl_conv1d_bwd_dx_pr with the feature-matching code plane of the embedding (eben_bl_fm_sums_codes; NULL: the
+ * forms above): the rows with a feature-matching term read act_hi and the codes instead of act_hi, act_lo and both planes of the
+ * reference rows.  Bit-identical results. */
+EBEN_API int eben_bl_conv1d_bwd_dx_c(const EbenConv1dDesc* d, const void* g_hi, const float* wp_bwd, const void* act_hi, const void* act_lo,
+                            const void* fm_codes, float mask_slope, int seg, const int* seg_map, int fm_rows, int ref_row_offset,
+                            const float* fm_sums, float fm_gs, void* dx_hi, void* dx_lo /* nullable */, void* stream);
+EBEN_API int eben_bl_conv1d_bwd_dx_pr_c(const EbenConv1dDesc* d, const void* g_hi, const float* wp_primed_fwd, const void* act_hi, const void* act_lo,
+                               const void* fm_codes, float mask_slope, int seg, const int* seg_map, int fm_rows, int ref_row_offset,
+                               const float* fm_sums, float fm_gs, void* dx_hi, void* dx_lo /* nullable */, void* stream);
 /* Weight (+ bias) gradient with both operands in the bundle layout (csrc/bl_dw.hip): the reduction runs along (batch, time) on
  * v_mfma_f32_32x32x16_bf16, both operand tiles arrive in LDS by buffer_load ... lds (descriptor bounds = the zero padding) and are
  * transposed on read -- no packing pre-pass, no conversion.  Slabs [nslab][c_out][row_stride] as eben_conv1d_bwd_dw's, except that
@@ -256,6 +265,12 @@ EBEN_API int eben_bl_tail_dw(const float* seeds, const void* x_hi, const void* x
 EBEN_API size_t eben_bl_fm_sums_workspace(int npairs);
 EBEN_API int eben_bl_fm_sums(const void* const* planes, const int64_t* units, int npairs, float* partial_ws, size_t ws_bytes, float* sums,
                     void* stream);
+/* eben_bl_fm_sums that also writes, for pairs whose codes[p] is not NULL, one byte per element of the pair's enhanced rows:
+ * bits 0-1 = sgn(a - r) + 1, bits 2-3 = sgn(a) + 1 (8 bytes per unit, at the unit's index in the hi plane) -- what the feature-matching
+ * term of the stacked input gradients needs of the pair (eben_bl_conv1d_bwd_dx_c: one 4-byte load per row quad in place of three
+ * 8-byte operand loads).  Same sums. */
+EBEN_API int eben_bl_fm_sums_codes(const void* const* planes, const int64_t* units, void* const* codes, int npairs, float* partial_ws,
+                                   size_t ws_bytes, float* sums, void* stream);
 
 /* ---- fused ResidualUnit forward (vibravox/torch_modules/dnn/eben_generator.py:287-316) ---------------------------------
  *   y = xin + lrelu( W_pw . ( W_dil (*) xin ), out_slope ),  xin = lrelu(x, in_slope)

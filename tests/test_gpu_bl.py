@@ -113,6 +113,7 @@ def test_chain_head_forward_backward(hip, name):
     assert rel_err(dx, xr2.grad) < 1e-5
     # weight gradient of the same masked gradient (hi plane only feeds it) against autograd on the rounded gradient
     hi_only = Planes.__new__(Planes)
+    hi_only.codes = None
     hi_only.hi, hi_only.lo, hi_only.rows, hi_only.channels, hi_only.length = masked.hi, None, batch, c_out, l_out
     wj = head_job(hip, x, v, scale, bias, hi_only, c_in, c_out, length, k, dil, pad, rpad, 0.2)
     nslab, rs = ctypes.c_int(0), ctypes.c_int(0)
@@ -339,6 +340,12 @@ def test_bundle_conv_input_gradient(hip, name):
     st = torch.cuda.current_stream().cuda_stream
     check(hip.eben_bl_conv1d_bwd_dx(ctypes.byref(d), gp.hi.data_ptr(), wp.data_ptr(), act.hi.data_ptr(), act.lo.data_ptr(), 0.2, half, seg_map, half, half,
                                     sums.data_ptr(), fm_gs, dx.hi.data_ptr(), dx.lo.data_ptr(), st), "bl_conv1d_bwd_dx")
+    # the same launch with the feature-matching code plane of the embedding in place of act_lo and the reference rows: bit for bit
+    dxc = Planes(rows4, spec.c_in, length, DEV)
+    codes = fm_codes_of(hip, act, half)
+    check(hip.eben_bl_conv1d_bwd_dx_c(ctypes.byref(d), gp.hi.data_ptr(), wp.data_ptr(), act.hi.data_ptr(), act.lo.data_ptr(), codes.data_ptr(), 0.2, half, seg_map,
+                                      half, half, sums.data_ptr(), fm_gs, dxc.hi.data_ptr(), dxc.lo.data_ptr(), st), "bl_conv1d_bwd_dx_c")
+    assert torch.equal(dxc.hi.view(torch.int16), dx.hi.view(torch.int16)) and torch.equal(dxc.lo.view(torch.int16), dx.lo.view(torch.int16))
     w = (v * scale.reshape(-1, 1, 1))
     base = F.conv_transpose1d(bf16_hi(g).double(), bf16_hi(w).double(), stride=spec.stride, padding=spec.pad_l, dilation=spec.dilation, groups=spec.groups,
                               output_padding=length - ((l_out - 1) * spec.stride - 2 * spec.pad_l + spec.dilation * (spec.ksize - 1) + 1))
@@ -363,6 +370,26 @@ def test_bundle_conv_input_gradient(hip, name):
         assert float((got != split).float().mean()) < 1e-3
     else:
         assert rel_err(got, dx32) < 1e-4
+
+
+def fm_codes_of(hip, act, half):
+    """The feature-matching code plane of an embedding (eben_bl_fm_sums_codes): (half, C / 8, L, 8) bytes, checked here against the signs."""
+    from vibravox_amd._lib import check
+
+    codes = torch.zeros((half, act.channels // 8, act.length, 8), dtype=torch.uint8, device=DEV)
+    ptrs = (ctypes.c_void_p * 2)(act.hi.data_ptr(), act.lo.data_ptr())
+    units = (ctypes.c_int64 * 1)(half * (act.channels // 8) * act.length)
+    cp = (ctypes.c_void_p * 1)(codes.data_ptr())
+    nbytes = hip.eben_bl_fm_sums_workspace(1)
+    ws = torch.empty(max(1, nbytes // 4), dtype=torch.float32, device=DEV)
+    sums = torch.empty(2, dtype=torch.float32, device=DEV)
+    check(hip.eben_bl_fm_sums_codes(ptrs, units, cp, 1, ws.data_ptr(), nbytes, sums.data_ptr(), torch.cuda.current_stream().cuda_stream), "bl_fm_sums_codes")
+    a = act.to_f32()
+    want = (torch.sign(a[:half] - a[half:]) + 1).to(torch.uint8) | ((torch.sign(a[:half]) + 1).to(torch.uint8) << 2)
+    got = codes.permute(0, 1, 3, 2).reshape(half, act.channels, act.length)
+    assert torch.equal(got, want)
+    np.testing.assert_allclose(sums.cpu().numpy(), [float((a[:half] - a[half:]).abs().sum()), float(a[:half].abs().sum())], rtol=2e-5)
+    return codes
 
 
 PR_LAYERS = {
@@ -425,6 +452,13 @@ def test_bundle_conv_input_gradient_phases_as_rows(hip, name):
     dx.hi.fill_(float("nan")); dx.lo.fill_(float("nan"))
     check(hip.eben_bl_conv1d_bwd_dx_pr(ctypes.byref(d), gp.hi.data_ptr(), img.data_ptr(), act.hi.data_ptr(), act.lo.data_ptr(), 0.2, half, seg_map, half, half,
                                        sums.data_ptr(), fm_gs, dx.hi.data_ptr(), dx.lo.data_ptr(), st), "bl_conv1d_bwd_dx_pr")
+    # ... and with the feature-matching code plane in place of act_lo and the reference rows: bit for bit
+    dxc = Planes(rows4, spec.c_in, length, DEV)
+    dxc.hi.fill_(float("nan")); dxc.lo.fill_(float("nan"))
+    codes = fm_codes_of(hip, act, half)
+    check(hip.eben_bl_conv1d_bwd_dx_pr_c(ctypes.byref(d), gp.hi.data_ptr(), img.data_ptr(), act.hi.data_ptr(), act.lo.data_ptr(), codes.data_ptr(), 0.2, half,
+                                         seg_map, half, half, sums.data_ptr(), fm_gs, dxc.hi.data_ptr(), dxc.lo.data_ptr(), st), "bl_conv1d_bwd_dx_pr_c")
+    assert torch.equal(dxc.hi.view(torch.int16), dx.hi.view(torch.int16)) and torch.equal(dxc.lo.view(torch.int16), dx.lo.view(torch.int16))
     w = (v * scale.reshape(-1, 1, 1))
     base = F.conv_transpose1d(bf16_hi(g).double(), bf16_hi(w).double(), stride=spec.stride, padding=spec.pad_l, dilation=spec.dilation, groups=spec.groups,
                               output_padding=length - ((l_out - 1) * spec.stride - 2 * spec.pad_l + spec.dilation * (spec.ksize - 1) + 1))

@@ -20,7 +20,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vibravox_amd import ops  # noqa: E402
 from vibravox_amd._lib import EbenBlHeadJob, check, load, ptr, stream  # noqa: E402
-from vibravox_amd.disc_engine_bl import BL, Planes, _ChainBL  # noqa: E402
+from vibravox_amd.disc_engine_bl import BL, FM_CODES, Planes, _ChainBL, _fm_sums  # noqa: E402
 from vibravox_amd.lightning_modules.eben import DISC_MATH_PLANS  # noqa: E402
 from vibravox_amd.torch_modules.dnn.eben_discriminator import DiscriminatorEBENMultiScales  # noqa: E402
 
@@ -53,6 +53,7 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--filter", default="")
     ap.add_argument("--only", default="", help="one layer, e.g. melgan.4 (the PMC passes of tools/pmc_family_bl.sh)")
+    ap.add_argument("--no-fm-rows", action="store_true", help="time the stacked input gradients without feature-matching rows (what those rows' four operand loads cost)")
     a = ap.parse_args()
     lib = load()
     dev = torch.device("cuda")
@@ -80,6 +81,7 @@ def main():
         job_f = (EbenBlHeadJob * 1)(ch.head_job(x_in, l_in, act0))
         g0 = Planes.from_f32(torch.randn(r4, sp.c_out, act0.length, device=dev), lo=True)
         g0v = Planes.__new__(Planes)
+        g0v.codes = None
         g0v.hi, g0v.lo, g0v.rows, g0v.channels, g0v.length = g0.hi[:r2], g0.lo[:r2], r2, g0.channels, g0.length
         job_b = (EbenBlHeadJob * 1)(ch.head_job(None, l_in, g0v))
         dxh = torch.empty_like(x_in)
@@ -120,8 +122,15 @@ def main():
             pr = lay.pr_desc(r4, cur.length) is not None   # strided MelGAN layers: the phases-as-rows form (as the engine launches it)
             wpb = lay.packed(2 if pr else 1, r4, cur.length)
             dx_fn = lib.eben_bl_conv1d_bwd_dx_pr if pr else lib.eben_bl_conv1d_bwd_dx
-            t_b = time_ms(lambda: check(dx_fn(ctypes.byref(d4), g.hi.data_ptr(), ptr(wpb), xin.hi.data_ptr(), xin.lo.data_ptr(), 0.2, half, seg_map,
-                                              half, half, ptr(sums), 0.1, gp.hi.data_ptr(), None, st)), a.iters)
+            fm_rows = 0 if a.no_fm_rows else half
+            # as the engine launches it: the feature-matching code plane of the embedding (written by its sums pass) instead of three operand planes
+            codes = None
+            if FM_CODES and fm_rows:
+                _fm_sums(lib, [xin], half, torch.empty(2, device=dev))
+                codes = xin.codes.data_ptr()
+            dx_fn = lib.eben_bl_conv1d_bwd_dx_pr_c if pr else lib.eben_bl_conv1d_bwd_dx_c
+            t_b = time_ms(lambda: check(dx_fn(ctypes.byref(d4), g.hi.data_ptr(), ptr(wpb), xin.hi.data_ptr(), xin.lo.data_ptr(), codes, 0.2, half, seg_map,
+                                              fm_rows, half, ptr(sums), 0.1, gp.hi.data_ptr(), None, st)), a.iters)
             t_w = time_ms(lambda: ch.weight_grads([(i, g, xin)], x_in, None, half), a.iters)
             wshape = sp.weight_shape()
             wel = wshape[0] * wshape[1] * wshape[2]

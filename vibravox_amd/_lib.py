@@ -114,6 +114,8 @@ SIGNATURES = {
     "eben_bl_dx_pr_desc": (c_int, [_D, _D]),
     "eben_bl_dx_pr_weights": (c_int, [_D, _P, _P, _P, _P]),
     "eben_bl_conv1d_bwd_dx_pr": (c_int, [_D, _P, _P, _P, _P, c_float, c_int, POINTER(c_int), c_int, c_int, _P, c_float, _P, _P, _P]),
+    "eben_bl_conv1d_bwd_dx_c": (c_int, [_D, _P, _P, _P, _P, _P, c_float, c_int, POINTER(c_int), c_int, c_int, _P, c_float, _P, _P, _P]),
+    "eben_bl_conv1d_bwd_dx_pr_c": (c_int, [_D, _P, _P, _P, _P, _P, c_float, c_int, POINTER(c_int), c_int, c_int, _P, c_float, _P, _P, _P]),
     "eben_bl_conv1d_bwd_dw_workspace": (c_size_t, [_D, POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
     "eben_bl_conv1d_bwd_dw": (c_int, [_D, _P, _P, c_int, _P, c_size_t, _P]),
     "eben_bl_head_fwd": (c_int, [POINTER(EbenBlHeadJob), c_int, c_int, _P]),
@@ -127,6 +129,7 @@ SIGNATURES = {
     "eben_bl_tail_dw": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_size_t, _P]),
     "eben_bl_fm_sums_workspace": (c_size_t, [c_int]),
     "eben_bl_fm_sums": (c_int, [POINTER(c_void_p), POINTER(c_int64), c_int, _P, c_size_t, _P, _P]),
+    "eben_bl_fm_sums_codes": (c_int, [POINTER(c_void_p), POINTER(c_int64), POINTER(c_void_p), c_int, _P, c_size_t, _P, _P]),
     "eben_ru_packed_floats": (c_size_t, [c_int]),
     "eben_ru_pack": (c_int, [c_int, _P, _P, _P, _P, _P, _P]),
     "eben_ru_fwd": (c_int, [c_int, c_int, c_int, c_int, _P, c_float, c_float, _P, _P, _P, _P, _P]),

@@ -621,13 +621,27 @@ constexpr int BLFM_BLOCKS = 1024;   // == FM_BLOCKS of direct.hip: the partial s
 struct BlFmTable {
   const u32x4* hi[BLFM_MAX_PAIRS]; const u32x4* lo[BLFM_MAX_PAIRS];
   long long units[BLFM_MAX_PAIRS];   // units of the enhanced rows; the reference rows follow them in the same planes
+  uint2* code[BLFM_MAX_PAIRS];       // nullable: one byte per element of the enhanced rows, the signs the input gradients' feature-matching term needs
 };
+// code byte of one element: bits 0-1 = sgn(a - r) + 1, bits 2-3 = sgn(a) + 1 (a = hi + lo of the enhanced row, r of the reference row, both
+// sums in fp32 as the input-gradient epilogues form them).  A unit of 8 channels = 8 bytes, at the index of the unit in the hi plane.
+__device__ __forceinline__ unsigned bl_fm_code(float av, float rv) {
+  const float dv = av - rv;
+  return (unsigned)((int)(dv > 0.f) - (int)(dv < 0.f) + 1) | ((unsigned)((int)(av > 0.f) - (int)(av < 0.f) + 1) << 2);
+}
+__device__ __forceinline__ uint2 bl_fm_code8(const float (&av)[8], const float (&rv)[8]) {
+  uint2 c;
+  c.x = bl_fm_code(av[0], rv[0]) | (bl_fm_code(av[1], rv[1]) << 8) | (bl_fm_code(av[2], rv[2]) << 16) | (bl_fm_code(av[3], rv[3]) << 24);
+  c.y = bl_fm_code(av[4], rv[4]) | (bl_fm_code(av[5], rv[5]) << 8) | (bl_fm_code(av[6], rv[6]) << 16) | (bl_fm_code(av[7], rv[7]) << 24);
+  return c;
+}
 __global__ __launch_bounds__(256) void bl_fm_partial_kernel(const BlFmTable T, float* __restrict__ partial) {
   __shared__ float red[4];
   const int p = blockIdx.y;
   const u32x4* hi = T.hi[p];
   const u32x4* lo = T.lo[p];
   const long long n = T.units[p];
+  uint2* code = T.code[p];
   const long long per = (n + BLFM_BLOCKS - 1) / BLFM_BLOCKS;
   const long long b0 = (long long)blockIdx.x * per;
   const long long b1 = b0 + per < n ? b0 + per : n;
@@ -640,10 +654,12 @@ __global__ __launch_bounds__(256) void bl_fm_partial_kernel(const BlFmTable T, f
     float a[8], l[8], r[8], q[8];
     bl_unpack8(ah0, a); bl_unpack8(al0, l); bl_unpack8(rh0, r); bl_unpack8(rl0, q);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { const float av = a[e] + l[e], rv = r[e] + q[e]; s1 += fabsf(av - rv); s2 += fabsf(av); }
+    for (int e = 0; e < 8; ++e) { a[e] += l[e]; r[e] += q[e]; s1 += fabsf(a[e] - r[e]); s2 += fabsf(a[e]); }
+    if (code) code[i] = bl_fm_code8(a, r);
     bl_unpack8(ah1, a); bl_unpack8(al1, l); bl_unpack8(rh1, r); bl_unpack8(rl1, q);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { const float av = a[e] + l[e], rv = r[e] + q[e]; s1 += fabsf(av - rv); s2 += fabsf(av); }
+    for (int e = 0; e < 8; ++e) { a[e] += l[e]; r[e] += q[e]; s1 += fabsf(a[e] - r[e]); s2 += fabsf(a[e]); }
+    if (code) code[i + 256] = bl_fm_code8(a, r);
   }
   for (; i < b1; i += 256) {
     float a[8], r[8];
@@ -651,6 +667,7 @@ __global__ __launch_bounds__(256) void bl_fm_partial_kernel(const BlFmTable T, f
     bl_load8(hi, lo, i + n, r);
 #pragma unroll
     for (int e = 0; e < 8; ++e) { s1 += fabsf(a[e] - r[e]); s2 += fabsf(a[e]); }
+    if (code) code[i] = bl_fm_code8(a, r);
   }
   s1 = block_sum_256(s1, red);
   s2 = block_sum_256(s2, red);
@@ -954,6 +971,11 @@ extern "C" int eben_bl_tail_dw(const float* seeds, const void* x_hi, const void*
 extern "C" size_t eben_bl_fm_sums_workspace(int npairs) { return sizeof(float) * 2 * BLFM_BLOCKS * (size_t)(npairs > 0 ? npairs : 0); }
 
 extern "C" int eben_bl_fm_sums(const void* const* planes, const int64_t* units, int npairs, float* partial_ws, size_t ws_bytes, float* sums, void* stream) {
+  return eben_bl_fm_sums_codes(planes, units, nullptr, npairs, partial_ws, ws_bytes, sums, stream);
+}
+
+extern "C" int eben_bl_fm_sums_codes(const void* const* planes, const int64_t* units, void* const* codes, int npairs, float* partial_ws, size_t ws_bytes,
+                                     float* sums, void* stream) {
   EBEN_REQUIRE(planes && units && npairs > 0 && partial_ws && sums, "bad bl_fm_sums arguments");
   if (ws_bytes < eben_bl_fm_sums_workspace(npairs)) return fail(EBEN_EWORKSPACE, "bl_fm_sums workspace too small");
   for (int p0 = 0; p0 < npairs; p0 += BLFM_MAX_PAIRS) {
@@ -963,6 +985,7 @@ extern "C" int eben_bl_fm_sums(const void* const* planes, const int64_t* units, 
       T.hi[i] = static_cast<const u32x4*>(planes[2 * (p0 + i)]);
       T.lo[i] = static_cast<const u32x4*>(planes[2 * (p0 + i) + 1]);
       T.units[i] = units[p0 + i];
+      T.code[i] = codes ? static_cast<uint2*>(codes[p0 + i]) : nullptr;
       if (!T.hi[i] || T.units[i] <= 0) return fail(EBEN_EINVAL, "feature-matching pair %d is null or empty", p0 + i);
     }
     float* part = partial_ws + (size_t)p0 * BLFM_BLOCKS * 2;

@@ -125,6 +125,7 @@ struct TapIO {
   // bundle layout (Canon.bl): input planes (xl: the lo plane of a split input), output planes (yl nullable), the saved activation
   // planes the epilogue takes its mask and feature-matching operands from (reference rows bl_ref_off batch rows behind the enhanced)
   const void* xh; const void* xl; void* yh; void* yl; const void* eh; const void* el; int bl_ref_off;
+  const void* ec;   // nullable: feature-matching code plane of the embedding eh / el (bl_edge.hip: bl_fm_code), 8 bytes per unit of its enhanced rows
   // phases as rows (eben_bl_conv1d_bwd_dx_pr): the launch is the stride-1 gather form of a strided conv's input gradient whose output rows
   // are (phase, channel); they are stored depth-to-space into planes of pr_CBy bundles x pr_Ly positions per batch row (pr_cbg bundles per group)
   int pr_S, pr_cbg, pr_Ly, pr_CBy, pr_order;   // pr_order 1: primed rows (channel bundle, phase, channel in bundle) -- tap4_kernel only

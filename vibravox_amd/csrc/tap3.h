@@ -29,6 +29,7 @@ struct Tap3Args {
   const u32x4* xh; const u32x4* xl;
   uint2* yh; uint2* yl;
   const uint2* eh; const uint2* el;
+  const unsigned* ec;   // nullable: feature-matching codes of the embedding (4 bytes per half unit), read by the rows b < res_rows instead of el and the reference rows
   int CBx, CBy, bl_ref_off, bl_pad;
   // phases as rows (TapIO.pr_S): the logical output rows of group g are (phase, channel of the group) and land in the PHYSICAL planes
   // [row][pr_CB][pr_Ly][8] at bundle g pr_cbg + (logical bundle % pr_cbg), position t pr_S + logical bundle / pr_cbg

@@ -37,7 +37,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
 #ifndef EBEN_T4_DBG
-#define EBEN_T4_DBG 0   // scratch-build ablations (wrong results): 1 no weight stream, 2 no input stream, 4 no barrier, 8 no MFMA, 16 no epilogue stores, 32 no mask / feature-matching loads
+#define EBEN_T4_DBG 0   // scratch-build ablations (wrong results): 1 no weight stream, 2 no input stream, 4 no barrier, 8 no MFMA, 16 no epilogue stores, 32 no mask / feature-matching loads, 32 no mask / feature-matching loads
 #endif
 #ifndef EBEN_T4_HB
 #define EBEN_T4_HB 2    // k-steps the fragment reads run ahead of the MFMAs (single-piece launches)
@@ -339,6 +339,9 @@ __global__ __launch_bounds__(512) void tap4_kernel(const Tap3Args P) {
     const int eb = P.em_seg > 0 ? P.em_map[es] * P.em_seg + (b - es * P.em_seg) : b;
     const bool fmr = P.fm_sums != nullptr && P.res_rows > 0 && b < P.res_rows;
     const bool masked = P.eh != nullptr && !(EBEN_T4_DBG & 32);
+    // feature-matching rows with a code plane (bl_edge.hip, bl_fm_code: one byte per element at half the hi plane's byte offsets): they
+    // read the mask and the codes -- one load batch per 128 x 32 columns -- instead of four operands per value in a batch per 32-row tile
+    const bool fmc = fmr && masked && P.ec != nullptr;
     const long long Lrow = (long long)P.Ly * 16;                                                    // bytes per bundle row
     const int m0w = T.mt * BM + wm * TM * 32;
     const long long tile0 = ((long long)((T.g * P.Mg + m0w) >> 3)) * Lrow;                         // this wave's first bundle row
@@ -409,13 +412,20 @@ __global__ __launch_bounds__(512) void tap4_kernel(const Tap3Args P) {
         if (lv[f][0]) *reinterpret_cast<u32x4*>(q) = U[0];
         if (lv[f][1]) *reinterpret_cast<u32x4*>(q + 16) = U[1];
       };
-      auto quad = [&](int i, int f, int r4, bool has_a, bool has_fm, const uint2 (&a_h)[4], const uint2 (&a_l)[4], const uint2 (&r_h)[4], const uint2 (&r_l)[4], uint2& oh_, uint2& ol_) {
+      auto quad = [&](int i, int f, int r4, bool has_a, bool has_fm, const uint2 (&a_h)[4], const uint2 (&a_l)[4], const uint2 (&r_h)[4], const uint2 (&r_l)[4], uint2& oh_, uint2& ol_,
+                      bool has_code = false, unsigned code = 0u) {
         float v[4], a0[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = acc[i][f][4 * r4 + e];
         if (has_a) {
           unpack(a_h[r4], a0);
-          if (has_fm) {
+          if (has_code) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const unsigned c = code >> (8 * e);
+              v[e] += fk1 * (float)((int)(c & 3u) - 1) - fk2 * (float)((int)((c >> 2) & 3u) - 1);
+            }
+          } else if (has_fm) {
             float a1[4], r0[4], r1[4];
             unpack(a_l[r4], a1); unpack(r_h[r4], r0); unpack(r_l[r4], r1);
 #pragma unroll
@@ -452,6 +462,33 @@ __global__ __launch_bounds__(512) void tap4_kernel(const Tap3Args P) {
             stu(i, f, OH, yhp);
             if (P.yl) stu(i, f, OL, ylp);
           }
+      } else if (fmc) {
+        const char* ecp = reinterpret_cast<const char*>(P.ec) + (((long long)eb * P.CBy * LrowP + tileP) >> 1);
+#pragma unroll
+        for (int f = 0; f < TN; ++f) {
+          u32x4 AU[TM][2];
+          uint2 CU[TM][2];
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            ldu(ehp, i, f, AU[i]);
+            const char* q = ecp + (((long long)i * LrowP + poff[f]) >> 1);
+            CU[i][0] = *reinterpret_cast<const uint2*>(q);
+            CU[i][1] = *reinterpret_cast<const uint2*>(q + (lv[f][1] ? 8 : 0));
+          }
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            uint2 AH[4], OH[4], OL[4];
+            to_halves(AU[i], AH);
+            // two whole code units (positions pos0, pos0 + 1) -> the four half units of this lane's row quads
+            unsigned x0 = CU[i][0].x, y0 = CU[i][0].y, x1 = CU[i][1].x, y1 = CU[i][1].y;
+            t4_swap32(x0, y0); t4_swap32(x1, y1);
+            const unsigned CW[4] = {x0, x1, y0, y1};
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) quad(i, f, r4, true, false, AH, AH, AH, AH, OH[r4], OL[r4], true, CW[r4]);
+            stu(i, f, OH, yhp);
+            if (P.yl) stu(i, f, OL, ylp);
+          }
+        }
       } else {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -538,6 +575,36 @@ __global__ __launch_bounds__(512) void tap4_kernel(const Tap3Args P) {
             for (int e = 0; e < 4; ++e) v[e] *= dlrelu(a0[e], P.emask_slope);
             finish(f, i, r4, v);
           }
+    } else if (fmc) {
+      const char* ecb = reinterpret_cast<const char*>(P.ec) + (((long long)eb * P.CBy * Lrow + tile0) >> 1);
+#pragma unroll
+      for (int f = 0; f < TN; ++f) {
+        uint2 ah[TM][4];
+        unsigned cw[TM][4];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int r4 = 0; r4 < 4; ++r4) {
+            const long long row = (long long)(4 * i + r4) * Lrow;
+            ah[i][r4] = ld2(ehb, row, f);
+            cw[i][r4] = *reinterpret_cast<const unsigned*>(ecb + ((row + (long long)loffs[f]) >> 1));
+          }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int r4 = 0; r4 < 4; ++r4) {
+            float v[4], a0[4];
+            biased(f, i, r4, v);
+            unpack(ah[i][r4], a0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const unsigned c = cw[i][r4] >> (8 * e);
+              v[e] += fk1 * (float)((int)(c & 3u) - 1) - fk2 * (float)((int)((c >> 2) & 3u) - 1);
+              v[e] *= dlrelu(a0[e], P.emask_slope);
+            }
+            finish(f, i, r4, v);
+          }
+      }
     } else {
 #pragma unroll
       for (int i = 0; i < TM; ++i) {

@@ -1005,6 +1005,13 @@ extern "C" int eben_bl_dx_pr_weights(const EbenConv1dDesc* d, const float* v, co
 extern "C" int eben_bl_conv1d_bwd_dx_pr(const EbenConv1dDesc* d, const void* g_hi, const float* wp_primed_fwd, const void* act_hi, const void* act_lo,
                                         float mask_slope, int seg, const int* seg_map, int fm_rows, int ref_row_offset, const float* fm_sums,
                                         float fm_gs, void* dx_hi, void* dx_lo, void* stream) {
+  return eben_bl_conv1d_bwd_dx_pr_c(d, g_hi, wp_primed_fwd, act_hi, act_lo, nullptr, mask_slope, seg, seg_map, fm_rows, ref_row_offset, fm_sums, fm_gs, dx_hi,
+                                    dx_lo, stream);
+}
+
+extern "C" int eben_bl_conv1d_bwd_dx_pr_c(const EbenConv1dDesc* d, const void* g_hi, const float* wp_primed_fwd, const void* act_hi, const void* act_lo,
+                                          const void* fm_codes, float mask_slope, int seg, const int* seg_map, int fm_rows, int ref_row_offset,
+                                          const float* fm_sums, float fm_gs, void* dx_hi, void* dx_lo, void* stream) {
   Canon c, q;
   int rc = canon_from_desc(d, &c);
   if (rc) return rc;
@@ -1019,6 +1026,7 @@ extern "C" int eben_bl_conv1d_bwd_dx_pr(const EbenConv1dDesc* d, const void* g_h
   io.emask_slope = mask_slope; io.em_seg = act_hi ? seg : 0;
   for (int i = 0; i < 4; ++i) io.em_map[i] = (seg > 0 && seg_map) ? seg_map[i] : i;
   io.xh = g_hi; io.yh = dx_hi; io.yl = dx_lo; io.eh = act_hi; io.el = act_lo; io.bl_ref_off = ref_row_offset;
+  io.ec = fm_rows > 0 ? fm_codes : nullptr;
   io.pr_S = g.S; io.pr_cbg = g.cbg; io.pr_Ly = c.Lin; io.pr_CBy = c.Cin / 8; io.pr_order = g.order;
   return tap3_launch(q, 0, io, 0, as_stream(stream));
 }
@@ -1040,6 +1048,13 @@ extern "C" int eben_bl_conv1d_fwd(const EbenConv1dDesc* d, const void* x_hi, con
 extern "C" int eben_bl_conv1d_bwd_dx(const EbenConv1dDesc* d, const void* g_hi, const float* wp_bwd, const void* act_hi, const void* act_lo,
                                      float mask_slope, int seg, const int* seg_map, int fm_rows, int ref_row_offset, const float* fm_sums,
                                      float fm_gs, void* dx_hi, void* dx_lo, void* stream) {
+  return eben_bl_conv1d_bwd_dx_c(d, g_hi, wp_bwd, act_hi, act_lo, nullptr, mask_slope, seg, seg_map, fm_rows, ref_row_offset, fm_sums, fm_gs, dx_hi, dx_lo,
+                                 stream);
+}
+
+extern "C" int eben_bl_conv1d_bwd_dx_c(const EbenConv1dDesc* d, const void* g_hi, const float* wp_bwd, const void* act_hi, const void* act_lo,
+                                       const void* fm_codes, float mask_slope, int seg, const int* seg_map, int fm_rows, int ref_row_offset,
+                                       const float* fm_sums, float fm_gs, void* dx_hi, void* dx_lo, void* stream) {
   Canon c;
   int rc = canon_from_desc(d, &c);
   if (rc) return rc;
@@ -1054,5 +1069,6 @@ extern "C" int eben_bl_conv1d_bwd_dx(const EbenConv1dDesc* d, const void* g_hi, 
   io.emask_slope = mask_slope; io.em_seg = act_hi ? seg : 0;
   for (int i = 0; i < 4; ++i) io.em_map[i] = (seg > 0 && seg_map) ? seg_map[i] : i;
   io.xh = g_hi; io.yh = dx_hi; io.yl = dx_lo; io.eh = act_hi; io.el = act_lo; io.bl_ref_off = ref_row_offset;
+  io.ec = fm_rows > 0 ? fm_codes : nullptr;
   return tap3_launch(c, 1, io, 0, as_stream(stream));
 }

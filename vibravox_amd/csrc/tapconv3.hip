@@ -603,6 +603,9 @@ __global__ __launch_bounds__(256, NPW >= 2 ? ((EBEN_T3_SPLIT_OCC2 && FM <= 2) ? 
     char* yhb = reinterpret_cast<char*>(P.yh) + (long long)b * P.CBy * Lrow + tile0;
     char* ylb = reinterpret_cast<char*>(P.yl) + (long long)b * P.CBy * Lrow + tile0;
     const bool masked = P.eh != nullptr && !(EBEN_T3_DBG & 32);
+    // feature-matching rows with a code plane (bl_edge.hip, bl_fm_code): one byte per element at half the hi plane's byte offsets
+    const bool fmc = fmr && masked && P.ec != nullptr;
+    const char* ecb = reinterpret_cast<const char*>(P.ec) + (((long long)eb * P.CBy * Lrow + tile0) >> 1);
     auto unpack = [](uint2 w, float (&f)[4]) {
       f[0] = __builtin_bit_cast(float, w.x << 16); f[1] = __builtin_bit_cast(float, w.x & 0xffff0000u);
       f[2] = __builtin_bit_cast(float, w.y << 16); f[3] = __builtin_bit_cast(float, w.y & 0xffff0000u);
@@ -670,8 +673,9 @@ __global__ __launch_bounds__(256, NPW >= 2 ? ((EBEN_T3_SPLIT_OCC2 && FM <= 2) ? 
         if (lv1) *reinterpret_cast<u32x4*>(q + 16) = U[1];
       };
       const int tiles = (P.Mg - m0 + 31) >> 5;   // 32-row tiles of this block that exist (uniform; Mg is a multiple of 32 here)
+      const char* ecp = reinterpret_cast<const char*>(P.ec) + (((long long)eb * P.CBy * LrowP + tileP) >> 1);
       u32x4 AU[FM][2];
-      if (masked && !fmr) {
+      if (masked && (!fmr || fmc)) {
 #pragma unroll
         for (int i = 0; i < FM; ++i) ldu(ehp, i < tiles ? i : 0, AU[i]);
       }
@@ -679,8 +683,20 @@ __global__ __launch_bounds__(256, NPW >= 2 ? ((EBEN_T3_SPLIT_OCC2 && FM <= 2) ? 
       for (int i = 0; i < FM; ++i) {
         if (i >= tiles) continue;
         uint2 AH[4], AL[4], RH[4], RL[4], OH[4], OL[4];
-        if (masked && !fmr) to_halves(AU[i], AH);
-        else if (masked) {
+        unsigned CW[4] = {0u, 0u, 0u, 0u};
+        if (masked && (!fmr || fmc)) {
+          to_halves(AU[i], AH);
+          if (fmc) {
+            // the two whole code units of this lane (positions pos0, pos0 + 1: 16 contiguous bytes) -> the four half units of its row quads
+            const int bd = bund(i);
+            const char* q = ecp + (((long long)(bd < P.pr_cbg ? bd : 0) * LrowP + poff) >> 1);
+            const uint2 c0 = *reinterpret_cast<const uint2*>(q);
+            const uint2 c1 = *reinterpret_cast<const uint2*>(q + (lv1 ? 8 : 0));
+            unsigned x0 = c0.x, y0 = c0.y, x1 = c1.x, y1 = c1.y;
+            swap32(x0, y0); swap32(x1, y1);
+            CW[0] = x0; CW[2] = y0; CW[1] = x1; CW[3] = y1;
+          }
+        } else if (masked) {
           u32x4 A2[2], L2[2], RH2[2], RL2[2];
           ldu(ehp, i, A2); ldu(elp, i, L2); ldu(rhp, i, RH2); ldu(rlp, i, RL2);
           to_halves(A2, AH); to_halves(L2, AL); to_halves(RH2, RH); to_halves(RL2, RL);
@@ -692,7 +708,13 @@ __global__ __launch_bounds__(256, NPW >= 2 ? ((EBEN_T3_SPLIT_OCC2 && FM <= 2) ? 
           for (int e = 0; e < 4; ++e) v[e] = acc[i][4 * r4 + e];
           if (masked) {
             unpack(AH[r4], a0);
-            if (fmr) {
+            if (fmc) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const unsigned c = CW[r4] >> (8 * e);
+                v[e] += fk1 * (float)((int)(c & 3u) - 1) - fk2 * (float)((int)((c >> 2) & 3u) - 1);
+              }
+            } else if (fmr) {
               float a1[4], r0[4], r1[4];
               unpack(AL[r4], a1); unpack(RH[r4], r0); unpack(RL[r4], r1);
 #pragma unroll
@@ -720,6 +742,7 @@ __global__ __launch_bounds__(256, NPW >= 2 ? ((EBEN_T3_SPLIT_OCC2 && FM <= 2) ? 
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
       uint2 ah[4], al[4], rh[4], rl[4];
+      unsigned cw[4];
       float bz[4][4];
 #pragma unroll
       for (int r4 = 0; r4 < 4; ++r4) {
@@ -733,7 +756,8 @@ __global__ __launch_bounds__(256, NPW >= 2 ? ((EBEN_T3_SPLIT_OCC2 && FM <= 2) ? 
         if (masked) {
           if constexpr (PREF) ah[r4] = pr ? ld2(ehb, row) : pah[i][r4];
           else ah[r4] = ld2(ehb, row);
-          if (fmr) { al[r4] = ld2(elb, row); rh[r4] = ld2(rhb, row); rl[r4] = ld2(rlb, row); }
+          if (fmc) cw[r4] = *reinterpret_cast<const unsigned*>(ecb + ((row + (long long)loff) >> 1));   // the half unit's four code bytes
+          else if (fmr) { al[r4] = ld2(elb, row); rh[r4] = ld2(rhb, row); rl[r4] = ld2(rlb, row); }
         }
       }
 #pragma unroll
@@ -747,7 +771,13 @@ __global__ __launch_bounds__(256, NPW >= 2 ? ((EBEN_T3_SPLIT_OCC2 && FM <= 2) ? 
         for (int e = 0; e < 4; ++e) v[e] = acc[i][4 * r4 + e] + bz[r4][e];
         if (masked) {
           unpack(ah[r4], a0);
-          if (fmr) {
+          if (fmc) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const unsigned c = cw[r4] >> (8 * e);
+              v[e] += fk1 * (float)((int)(c & 3u) - 1) - fk2 * (float)((int)((c >> 2) & 3u) - 1);
+            }
+          } else if (fmr) {
             float a1[4], r0[4], r1[4];
             unpack(al[r4], a1); unpack(rh[r4], r0); unpack(rl[r4], r1);
 #pragma unroll
@@ -1477,13 +1507,13 @@ int tap3_launch(const Canon& c, int dir, const TapIO& io, int reflect, hipStream
   Tap3Args a;
   a.x = io.x; a.xmask = io.in_mode ? io.xmask : io.x; a.in_mode = io.in_mode; a.wp = reinterpret_cast<const u32x4*>(io.wp); a.tab = reinterpret_cast<const int*>(io.wp + p.tab_off_floats);
   a.bias = io.bias; a.res = io.res; a.emask = io.emask; a.y = io.y;
-  a.xh = a.xl = nullptr; a.yh = a.yl = nullptr; a.eh = a.el = nullptr; a.CBx = a.CBy = a.bl_ref_off = a.bl_pad = 0;
+  a.xh = a.xl = nullptr; a.yh = a.yl = nullptr; a.eh = a.el = nullptr; a.ec = nullptr; a.CBx = a.CBy = a.bl_ref_off = a.bl_pad = 0;
   a.pr_S = a.pr_cbg = a.pr_Ly = a.pr_order = 0;
   if (c.bl) {
     if (!io.xh || !io.yh || (p.npx > 1 && !io.xl)) return fail(EBEN_EINVAL, "tap3: null bundle-layout plane");
     a.xh = static_cast<const u32x4*>(io.xh); a.xl = static_cast<const u32x4*>(io.xl);
     a.yh = static_cast<uint2*>(io.yh); a.yl = static_cast<uint2*>(io.yl);
-    a.eh = static_cast<const uint2*>(io.eh); a.el = static_cast<const uint2*>(io.el);
+    a.eh = static_cast<const uint2*>(io.eh); a.el = static_cast<const uint2*>(io.el); a.ec = static_cast<const unsigned*>(io.ec);
     a.CBx = p.Cx >> 3; a.CBy = p.Cy >> 3; a.bl_ref_off = io.bl_ref_off;
     a.x = nullptr; a.xmask = nullptr;
     if (io.pr_S > 0) {

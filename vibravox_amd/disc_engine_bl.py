@@ -35,6 +35,30 @@ BL = 0x100   # EBEN_LAYOUT_BL
 SPLIT_MELGAN = __import__("os").environ.get("EBEN_SPLIT_MELGAN", "0") != "0"
 #: the four stacked seed blocks of a chain's backward from one launch (eben_hinge_bwd_stacked); 0: a memset + three launches
 STACKED_SEEDS = __import__("os").environ.get("EBEN_STACKED_SEEDS", "1") != "0"
+#: the feature-matching rows of the stacked input gradients read a one-byte code plane of each embedding (signs of a - r and of a, written by
+#: the feature-matching sums pass) instead of three more operand planes; 0: the four-operand form (bit-identical results either way)
+FM_CODES = __import__("os").environ.get("EBEN_FM_CODES", "1") != "0"
+
+
+def _fm_sums(lib, acts, half: int, sums_out: torch.Tensor) -> None:
+    """eben_bl_fm_sums(_codes) over the embeddings `acts` (2 half rows each: enhanced rows, then reference rows) into `sums_out`."""
+    k = len(acts)
+    ptrs = (ctypes.c_void_p * (2 * k))()
+    units = (ctypes.c_int64 * k)()
+    codes = (ctypes.c_void_p * k)()
+    for j, pl in enumerate(acts):
+        ptrs[2 * j], ptrs[2 * j + 1] = _addr(pl.hi), _addr(pl.lo)
+        units[j] = half * (pl.channels // 8) * pl.length
+        if FM_CODES:
+            if pl.codes is None or pl.codes.shape[0] != half:
+                pl.codes = torch.empty((half, pl.channels // 8, pl.length, 8), dtype=torch.uint8, device=pl.hi.device)
+            codes[j] = pl.codes.data_ptr()
+    ws_bytes = lib.eben_bl_fm_sums_workspace(k)
+    ws = torch.empty(max(1, (ws_bytes + 3) // 4), dtype=torch.float32, device=acts[0].hi.device)
+    if FM_CODES:
+        check(lib.eben_bl_fm_sums_codes(ptrs, units, codes, k, ptr(ws), ws_bytes, ptr(sums_out), _stream()), "bl_fm_sums_codes")
+    else:
+        check(lib.eben_bl_fm_sums(ptrs, units, k, ptr(ws), ws_bytes, ptr(sums_out), _stream()), "bl_fm_sums")
 
 
 def _addr(t: Optional[torch.Tensor]) -> Optional[int]:
@@ -48,11 +72,14 @@ def _addr(t: Optional[torch.Tensor]) -> Optional[int]:
 class Planes:
     """hi / lo planes of one (rows, channels, length) tensor in the bundle layout."""
 
-    __slots__ = ("hi", "lo", "rows", "channels", "length")
+    __slots__ = ("hi", "lo", "rows", "channels", "length", "codes")
 
     def __init__(self, rows: int, channels: int, length: int, device, lo: bool = True):
         assert channels % 8 == 0
         self.rows, self.channels, self.length = rows, channels, length
+        #: feature-matching code plane of an embedding (one byte per element of its first rows / 2 rows: the signs the stacked input
+        #: gradients' feature-matching term needs; written by eben_bl_fm_sums_codes, attached by the engine)
+        self.codes = None
         self.hi = torch.empty((rows, channels // 8, length, 8), dtype=torch.bfloat16, device=device)
         self.lo = torch.empty_like(self.hi) if lo else None
 
@@ -60,6 +87,7 @@ class Planes:
         """Rows [r0, r1) of the same storage (the leading dimension: still contiguous)."""
         v = Planes.__new__(Planes)
         v.rows, v.channels, v.length = r1 - r0, self.channels, self.length
+        v.codes = None
         v.hi = self.hi[r0:r1]
         v.lo = None if self.lo is None else self.lo[r0:r1]
         return v
@@ -198,8 +226,9 @@ class _ChainBL:
             wp = lay.packed(2 if pr else 1, rows, x_in.length)
             tm = ops.kernel_timer_for(lay.spec, "dx")
             e0 = tm.start() if tm is not None else None
-            dx_fn = lib.eben_bl_conv1d_bwd_dx_pr if pr else lib.eben_bl_conv1d_bwd_dx
-            check(dx_fn(ctypes.byref(d), _addr(g.hi), ptr(wp), _addr(x_in.hi), _addr(x_in.lo), self.layers[i - 1].spec.out_slope, half,
+            dx_fn = lib.eben_bl_conv1d_bwd_dx_pr_c if pr else lib.eben_bl_conv1d_bwd_dx_c
+            codes = x_in.codes.data_ptr() if (FM_CODES and x_in.codes is not None and x_in.codes.shape[0] == half) else None
+            check(dx_fn(ctypes.byref(d), _addr(g.hi), ptr(wp), _addr(x_in.hi), _addr(x_in.lo), codes, self.layers[i - 1].spec.out_slope, half,
                         seg_map, half, half, fm_sums_addr + 8 * (i - 1), fm_gs, _addr(gp.hi), _addr(gp.lo), st), "bl_conv1d_bwd_dx")
             if tm is not None:
                 tm.stop(e0, rows)
@@ -268,6 +297,7 @@ class _ChainBL:
         lay = self.layers[0]
         v, gain, bias = lay.params()
         view = Planes.__new__(Planes)
+        view.codes = None
         view.hi, view.lo, view.rows, view.channels, view.length = g0.hi[2 * half:], None, 2 * half, g0.channels, g0.length
         job = self.head_job(x_full, x_full.shape[2], view)
         nslab, row_stride = ctypes.c_int(0), ctypes.c_int(0)
@@ -419,16 +449,7 @@ class DiscriminatorEngineBL(DiscriminatorEngine):
             a0 = act0[i].rows_slice(q0, q1)
             self.chains[i].forward_body(a0, [p.rows_slice(q0, q1) for p in planes[i]], logits[i][q0:q1])
             if fm:
-                acts = [act0[i]] + planes[i]
-                k = len(acts)
-                ptrs = (ctypes.c_void_p * (2 * k))()
-                units = (ctypes.c_int64 * k)()
-                for j, pl in enumerate(acts):
-                    ptrs[2 * j], ptrs[2 * j + 1] = _addr(pl.hi), _addr(pl.lo)
-                    units[j] = half * (pl.channels // 8) * pl.length
-                ws_bytes = lib.eben_bl_fm_sums_workspace(k)
-                ws = torch.empty(max(1, (ws_bytes + 3) // 4), dtype=torch.float32, device=acts[0].hi.device)
-                check(lib.eben_bl_fm_sums(ptrs, units, k, ptr(ws), ws_bytes, ptr(fm_sums[2 * fm_first[i]:]), _stream()), "bl_fm_sums")
+                _fm_sums(lib, [act0[i]] + planes[i], half, fm_sums[2 * fm_first[i]:])
             return True
 
         def run(i):
@@ -505,15 +526,7 @@ class DiscriminatorEngineBL(DiscriminatorEngine):
             # embeddings (1.6 GB at 64 rows) runs beside the other chains' MFMA-bound layers instead of alone behind the join
             # ([MI355X] one launch over all 35 pairs after the join: 0.27 ms of the step's critical path)
             acts, logits = self.chains[i].forward_body(act0[i])
-            k = len(acts)
-            ptrs = (ctypes.c_void_p * (2 * k))()
-            units = (ctypes.c_int64 * k)()
-            for j, pl in enumerate(acts):
-                ptrs[2 * j], ptrs[2 * j + 1] = _addr(pl.hi), _addr(pl.lo)
-                units[j] = half * (pl.channels // 8) * pl.length
-            ws_bytes = lib.eben_bl_fm_sums_workspace(k)
-            ws = torch.empty(max(1, (ws_bytes + 3) // 4), dtype=torch.float32, device=acts[0].hi.device)
-            check(lib.eben_bl_fm_sums(ptrs, units, k, ptr(ws), ws_bytes, ptr(fm_sums[2 * fm_first[i]:]), _stream()), "bl_fm_sums")
+            _fm_sums(lib, acts, half, fm_sums[2 * fm_first[i]:])
             return acts, logits
 
         def run(i):
