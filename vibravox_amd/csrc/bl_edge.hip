@@ -955,10 +955,8 @@ extern "C" int eben_bl_tail_dw(const float* seeds, const void* x_hi, const void*
   if (ws_bytes < eben_bl_tail_dw_workspace(rows, channels, l_out, ksize, nbranch, &ns, nullptr)) return fail(EBEN_EWORKSPACE, "bl_tail_dw workspace too small");
   static const int un = getenv("EBEN_TAIL_DW_UN") ? atoi(getenv("EBEN_TAIL_DW_UN")) : 4;
   if (ksize == 3 && un > 1) {
-    if (un >= 4) hipLaunchKernelGGL((bl_tail_dw_k_kernel<3, 4>), dim3(channels / 8, ns, nbranch), dim3(256), 0, as_stream(stream), seeds, static_cast<const u32x4*>(x_hi),
-                                    static_cast<const u32x4*>(x_lo), rows, channels / 8, length, pad, l_out, ns, slabs);
-    else hipLaunchKernelGGL((bl_tail_dw_k_kernel<3, 2>), dim3(channels / 8, ns, nbranch), dim3(256), 0, as_stream(stream), seeds, static_cast<const u32x4*>(x_hi),
-                            static_cast<const u32x4*>(x_lo), rows, channels / 8, length, pad, l_out, ns, slabs);
+    hipLaunchKernelGGL((bl_tail_dw_k_kernel<3, 4>), dim3(channels / 8, ns, nbranch), dim3(256), 0, as_stream(stream), seeds, static_cast<const u32x4*>(x_hi),
+                       static_cast<const u32x4*>(x_lo), rows, channels / 8, length, pad, l_out, ns, slabs);
     EBEN_CHECK_LAUNCH("bl_tail_dw_k_kernel");
     return EBEN_OK;
   }
