@@ -141,8 +141,10 @@ _aux = {"device": None, "streams": None}
 #: carries the generator's weight gradients, the weight pre-packing and (spread backward) one PQMF-band chain gets the high one: the
 #: step ends on that work and every other queue's kernels can absorb a delay.  [MI355X, same box] ms/step: "0,0,0" 15.27 / 15.07,
 #: "0,0,-1" 15.12 / 14.92 / 14.94, "-1,0,0" 15.42, "0,-1,0" 15.69, "-1,0,-1" 15.19, "0,-1,-1" 15.13, "-1,-1,-1" 15.27; the MelGAN
-#: layer-4 forward launch inside the step 0.438 -> 0.36 ms
-AUX_PRIORITY = tuple(int(t) for t in os.environ.get("EBEN_AUX_PRIORITY", "0,0,-1").split(","))
+#: layer-4 forward launch inside the step 0.438 -> 0.36 ms.  Round 5 (9.3 ms step, persistent tile kernels that hold a CU for their whole
+#: launch): the high priority no longer pays -- "0,0,-1" 9.282 / 9.287 / 9.269, "0,0,0" 9.199 / 9.223 / 9.229, "-1,0,0" 9.305 / 9.291 /
+#: 9.322 (same box, 100 steps each) -- all default
+AUX_PRIORITY = tuple(int(t) for t in os.environ.get("EBEN_AUX_PRIORITY", "0,0,0").split(","))
 
 
 def aux_stream(i: int, device=None) -> "torch.cuda.Stream":
