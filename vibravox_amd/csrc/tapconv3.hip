@@ -920,7 +920,9 @@ static bool plan_big(const Canon& c, int dir, int Jmin, Tap3Plan* p) {
   // MFMAs, and their epilogue (mask and feature-matching operands in, 8-byte pieces out) is what one consumer wave per SIMD cannot
   // hide -- tap3's eight to twenty waves per CU overlap it across blocks.
   static const int min_ks = env_int3("EBEN_BIG_MIN_KS", 100);     // MFMA k-steps of one output tile (x 3 for hi + lo operands)
-  static const int min_ks_dx = env_int3("EBEN_BIG_MIN_KS_DX", 100);
+  // (input gradients from 50: the PQMF-band L6 -- 768 -> 768, 5 taps, 60 k-steps, 192-row tiles -- 0.083 -> 0.071 ms now that the rows with
+  // a feature-matching term read the code plane; it lost here while they read four operands per value)
+  static const int min_ks_dx = env_int3("EBEN_BIG_MIN_KS_DX", 50);
   // [MI355X] the phase-scatter input gradients of the stride-4 layers (one output phase per tile: 8-byte stores 64 bytes apart, the mask
   // read the same way) lose here against tap3's many small blocks -- MelGAN L3 / L4 0.416 / 0.402 -> 0.506 / 0.444 ms: the epilogue's
   // partial lines are what a block per CU cannot hide; they run phases-as-rows (eben_bl_conv1d_bwd_dx_pr) or stay with tap3
