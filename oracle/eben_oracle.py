@@ -339,7 +339,13 @@ class OracleTrainer:
 
     def __init__(self, g_sd: SD, d_sd: SD, p: int = 2, q: int = 4, lr: float = 3e-4, betas=(0.5, 0.9),
                  balancing: Optional[str] = "ema", beta_ema: float = 0.9, sample_rate: int = 16000,
-                 use_mrstft: bool = True):
+                 use_mrstft: bool = True, update_discriminator_ratio: float = 1.0, time_loss: Optional[str] = None,
+                 use_feature_matching: bool = True, use_adversarial: bool = True):
+        """The optional arguments are the reference's other legal configurations (eben.py:67-76, 194-211):
+        ``balancing`` None / "simple" / "ema"; ``update_discriminator_ratio`` in [0, 1] (the ``torch.rand(1)`` draw of :118,
+        taken from torch's global CPU generator exactly where the reference takes it); ``time_loss`` "l1" =
+        ``reconstructive_loss_time_fn = torch.nn.L1Loss()``; feature-matching-only / adversarial-only."""
+        assert balancing in {None, "simple", "ema"} and 0 <= update_discriminator_ratio <= 1 and time_loss in {None, "l1"}
         self.g = {k: v.clone().requires_grad_(v.dtype.is_floating_point and not k.startswith("pqmf.")) for k, v in g_sd.items()}
         self.d = {k: v.clone().requires_grad_(True) for k, v in d_sd.items()}
         self.p, self.q = p, q
@@ -352,6 +358,8 @@ class OracleTrainer:
         self.fir = a_weighting_fir(sample_rate) if use_mrstft else None
         self.use_mrstft = use_mrstft
         self.sample_rate = sample_rate
+        self.ratio, self.time_loss = update_discriminator_ratio, time_loss
+        self.use_fm, self.use_adv = use_feature_matching, use_adversarial
 
     def _balance(self, losses: Dict[str, Tensor]) -> Tuple[Dict[str, Tensor], List[Tensor], List[Tensor]]:
         """eben.py:222-240 incl. the first-call quirk (init with current norms, then EMA anyway)."""
@@ -377,10 +385,15 @@ class OracleTrainer:
         losses: Dict[str, Tensor] = {}
         if self.use_mrstft:
             losses["reconstructive_loss_freq"] = mrstft_loss(enhanced, reference, sample_rate=self.sample_rate, fir=self.fir)
-        emb_enh = discriminator_forward(self.d, bands_enh, enhanced, self.q)
-        emb_ref = discriminator_forward(self.d, bands_ref, reference, self.q)
-        losses["feature_matching_loss"] = feature_loss(emb_enh, emb_ref)
-        losses["adv_loss_gen"] = hinge_loss(emb_enh, 1)
+        if self.time_loss == "l1":   # eben.py:199-202 with torch.nn.L1Loss
+            losses["reconstructive_loss_temp"] = (enhanced - reference).abs().mean()
+        if self.use_fm or self.use_adv:   # eben.py:203-211
+            emb_enh = discriminator_forward(self.d, bands_enh, enhanced, self.q)
+            if self.use_fm:
+                emb_ref = discriminator_forward(self.d, bands_ref, reference, self.q)
+                losses["feature_matching_loss"] = feature_loss(emb_enh, emb_ref)
+            if self.use_adv:
+                losses["adv_loss_gen"] = hinge_loss(emb_enh, 1)
         for k, v in losses.items():
             logs[f"train/generator/{k}"] = v.detach().clone()
         if self.balancing is not None:
@@ -395,11 +408,17 @@ class OracleTrainer:
         for t in self.d_params:
             t.requires_grad_(True)
 
-        # ---- discriminator phase (eben.py:114-128); G frozen
+        # ---- discriminator phase (eben.py:114-128); G frozen.  Without an adversarial loss the term table is empty and the
+        # `and` of :118 short-circuits: no draw is taken.
+        logs["enhanced"] = enhanced.detach()
+        if not self.use_adv:
+            return logs
         emb_enh = discriminator_forward(self.d, bands_enh.detach(), enhanced.detach(), self.q)
         emb_ref = discriminator_forward(self.d, bands_ref, reference, self.q)
         real = hinge_loss(emb_ref, 1)
         fake = hinge_loss(emb_enh, -1)
+        if not bool(torch.rand(1) < self.ratio):
+            return logs
         logs["train/discriminator/real_loss"] = real.detach().clone()
         logs["train/discriminator/fake_loss"] = fake.detach().clone()
         d_total = real + fake
@@ -407,5 +426,4 @@ class OracleTrainer:
         d_total.backward()
         self.d_opt.step()
         self.d_opt.zero_grad()
-        logs["enhanced"] = enhanced.detach()
         return logs

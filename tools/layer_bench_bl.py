@@ -88,7 +88,7 @@ def main():
         skip = bool(a.only) and a.only != cname + ".0"
         t_f = 1.0 if skip else time_ms(lambda: check(lib.eben_bl_head_fwd(job_f, 1, r2, st)), a.iters)
         t_b = 1.0 if skip else time_ms(lambda: check(lib.eben_bl_head_dx(job_b, 1, r2, ptr(dxh), st)), a.iters)
-        t_w = 1.0 if skip else time_ms(lambda: ch.weight_grads([], x_in, g0, half), a.iters)
+        t_w = 1.0 if skip else time_ms(lambda: ch.weight_grads([], x_in, g0.rows_slice(r2, r4), half), a.iters)
         macs2 = r2 * sp.c_out * sp.ksize * act0.length
         el = sp.c_out * act0.length
         cf, rf = cell(t_f, 2.0 * macs2, r2 * (4 * c_in * l_in + 4 * el))
@@ -131,7 +131,7 @@ def main():
             dx_fn = lib.eben_bl_conv1d_bwd_dx_pr_c if pr else lib.eben_bl_conv1d_bwd_dx_c
             t_b = time_ms(lambda: check(dx_fn(ctypes.byref(d4), g.hi.data_ptr(), ptr(wpb), xin.hi.data_ptr(), xin.lo.data_ptr(), codes, 0.2, half, seg_map,
                                               fm_rows, half, ptr(sums), 0.1, gp.hi.data_ptr(), None, st)), a.iters)
-            t_w = time_ms(lambda: ch.weight_grads([(i, g, xin)], x_in, None, half), a.iters)
+            t_w = time_ms(lambda: ch.weight_grads([(i, g.rows_slice(r2, r4), xin)], x_in, None, half), a.iters)
             wshape = sp.weight_shape()
             wel = wshape[0] * wshape[1] * wshape[2]
             macs1 = wel * d.l_out                      # per batch row
@@ -161,7 +161,7 @@ def main():
                                                          ptr(tail.scale), ptr(bias.detach()), 1.0, ptr(logits), st)), a.iters)
         t_b = time_ms(lambda: check(lib.eben_bl_tail_dx(ptr(seeds), r4, cur.channels, cur.length, sp.ksize, sp.pad_l, ptr(v.detach()), ptr(tail.scale), xin.hi.data_ptr(),
                                                         xin.lo.data_ptr(), 0.2, half, seg_map, half, half, ptr(sums), 0.1, gt.hi.data_ptr(), None, st)), a.iters)
-        t_w = time_ms(lambda: ch.weight_grads([(n - 1, seeds, xin)], x_in, None, half), a.iters)
+        t_w = time_ms(lambda: ch.weight_grads([(n - 1, seeds[r2:], xin)], x_in, None, half), a.iters)
         nin = cur.channels * cur.length
         macs1 = nin * sp.ksize
         cf, rf = cell(t_f, 2.0 * r2 * macs1, r2 * 4 * nin)

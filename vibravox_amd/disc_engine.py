@@ -692,7 +692,7 @@ class DiscriminatorEngine:
             return None
         pend, *_keep = self._pending
         main = torch.cuda.current_stream()
-        for st in set(self._streams):
+        for st in set(self._streams) | set(getattr(self, "_used_streams", None) or ()):
             main.wait_stream(st)
         sink = getattr(self, "_sink", None)
         if sink is not None:   # already in the gradient buckets and reported chain by chain (backward_finish): nothing to inject

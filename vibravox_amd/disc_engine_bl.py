@@ -196,48 +196,60 @@ class _ChainBL:
         return acts, logits
 
     # ---- backward: stacked input gradients down to the head's output; weight-gradient jobs ---------------------------------------
-    def backward_body(self, acts: List[Planes], seeds: torch.Tensor, half: int, want_param_grads: bool, fm_sums_addr: int, fm_gs: float):
+    def backward_body(self, acts: List[Planes], seeds: torch.Tensor, half: int, want_param_grads: bool, fm_sums_addr: int, fm_gs: float,
+                      part: str = "all"):
         """seeds (4 half, 1, L) rows [fm | adv | fake | real]; returns (gradient planes at the head's output, 4 half rows, and the
-        weight-gradient jobs (layer index, gradient at the layer's output, the layer's input))."""
+        weight-gradient jobs (layer index, gradient rows [fake | real] at the layer's output, the layer's input)).
+        ``part``: "all" = the four row blocks in one pass; "gen" = rows [fm | adv] only (``seeds`` = those 2 half rows: what the
+        generator's backward waits for); "disc" = rows [fake | real] only (what the weight gradients read) -- the same launches over half
+        the rows each, so that the second pass leaves the step's critical path (DiscriminatorEngineBL.backward_launch)."""
         lib = load()
         st = _stream()
         n = len(self.layers)
-        rows = 4 * half
-        seg_map = (ctypes.c_int * 4)(0, 0, 0, 1)
+        if part == "all":
+            rows, seg_map, fm_rows, d0 = 4 * half, (ctypes.c_int * 4)(0, 0, 0, 1), half, 2 * half
+        elif part == "gen":
+            rows, seg_map, fm_rows, d0 = 2 * half, (ctypes.c_int * 2)(0, 0), half, None
+        else:
+            rows, seg_map, fm_rows, d0 = 2 * half, (ctypes.c_int * 2)(0, 1), 0, 0
+        assert seeds.shape[0] == rows
+        want_param_grads = want_param_grads and d0 is not None
         jobs = []
         tail = self.layers[-1]
         sp = tail.spec
         x_in = acts[n - 2]
         v, _, _ = tail.params()
         if want_param_grads:
-            jobs.append((n - 1, seeds, x_in))
+            jobs.append((n - 1, seeds[d0:], x_in))
         g = Planes(rows, x_in.channels, x_in.length, seeds.device, lo=False)
         check(lib.eben_bl_tail_dx(ptr(seeds), rows, x_in.channels, x_in.length, sp.ksize, sp.pad_l, ptr(v.detach()), ptr(tail.scale), _addr(x_in.hi),
-                                  _addr(x_in.lo), self.layers[n - 2].spec.out_slope, half, seg_map, half, half, fm_sums_addr + 8 * (n - 2), fm_gs,
+                                  _addr(x_in.lo), self.layers[n - 2].spec.out_slope, half, seg_map, fm_rows, half, fm_sums_addr + 8 * (n - 2), fm_gs,
                                   _addr(g.hi), None, st), "bl_tail_dx")
         for i in range(n - 2, 0, -1):
             lay = self.layers[i]
             x_in = acts[i - 1]
             if want_param_grads:
-                jobs.append((i, g, x_in))
+                jobs.append((i, g.rows_slice(d0, rows), x_in))
             d = ops.conv_desc(lay.spec_lin, rows, x_in.length, lay.math_dx)
-            gp = Planes(rows, x_in.channels, x_in.length, seeds.device, lo=(i == 1))   # the head's input gradient reads hi + lo
+            # the head's input gradient (rows [fm | adv]) reads hi + lo
+            gp = Planes(rows, x_in.channels, x_in.length, seeds.device, lo=(i == 1 and part != "disc"))
             pr = lay.pr_desc(rows, x_in.length) is not None
             wp = lay.packed(2 if pr else 1, rows, x_in.length)
             tm = ops.kernel_timer_for(lay.spec, "dx")
             e0 = tm.start() if tm is not None else None
             dx_fn = lib.eben_bl_conv1d_bwd_dx_pr_c if pr else lib.eben_bl_conv1d_bwd_dx_c
-            codes = x_in.codes.data_ptr() if (FM_CODES and x_in.codes is not None and x_in.codes.shape[0] == half) else None
+            codes = x_in.codes.data_ptr() if (fm_rows and FM_CODES and x_in.codes is not None and x_in.codes.shape[0] == half) else None
             check(dx_fn(ctypes.byref(d), _addr(g.hi), ptr(wp), _addr(x_in.hi), _addr(x_in.lo), codes, self.layers[i - 1].spec.out_slope, half,
-                        seg_map, half, half, fm_sums_addr + 8 * (i - 1), fm_gs, _addr(gp.hi), _addr(gp.lo), st), "bl_conv1d_bwd_dx")
+                        seg_map, fm_rows, half, fm_sums_addr + 8 * (i - 1), fm_gs, _addr(gp.hi), _addr(gp.lo), st), "bl_conv1d_bwd_dx")
             if tm is not None:
                 tm.stop(e0, rows)
             g = gp
-        return g, jobs
+        return g, jobs, (None if d0 is None else g.rows_slice(d0, rows))
 
     def weight_grads(self, jobs, x_full: torch.Tensor, g0: Optional[Planes], half: int, sink=None):
-        """Weight gradients of every layer (rows [fake | real] of the stacked gradients against the layer inputs [enhanced |
-        reference]): head from (g0, the chain's fp32 input), tap-conv layers by ``eben_bl_conv1d_bwd_dw``, the logits layer per branch."""
+        """Weight gradients of every layer (rows [fake | real] of the stacked gradients -- what ``backward_body`` put into the jobs and
+        ``g0`` -- against the layer inputs [enhanced | reference]): head from (g0, the chain's fp32 input), tap-conv layers by
+        ``eben_bl_conv1d_bwd_dw``, the logits layer per branch."""
         lib = load()
         st = _stream()
         n = len(self.layers)
@@ -247,7 +259,7 @@ class _ChainBL:
         for i, g, x_in in jobs:
             lay = self.layers[i]
             if i == n - 1:
-                gf, gr = self._tail_dw(lay, g[2 * half:], x_in, half, st, wn_jobs)
+                gf, gr = self._tail_dw(lay, g, x_in, half, st, wn_jobs)
                 logits = (i, gf, gr)
             else:
                 grads[i] = self._mid_dw(lay, g, x_in, half, st, wn_jobs, sink)
@@ -285,7 +297,7 @@ class _ChainBL:
             ws = d._bl_dw_ws = (nbytes, nslab.value, row_stride.value, perm.value)
         nbytes, nslab, row_stride, perm = ws
         slabs = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=g.hi.device)
-        check(lib.eben_bl_conv1d_bwd_dw(ctypes.byref(d), _addr(g.hi[2 * half:]), _addr(x_in.hi), 1 if bias is not None else 0, ptr(slabs), nbytes, st),
+        check(lib.eben_bl_conv1d_bwd_dw(ctypes.byref(d), _addr(g.hi), _addr(x_in.hi), 1 if bias is not None else 0, ptr(slabs), nbytes, st),
               "bl_conv1d_bwd_dw")
         dv, dg, dbias = self._outputs(lay, sink, g.hi.device)
         rows = v.shape[0]
@@ -298,7 +310,7 @@ class _ChainBL:
         v, gain, bias = lay.params()
         view = Planes.__new__(Planes)
         view.codes = None
-        view.hi, view.lo, view.rows, view.channels, view.length = g0.hi[2 * half:], None, 2 * half, g0.channels, g0.length
+        view.hi, view.lo, view.rows, view.channels, view.length = g0.hi, None, 2 * half, g0.channels, g0.length
         job = self.head_job(x_full, x_full.shape[2], view)
         nslab, row_stride = ctypes.c_int(0), ctypes.c_int(0)
         nbytes = lib.eben_bl_head_dw_workspace(ctypes.byref(job), 2 * half, ctypes.byref(nslab), ctypes.byref(row_stride))
@@ -475,6 +487,19 @@ class DiscriminatorEngineBL(DiscriminatorEngine):
 
         return self._launch_on_streams(run, forward=True, order=[n - 1] + list(range(n - 1)))
 
+    def _join_pending(self):
+        """Weight-gradient work of an earlier step that nobody collected (an exception between ``backward_finish`` and
+        ``collect_param_grads``, a skipped batch): its kernels still read the static planes -- the current stream waits for the chains'
+        streams and the work is dropped, instead of failing every later step."""
+        if getattr(self, "_pending", None) is not None:
+            main = torch.cuda.current_stream()
+            for st in set(self._streams or ()):
+                main.wait_stream(st)
+            if getattr(self, "_used_streams", None):
+                for st in self._used_streams:
+                    main.wait_stream(st)
+            self._pending = None
+
     @torch.no_grad()
     def forward_reference(self, bands_ref, audio_ref):
         """The reference half of the batch (rows B .. 2B: it does not depend on the generator) on the chains' streams, to run underneath
@@ -484,7 +509,7 @@ class DiscriminatorEngineBL(DiscriminatorEngine):
         st = self._static_for(half, bands_ref, audio_ref)
         # the planes are static per shape: every consumer of the previous step's embeddings (stacked input gradients, weight gradients)
         # must have been joined before they are rewritten
-        assert not getattr(self, "_pending", None), "forward_reference while the previous step's discriminator work is still pending (join it first)"
+        self._join_pending()
         st["sub"][half:].copy_(bands_ref[:, -self.q:, :])
         st["wav"][half:].copy_(audio_ref)
         if "fwd_ref" not in self._graphs:
@@ -502,6 +527,8 @@ class DiscriminatorEngineBL(DiscriminatorEngine):
         sub, wav, inputs, act0 = st["sub"], st["wav"], st["inputs"], st["act0"]
         pre = getattr(self, "_ref_done", None)
         self._ref_done = None
+        if pre is None:
+            self._join_pending()
         if pre is not None and pre[0] == half and pre[1] is st:
             # the reference rows are on their way (forward_reference): the enhanced rows + the feature-matching sums behind them
             sub[:half].copy_(bands[:, -self.q:, :])
@@ -576,6 +603,51 @@ class DiscriminatorEngineBL(DiscriminatorEngine):
         return {"feature_matching_loss": vals[0], "adv_loss_gen": vals[1], "fake_loss": vals[2], "real_loss": vals[3]}
 
     # ---- backward --------------------------------------------------------------------------------------------------------------
+    #: The stacked backward as TWO passes of 2B rows: rows [fm | adv] -- the generator's gradient signals, what the step's critical path
+    #: (balancing, generator backward, generator Adam) waits for -- first; rows [fake | real] and the weight gradients they feed behind
+    #: them on the same chain streams, joined only in front of the discriminator's Adam.  Same launches, same values (every row of a
+    #: stacked pass is independent of the others); the second half of the input-gradient work (config 2: ~1.2 of 2.4 ms) moves underneath
+    #: the generator backward.  EBEN_SPLIT_BWD=0: one 4B-row pass (rounds 2-5).
+    split_backward: bool = __import__("os").environ.get("EBEN_SPLIT_BWD", "1") != "0"
+
+    def _seeds(self, lib, s, i, dev):
+        """rows [fm | adv | fake | real] of chain i: zeros and the three hinge derivatives (targets +1, -1 on the enhanced rows, +1 on the
+        reference rows)"""
+        half = s["half"]
+        lg = s["logits"][i]
+        one = s["static"]["one"]
+        inv_scales = 1.0 / len(self.chains)
+        per = lg[:half].numel()
+        if STACKED_SEEDS:
+            seeds = torch.empty((4 * half,) + tuple(lg.shape[1:]), dtype=torch.float32, device=dev)
+            check(lib.eben_hinge_bwd_stacked(ptr(lg[:half]), ptr(lg[half:]), per, ptr(one), inv_scales * self.seed_weights[0],
+                                             inv_scales * self.seed_weights[1], inv_scales * self.seed_weights[2], ptr(seeds), _stream()), "hinge_bwd_stacked")
+        else:   # a memset and one launch per seed block (bisecting aid: the same values)
+            seeds = torch.zeros((4 * half,) + tuple(lg.shape[1:]), dtype=torch.float32, device=dev)
+            flat = seeds.reshape(-1)
+            for k2, (rows, target) in enumerate(((lg[:half], 1.0), (lg[:half], -1.0), (lg[half:], 1.0))):
+                check(lib.eben_hinge_bwd(ptr(rows), rows.numel(), target, ptr(one), inv_scales * self.seed_weights[k2], ptr(flat[(k2 + 1) * per:]),
+                                         _stream()), "hinge_bwd")
+        return seeds
+
+    def _launch_weight_grads(self, s, i, jobs, g0, half):
+        """Chain i's weight gradients on the current (the chain's) stream; returns what ``collect_param_grads`` reads."""
+        # with a data-parallel sink the launches write straight into its gradient buckets: static addresses, part of the signature
+        sink = self._sink
+        sink_sig = None if sink is None else tuple(0 if (b := sink.grad_buffer(p)) is None else b.data_ptr()
+                                                   for lay in self.chains[i].layers for p in lay.params() if p is not None)
+        jobs_sig = tuple((k, (g.hi.data_ptr() if isinstance(g, Planes) else g.data_ptr()), x.hi.data_ptr(), x.lo.data_ptr()) for k, g, x in jobs)
+        sig = (half, s["inputs"][i].data_ptr(), g0.hi.data_ptr(), jobs_sig, self._chain_sig(self.chains[i], -1), sink_sig)
+        dw_body = lambda: self.chains[i].weight_grads(jobs, s["inputs"][i], g0, half, sink)
+        # A replay rewrites the gradients of the previous replay in place, and without a sink those tensors BECOME ``.grad``
+        # (inject_grads): while a parameter still holds a gradient (accumulation over steps, zero_grad(set_to_none=False), a
+        # caller that does not zero) the launches run eagerly into fresh tensors, as gen_engine._deferrable has it.
+        held = sink is None and any(p.grad is not None for lay in self.chains[i].layers for p in lay.params() if p is not None)
+        out = dw_body() if held else self._graphs["dw"][i].run(sig, dw_body, torch.cuda.current_stream())
+        if sink is not None:
+            sink.mark_ready([p for lay in self.chains[i].layers for p in lay.params() if p is not None and p.requires_grad])
+        return out
+
     @torch.no_grad()
     def backward_launch(self, want_param_grads: bool = True, sink=None):
         self._sink = sink
@@ -584,44 +656,92 @@ class DiscriminatorEngineBL(DiscriminatorEngine):
         half = s["half"]
         dev = s["logits"][0].device
         one = s["static"]["one"]
-        inv_scales = 1.0 / len(self.chains)
         sums_ptr = ptr(s["fm_sums"])
+        split = self.split_backward
+        n = len(self.chains)
+
+        def sig_of(i, tag):
+            return (half, tag, tuple(self.seed_weights), s["fm_inv"], sums_ptr, s["logits"][i].data_ptr(),
+                    tuple((a.hi.data_ptr(), a.lo.data_ptr(), a.length, None if a.codes is None else a.codes.data_ptr()) for a in s["acts"][i]),
+                    self._chain_sig(self.chains[i], 1))
 
         def body(i):
-            lg = s["logits"][i]
-            # rows [fm | adv | fake | real]: zeros and the three hinge derivatives (targets +1, -1 on the enhanced rows, +1 on the reference rows)
-            per = lg[:half].numel()
-            if STACKED_SEEDS:
-                seeds = torch.empty((4 * half,) + tuple(lg.shape[1:]), dtype=torch.float32, device=dev)
-                check(lib.eben_hinge_bwd_stacked(ptr(lg[:half]), ptr(lg[half:]), per, ptr(one), inv_scales * self.seed_weights[0],
-                                                 inv_scales * self.seed_weights[1], inv_scales * self.seed_weights[2], ptr(seeds), _stream()), "hinge_bwd_stacked")
-            else:   # a memset and one launch per seed block (bisecting aid: the same values)
-                seeds = torch.zeros((4 * half,) + tuple(lg.shape[1:]), dtype=torch.float32, device=dev)
-                flat = seeds.reshape(-1)
-                for k2, (rows, target) in enumerate(((lg[:half], 1.0), (lg[:half], -1.0), (lg[half:], 1.0))):
-                    check(lib.eben_hinge_bwd(ptr(rows), rows.numel(), target, ptr(one), inv_scales * self.seed_weights[k2], ptr(flat[(k2 + 1) * per:]),
-                                             _stream()), "hinge_bwd")
+            seeds = self._seeds(lib, s, i, dev)
+            if split:
+                g, _, _ = self.chains[i].backward_body(s["acts"][i], seeds[:2 * half], half, False, sums_ptr + 8 * s["fm_first"][i], s["fm_inv"], "gen")
+                return g, [], None, seeds
             return self.chains[i].backward_body(s["acts"][i], seeds, half, want_param_grads, sums_ptr + 8 * s["fm_first"][i], s["fm_inv"]) + (seeds,)
 
         def run(i):
-            sig = (half, want_param_grads, tuple(self.seed_weights), s["fm_inv"], sums_ptr, s["logits"][i].data_ptr(),
-                   tuple((a.hi.data_ptr(), a.lo.data_ptr(), a.length) for a in s["acts"][i]), self._chain_sig(self.chains[i], 1))
-            out = self._graphs["bwd"][i].run(sig, lambda: body(i), torch.cuda.current_stream())
+            out = self._graphs["bwd"][i].run(sig_of(i, (want_param_grads, split)), lambda: body(i), torch.cuda.current_stream())
             self._mark_used(self.chains[i], 1)
+            if split:
+                ev = torch.cuda.Event()
+                ev.record()
+                return out + (ev,)
             return out
 
-        self._bwd = (self._launch_on_streams(run), want_param_grads, (one,))
+        res = self._launch_on_streams(run)
+        self._pending = None
+        if split and want_param_grads:
+            # second pass, not waited for by the main stream: rows [fake | real] down every chain, then the chain's weight gradients
+            if "bwd_d" not in self._graphs:
+                self._graphs["bwd_d"] = [ops.ReplayedChain() for _ in range(n)]
+            pend = [None] * n
+            keep = [None] * n
+
+            def body_d(i):
+                seeds = res[i][3]
+                g, jobs, g0 = self.chains[i].backward_body(s["acts"][i], seeds[2 * half:], half, True, sums_ptr + 8 * s["fm_first"][i], s["fm_inv"], "disc")
+                return g, jobs, g0
+
+            for i in [n - 1] + list(range(n - 1)):
+                with torch.cuda.stream(self._second_pass_stream(i, res[i][4])):
+                    sig = sig_of(i, "disc") + (res[i][3].data_ptr(),)
+                    out = self._graphs["bwd_d"][i].run(sig, lambda i=i: body_d(i), torch.cuda.current_stream())
+                    keep[i] = out
+                    pend[i] = self._launch_weight_grads(s, i, out[1], out[2], half)
+            self._pending = (pend, s, res, keep)   # keeps the saved activations and the stacked gradients alive until the kernels have run
+        self._bwd = (res, want_param_grads, (one,))
+
+    #: priority of the streams the second pass (rows [fake | real] + weight gradients) runs on; None: the chains' own streams
+    second_pass_priority = (lambda v: None if v in ("", "none") else int(v))(__import__("os").environ.get("EBEN_SPLIT_BWD_PRIORITY", "none"))
+
+    def _second_pass_stream(self, i, after: "torch.cuda.Event"):
+        st = self._chain_stream(i)
+        if self.second_pass_priority is None:
+            return st
+        low = getattr(self, "_low_streams", None)
+        if low is None:
+            low = self._low_streams = {}
+        if st not in low:
+            low[st] = torch.cuda.Stream(device=st.device, priority=self.second_pass_priority)
+        low[st].wait_event(after)
+        self._used_streams = set(self._used_streams) | {low[st]}
+        return low[st]
+
+    def _chain_stream(self, i):
+        """The stream chain i's backward was launched on by the last ``_launch_on_streams`` (spread_backward may move one chain)."""
+        streams = list(self._streams)
+        if self.spread_backward and len(self.chains) >= 3:
+            streams[len(self.chains) - 2] = ops.aux_stream(2, streams[0].device)
+        return streams[i]
 
     @torch.no_grad()
     def backward_finish(self):
         lib = load()
         res, want_param_grads, _keep = self._bwd
-        self._join_streams()
+        split = len(res[0]) == 5
+        main = torch.cuda.current_stream()
+        if split:
+            for r in res:
+                main.wait_event(r[4])   # rows [fm | adv] of every chain; what follows on the chains' streams is joined by collect_param_grads
+        else:
+            self._join_streams()
         self._bwd = _keep = None
         s = self._state
         half = s["half"]
         dev = s["logits"][0].device
-        main = torch.cuda.current_stream()
         n = len(self.chains)
         for r in res:
             r[0].hi.record_stream(main)
@@ -642,25 +762,11 @@ class DiscriminatorEngineBL(DiscriminatorEngine):
         ga = torch.empty((rows, 1, wav.shape[2]), dtype=torch.float32, device=dev)
         jobs = (EbenBlHeadJob * 1)(self.chains[-1].head_job(None, wav.shape[2], res[-1][0]))
         check(lib.eben_bl_head_dx(jobs, 1, rows, ptr(ga), _stream()), "bl_head_dx")
-        self._pending = None
-        if want_param_grads:
+        if want_param_grads and not split:
             pend = [None] * n
             for i in [n - 1] + list(range(n - 1)):   # the longest chain first
                 with torch.cuda.stream(self._streams[i]):
-                    # with a data-parallel sink the launches write straight into its gradient buckets: static addresses, part of the signature
-                    sink = self._sink
-                    sink_sig = None if sink is None else tuple(0 if (b := sink.grad_buffer(p)) is None else b.data_ptr()
-                                                               for lay in self.chains[i].layers for p in lay.params() if p is not None)
-                    jobs_sig = tuple((k, (g.hi.data_ptr() if isinstance(g, Planes) else g.data_ptr()), x.hi.data_ptr(), x.lo.data_ptr()) for k, g, x in res[i][1])
-                    sig = (half, s["inputs"][i].data_ptr(), res[i][0].hi.data_ptr(), jobs_sig, self._chain_sig(self.chains[i], -1), sink_sig)
-                    dw_body = lambda i=i: self.chains[i].weight_grads(res[i][1], s["inputs"][i], res[i][0], half, sink)
-                    # A replay rewrites the gradients of the previous replay in place, and without a sink those tensors BECOME ``.grad``
-                    # (inject_grads): while a parameter still holds a gradient (accumulation over steps, zero_grad(set_to_none=False), a
-                    # caller that does not zero) the launches run eagerly into fresh tensors, as gen_engine._deferrable has it.
-                    held = sink is None and any(p.grad is not None for lay in self.chains[i].layers for p in lay.params() if p is not None)
-                    pend[i] = dw_body() if held else self._graphs["dw"][i].run(sig, dw_body, torch.cuda.current_stream())
-                    if self._sink is not None:
-                        self._sink.mark_ready([p for lay in self.chains[i].layers for p in lay.params() if p is not None and p.requires_grad])
+                    pend[i] = self._launch_weight_grads(s, i, res[i][1], res[i][2], half)
             self._pending = (pend, s, res)   # keeps the saved activations and the stacked gradients alive until the kernels have run
         self._state = None
         return gb[:half], ga[:half], gb[half:], ga[half:]

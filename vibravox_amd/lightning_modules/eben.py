@@ -141,8 +141,7 @@ class EBENLightningModule(BaseSELightningModule):
         optimizer.step()
 
     def training_step(self, batch: Dict[str, torch.Tensor], batch_idx: int = 0):
-        if (self.exploit_step_redundancy and self.adversarial_loss_fn is not None and self.feature_matching_loss_fn is not None
-                and self.dynamic_loss_balancing is not None):
+        if self.exploit_step_redundancy and self.adversarial_loss_fn is not None and self.feature_matching_loss_fn is not None:
             step = self._training_step_engine if self._engine_usable(batch) else self._training_step_fused
         else:
             step = self._training_step_literal
@@ -311,12 +310,17 @@ class EBENLightningModule(BaseSELightningModule):
                 seeds.append(own[key])
         atomic_norms = None
         pre = getattr(self.generator, "_last_pre", None)
-        if self.fused_norms and pre is not None and pre.shape[0] == bands.shape[0] and pre.shape[2] == bands.shape[2]:
+        if self.dynamic_loss_balancing is None:
+            pass   # eben.py:107-108: no balancing -- no norms, every lambda is 1
+        elif self.fused_norms and pre is not None and pre.shape[0] == bands.shape[0] and pre.shape[2] == bands.shape[2]:
             atomic_norms = ops.last_conv_grad_norms(seeds, bands, pre, self.generator.last_conv)   # one pass for the three losses
-        if atomic_norms is None:
+        if atomic_norms is None and self.dynamic_loss_balancing is not None:
             with ops.input_grads_disabled():   # only last_conv's weight gradient is wanted: its input gradient would be computed and dropped
                 atomic_norms = [torch.norm(torch.autograd.grad(bands, leaf, grad_outputs=s, retain_graph=True)[0]).detach() for s in seeds]
-        if self.fused_balancing and len(seeds) <= 8 and atomic_norms[0].is_cuda:
+        if self.dynamic_loss_balancing is None:
+            backprop_loss_generator = sum(loss.detach() for loss in losses.values())
+            seed = seeds[0] if len(seeds) == 1 else ops.weighted_sum(seeds, self._unit_lambdas(len(seeds), seeds[0].device))
+        elif self.fused_balancing and len(seeds) <= 8 and atomic_norms[0].is_cuda:
             lambdas, backprop_loss_generator = self._update_lambdas_fused(atomic_norms, [loss.detach() for loss in losses.values()])
             seed = ops.weighted_sum(seeds, self._bal["lam"])
         else:
@@ -405,8 +409,11 @@ class EBENLightningModule(BaseSELightningModule):
         leaf = self.generator.last_conv.weight
         with ops.weight_grads_disabled():  # only d/d(bands) is wanted from these passes
             seeds = [torch.autograd.grad(loss, bands, retain_graph=True)[0] for loss in losses.values()]
-        atomic_norms = [torch.norm(torch.autograd.grad(bands, leaf, grad_outputs=s, retain_graph=True)[0]).detach() for s in seeds]
-        lambdas = self._update_lambdas(atomic_norms)
+        if self.dynamic_loss_balancing is None:   # eben.py:107-108: the plain sum
+            lambdas = [1.0] * len(seeds)
+        else:
+            atomic_norms = [torch.norm(torch.autograd.grad(bands, leaf, grad_outputs=s, retain_graph=True)[0]).detach() for s in seeds]
+            lambdas = self._update_lambdas(atomic_norms)
         backprop_loss_generator = sum(loss.detach() * lam for loss, lam in zip(losses.values(), lambdas))
         self.log("train/generator/backprop_loss", backprop_loss_generator, sync_dist=True)
         seed = None
@@ -526,6 +533,13 @@ class EBENLightningModule(BaseSELightningModule):
             for name, branch, target in _DISCRIMINATOR_TERMS:
                 out[name] = self.adversarial_loss_fn(embeddings=embeddings(branch), target=target)
         return out
+
+    def _unit_lambdas(self, n: int, device) -> torch.Tensor:
+        """n ones on the device (the weighted seed sum of a step without balancing)."""
+        ones = getattr(self, "_ones", None)
+        if ones is None or ones.numel() != n or ones.device != device:
+            ones = self._ones = torch.ones(n, dtype=torch.float32, device=device)
+        return ones
 
     def _update_lambdas(self, atomic_norms):
         """Loss weights from the gradient norms at ``generator.last_conv.weight`` (eben.py:229-237): the state is initialised
