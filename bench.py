@@ -143,7 +143,7 @@ HBM_PEAK = 8.0e12
 
 def step_roofline_ms(disc_math, scale):
     """Mixed roofline of the minimal step F_min = 2 (3 G + 8 D) with NO credit for work this build adds on top of it (the
-    hi + lo products of the PQMF-band forwards, the six-piece products of the fp32-grade generator forward): the eight discriminator
+    hi + lo products of the PQMF-band forwards, the three / six piece products of the generator forward): the eight discriminator
     passes at max(FLOP / MFMA peak of `dtype`, bytes / HBM), the three generator passes likewise (HBM-bound: G_BYTES per pass; half
     of it for the two backward passes on bf16 operands)."""
     f32, bf16 = MFMA_F32_PEAK_TFLOPS * 1e12, MFMA_BF16_PEAK_TFLOPS * 1e12
@@ -174,8 +174,8 @@ def main():
                     help="discriminator contractions: 'bf16_bl' (default) = bf16 MFMA operands with fp32 accumulate, embeddings and stacked "
                          "gradients at rest as bf16 bundles (hi + lo planes, disc_engine_bl.py; BASELINE config 2 names bf16; the PQMF-band "
                          "discriminators' forward takes hi + lo operands, see DESIGN.md), 'bf16' = the same arithmetic on fp32 tensors at rest, "
-                         "'f32' = exact fp32 products, 'bf16_plain' = every contraction on single bf16 operands; the generator's forward is "
-                         "fp32-grade either way")
+                         "'f32' = exact fp32 products, 'bf16_plain' = every contraction on single bf16 operands; the generator's forward takes hi + lo "
+                         "bf16 operands (three products, ~2^-17) inside a step whose generator backward is bf16, else fp32-grade six-product arithmetic")
     ap.add_argument("--gen-bwd-math", default=None, choices=["bf16", "f32"],
                     help="generator backward contractions (default: bf16 with a bf16 discriminator, else f32)")
     ap.add_argument("--stft-math", default=None, choices=["bf16x3", "folded", "dense", "folded_x3", "folded_x6"],
@@ -252,6 +252,11 @@ def main():
     mod.gen_backward_math = args.gen_bwd_math or ("bf16" if bf16 else "f32")
     mod.stft_math = args.stft_math or ("folded_x3" if bf16 else "folded")
     gen_bwd_math, stft_math = mod.gen_backward_math, mod.stft_math   # of the measured steps (the fp32 leg below changes the module's)
+    # the generator forward's arithmetic INSIDE the measured steps (lightning_modules/eben.py: forward_math scope of the engine step)
+    gen_fwd_x3 = gen_bwd_math == "bf16" and bool(mod.ru_forward_x3)
+    gen_fwd_desc = ("hi + lo bf16 operands, three MFMAs per product (EBEN_MATH_BF16X3, ~2^-17 per product; EBEN_RU_FWD_X3=0 selects the "
+                    "fp32-grade six-product form), fp32 accumulate, fp32 activations at rest" if gen_fwd_x3 else
+                    "fp32-grade (three bf16 pieces per operand, six MFMAs per product, EBEN_MATH_BF16X6), fp32 activations at rest")
     syncs = []
     if use_ddp:
         g_opt, d_opt = mod.optimizers()
@@ -333,7 +338,10 @@ def main():
     # the chained ones settle one after the other) finish settling before ANY leg's clock starts; reported as `settle_steps`
     def settle_graphs(done_before=0):
         n = 0
-        while n < 12 and (ops.graphs_pending() or done_before + n < 2):   # (no sequence has a signature before its first step)
+        # multi-rank: the captures are voted step by step (ops.CaptureGate: ~3 steps per level of chained sequences) and the vote must
+        # have SETTLED on every rank (same step everywhere) before the clock starts -- no blocking collective inside the timed region
+        gated = ops.capture_gate.active()
+        while n < (60 if gated else 12) and ((gated and not ops.capture_gate.settled) or ops.graphs_pending() or done_before + n < 2):   # (no sequence has a signature before its first step)
             mod.training_step(next_batch())
             n += 1
         torch.cuda.synchronize()
@@ -472,9 +480,10 @@ def main():
                                        "(noise slice + mix + crop/pad to 2.5 s + time masking)" if args.workload == "noisybwe" else "")),
                        "global_batch": world * args.batch, "samples_per_clip": cut, "parallelism": f"dp{world}",
                        "weights": "random init, torch.manual_seed(42)", "disc_math": args.disc_math,
+                       "gen_forward_math": "bf16x3" if gen_fwd_x3 else "bf16x6", "EBEN_RU_FWD_X3": int(bool(mod.ru_forward_x3)),
                        "precision": (f"discriminator contractions on bf16 MFMA operands with fp32 accumulate (MelGAN: every pass; PQMF-band "
                                      f"discriminators: input / weight gradients -- their forward takes hi + lo bf16 operands (3 MFMAs per product), which keeps the discriminator "
-                                     f"gradient within 3.4e-2 of the fp32 step's, tests/test_gpu_models.py); generator forward, losses, Adam, "
+                                     f"gradient within 3.4e-2 of the fp32 step's, tests/test_gpu_models.py); generator forward: {gen_fwd_desc}; losses, Adam, "
                                      f"parameters: fp32; discriminator embeddings / stacked gradients at rest: "
                                      f"{'bf16 bundles [row][channels / 8][position][8], hi + lo planes where the fp32 value is needed' if args.disc_math == 'bf16_bl' else 'fp32'}; generator backward contractions: {gen_bwd_math}; MRSTFT DFT contractions: {stft_desc}"
                                      if args.disc_math in ("bf16", "bf16_bl") else
@@ -493,8 +502,8 @@ def main():
         f_min = 2.0 * (3 * 6.727e8 + 8 * 2.5255e9) * audio_s
         line["step_work"] = {"f_min_flop": f_min, "achieved_tflops": round(f_min / (dt / args.steps) / 1e12, 1)}
         line["step_roofline_f_min"] = {"ideal_ms": round(f_min / (peak * 1e12) * 1e3, 3), "frac": round(f_min / (peak * 1e12) * 1e3 / ms, 4),
-                                       "note": "F_min alone on the dense MFMA peak of `dtype` (no credit for the hi + lo forward products, the "
-                                               "fp32-grade generator forward or any byte)"}
+                                       "note": "F_min alone on the dense MFMA peak of `dtype` (no credit for the hi + lo forward products of "
+                                               "the discriminators / the generator or any byte)"}
         if dt32 is not None:
             ms32 = dt32 / args.steps * 1e3
             line["value_f32"] = round(audio_s / (dt32 / args.steps), 2)

@@ -207,3 +207,104 @@ def test_engine_step_exchange_sequence_two_ranks():
     for p in procs:
         p.join(timeout=30)
     assert sorted(results) == [(0, "ok"), (1, "ok")], results
+
+
+# ---- multi-rank graph captures: the ranks agree on the step (ops.CaptureGate) ---------------------------------------------------------
+def _capture_gate_worker(rank, world, port, q):
+    """Drives the state machines of ``ops.ReplayedChain`` / ``ops.ReplayedPrepack`` over 16 steps of a mock train step -- a forward chain,
+    a backward chain whose signature contains the forward's output address (it settles one level later, like the engine's), a prepack --
+    with a recorder in place of the HIP capture and gloo all-reduces as the gradient buckets.  Rank 1's allocator history differs: its
+    forward sees a one-off signature in step 1, so that WITHOUT the gate its captures would land one step after rank 0's."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from vibravox_amd import ops
+
+        gate = ops.capture_gate
+        gate.reset()
+        assert gate.active()
+        log = []          # (step, event) in program order: captures and collectives
+        inflight = [0]    # collectives issued and not yet waited for
+        step = [0]
+
+        class FakeGraph:
+            def __init__(self, name):
+                self.name = name
+
+            def replay(self):
+                log.append((step[0], "replay " + self.name))
+
+        def fake_chain_capture(fn, stream_):
+            assert inflight[0] == 0, "a capture started while a bucket's collective was in flight"
+            out = fn()
+            log.append((step[0], "capture chain " + out[0]))
+            return FakeGraph(out[0]), out
+
+        def fake_prepack_capture(body, stream_):
+            assert inflight[0] == 0, "a capture started while a bucket's collective was in flight"
+            body()
+            log.append((step[0], "capture prepack"))
+            return FakeGraph("prepack")
+
+        ops.ReplayedChain._capture = staticmethod(fake_chain_capture)
+        ops.ReplayedPrepack._capture = staticmethod(fake_prepack_capture)
+        ops.ReplayedChain.enabled = ops.ReplayedPrepack.enabled = True
+        works = []
+
+        def drain():
+            for w in works:
+                w.wait()
+            works.clear()
+            inflight[0] = 0
+
+        gate.register_drain(drain)
+        fwd, bwd, pre = ops.ReplayedChain(), ops.ReplayedChain(), ops.ReplayedPrepack()
+        bucket = [torch.ones(4) * (rank + 1) for _ in range(2)]
+        for s in range(16):
+            step[0] = s
+            # forward: rank 1's signature is different ONCE (an allocation that moved)
+            fsig = ("fwd", 1000 + (7 if (rank == 1 and s == 1) else 0))
+            out = fwd.run(fsig, lambda: ("fwd", 0x5000 if fwd.graph is None else 0x9000), None)
+            # backward: reads the forward's output (its address changes once the forward replays from its pool)
+            addr = 0x9000 if fwd.graph is not None else 0x5000 + s   # eager outputs move around, pooled ones do not
+            bwd.run(("bwd", addr), lambda: ("bwd", 0), None)
+            # gradient buckets: issued asynchronously, waited for in front of "Adam"
+            for b in bucket:
+                works.append(dist.all_reduce(b, op=dist.ReduceOp.SUM, async_op=True))
+                inflight[0] += 1
+                log.append((s, "allreduce"))
+            pre.run(("prepack", 1), lambda: None, None)   # rebuilds the weight images while the exchange is in flight
+            drain()
+            gate.step_end()
+        captures = [e for e in log if e[1].startswith("capture")]
+        assert {c[1] for c in captures} == {"capture chain fwd", "capture chain bwd", "capture prepack"}, captures
+        assert gate.settled and not gate.open
+        assert fwd.graph is not None and bwd.graph is not None and pre.graph is not None
+        assert ops.graphs_pending() == 0
+        q.put((rank, "ok", captures, [e for e in gate.history], [e for e in log if e[1] == "allreduce"]))
+    except Exception as e:  # pragma: no cover
+        import traceback
+
+        q.put((rank, f"{type(e).__name__}: {e}\n{traceback.format_exc()}", None, None, None))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_graph_captures_happen_in_the_same_step_on_both_ranks():
+    """ops.CaptureGate: identical capture steps, identical vote history and identical collective order on the two ranks although rank 1's
+    signatures settle one step later; no capture while a collective is in flight (asserted inside the recorder)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_capture_gate_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted((q.get(timeout=100) for _ in procs), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=30)
+    assert [r[1] for r in results] == ["ok", "ok"], results
+    (_, _, cap0, hist0, coll0), (_, _, cap1, hist1, coll1) = results
+    assert cap0 == cap1 and len(cap0) == 3          # same sequences captured in the same steps
+    assert hist0 == hist1                           # same votes, same outcome, settled in the same step
+    assert coll0 == coll1 and len(coll0) == 32      # the collectives' program order never depended on the captures

@@ -79,7 +79,7 @@ def test_oracle_trainer_matches_reference_replay(golden, vgolden, name):
 
 # ---- GPU: the product's LightningModule in the same configurations ------------------------------------------------------------------
 def _make_module(golden, cfg):
-    from test_gpu_models import DEV, build_discriminator, build_generator
+    from tests.test_gpu_models import DEV, build_discriminator, build_generator
     from vibravox_amd.lightning_modules.eben import EBENLightningModule
     from vibravox_amd.optim import FusedAdam
     from vibravox_amd.torch_modules.losses.feature_loss import FeatureLossForDiscriminatorMelganMultiScales
@@ -147,7 +147,7 @@ def test_bundle_layout_plan_in_the_other_configurations(hip, golden, vgolden, na
     special-cases: a skipped discriminator update launches neither the [fake | real] pass nor a weight gradient and leaves every
     discriminator bit where it was; no balancing / "simple" balancing change the seed arithmetic.  bf16 tolerances
     (test_gpu_models.BF16_STEP_TOLERANCES) against the reference replay."""
-    from test_gpu_models import BF16_STEP_TOLERANCES as TOL
+    from tests.test_gpu_models import BF16_STEP_TOLERANCES as TOL
 
     cfg, steps = VARIANTS[name]
     mod, d_sd, dev = _make_module(golden, cfg)

@@ -267,7 +267,7 @@ static void make_bldw_plan(const Canon& c, BlDwPlan* p) {
   // 192-column tiles where 256-column ones leave the second round of block slots mostly empty: MelGAN L4's 328 tiles become 440 on
   // 512 slots ([MI355X] 0.287 -> 0.263 ms; forced on the other layers it loses 3-10 %: more A-tile bytes per MFMA)
   static const int fn3 = getenv("EBEN_BLDW_FN3") ? atoi(getenv("EBEN_BLDW_FN3")) : 1;
-  if (fn3 && p->FN == 4) {
+  if (fn3 && p->FN == 4 && p->FM == 2) {   // 128-row tiles only (the one shape it pays on; no 64-row instantiation)
     const int t4 = ceil_div(p->NQW + 1, 32) * ceil_div(p->Mg, 64 * p->FM) * p->G, t3 = ceil_div(p->NQW + 1, 24) * ceil_div(p->Mg, 64 * p->FM) * p->G;
     if (fn3 == 2 || (t4 <= 512 && t4 > 256 && t3 <= 512)) p->FN = 3;
   }
@@ -312,12 +312,11 @@ static void make_bldw_plan(const Canon& c, BlDwPlan* p) {
 
 template <int FM, int FN>
 static int launch_bldw(const BlDwArgs& a, const BlDwPlan& p, hipStream_t st) {
-  static bool attr_set = false;
+  static LdsAttrOnce attr_once;
   auto kern = bl_dw_kernel<FM, FN>;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  {
+    const hipError_t e = lds_attr_once(attr_once, reinterpret_cast<const void*>(kern));
     if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(bl_dw)");
-    attr_set = true;
   }
   const long long nb = (long long)p.nnt * p.nmt * p.G * p.nsplit;
   hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(256), p.lds_bytes, st, a);
@@ -361,5 +360,5 @@ extern "C" int eben_bl_conv1d_bwd_dw(const EbenConv1dDesc* d, const void* dy_hi,
   a.xneed = BLDW_BKT + bldw_floordiv((c.k - 1) * c.d - c.pl, c.s) - p.amin + 1;
   hipStream_t st = as_stream(stream);
   if (p.FM == 2) return p.FN == 4 ? launch_bldw<2, 4>(a, p, st) : p.FN == 3 ? launch_bldw<2, 3>(a, p, st) : p.FN == 2 ? launch_bldw<2, 2>(a, p, st) : launch_bldw<2, 1>(a, p, st);
-  return p.FN == 4 ? launch_bldw<1, 4>(a, p, st) : p.FN == 3 ? launch_bldw<1, 3>(a, p, st) : p.FN == 2 ? launch_bldw<1, 2>(a, p, st) : launch_bldw<1, 1>(a, p, st);
+  return p.FN == 4 ? launch_bldw<1, 4>(a, p, st) : p.FN == 2 ? launch_bldw<1, 2>(a, p, st) : launch_bldw<1, 1>(a, p, st);
 }

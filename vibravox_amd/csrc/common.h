@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -22,6 +24,33 @@ inline int fail(int code, const char* fmt, ...) {
 inline int hip_fail(hipError_t e, const char* what) {
   snprintf(tls_error_buffer(), 512, "%s: %s", what, hipGetErrorString(e));
   return (int)e;
+}
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is PER DEVICE: a process that touches a second GPU needs it there too.  One bit per
+// device ordinal (mod 64) and kernel; setting it twice (two host threads racing) is harmless.
+struct LdsAttrOnce { std::atomic<unsigned long long> devices{0ull}; };
+inline int current_device_ordinal() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+  return dev;
+}
+inline hipError_t lds_attr_once(LdsAttrOnce& once, const void* kern) {
+  const unsigned long long bit = 1ull << (current_device_ordinal() & 63);
+  if (once.devices.load(std::memory_order_acquire) & bit) return hipSuccess;
+  const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e == hipSuccess) once.devices.fetch_or(bit, std::memory_order_release);
+  return e;
+}
+// compute units of the CURRENT device (cached per ordinal)
+inline int device_cus() {
+  static std::atomic<int> cache[64];
+  const int dev = current_device_ordinal() & 63;
+  int n = cache[dev].load(std::memory_order_relaxed);
+  if (n <= 0) {
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cache[dev].store(n, std::memory_order_relaxed);
+  }
+  return n;
 }
 #define EBEN_CHECK_LAUNCH(what)                         \
   do {                                                  \

@@ -397,12 +397,11 @@ static void make_dw3_plan(const Canon& c, Dw3Plan* p) {
 
 template <int FM, int FN, int WAVES_M, int XRB, bool SP>
 static int launch_dw3_sp(const Dw3Args& a, const Dw3Plan& p, hipStream_t st) {
-  static bool attr_set = false;
+  static LdsAttrOnce attr_once;
   auto kern = conv_dw3_kernel<FM, FN, WAVES_M, XRB, SP>;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  {
+    const hipError_t e = lds_attr_once(attr_once, reinterpret_cast<const void*>(kern));
     if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(conv_dw3)");
-    attr_set = true;
   }
   constexpr int MT = WAVES_M * FM;
   const int npack = p.G * p.nmt * MT * p.nbg * 2 * ((p.nct * p.BKT + 31) / 32);

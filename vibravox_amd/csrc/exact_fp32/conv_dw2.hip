@@ -302,12 +302,11 @@ static void make_dw2_plan(const Canon& c, Dw2Plan* p) {
 
 template <int FM, int FN, int WAVES_M, int XR>
 static int launch_dw2(const Dw2Args& a, const Dw2Plan& p, hipStream_t st) {
-  static bool attr_set = false;
+  static LdsAttrOnce attr_once;
   auto kern = conv_dw2_kernel<FM, FN, WAVES_M, XR>;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  {
+    const hipError_t e = lds_attr_once(attr_once, reinterpret_cast<const void*>(kern));
     if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(conv_dw2)");
-    attr_set = true;
   }
   const int npack = p.G * p.nmt * a.B * p.nct;
   hipLaunchKernelGGL((dw_pack_a_kernel<FM, WAVES_M>), dim3(npack), dim3(256), 0, st, a);

@@ -484,13 +484,12 @@ extern "C" int eben_ru_pack(int channels, const float* v_dil, const float* scale
 
 template <int CT>
 static int launch_ru(const RuArgs& a, hipStream_t st) {
-  static bool attr_set = false;
+  static LdsAttrOnce attr_once;
   auto kern = ru_fwd_kernel<CT>;
   const size_t lds = sizeof(float) * (2 * 16 * 64 * CT + (size_t)32 * CT * a.XS);
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  {
+    const hipError_t e = lds_attr_once(attr_once, reinterpret_cast<const void*>(kern));
     if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(ru_fwd)");
-    attr_set = true;
   }
   hipLaunchKernelGGL(kern, dim3(a.B * a.ntt), dim3(256), lds, st, a);
   EBEN_CHECK_LAUNCH("ru_fwd_kernel");
@@ -528,13 +527,12 @@ extern "C" int eben_ru_pack_bwd(int channels, const float* v_dil, const float* s
 
 template <int CT>
 static int launch_ru_bwd(const RuBwdArgs& a, hipStream_t st) {
-  static bool attr_set = false;
+  static LdsAttrOnce attr_once;
   auto kern = ru_bwd_kernel<CT>;
   const size_t lds = sizeof(float) * (2 * 16 * 64 * CT + (size_t)32 * CT * a.GS);
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  {
+    const hipError_t e = lds_attr_once(attr_once, reinterpret_cast<const void*>(kern));
     if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(ru_bwd)");
-    attr_set = true;
   }
   hipLaunchKernelGGL(kern, dim3(a.B * a.ntt), dim3(256), lds, st, a);
   EBEN_CHECK_LAUNCH("ru_bwd_kernel");

@@ -614,12 +614,11 @@ __global__ __launch_bounds__(256) void pack2_kernel(const Pack2Args P) {
 
 template <int FM, int NW, int XR, bool H16 = false, int IMT = -1>
 static int launch2_cfg(const Tap2Args& a, int nblocks, size_t lds, hipStream_t st) {
-  static bool attr_set = false;
+  static LdsAttrOnce attr_once;
   auto kern = tap2_kernel<FM, NW, XR, H16, IMT>;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  {
+    const hipError_t e = lds_attr_once(attr_once, reinterpret_cast<const void*>(kern));
     if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(tap2)");
-    attr_set = true;
   }
   hipLaunchKernelGGL(kern, dim3(nblocks), dim3(NW * 64), lds, st, a);
   EBEN_CHECK_LAUNCH("tap2_kernel");

@@ -431,13 +431,12 @@ __global__ __launch_bounds__(256, (CT * RT >= 4) ? 2 : 3) void rubl_dw_kernel(co
 // ---- host side -----------------------------------------------------------------------------------------------------------------
 template <int CT, int NW, int G>
 static int launch_rubl_bwd(const RublBwdArgs& a, hipStream_t st) {
-  static bool attr_set = false;
+  static LdsAttrOnce attr_once;
   auto kern = rubl_bwd_kernel<CT, NW, G>;
   const size_t lds = (size_t)2 * G * 2 * CT * 64 * 16 + (size_t)(4 * CT) * (NW * 32) * 16;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  {
+    const hipError_t e = lds_attr_once(attr_once, reinterpret_cast<const void*>(kern));
     if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(rubl_bwd)");
-    attr_set = true;
   }
   hipLaunchKernelGGL(kern, dim3(a.B * a.ntt), dim3(NW * 64), lds, st, a);
   EBEN_CHECK_LAUNCH("rubl_bwd_kernel");
@@ -446,14 +445,13 @@ static int launch_rubl_bwd(const RublBwdArgs& a, hipStream_t st) {
 
 template <int CT, int RT, int BKT>
 static int launch_rubl_dw(const RublDwArgs& a, hipStream_t st) {
-  static bool attr_set = false;
+  static LdsAttrOnce attr_once;
   auto kern = rubl_dw_kernel<CT, RT, BKT>;
   constexpr int CB = 4 * CT, RB = 4 * RT, TS = BKT + 4, XP = (BKT + 2 * RUBL_DMAX + 63) / 64, RS = XP * 64 + 4;
   const size_t lds = (size_t)2 * 16 * (2 * RB * TS + CB * TS + CB * RS);
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  {
+    const hipError_t e = lds_attr_once(attr_once, reinterpret_cast<const void*>(kern));
     if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(rubl_dw)");
-    attr_set = true;
   }
   const long long nb = (long long)a.B * a.nseg * (CT / RT);
   if (nb > 0x7fffffffLL) return fail(EBEN_EINVAL, "rubl_dw grid too large");

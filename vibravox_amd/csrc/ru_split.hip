@@ -672,14 +672,13 @@ static int rs_pieces(int math) {
 
 template <int CT, int NW, int NP, int KSC, bool BL = false>
 static int launch_ru3_fwd(const Ru3Args& a, hipStream_t st) {
-  static bool attr_set = false;
+  static LdsAttrOnce attr_once;
   auto kern = ru3_fwd_kernel<CT, NW, NP, KSC, BL>;
   constexpr int XS = NW * 32 + 2 * RS_DMAX + 6;
   const size_t lds = (size_t)2 * KSC * NP * CT * 64 * 16 + sizeof(float) * 32 * CT * XS;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  {
+    const hipError_t e = lds_attr_once(attr_once, reinterpret_cast<const void*>(kern));
     if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(ru3_fwd)");
-    attr_set = true;
   }
   hipLaunchKernelGGL(kern, dim3(a.B * a.ntt), dim3(NW * 64), lds, st, a);
   EBEN_CHECK_LAUNCH("ru3_fwd_kernel");
@@ -688,14 +687,13 @@ static int launch_ru3_fwd(const Ru3Args& a, hipStream_t st) {
 
 template <int CT, int NW, int NP, int G>
 static int launch_ru3_bwd(const Ru3BwdArgs& a, hipStream_t st) {
-  static bool attr_set = false;
+  static LdsAttrOnce attr_once;
   auto kern = ru3_bwd_kernel<CT, NW, NP, G>;
   constexpr int GS = NW * 32 + 4;
   const size_t lds = (size_t)2 * G * 2 * NP * CT * 64 * 16 + sizeof(float) * 32 * CT * GS;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  {
+    const hipError_t e = lds_attr_once(attr_once, reinterpret_cast<const void*>(kern));
     if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(ru3_bwd)");
-    attr_set = true;
   }
   hipLaunchKernelGGL(kern, dim3(a.B * a.ntt), dim3(NW * 64), lds, st, a);
   EBEN_CHECK_LAUNCH("ru3_bwd_kernel");

@@ -724,20 +724,14 @@ __global__ __launch_bounds__(512) void tap4_kernel(const Tap3Args P) {
 // ---------------------------------------------------------------------------------------------------------------------------------
 template <int WM, int WN, int TM, int TN, int NP, int KSC, int RING, int HB>
 static int launch4(const Tap3Plan& p, const Tap3Args& a, hipStream_t st) {
-  static bool attr_set = false;
+  static LdsAttrOnce attr_once;
   auto kern = tap4_kernel<WM, WN, TM, TN, NP, KSC, RING, HB>;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  {
+    const hipError_t e = lds_attr_once(attr_once, reinterpret_cast<const void*>(kern));
     if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(tap4)");
-    attr_set = true;
   }
-  static int cus = 0;
-  if (cus == 0) {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-    static const int force = getenv("EBEN_BIG_BLOCKS") ? atoi(getenv("EBEN_BIG_BLOCKS")) : 0;
-    cus = force > 0 ? force : n;
-  }
+  static const int force = getenv("EBEN_BIG_BLOCKS") ? atoi(getenv("EBEN_BIG_BLOCKS")) : 0;
+  const int cus = force > 0 ? force : device_cus();   // of the current device: one persistent block per CU
   Tap3Args b = a;
   const int nb = a.big_tiles < cus ? a.big_tiles : cus;
   b.xq = (unsigned)(nb / 8); b.xr = (unsigned)(nb % 8);

@@ -496,12 +496,11 @@ static int launch_pack(const Canon& c, const TapPlan& p, const float* w, const f
 // ---- tapconv launcher -----------------------------------------------------------------------
 template <int WM, int WN, int FM, int FN>
 static int launch_cfg(const TapArgs& a, int nblocks, size_t lds, hipStream_t st) {
-  static bool attr_set = false;
+  static LdsAttrOnce attr_once;
   auto kern = tapconv_kernel<WM, WN, FM, FN>;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  {
+    const hipError_t e = lds_attr_once(attr_once, reinterpret_cast<const void*>(kern));
     if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(tapconv)");
-    attr_set = true;
   }
   hipLaunchKernelGGL(kern, dim3(nblocks), dim3(WM * WN * 64), lds, st, a);
   EBEN_CHECK_LAUNCH("tapconv_kernel");

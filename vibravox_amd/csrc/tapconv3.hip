@@ -1367,12 +1367,11 @@ __global__ __launch_bounds__(256) void pack3_multi_kernel(const Pack3Table T) {
 
 template <int FM, int XRB, bool IM, int NPW = 1, int NPX = 1, bool BL = false>
 static int launch3_im(const Tap3Args& a, int nblocks, size_t lds, hipStream_t st) {
-  static bool attr_set = false;
+  static LdsAttrOnce attr_once;
   auto kern = tap3_kernel<FM, XRB, IM, NPW, NPX, BL>;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  {
+    const hipError_t e = lds_attr_once(attr_once, reinterpret_cast<const void*>(kern));
     if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(tap3)");
-    attr_set = true;
   }
   hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), lds, st, a);
   EBEN_CHECK_LAUNCH("tap3_kernel");
@@ -1454,11 +1453,10 @@ static int tap3_pack_coalesced(const Pack3Args& a, hipStream_t st, int* rc) {
   const long long weights = (long long)a.G * a.Cout_g * a.Cin_g * a.k;
   const size_t lds = sizeof(float) * (size_t)(a.mode == 0 ? 32 : 16) * (size_t)(((a.mode == 0 ? 16 : 32) * a.k) | 1);
   if (min_w <= 0 || a.dense || weights < min_w || lds > 150 * 1024 || a.nph > 8) return 0;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pack3c_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  static LdsAttrOnce attr_once;
+  {
+    const hipError_t e = lds_attr_once(attr_once, reinterpret_cast<const void*>(pack3c_kernel));
     if (e != hipSuccess) { *rc = hip_fail(e, "hipFuncSetAttribute(pack3c)"); return 1; }
-    attr_set = true;
   }
   const long long items = (long long)a.G * a.nmt * a.FM * a.ncc * a.CP;
   hipLaunchKernelGGL(pack3c_kernel, dim3((unsigned)items), dim3(256), lds, st, a);

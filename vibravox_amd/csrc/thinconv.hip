@@ -317,12 +317,11 @@ __global__ __launch_bounds__(256) void thin_pack_kernel(const ThinPackArgs P) {
 
 template <int MT, int BN, int NP = 1>
 static int launch_thin_cfg(const ThinArgs& a, int nblocks, size_t lds, hipStream_t st) {
-  static bool attr_set = false;
+  static LdsAttrOnce attr_once;
   auto kern = thin_kernel<MT, BN, NP>;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  {
+    const hipError_t e = lds_attr_once(attr_once, reinterpret_cast<const void*>(kern));
     if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(thin)");
-    attr_set = true;
   }
   hipLaunchKernelGGL(kern, dim3(nblocks), dim3(BN), lds, st, a);
   EBEN_CHECK_LAUNCH("thin_kernel");

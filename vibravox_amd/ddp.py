@@ -65,6 +65,8 @@ class GradSync:
                 if _comm_streams.get(dev) is None:
                     _comm_streams[dev] = torch.cuda.Stream(device=dev)
                 self.comm_stream = _comm_streams[dev]
+            # no graph capture starts while a bucket's exchange is in flight (ops.CaptureGate)
+            ops.capture_gate.register_drain(self.comm_stream.synchronize)
         else:
             self.comm_stream = None
         self.overlap = overlap

@@ -30,6 +30,7 @@ from __future__ import annotations
 
 import ctypes
 import dataclasses
+import contextlib
 import os
 from typing import Dict, List, Optional
 
@@ -52,10 +53,10 @@ BWD_GROUPS = os.environ.get("EBEN_GEN_BWD_GROUPS", "2,2,3")
 # fp32 arithmetic at 6/16 of the fp32 MFMA's cost); "f32" selects the v_mfma_f32_32x32x2_f32 kernels (bisecting aid).
 _RU_MATH = {"f32": ops.MATH_F32, "bf16x6": ops.MATH_BF16X6, "bf16x3": ops.MATH_BF16X3, "bf16": ops.MATH_BF16}
 RU_FWD_MATH = _RU_MATH[os.environ.get("EBEN_RU_FWD_MATH", "bf16x6")]
-# the arithmetic of the ResidualUnit forwards from now on: EBENLightningModule sets "bf16x3" (hi + lo operands, three piece products) at
-# the head of every training step of the bf16-mixed plan and the default for the other plans (the weight images are cached per
-# arithmetic; the prepack behind the optimiser step rebuilds the ones of the step that just ran); a generator that never trained in
-# this process -- from_pretrained inference -- runs RU_FWD_MATH
+# the arithmetic of the ResidualUnit forwards right now: EBENLightningModule's engine train step of the bf16-mixed plan runs inside
+# ``forward_math("bf16x3")`` (hi + lo operands, three piece products; the weight images are cached per arithmetic and the prepack behind
+# the optimiser step -- inside the same block -- rebuilds the ones of the step that just ran); everything outside a train step --
+# validation, prediction, from_pretrained inference -- runs RU_FWD_MATH
 _ru_fwd_math = [RU_FWD_MATH]
 
 
@@ -81,6 +82,21 @@ def set_forward_math(name=None) -> None:
     (``EBEN_RU_FWD_MATH`` / ``EBEN_GEN_CONV_FWD_MATH``: fp32-grade six-product arithmetic)."""
     set_ru_forward_math(name)
     _conv_fwd_math[0] = CONV_FWD_MATH if name is None else _RU_MATH[name]
+
+
+@contextlib.contextmanager
+def forward_math(name=None):
+    """``set_forward_math(name)`` for the duration of a ``with`` block, the previous arithmetic restored on exit (also on an exception):
+    the train step of the bf16-mixed plan runs inside one, so that a validation / prediction forward of the same process computes in the
+    default fp32-grade arithmetic whether or not a train step ran before it."""
+    saved = (_ru_fwd_math[0], _conv_fwd_math[0])
+    set_forward_math(name)
+    try:
+        yield
+    finally:
+        _ru_fwd_math[0], _conv_fwd_math[0] = saved
+
+
 #: strided convs from this stride up run as space-to-depth + stride-1 tap-conv where the tap-conv does not cover them directly (0: never)
 S2D_MIN_STRIDE = int(os.environ.get("EBEN_GEN_S2D_MIN_STRIDE", "8"))
 

@@ -149,6 +149,7 @@ class EBENLightningModule(BaseSELightningModule):
         flush = getattr(self, "flush_logged", None)   # Lightning-free stand-in: the step's sync_dist values as one collective
         if flush is not None:
             flush()
+        ops.capture_gate.step_end()   # multi-rank: the ranks' vote on graph captures in the next step (a no-op on one rank / once settled)
         return out
 
     #: run the discriminator passes batched and outside autograd (vibravox_amd/disc_engine.py)
@@ -156,11 +157,13 @@ class EBENLightningModule(BaseSELightningModule):
     #: arithmetic of the discriminator contractions inside the engine: a key of DISC_MATH_PLANS -- "f32" (bit-exact fp32
     #: products), "bf16" (bf16 MFMA operands, fp32 accumulate, activation operand split -- BASELINE config 2), "bf16_plain" --
     #: or a plan the engine understands.  The generator's forward computes in fp32-grade split-bf16 products (gen_engine.RU_FWD_MATH /
-    #: CONV_FWD_MATH = EBEN_MATH_BF16X6: every mantissa bit of both fp32 operands, fp32 accumulation) in every plan.
+    #: CONV_FWD_MATH = EBEN_MATH_BF16X6: every mantissa bit of both fp32 operands, fp32 accumulation) -- except INSIDE the engine
+    #: train step of the bf16-mixed plan (gen_backward_math "bf16" and ``ru_forward_x3``), whose forward takes hi + lo operands
+    #: (EBEN_MATH_BF16X3, ~2^-17 per product); validation / prediction forwards are fp32-grade in every plan.
     disc_math: str = os.environ.get("EBEN_DISC_MATH", "f32")
-    #: arithmetic of the generator's BACKWARD contractions (input / weight gradients) in the engine step; its forward --
-    #: the product's output -- is fp32-grade either way (six-piece bf16 products, <= 2^-26 dropped per product: within 2x of the
-    #: fp32 MFMA kernels' own error against fp64, tests/test_gpu_ops.py; EBEN_RU_FWD_MATH=f32 selects those kernels)
+    #: arithmetic of the generator's BACKWARD contractions (input / weight gradients) in the engine step; "bf16" also moves the step's
+    #: forward to hi + lo operands (see ``ru_forward_x3``; "f32": six-piece bf16 products, <= 2^-26 dropped per product: within 2x of
+    #: the fp32 MFMA kernels' own error against fp64, tests/test_gpu_ops.py; EBEN_RU_FWD_MATH=f32 selects those kernels)
     gen_backward_math: str = os.environ.get("EBEN_GEN_BWD_MATH", "f32")
 
     #: arithmetic of the MRSTFT loss's windowed-DFT contractions in the engine step (mrstft_loss.MultiResolutionSTFTLoss.stft_math):
@@ -230,6 +233,14 @@ class EBENLightningModule(BaseSELightningModule):
             self.phase_events.append((label, ev))
 
     def _training_step_engine(self, batch: Dict[str, torch.Tensor]):
+        # bf16-mixed: the generator forward on hi + lo operands (three piece products, 2^-17 each) instead of the fp32-grade six -- the
+        # output stays orders of magnitude inside north_star's 1e-5 MSE (tests: < 1e-8 against the oracle at config 2).  Scoped to the
+        # step (its forward and the weight-image rebuilds behind the optimiser steps): evaluation forwards keep the default arithmetic.
+        from .. import gen_engine
+        with gen_engine.forward_math("bf16x3" if self.gen_backward_math == "bf16" and self.ru_forward_x3 else None):
+            return self._training_step_engine_body(batch)
+
+    def _training_step_engine_body(self, batch: Dict[str, torch.Tensor]):
         """``_training_step_fused`` with the discriminator side run by ``DiscriminatorEngine``: one
         batch-2B forward for the enhanced and reference branches and one stacked backward for the four
         gradient signals (feature matching, adversarial, fake, real).  Same logged values, same
@@ -259,10 +270,6 @@ class EBENLightningModule(BaseSELightningModule):
             # Measured for the bundle-layout engine only (0.2 ms of a 10 ms step); the fp32-at-rest engines keep the
             # one-piece forward unless EBEN_SPLIT_D_FWD=1 asks for it.
             engine.forward_reference(bands_ref, reference_speech)
-        # bf16-mixed: the ResidualUnit forwards on hi + lo operands (three piece products, 2^-17 each) instead of the fp32-grade six --
-        # the output stays orders of magnitude inside north_star's 1e-5 MSE (tests: < 1e-8 against the oracle at config 2)
-        from .. import gen_engine
-        gen_engine.set_forward_math("bf16x3" if self.gen_backward_math == "bf16" and self.ru_forward_x3 else None)
         with ops.backward_math({"f32": ops.MATH_F32, "bf16": ops.MATH_BF16}[self.gen_backward_math]):
             enhanced_speech, bands = self.generator(corrupted_speech)
         self._mark("generator forward")

@@ -410,6 +410,8 @@ _replayed = weakref.WeakSet()   # every ReplayedPrepack / ReplayedChain alive: g
 def graphs_pending() -> int:
     """Launch sequences that are in use but still run eagerly on their way to a capture (a step that captures takes tens of ms: a
     measurement waits until this is 0)."""
+    if capture_gate.settled and capture_gate.active():
+        return 0   # multi-rank: the gate has closed for good, whatever still runs eagerly stays eager
     n = 0
     for r in list(_replayed):
         if type(r).enabled and r.sig is not None and r.graph is None and not ReplayedPrepack._multi_rank():
@@ -418,12 +420,101 @@ def graphs_pending() -> int:
 
 
 #: Multi-rank runs replay the collective-free launch sequences as graphs like a single-GPU run does (every graph holds the launches of ONE
-#: stream between two joins; the all-reduces are issued outside them, from ``GradSync.mark_ready`` / ``finish``).  The captures happen in
-#: the first steps, in the same program order on every rank (SPMD: the signatures settle in the same step everywhere), each with
-#: ``capture_error_mode="thread_local"`` so that the process group's watchdog thread may go on querying its events; a capture's device-wide
-#: synchronisation merely waits for the exchange in flight, which every rank has issued before it reaches the capture.  Without the graphs a
-#: rank enqueues ~11 ms of host work per ~12 ms step.  ``EBEN_DDP_GRAPHS=0`` is the escape hatch (eager launches).
+#: stream between two joins; the all-reduces are issued outside them, from ``GradSync.mark_ready`` / ``finish``).  WHEN a sequence is
+#: captured is agreed by all ranks (``CaptureGate``: a vote at the end of each of the first steps; captures only in steps every rank
+#: opened, each behind a drain of the communication streams, with ``capture_error_mode="thread_local"`` so that the process group's
+#: watchdog thread may go on querying its events).  Without the graphs a rank enqueues ~11 ms of host work per ~9 ms step.
+#: ``EBEN_DDP_GRAPHS=0`` is the escape hatch (eager launches).  No N > 1 run on hardware has happened yet: the
+#: protocol is covered by the world-size-2 gloo test of tests/test_ddp_gloo.py with a recorder in place of the HIP capture.
 DDP_GRAPHS = os.environ.get("EBEN_DDP_GRAPHS", "1") != "0"
+
+
+class CaptureGate:
+    """Multi-rank agreement on WHEN launch sequences are captured into HIP graphs (one process per GPU, ``WORLD_SIZE > 1``).
+
+    A capture is a host-side event of tens of milliseconds with a device-wide synchronisation at both ends.  On one rank its timing is
+    nobody else's business; with several ranks exchanging gradient buckets it has to be the SAME step on every rank -- else one rank
+    sits in a capture while the others wait for it inside a collective, step after step, and which step that is depends on each rank's
+    allocator history (a signature contains addresses).  The gate makes the decision a function of the step index agreed by all ranks:
+
+      * a ``ReplayedChain`` / ``ReplayedPrepack`` that reaches its capture threshold is HELD (it goes on running eagerly) and the rank
+        votes "ready"; a sequence still counting eager rounds makes the rank vote "busy"; a rank with neither votes "idle";
+      * ``step_end()`` -- called by the train step after its last collective was issued -- all-reduces the three flags (one tiny
+        blocking collective per step, only until the gate has settled) and opens the gate for the NEXT step iff at least one rank is
+        ready and every rank is ready or idle: all ranks see the same sums, so all open in the same step;
+      * in an open step exactly the sequences held before it are captured, each after ``drain()``: no capture starts while a gradient
+        bucket's collective is in flight (the communication streams registered by ``ddp.GradSync`` are synchronised first);
+      * after three consecutive votes with nothing ready or busy anywhere the gate SETTLES: no more votes, no more captures (a
+        signature that turns up later -- a validation shape -- runs eagerly for good).
+
+    Single-rank runs (and ``EBEN_DDP_GRAPHS=0``, which keeps multi-rank runs eager altogether) never consult it."""
+
+    QUIET_VOTES = 3
+
+    def __init__(self):
+        self._drains = []
+        self.reset()
+
+    def reset(self) -> None:
+        self.open, self.settled = False, False
+        self.ready = self.busy = self.quiet = self.step = 0
+        #: (step index, what) of every capture under the gate and every vote result: identical on all ranks (tests/test_ddp_gloo.py)
+        self.history = []
+
+    @staticmethod
+    def active() -> bool:
+        d = torch.distributed
+        return DDP_GRAPHS and d.is_available() and d.is_initialized() and d.get_world_size() > 1
+
+    def register_drain(self, fn) -> None:
+        """fn(): returns once none of the caller's collectives is in flight (``ddp.GradSync``: synchronise the communication stream)."""
+        if fn not in self._drains:
+            self._drains.append(fn)
+
+    def drain(self) -> None:
+        for fn in self._drains:
+            fn()
+
+    def counting(self) -> None:
+        """A sequence ran one of its eager rounds below the capture threshold."""
+        if not self.settled:
+            self.busy += 1
+
+    def may_capture(self, seq, what: str = "") -> bool:
+        """Called by a sequence AT its capture threshold: True = capture now (gate open and the sequence was held before this step)."""
+        if self.settled:
+            return False
+        if self.open and getattr(seq, "_held_since", None) is not None and seq._held_since < self.step:
+            self.drain()
+            self.history.append((self.step, "capture " + what))
+            seq._held_since = None
+            return True
+        if getattr(seq, "_held_since", None) is None:
+            seq._held_since = self.step
+        self.ready += 1
+        return False
+
+    def step_end(self, group=None) -> None:
+        if self.settled or not self.active():
+            return
+        d = torch.distributed
+        world = d.get_world_size(group)
+        ready, busy = int(self.ready > 0), int(self.busy > 0)
+        dev = torch.device("cuda", torch.cuda.current_device()) if d.get_backend(group) == "nccl" else torch.device("cpu")
+        vote = torch.tensor([ready, int(not ready and not busy), busy], dtype=torch.int32, device=dev)
+        d.all_reduce(vote, op=d.ReduceOp.SUM, group=group)
+        r, idle, b = (int(v) for v in vote.tolist())
+        self.open = r >= 1 and r + idle == world
+        self.quiet = self.quiet + 1 if (r == 0 and b == 0) else 0
+        self.history.append((self.step, f"vote ready {r} idle {idle} busy {b} -> {'open' if self.open else 'closed'}"))
+        if self.quiet >= self.QUIET_VOTES:
+            self.settled, self.open = True, False
+            self.history.append((self.step, "settled"))
+        self.ready = self.busy = 0
+        self.step += 1
+
+
+capture_gate = CaptureGate()
 
 
 def graphs_captured() -> int:
@@ -456,6 +547,14 @@ class ReplayedPrepack:
         d = torch.distributed
         return d.is_available() and d.is_initialized() and d.get_world_size() > 1
 
+    @staticmethod
+    def _capture(body, stream_):
+        """``body()`` recorded into a HIP graph on ``stream_`` (tests substitute a recorder)."""
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=stream_, capture_error_mode="thread_local"):
+            body()
+        return graph
+
     def run(self, sig, body, stream_) -> bool:
         """Runs (or replays) ``body`` on ``stream_`` (a torch side stream, current on entry); True when it was a replay, in which
         case the caller refreshes its own cache keys (the body's bookkeeping did not run)."""
@@ -468,13 +567,17 @@ class ReplayedPrepack:
         if self.graph is not None:
             self.graph.replay()
             return True
+        gated = capture_gate.active()
         if self.rounds < 3:
+            if gated:
+                capture_gate.counting()
             body()
             return False
-        graph = torch.cuda.CUDAGraph()
+        if gated and not capture_gate.may_capture(self, "prepack"):
+            body()
+            return False
         try:
-            with torch.cuda.graph(graph, stream=stream_, capture_error_mode="thread_local"):
-                body()
+            graph = self._capture(body, stream_)
         except Exception as exc:   # capture is an optimisation: fall back to eager launches for good
             import warnings
 
@@ -513,6 +616,16 @@ class ReplayedChain:
         self._seen = {}     # signature -> eager rounds so far (signatures that strictly alternate still reach their second round)
         _replayed.add(self)
 
+    @staticmethod
+    def _capture(fn, stream_):
+        """(graph, what ``fn()`` returned while it was recorded) -- tests substitute a recorder.  stream_ None: torch's own capture
+        stream (a sequence that normally runs on the default stream, which cannot capture); the replays are launched on whatever stream
+        is current then."""
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=stream_, capture_error_mode="thread_local"):
+            out = fn()
+        return graph, out
+
     def run(self, sig, fn, stream_):
         if not self.enabled or ReplayedPrepack._multi_rank() or _timers_enabled():
             return fn()
@@ -529,14 +642,16 @@ class ReplayedChain:
         self._seen[sig] = self.rounds
         while len(self._seen) > 4 * max(1, self.KEEP):   # bounded: forget the oldest signatures' counts
             self._seen.pop(next(iter(self._seen)))
+        gated = capture_gate.active()
         if self.rounds < 2:
+            if gated:
+                capture_gate.counting()
             return fn()
-        graph = torch.cuda.CUDAGraph()
+        if gated and not capture_gate.may_capture(self, "chain"):
+            self._seen[sig] = self.rounds = 1   # held at the threshold: the next sighting asks again
+            return fn()
         try:
-            # stream_ None: torch's own capture stream (a sequence that normally runs on the default stream, which cannot capture);
-            # the replays are launched on whatever stream is current then
-            with torch.cuda.graph(graph, stream=stream_, capture_error_mode="thread_local"):
-                out = fn()
+            graph, out = self._capture(fn, stream_)
         except Exception as exc:   # capture is an optimisation: fall back to eager launches for good
             import warnings
 
