@@ -36,7 +36,11 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #endif
 constexpr int BLDW_BKT = 64;    // time steps per K chunk
 constexpr int BLDW_TS = 68;     // A row stride in units (64 + 4: = 4 mod 16)
-constexpr int BLDW_RS = 132;    // X row stride in units (two whole 64-unit LDS-DMA pieces + 4)
+constexpr int BLDW_RS_MAX = 132;   // largest X row stride in units (two whole 64-unit LDS-DMA pieces + 4)
+// X row stride of a layer: the units a chunk reads (64 time steps + the taps' reach), rounded up to 4 mod 16 -- the second LDS-DMA piece
+// of a row is issued for its first xneed - 64 lanes only, so a row no longer occupies two whole pieces ([MI355X] PQMF-band layers: 2.1 ->
+// 1.1 KB per row, 3 -> 4-5 blocks per CU)
+static int bldw_row_stride(int xneed) { int rs = xneed <= 4 ? 4 : xneed; while ((rs & 15) != 4) ++rs; return rs > BLDW_RS_MAX ? BLDW_RS_MAX : rs; }
 
 struct BlDwArgs {
   const u32x4* ah; const u32x4* xh;
@@ -46,6 +50,7 @@ struct BlDwArgs {
   int NQW;                       // weight column bundles (CgB * k); bundle NQW is the bias column
   int has_bias, nnt, nmt, nsplit, nct, nchunks, XR, xneed;   // xneed: units of an X row a chunk reads (64 time steps + the taps' reach)
   int dense, c_in_g, c_out_g, row_stride;
+  int RS;                        // X row stride in LDS units (bldw_row_stride)
   long long slab_stride;
 };
 
@@ -73,7 +78,8 @@ __device__ __forceinline__ void bl_dma_piece(const u32x4* src, unsigned dst) {
 
 template <int FM, int FN>
 __global__ __launch_bounds__(256, 2) void bl_dw_kernel(const BlDwArgs P) {
-  constexpr int BM = 64 * FM, BMB = BM / 8, BNQ = 8 * FN, BKT = BLDW_BKT, TS = BLDW_TS, RS = BLDW_RS;
+  constexpr int BM = 64 * FM, BMB = BM / 8, BNQ = 8 * FN, BKT = BLDW_BKT, TS = BLDW_TS;
+  const int RS = P.RS;
   extern __shared__ __attribute__((aligned(16))) u32x4 smem_bldw[];
   typedef __attribute__((address_space(3))) void* lds_t;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -95,10 +101,10 @@ __global__ __launch_bounds__(256, 2) void bl_dw_kernel(const BlDwArgs P) {
   const int xrows = (cb_hi - cb_lo + 1) * P.S;        // X rows of this tile: (channel bundle, stride phase)
 
   const int a_units = BMB * TS, buf_units = a_units + P.XR * RS;
-  // LDS: [ones row: RS units of (1, 0, 0, 0 | 0, 0, 0, 0)] [buffer 0: A rows, X rows] [buffer 1]
-  for (int i = tid; i < RS; i += 256) smem_bldw[i] = u32x4{0x00003f80u, 0u, 0u, 0u};
+  // LDS: [ones row: TS units of (1, 0, 0, 0 | 0, 0, 0, 0)] [buffer 0: A rows, X rows] [buffer 1]
+  for (int i = tid; i < BLDW_TS; i += 256) smem_bldw[i] = u32x4{0x00003f80u, 0u, 0u, 0u};   // read at units koff .. koff + 3 + 16 ks < 64
   const unsigned lds0 = (unsigned)(unsigned long long)(lds_t)smem_bldw;
-  const unsigned ones_addr = lds0, buf_addr = lds0 + RS * 16;
+  const unsigned ones_addr = lds0, buf_addr = lds0 + BLDW_TS * 16;
 
   // ---- per-lane fragment addresses (bytes inside a buffer), fixed for the launch -----------------------------------------------
   // ds_read_b64_tr_b16: this lane SUPPLIES the 8-byte row (4 consecutive channels at one time step) of
@@ -168,12 +174,13 @@ __global__ __launch_bounds__(256, 2) void bl_dw_kernel(const BlDwArgs P) {
       if (cb > P.CgB - 1) cb = P.CgB - 1;
       const u32x4* row = xb + (long long)cb * P.Lx;
       const unsigned rdst = dst + (unsigned)((a_units + xr * RS) * 16);
-#pragma unroll
-      for (int piece = 0; piece < 2; ++piece) {
-        // unit u of the row = position (t0 + amin + u) S + p; outside [0, Lx): the zero unit
-        // (units behind the taps' reach are never read: zeros instead of a second kilobyte of the row per chunk)
-        const int pos = (t0 + P.amin + piece * 64 + lane) * P.S + p;
-        bl_dma_piece((pos >= 0 && pos < P.Lx && piece * 64 + lane < P.xneed) ? row + pos : zero, __builtin_amdgcn_readfirstlane(rdst + (unsigned)(piece * 64 * 16)));
+      // unit u of the row = position (t0 + amin + u) S + p; outside [0, Lx): the zero unit.  The second piece covers the taps' reach
+      // behind the 64 time steps: its lanes past xneed are switched off (the row's stride is RS < 128 units)
+      const int pos0 = (t0 + P.amin + lane) * P.S + p;
+      bl_dma_piece((pos0 >= 0 && pos0 < P.Lx) ? row + pos0 : zero, __builtin_amdgcn_readfirstlane(rdst));
+      if (64 + lane < P.xneed) {
+        const int pos1 = pos0 + 64 * P.S;
+        bl_dma_piece((pos1 >= 0 && pos1 < P.Lx) ? row + pos1 : zero, __builtin_amdgcn_readfirstlane(rdst + (unsigned)(64 * 16)));
       }
     }
   };
@@ -238,7 +245,7 @@ __global__ __launch_bounds__(256, 2) void bl_dw_kernel(const BlDwArgs P) {
 
 // ---------------------------------------------------------------------------------------------------------------------------------
 struct BlDwPlan {
-  int ok, G, Mg, Cg, MgB, CgB, dense, FM, FN, nmt, nnt, NQW, nct, nchunks, nsplit, XR, amin, row_stride, perm_k;
+  int ok, G, Mg, Cg, MgB, CgB, dense, FM, FN, nmt, nnt, NQW, nct, nchunks, nsplit, XR, amin, row_stride, perm_k, xneed, RS;
   size_t lds_bytes;
   long long slab_stride;
 };
@@ -264,6 +271,11 @@ static void make_bldw_plan(const Canon& c, BlDwPlan* p) {
   // [MI355X, 64 rows] MelGAN L1-L5 0.124 / 0.106 / 0.286 / 0.331 / 0.175 -> 0.097 / 0.085 / 0.255 / 0.301 / 0.146 ms; the PQMF-band
   // layers (7 taps, 42-84 column bundles: three 256-column tiles where six 128-column ones covered them as well) lose 10-40 %
   p->FN = (fn_max >= 4 && (c.k >= 16 || p->NQW >= 256)) ? 4 : p->NQW + 1 > 8 ? 2 : 1;
+  // 192-column tiles where they cover the layer's columns in fewer tiles than 128-column ones (22 column bundles: 1 tile for 2; 43: 2
+  // for 3): every tile reads the whole A rows and (these layers: 3-6 channel bundles) nearly all of the X rows, so traffic falls with
+  // the tile count
+  static const int fn3_thin = getenv("EBEN_BLDW_FN3_THIN") ? atoi(getenv("EBEN_BLDW_FN3_THIN")) : 1;
+  if (fn3_thin && p->FN == 2 && ceil_div(p->NQW + 1, 24) < ceil_div(p->NQW + 1, 16)) p->FN = 3;
   // 192-column tiles where 256-column ones leave the second round of block slots mostly empty: MelGAN L4's 328 tiles become 440 on
   // 512 slots ([MI355X] 0.287 -> 0.263 ms; forced on the other layers it loses 3-10 %: more A-tile bytes per MFMA)
   static const int fn3 = getenv("EBEN_BLDW_FN3") ? atoi(getenv("EBEN_BLDW_FN3")) : 1;
@@ -277,7 +289,9 @@ static void make_bldw_plan(const Canon& c, BlDwPlan* p) {
   int ncb = (BNQ - 1) / c.k + 2;
   if (ncb > p->CgB) ncb = p->CgB;
   p->XR = ncb * c.s;
-  p->lds_bytes = 16ull * (BLDW_RS + 2ull * ((64 * p->FM / 8) * BLDW_TS + p->XR * BLDW_RS));
+  p->xneed = BLDW_BKT + amax - p->amin + 1;
+  p->RS = bldw_row_stride(p->xneed);
+  p->lds_bytes = 16ull * (BLDW_TS + 2ull * ((64 * p->FM / 8) * BLDW_TS + (unsigned long long)p->XR * p->RS));
   if (p->lds_bytes > 160 * 1024) return;
   p->nct = ceil_div(c.Lout, BLDW_BKT);
   p->nchunks = c.B * p->nct;
@@ -357,8 +371,8 @@ extern "C" int eben_bl_conv1d_bwd_dw(const EbenConv1dDesc* d, const void* dy_hi,
   a.S = c.s; a.d = c.d; a.k = c.k; a.pad = c.pl; a.amin = p.amin; a.NQW = p.NQW; a.has_bias = has_bias ? 1 : 0;
   a.nnt = p.nnt; a.nmt = p.nmt; a.nsplit = p.nsplit; a.nct = p.nct; a.nchunks = p.nchunks; a.XR = p.XR;
   a.dense = p.dense; a.c_in_g = c.Cin / c.g; a.c_out_g = c.Cout / c.g; a.row_stride = p.row_stride; a.slab_stride = p.slab_stride;
-  a.xneed = BLDW_BKT + bldw_floordiv((c.k - 1) * c.d - c.pl, c.s) - p.amin + 1;
+  a.xneed = p.xneed; a.RS = p.RS;
   hipStream_t st = as_stream(stream);
   if (p.FM == 2) return p.FN == 4 ? launch_bldw<2, 4>(a, p, st) : p.FN == 3 ? launch_bldw<2, 3>(a, p, st) : p.FN == 2 ? launch_bldw<2, 2>(a, p, st) : launch_bldw<2, 1>(a, p, st);
-  return p.FN == 4 ? launch_bldw<1, 4>(a, p, st) : p.FN == 2 ? launch_bldw<1, 2>(a, p, st) : launch_bldw<1, 1>(a, p, st);
+  return p.FN == 4 ? launch_bldw<1, 4>(a, p, st) : p.FN == 3 ? launch_bldw<1, 3>(a, p, st) : p.FN == 2 ? launch_bldw<1, 2>(a, p, st) : launch_bldw<1, 1>(a, p, st);
 }
