@@ -31,8 +31,11 @@ from ._lib import stream as _stream
 from .disc_engine import DiscriminatorEngine, _Layer
 
 BL = 0x100   # EBEN_LAYOUT_BL
-#: split forward (forward_reference): also run MelGAN's reference half underneath the generator forward (default: MelGAN whole, behind it)
-SPLIT_MELGAN = __import__("os").environ.get("EBEN_SPLIT_MELGAN", "0") != "0"
+#: split forward (forward_reference): also run MelGAN's reference half underneath the generator forward (0: MelGAN whole, behind it -- the
+#: default of rounds 4-5, when its heavy layers lost more as two 32-row launches than the overlap gave back; with the two-pass backward
+#: [MI355X, same box, 3 x alternated, 100 steps] 9.03 / 9.08 / 8.99 -> 8.96 / 9.03 / 8.94 ms per step, and 8.90 / 8.92 / 8.88 together
+#: with EBEN_D_BWD_SPREAD=0)
+SPLIT_MELGAN = __import__("os").environ.get("EBEN_SPLIT_MELGAN", "1") != "0"
 #: the four stacked seed blocks of a chain's backward from one launch (eben_hinge_bwd_stacked); 0: a memset + three launches
 STACKED_SEEDS = __import__("os").environ.get("EBEN_STACKED_SEEDS", "1") != "0"
 #: the feature-matching rows of the stacked input gradients read a one-byte code plane of each embedding (signs of a - r and of a, written by
@@ -609,6 +612,9 @@ class DiscriminatorEngineBL(DiscriminatorEngine):
     #: stacked pass is independent of the others); the second half of the input-gradient work (config 2: ~1.2 of 2.4 ms) moves underneath
     #: the generator backward.  EBEN_SPLIT_BWD=0: one 4B-row pass (rounds 2-5).
     split_backward: bool = __import__("os").environ.get("EBEN_SPLIT_BWD", "1") != "0"
+    #: with the two-pass backward the three PQMF-band chains stay in series on ONE stream (the fp32-at-rest engines move the last of them
+    #: to the side stream): [MI355X, same box, 3 x alternated] 9.03 / 9.08 / 8.99 -> 8.97 / 8.98 / 8.93 ms per step
+    spread_backward = __import__("os").environ.get("EBEN_D_BWD_SPREAD", "0") != "0"
 
     def _seeds(self, lib, s, i, dev):
         """rows [fm | adv | fake | real] of chain i: zeros and the three hinge derivatives (targets +1, -1 on the enhanced rows, +1 on the
