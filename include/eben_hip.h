@@ -228,6 +228,12 @@ EBEN_API int eben_bl_conv1d_bwd_dx_pr_c(const EbenConv1dDesc* d, const void* g_h
 EBEN_API size_t eben_bl_conv1d_bwd_dw_workspace(const EbenConv1dDesc* d, int* nslab, int* row_stride, int* col_perm_k);
 EBEN_API int eben_bl_conv1d_bwd_dw(const EbenConv1dDesc* d, const void* dy_hi, const void* x_hi, int has_bias, float* slabs, size_t ws_bytes,
                           void* stream);
+/* n weight gradients in as few launches as their tile shapes allow (consecutive problems of one shape share a launch): the same layer
+ * index of the three PQMF-band discriminators (vibravox/torch_modules/dnn/eben_discriminator.py:27-28 -- same channels and taps, their own
+ * dilation, length, operands and slabs).  Problem i is exactly eben_bl_conv1d_bwd_dw(descs[i], dy_hi[i], x_hi[i], has_bias, slabs[i],
+ * ws_bytes[i]): same slabs, bit for bit. */
+EBEN_API int eben_bl_conv1d_bwd_dw_multi(const EbenConv1dDesc* const* descs, const void* const* dy_hi, const void* const* x_hi, int has_bias,
+                                float* const* slabs, const size_t* ws_bytes, int n, void* stream);
 /* Chain heads: ReflectionPad1d(reflect_pad) + Conv1d(c_in -> c_out, ksize, dilation, groups = c_in, zero padding `pad`, stride 1)
  * + bias + LeakyReLU(out_slope), fp32 (batch, c_in, l_in) in, bundle planes out (eben_discriminator.py:66-76 layer 0,
  * melgan_discriminator.py:89-98 layer 0).  `jobs` is a HOST array of up to 4 heads run by ONE launch (the three PQMF-band chains

@@ -521,3 +521,47 @@ def test_bundle_conv_weight_gradient(hip, name):
     (out * bf16_hi(dy).double()).sum().backward()
     assert rel_err(dv, wr.grad) < 3e-5, rel_err(dv, wr.grad)
     assert rel_err(dbias, br.grad) < 3e-5
+
+
+@pytest.mark.parametrize("shape", ["pqmf_l1", "pqmf_l4", "pqmf_l6", "mixed"])
+def test_weight_gradients_of_three_chains_in_one_launch(hip, shape):
+    """eben_bl_conv1d_bwd_dw_multi: the same layer index of the three PQMF-band discriminators (dilation 1 / 2 / 3, their own lengths,
+    operands and slabs) as one launch -- slab for slab the bytes of three eben_bl_conv1d_bwd_dw launches.  "mixed": problems of different
+    tile shapes in one call fall apart into one launch per run of equal shapes."""
+    from vibravox_amd import ops
+    from vibravox_amd._lib import check
+
+    kws = {"pqmf_l1": [dict(c_in=24, c_out=48, ksize=7, stride=2, dilation=d, pad_l=3, pad_r=3, groups=4) for d in (1, 2, 3)],
+           "pqmf_l4": [dict(c_in=192, c_out=384, ksize=7, stride=2, dilation=d, pad_l=3, pad_r=3, groups=4) for d in (1, 2, 3)],
+           "pqmf_l6": [dict(c_in=768, c_out=768, ksize=5, stride=1, dilation=d, pad_l=2, pad_r=2, groups=4) for d in (1, 2, 3)],
+           "mixed": [dict(c_in=24, c_out=48, ksize=7, stride=2, dilation=1, pad_l=3, pad_r=3, groups=4),
+                     dict(c_in=24, c_out=48, ksize=7, stride=2, dilation=2, pad_l=3, pad_r=3, groups=4),
+                     dict(c_in=64, c_out=256, ksize=41, stride=4, pad_l=20, pad_r=20, groups=4)]}[shape]
+    rows = 4
+    lengths = [1003, 997, 1001] if shape != "pqmf_l6" else [140, 134, 129]
+    st = torch.cuda.current_stream().cuda_stream
+    k = len(kws)
+    descs = (ctypes.POINTER(ops.EbenConv1dDesc) * k)()
+    dys, xs, sl = (ctypes.c_void_p * k)(), (ctypes.c_void_p * k)(), (ctypes.c_void_p * k)()
+    nbs = (ctypes.c_size_t * k)()
+    keep, single = [], []
+    for j, (kw, length) in enumerate(zip(kws, lengths)):
+        spec = ops.ConvSpec(**kw)
+        l_out = spec.out_len(length)
+        dy = planes_of(formula_tensor(f"blmulti/{shape}/{j}/dy", (rows, spec.c_out, l_out)).to(DEV), lo=False)
+        x = planes_of(formula_tensor(f"blmulti/{shape}/{j}/x", (rows, spec.c_in, length)).to(DEV), lo=False)
+        d = ops.conv_desc(spec, rows, length, ops.MATH_BF16 | BL)
+        nbytes = hip.eben_bl_conv1d_bwd_dw_workspace(ctypes.byref(d), None, None, None)
+        assert nbytes > 0
+        one = torch.full((nbytes // 4,), float("nan"), dtype=torch.float32, device=DEV)
+        check(hip.eben_bl_conv1d_bwd_dw(ctypes.byref(d), dy.hi.data_ptr(), x.hi.data_ptr(), 1, one.data_ptr(), nbytes, st), "bl_conv1d_bwd_dw")
+        many = torch.full((nbytes // 4,), float("nan"), dtype=torch.float32, device=DEV)
+        descs[j] = ctypes.pointer(d)
+        dys[j], xs[j], sl[j], nbs[j] = dy.hi.data_ptr(), x.hi.data_ptr(), many.data_ptr(), nbytes
+        keep.append((d, dy, x, many))
+        single.append(one)
+    check(hip.eben_bl_conv1d_bwd_dw_multi(descs, dys, xs, 1, sl, nbs, k, st), "bl_conv1d_bwd_dw_multi")
+    torch.cuda.synchronize()
+    for one, (_, _, _, many) in zip(single, keep):
+        # the slabs hold every weight's partial sums; columns no weight owns stay what they were (NaN here, both ways)
+        assert torch.equal(torch.nan_to_num(one, nan=-7.0), torch.nan_to_num(many, nan=-7.0))

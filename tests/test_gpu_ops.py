@@ -12,6 +12,8 @@ import torch
 from formula import formula_tensor
 from oracle import eben_oracle as O
 
+ROOT = __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))
+
 pytestmark = pytest.mark.gpu
 
 
@@ -1322,3 +1324,83 @@ def test_full_size_melgan_layer4_forward_against_fp64(hip, math_name):
         rounded = ref_conv(x.bfloat16().double(), w.float().bfloat16().double())
         assert float((y.cpu().double() - rounded).abs().max()) < 3e-5 * scale
         assert float((y.cpu().double() - exact).abs().max()) < 1e-2 * scale
+
+
+@pytest.mark.parametrize("ntaps,length,batch", [(101, 31968, 3), (101, 1000, 2), (7, 37, 1), (100, 2049, 2), (4, 5, 1)])
+def test_single_band_fir_and_adjoint(hip, ntaps, length, batch):
+    """The stride-1 single-band FIR kernel (direct.hip fir1_kernel: the A-weighting prefilter of the MRSTFT loss, auraloss FIRFilter "aw",
+    and its adjoint in the backward) against float64, the adjoint identity <A x, y> = <x, A^T y>, and -- through EBEN_FIR1=0 in a second
+    process -- bit for bit against the generic FIR-bank kernels it replaces on this shape."""
+    import subprocess
+    import sys
+
+    import torch.nn.functional as F
+
+    from vibravox_amd import ops
+
+    DEV = torch.device("cuda")
+    g = torch.Generator().manual_seed(ntaps * 1000 + length)
+    x = torch.randn(batch, 1, length, generator=g)
+    y = torch.randn(batch, 1, length, generator=g)
+    w = torch.randn(1, ntaps, generator=g) / ntaps
+    off0 = -(ntaps // 2)
+    xd, yd, wd = x.to(DEV), y.to(DEV), w.to(DEV)
+    ax = ops._fir_decimate(xd, wd, length, 1, ntaps, 1, off0)
+    aty = ops._fir_interp_sum(yd, wd, length, 1, ntaps, 1, off0)
+    ref = F.conv1d(F.pad(x.double(), (-off0, ntaps - 1 + off0)), w.double().reshape(1, 1, ntaps))
+    assert float((ax.cpu().double() - ref).abs().max()) < 2e-6 * float(ref.abs().max()) + 1e-7
+    lhs, rhs = float((ax.double() * yd.double()).sum()), float((xd.double() * aty.double()).sum())
+    assert abs(lhs - rhs) < 1e-5 * (abs(lhs) + 1.0)
+    code = ("import sys, torch; sys.path.insert(0, %r); from vibravox_amd import ops; d = torch.device('cuda');"
+            "g = torch.Generator().manual_seed(%d); x = torch.randn(%d, 1, %d, generator=g); y = torch.randn(%d, 1, %d, generator=g);"
+            "w = torch.randn(1, %d, generator=g) / %d;"
+            "a = ops._fir_decimate(x.to(d), w.to(d), %d, 1, %d, 1, %d); b = ops._fir_interp_sum(y.to(d), w.to(d), %d, 1, %d, 1, %d);"
+            "torch.save((a.cpu(), b.cpu()), sys.argv[1])"
+            % (ROOT, ntaps * 1000 + length, batch, length, batch, length, ntaps, ntaps, length, ntaps, off0, length, ntaps, off0))
+    import os
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "generic.pt")
+        subprocess.run([sys.executable, "-c", code, path], check=True, env={**os.environ, "EBEN_FIR1": "0"}, timeout=300)
+        ga, gb = torch.load(path)
+    assert torch.equal(ga, ax.cpu()) and torch.equal(gb, aty.cpu())
+
+
+@pytest.mark.parametrize("win,hop,n_fft,t,rows", [(240, 50, 512, 31968, 3), (600, 120, 1024, 31968, 2), (1200, 240, 2048, 31968, 2), (240, 50, 512, 1300, 2),
+                                                  (600, 120, 1024, 2500, 1), (1200, 240, 2048, 2600, 1)])
+def test_folded_framing_and_overlap_add_tiled_kernels_are_bit_identical(hip, win, hop, n_fft, t, rows):
+    """eben_stft_frames_folded through the LDS transpose and eben_overlap_add_folded from the LDS tile (direct.hip) against the gather kernels
+    they replace (EBEN_STFT_FRAMES_T=0 / EBEN_OLA_TILED=0 in a second process): the same sums of the same samples, bit for bit -- full-size
+    clips and clips a few tiles long (both reflected ends inside one or two blocks)."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+
+    code = ("import sys, ctypes, torch; sys.path.insert(0, %r)\n"
+            "from vibravox_amd._lib import check, load, ptr, stream\n"
+            "lib = load(); d = torch.device('cuda'); win, hop, t, rows = %d, %d, %d, %d\n"
+            "pad = win // 2; frames = 1 + t // hop\n"
+            "g = torch.Generator().manual_seed(win + t); sig = torch.randn(rows, t, generator=g).to(d)\n"
+            "fr = torch.empty(win * rows * frames, device=d)\n"
+            "check(lib.eben_stft_frames_folded(ptr(sig), ptr(fr), rows, t, win, hop, pad, frames, 0, stream()), 'frames')\n"
+            "dfr = torch.randn(win * rows * frames, generator=g).to(d); dsig = torch.zeros(rows, t, device=d)\n"
+            "check(lib.eben_overlap_add_folded(ptr(dfr), ptr(dsig), rows, t, win, frames, hop, pad, 0, frames, rows * frames, stream()), 'ola')\n"
+            "acc = torch.ones(rows, t, device=d)\n"
+            "check(lib.eben_overlap_add_folded(ptr(dfr), ptr(acc), rows, t, win, frames, hop, pad, 1, frames, rows * frames, stream()), 'ola')\n"
+            "torch.cuda.synchronize(); torch.save((fr.cpu(), dsig.cpu(), acc.cpu()), sys.argv[1])\n" % (ROOT, win, hop, t, rows))
+    outs = []
+    with tempfile.TemporaryDirectory() as td:
+        for k, env in enumerate(({}, {"EBEN_STFT_FRAMES_T": "0", "EBEN_OLA_TILED": "0"})):
+            path = os.path.join(td, f"o{k}.pt")
+            subprocess.run([sys.executable, "-c", code, path], check=True, env={**os.environ, **env}, timeout=300)
+            outs.append(torch.load(path))
+    for a, b in zip(*outs):
+        assert torch.isfinite(a).all() and torch.equal(a, b)
+    # adjointness of the pair: <frames(s), g> = <s, overlap_add(g)> (float64 sums of the fp32 results)
+    fr, dsig, _ = outs[0]
+    g = torch.Generator().manual_seed(win + t)
+    sig = torch.randn(rows, t, generator=g)
+    dfr = torch.randn(win * rows * (1 + t // hop), generator=g)
+    lhs, rhs = float((fr.double() * dfr.double()).sum()), float((sig.double() * dsig.double()).sum())
+    assert abs(lhs - rhs) < 1e-5 * (abs(lhs) + abs(rhs) + 1.0), (lhs, rhs)

@@ -168,3 +168,29 @@ def test_bundle_layout_plan_in_the_other_configurations(hip, golden, vgolden, na
                 # after a discriminator update the bf16 and fp32 trajectories have parted by one Adam step: the later steps get the wide bar
                 np.testing.assert_allclose(mod.logged[k].item(), vgolden[f"var/{name}/step{i}/{k}"], rtol=rtol if i == 0 else 5e-2, err_msg=f"{name} step {i} {k}")
     assert type(mod._disc_engine).__name__ == "DiscriminatorEngineBL"
+
+
+@pytest.mark.gpu
+def test_grouped_weight_gradients_equal_chain_by_chain(hip, golden):
+    """The three PQMF-band chains' weight gradients as one launch sequence (EBEN_DW_GROUP, ``_ChainBL.weight_grads_group``) and the
+    two-pass stacked backward (EBEN_SPLIT_BWD) against chain by chain / one 4B-row pass: the discriminator after one step is bit-identical
+    (same kernels on the same operands; only the launches they travel in differ)."""
+    from tests.test_gpu_models import DEV
+    from vibravox_amd.disc_engine_bl import DiscriminatorEngineBL
+
+    outs = []
+    saved = DiscriminatorEngineBL.group_weight_grads, DiscriminatorEngineBL.split_backward
+    try:
+        for group, split in ((True, True), (False, True), (False, False)):
+            DiscriminatorEngineBL.group_weight_grads, DiscriminatorEngineBL.split_backward = group, split
+            mod, _, dev = _make_module(golden, {})
+            mod.disc_math, mod.gen_backward_math = "bf16_bl", "bf16"
+            torch.manual_seed(3)
+            for i, (bc, air) in enumerate(variant_batches("none", 2)):
+                mod.training_step({"audio_body_conducted": bc.to(dev), "audio_airborne": air.to(dev)})
+            torch.cuda.synchronize()
+            outs.append({k: v.clone() for k, v in mod.discriminator.state_dict().items()})
+    finally:
+        DiscriminatorEngineBL.group_weight_grads, DiscriminatorEngineBL.split_backward = saved
+    for other in outs[1:]:
+        assert all(torch.equal(outs[0][k], other[k]) for k in outs[0]), [k for k in outs[0] if not torch.equal(outs[0][k], other[k])]

@@ -118,6 +118,7 @@ SIGNATURES = {
     "eben_bl_conv1d_bwd_dx_pr_c": (c_int, [_D, _P, _P, _P, _P, _P, c_float, c_int, POINTER(c_int), c_int, c_int, _P, c_float, _P, _P, _P]),
     "eben_bl_conv1d_bwd_dw_workspace": (c_size_t, [_D, POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
     "eben_bl_conv1d_bwd_dw": (c_int, [_D, _P, _P, c_int, _P, c_size_t, _P]),
+    "eben_bl_conv1d_bwd_dw_multi": (c_int, [POINTER(_D), POINTER(_P), POINTER(_P), c_int, POINTER(_P), POINTER(c_size_t), c_int, _P]),
     "eben_bl_head_fwd": (c_int, [POINTER(EbenBlHeadJob), c_int, c_int, _P]),
     "eben_bl_head_dx": (c_int, [POINTER(EbenBlHeadJob), c_int, c_int, _P, _P]),
     "eben_bl_head_dw_workspace": (c_size_t, [POINTER(EbenBlHeadJob), c_int, POINTER(c_int), POINTER(c_int)]),

@@ -77,7 +77,7 @@ __device__ __forceinline__ void bl_dma_piece(const u32x4* src, unsigned dst) {
 }
 
 template <int FM, int FN>
-__global__ __launch_bounds__(256, 2) void bl_dw_kernel(const BlDwArgs P) {
+__device__ __forceinline__ void bl_dw_body(const BlDwArgs& P, unsigned bid, unsigned nblk) {
   constexpr int BM = 64 * FM, BMB = BM / 8, BNQ = 8 * FN, BKT = BLDW_BKT, TS = BLDW_TS;
   const int RS = P.RS;
   extern __shared__ __attribute__((aligned(16))) u32x4 smem_bldw[];
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256, 2) void bl_dw_kernel(const BlDwArgs P) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
 
-  unsigned id = xcd_remap(blockIdx.x, gridDim.x);
+  unsigned id = xcd_remap(bid, nblk);
   const int z = __builtin_amdgcn_readfirstlane(id % P.nsplit); id /= P.nsplit;
   const int nti = __builtin_amdgcn_readfirstlane(id % P.nnt); id /= P.nnt;
   const int mt = __builtin_amdgcn_readfirstlane(id % P.nmt);
@@ -243,6 +243,27 @@ __global__ __launch_bounds__(256, 2) void bl_dw_kernel(const BlDwArgs P) {
   }
 }
 
+template <int FM, int FN>
+__global__ __launch_bounds__(256, 2) void bl_dw_kernel(const BlDwArgs P) { bl_dw_body<FM, FN>(P, blockIdx.x, gridDim.x); }
+
+// Several layers of ONE tile shape in one launch (the same layer index of the three PQMF-band discriminators: same channels and taps,
+// their own dilation, length, operands and slabs): block -> problem by the prefix sums of the problems' block counts.  [MI355X] a thin
+// layer's launch is mostly fixed cost (64 rows 37-40 us, 192 rows 66-87 us): three problems per launch pay it once.
+constexpr int BLDW_MULTI = 4;
+struct BlDwTable {
+  int n;
+  unsigned first[BLDW_MULTI + 1];
+  BlDwArgs job[BLDW_MULTI];
+};
+template <int FM, int FN>
+__global__ __launch_bounds__(256, 2) void bl_dw_multi_kernel(const BlDwTable T) {
+  int j = 0;
+#pragma unroll 1
+  while (j + 1 < T.n && blockIdx.x >= T.first[j + 1]) ++j;
+  j = __builtin_amdgcn_readfirstlane(j);
+  bl_dw_body<FM, FN>(T.job[j], blockIdx.x - T.first[j], T.first[j + 1] - T.first[j]);
+}
+
 // ---------------------------------------------------------------------------------------------------------------------------------
 struct BlDwPlan {
   int ok, G, Mg, Cg, MgB, CgB, dense, FM, FN, nmt, nnt, NQW, nct, nchunks, nsplit, XR, amin, row_stride, perm_k, xneed, RS;
@@ -354,8 +375,8 @@ extern "C" size_t eben_bl_conv1d_bwd_dw_workspace(const EbenConv1dDesc* d, int* 
   return sizeof(float) * (size_t)p.slab_stride * p.nsplit;
 }
 
-extern "C" int eben_bl_conv1d_bwd_dw(const EbenConv1dDesc* d, const void* dy_hi, const void* x_hi, int has_bias, float* slabs, size_t ws_bytes,
-                                     void* stream) {
+static int bldw_args(const EbenConv1dDesc* d, const void* dy_hi, const void* x_hi, int has_bias, float* slabs, size_t ws_bytes, BlDwArgs* out,
+                     BlDwPlan* plan) {
   Canon c;
   int rc = canon_from_desc(d, &c);
   if (rc) return rc;
@@ -372,7 +393,65 @@ extern "C" int eben_bl_conv1d_bwd_dw(const EbenConv1dDesc* d, const void* dy_hi,
   a.nnt = p.nnt; a.nmt = p.nmt; a.nsplit = p.nsplit; a.nct = p.nct; a.nchunks = p.nchunks; a.XR = p.XR;
   a.dense = p.dense; a.c_in_g = c.Cin / c.g; a.c_out_g = c.Cout / c.g; a.row_stride = p.row_stride; a.slab_stride = p.slab_stride;
   a.xneed = p.xneed; a.RS = p.RS;
+  *out = a; *plan = p;
+  return EBEN_OK;
+}
+
+extern "C" int eben_bl_conv1d_bwd_dw(const EbenConv1dDesc* d, const void* dy_hi, const void* x_hi, int has_bias, float* slabs, size_t ws_bytes,
+                                     void* stream) {
+  BlDwArgs a;
+  BlDwPlan p;
+  const int rc = bldw_args(d, dy_hi, x_hi, has_bias, slabs, ws_bytes, &a, &p);
+  if (rc) return rc;
   hipStream_t st = as_stream(stream);
   if (p.FM == 2) return p.FN == 4 ? launch_bldw<2, 4>(a, p, st) : p.FN == 3 ? launch_bldw<2, 3>(a, p, st) : p.FN == 2 ? launch_bldw<2, 2>(a, p, st) : launch_bldw<2, 1>(a, p, st);
   return p.FN == 4 ? launch_bldw<1, 4>(a, p, st) : p.FN == 3 ? launch_bldw<1, 3>(a, p, st) : p.FN == 2 ? launch_bldw<1, 2>(a, p, st) : launch_bldw<1, 1>(a, p, st);
+}
+
+namespace eben {
+template <int FM, int FN>
+static int launch_bldw_multi(const BlDwTable& T, size_t lds, hipStream_t st) {
+  static LdsAttrOnce attr_once;
+  auto kern = bl_dw_multi_kernel<FM, FN>;
+  {
+    const hipError_t e = lds_attr_once(attr_once, reinterpret_cast<const void*>(kern));
+    if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(bl_dw_multi)");
+  }
+  hipLaunchKernelGGL(kern, dim3(T.first[T.n]), dim3(256), lds, st, T);
+  EBEN_CHECK_LAUNCH("bl_dw_multi_kernel");
+  return EBEN_OK;
+}
+}  // namespace eben
+
+extern "C" int eben_bl_conv1d_bwd_dw_multi(const EbenConv1dDesc* const* descs, const void* const* dy_hi, const void* const* x_hi, int has_bias,
+                                           float* const* slabs, const size_t* ws_bytes, int n, void* stream) {
+  EBEN_REQUIRE(descs && dy_hi && x_hi && slabs && ws_bytes && n > 0, "bad eben_bl_conv1d_bwd_dw_multi arguments");
+  hipStream_t st = as_stream(stream);
+  // runs of consecutive problems with the same tile shape share a launch; anything else gets its own
+  int i = 0;
+  while (i < n) {
+    BlDwTable T;
+    T.n = 0; T.first[0] = 0;
+    BlDwPlan p0{};
+    size_t lds = 0;
+    while (i < n && T.n < BLDW_MULTI) {
+      BlDwArgs a;
+      BlDwPlan p;
+      const int rc = bldw_args(descs[i], dy_hi[i], x_hi[i], has_bias, slabs[i], ws_bytes[i], &a, &p);
+      if (rc) return rc;
+      if (T.n > 0 && (p.FM != p0.FM || p.FN != p0.FN)) break;
+      const long long nb = (long long)p.nnt * p.nmt * p.G * p.nsplit;
+      if (nb <= 0 || nb > 0x3fffffffLL - (long long)T.first[T.n]) return fail(EBEN_EINVAL, "bl bwd_dw_multi grid too large");
+      if (T.n == 0) p0 = p;
+      T.job[T.n] = a;
+      T.first[T.n + 1] = T.first[T.n] + (unsigned)nb;
+      if (p.lds_bytes > lds) lds = p.lds_bytes;
+      ++T.n; ++i;
+    }
+    int rc;
+    if (p0.FM == 2) rc = p0.FN == 4 ? launch_bldw_multi<2, 4>(T, lds, st) : p0.FN == 3 ? launch_bldw_multi<2, 3>(T, lds, st) : p0.FN == 2 ? launch_bldw_multi<2, 2>(T, lds, st) : launch_bldw_multi<2, 1>(T, lds, st);
+    else rc = p0.FN == 4 ? launch_bldw_multi<1, 4>(T, lds, st) : p0.FN == 3 ? launch_bldw_multi<1, 3>(T, lds, st) : p0.FN == 2 ? launch_bldw_multi<1, 2>(T, lds, st) : launch_bldw_multi<1, 1>(T, lds, st);
+    if (rc) return rc;
+  }
+  return EBEN_OK;
 }

@@ -520,6 +520,64 @@ __global__ __launch_bounds__(256) void overlap_add_folded_kernel(const float* __
   }
 }
 
+// The same sums from an LDS tile.  The kernel above gathers straight from the buffer with the lanes on consecutive samples, i.e. on
+// consecutive ROWS of it (a row = one window sample of every frame): 64 cache lines per load, ten loads per output -- 34-50 us for the
+// 20 MB of one resolution.  Here a block owns OLA_U consecutive samples of one item: the frames that reach them (+ the ones the reflected
+// ends fold in) are read once, row segment by row segment, unfolded into tile[frame][window sample] = dE[|m|] +- dO[|m|], and every output
+// sums its <= win / hop + 1 tile entries (lanes = consecutive samples = consecutive tile entries).  Same terms in the same order: bit-identical.
+constexpr int OLA_U = 512;
+__device__ __forceinline__ float ola_tile_gather(const float* __restrict__ tile, int q, int win, int frames, int hop, int pad, int f_lo) {
+  const int s = q + pad;  // = f*hop + j
+  if (s < 0) return 0.f;
+  int fmax = s / hop;
+  if (fmax > frames - 1) fmax = frames - 1;
+  const int fmin = s - win + 1 <= 0 ? 0 : (s - win + hop) / hop;
+  float acc = 0.f;
+  for (int f = fmin; f <= fmax; ++f) acc += tile[(f - f_lo) * win + (s - f * hop)];
+  return acc;
+}
+__global__ __launch_bounds__(256) void overlap_add_folded_t_kernel(const float* __restrict__ buf, float* __restrict__ x, int lx, int win,
+                                                                   int frames, int hop, int pad, int accumulate, long long row_stride,
+                                                                   long long j_stride, int fcap) {
+  extern __shared__ __attribute__((aligned(16))) float ola_tile[];   // fcap x win
+  const int b = blockIdx.y, u0 = blockIdx.x * OLA_U, tid = threadIdx.x;
+  const int h = win >> 1;
+  const int qlo = u0, qhi = (u0 + OLA_U < lx ? u0 + OLA_U : lx) - 1;
+  int f_lo = qlo <= pad ? 0 : (qlo + pad - win + hop) / hop;   // = ceil((qlo + pad - win + 1) / hop) for a positive numerator
+  if (f_lo < 0) f_lo = 0;
+  int smax = qhi + pad;
+  if (qhi >= lx - 1 - pad) {   // samples whose mirror image past the end folds back onto them
+    const int ulo = qlo > lx - 1 - pad ? qlo : lx - 1 - pad;
+    const int sm = 2 * (lx - 1) - ulo + pad;
+    if (sm > smax) smax = sm;
+  }
+  int f_hi = smax / hop;
+  if (f_hi > frames - 1) f_hi = frames - 1;
+  int nf = f_hi - f_lo + 1;
+  if (nf > fcap) nf = fcap;   // never (fcap is sized for the worst tile)
+  const float* bb = buf + (long long)b * row_stride;
+  // unfold: entry (frame fl, m) of the two row blocks -> window samples h + m and h - m of that frame
+  const int per = nf * h;
+  for (int i = tid; i < per; i += 256) {
+    const int m = i / nf, fl = i - m * nf;
+    const float e = bb[(long long)m * j_stride + f_lo + fl];
+    const float o = m ? bb[(long long)(h + m) * j_stride + f_lo + fl] : 0.f;
+    float* row = ola_tile + fl * win;
+    row[h + m] = e + o;
+    if (m) row[h - m] = e - o;
+    else row[0] = 0.f;   // window sample 0 carries no weight
+  }
+  __syncthreads();
+  for (int u = u0 + tid; u <= qhi; u += 256) {
+    float v = ola_tile_gather(ola_tile, u, win, frames, hop, pad, f_lo);
+    if (u >= 1 && u <= pad) v += ola_tile_gather(ola_tile, -u, win, frames, hop, pad, f_lo);
+    if (u <= lx - 2 && 2 * (lx - 1) - u <= lx - 1 + pad) v += ola_tile_gather(ola_tile, 2 * (lx - 1) - u, win, frames, hop, pad, f_lo);
+    const long long i = (long long)b * lx + u;
+    if (accumulate) v += x[i];
+    x[i] = v;
+  }
+}
+
 // buf element (item b, sample j of the window, frame f) sits at b*row_stride + j*j_stride + f
 __global__ __launch_bounds__(256) void overlap_add_kernel(const float* __restrict__ buf, float* __restrict__ x, int lx, int win,
                                                           int frames, int hop, int pad, int reflect, int accumulate,
@@ -629,6 +687,78 @@ extern "C" int eben_device_info(char* name, size_t name_bytes) {
   return prop.multiProcessorCount;
 }
 
+namespace eben {
+// Single-band stride-1 FIR and its adjoint: out[i] = sum_j w[j] in[i + off + SGN j], j ascending (zero outside the input) -- the A-weighting
+// prefilter of the MRSTFT loss (101 taps; auraloss FIRFilter "aw", multi_stft.yaml:15-18) forward (SGN = +1) and backward (SGN = -1).
+// The generic kernels above spend two LDS reads per multiply-add on it (27 / 54 us for 64 x 32000 samples).  Here a thread owns four
+// consecutive outputs and walks the taps four at a time over a window of eight inputs held in registers: one 16-byte LDS read (lanes
+// 16 bytes apart: conflict-free) per sixteen multiply-adds, the taps from the scalar cache.  Same products in the same order as the
+// generic kernels: bit-identical results.
+constexpr int FIR1_BLOCK = 1024;   // outputs per block
+template <int SGN>
+__global__ __launch_bounds__(256) void fir1_kernel(const float* __restrict__ in, const float* __restrict__ w, float* __restrict__ out,
+                                                   int lin, int lout, int ntaps, int off) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int b = blockIdx.y, i0 = blockIdx.x * FIR1_BLOCK, tid = threadIdx.x;
+  // xs[r + sh] = in[base + r]; sh aligns the windows of the SGN = -1 walk to 16 bytes
+  const int base = SGN > 0 ? i0 + off : i0 + off - (ntaps - 1);
+  const int sh = SGN > 0 ? 0 : (4 - ((ntaps - 1 - 3) & 3)) & 3;
+  const int span = FIR1_BLOCK + ntaps - 1;
+  const int total = ((span + sh + 3) & ~3) + 8;
+  const float* xr = in + (long long)b * lin;
+  for (int r = tid; r < total; r += 256) {
+    const int q = base + r - sh;
+    smem[r] = (r >= sh && r < span + sh && q >= 0 && q < lin) ? xr[q] : 0.f;
+  }
+  __syncthreads();
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  float v[8];
+  if (SGN > 0) {
+    const float* xp = smem + 4 * tid;
+    *reinterpret_cast<f32x4*>(v) = *reinterpret_cast<const f32x4*>(xp);
+    for (int j0 = 0; j0 < ntaps; j0 += 4) {
+      *reinterpret_cast<f32x4*>(v + 4) = *reinterpret_cast<const f32x4*>(xp + j0 + 4);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float wk = j0 + k < ntaps ? w[j0 + k] : 0.f;   // uniform: scalar loads
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = fmaf(wk, v[e + k], acc[e]);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = v[e + 4];
+    }
+  } else {
+    // input index of (output e, tap j) in xs: 4 tid + e + (ntaps - 1) - j + sh = w0 + (e - k + 3) with w0 = 4 tid + ntaps - 4 + sh - j0
+    const float* xp = smem + 4 * tid + (ntaps - 4 + sh);
+    *reinterpret_cast<f32x4*>(v + 4) = *reinterpret_cast<const f32x4*>(xp + 4);
+    for (int j0 = 0; j0 < ntaps; j0 += 4) {
+      *reinterpret_cast<f32x4*>(v) = *reinterpret_cast<const f32x4*>(xp - j0);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float wk = j0 + k < ntaps ? w[j0 + k] : 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = fmaf(wk, v[e - k + 3], acc[e]);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e + 4] = v[e];
+    }
+  }
+  const int i = i0 + 4 * tid;
+  float* o = out + (long long)b * lout + i;
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    if (i + e < lout) o[e] = acc[e];
+}
+static const bool fir1_enabled = !(getenv("EBEN_FIR1") && atoi(getenv("EBEN_FIR1")) == 0);
+template <int SGN>
+static int fir1_launch(const float* in, const float* w, float* out, int batch, int lin, int lout, int ntaps, int off, hipStream_t st) {
+  const size_t lds = sizeof(float) * (size_t)(FIR1_BLOCK + ntaps + 16);
+  hipLaunchKernelGGL(fir1_kernel<SGN>, dim3(ceil_div(lout, FIR1_BLOCK), batch), dim3(256), lds, st, in, w, out, lin, lout, ntaps, off);
+  EBEN_CHECK_LAUNCH("fir1_kernel");
+  return EBEN_OK;
+}
+}  // namespace eben
+
 extern "C" int eben_fir_decimate(const float* x, const float* w, float* y, int batch, int lx, int ly, int bands, int ntaps,
                                  int stride, int off0, void* stream) {
   EBEN_REQUIRE(x && w && y && batch > 0 && lx > 0 && ly > 0 && bands > 0 && ntaps > 0 && stride > 0, "bad fir_decimate arguments");
@@ -642,6 +772,7 @@ extern "C" int eben_fir_decimate(const float* x, const float* w, float* y, int b
     EBEN_CHECK_LAUNCH("pqmf_analysis_kernel");
     return EBEN_OK;
   }
+  if (fir1_enabled && stride == 1 && bands == 1 && ntaps >= 4) return fir1_launch<1>(x, w, y, batch, lx, ly, ntaps, off0, as_stream(stream));
   const size_t lds = sizeof(float) * (FIR_MAX_W + (size_t)255 * stride + ntaps);
   EBEN_REQUIRE(lds <= 64 * 1024, "fir_decimate stride %d too large", stride);
   hipLaunchKernelGGL(fir_decimate_kernel, dim3(ceil_div(ly, 256), batch), dim3(256), lds, as_stream(stream), x, w, y, lx, ly,
@@ -666,6 +797,7 @@ extern "C" int eben_fir_interp_sum(const float* y, const float* w, float* x, int
     EBEN_CHECK_LAUNCH("pqmf_synthesis_kernel");
     return EBEN_OK;
   }
+  if (fir1_enabled && stride == 1 && bands == 1 && ntaps >= 4) return fir1_launch<-1>(y, w, x, batch, ly, lx, ntaps, -off0, as_stream(stream));
   const int tile_t = (255 + ntaps - 1) / stride + 3;
   const size_t lds = sizeof(float) * (FIR_MAX_W + (size_t)bands * tile_t);
   EBEN_REQUIRE(lds <= 64 * 1024, "fir_interp_sum tile too large");
@@ -1219,6 +1351,15 @@ extern "C" int eben_overlap_add_folded(const float* frames_buf, float* x, int ba
                                        int accumulate, long long row_stride, long long j_stride, void* stream) {
   EBEN_REQUIRE(frames_buf && x && batch > 0 && lx > 0 && win > 0 && (win & 1) == 0 && frames > 0 && hop > 0 && pad >= 0 && pad < lx,
                "bad overlap_add_folded arguments");
+  static const bool tiled = !(getenv("EBEN_OLA_TILED") && atoi(getenv("EBEN_OLA_TILED")) == 0);
+  const int fcap = OLA_U / hop + win / hop + pad / hop + 4;
+  const size_t lds = sizeof(float) * (size_t)fcap * win;
+  if (tiled && lds <= 64 * 1024 && pad < win && lx > 2 * pad) {
+    hipLaunchKernelGGL(overlap_add_folded_t_kernel, dim3(ceil_div(lx, OLA_U), batch), dim3(256), lds, as_stream(stream), frames_buf, x, lx, win,
+                       frames, hop, pad, accumulate, row_stride, j_stride, fcap);
+    EBEN_CHECK_LAUNCH("overlap_add_folded_t_kernel");
+    return EBEN_OK;
+  }
   hipLaunchKernelGGL(overlap_add_folded_kernel, dim3(grid_for((size_t)lx, 256), batch), dim3(256), 0, as_stream(stream), frames_buf, x,
                      lx, win, frames, hop, pad, accumulate, row_stride, j_stride);
   EBEN_CHECK_LAUNCH("overlap_add_folded_kernel");
@@ -1280,11 +1421,55 @@ __global__ __launch_bounds__(256) void stft_frames_folded_kernel(const float* __
     }
   }
 }
+// The same rows through an LDS transpose (split = 0): the kernel above reads the signal with the lanes on consecutive FRAMES, i.e. hop
+// samples apart -- 64 cache lines per load instruction, 30-44 us for the 40 MB of one resolution.  Here a block owns (item, 64 frames, 64
+// values of m): its loads run along m (consecutive samples: s[.. + m] ascending, s[.. - m] descending), the sums go through a 64 x 65 tile,
+// its stores run along the frames (256 contiguous bytes per row).  Same sums of the same samples: bit-identical.
+__global__ __launch_bounds__(256) void stft_frames_folded_t_kernel(const float* __restrict__ sig, float* __restrict__ out, int rows, int t,
+                                                                   int win, int hop, int pad, int frames) {
+  __shared__ float te[64][65], to[64][65];
+  const int h = win >> 1;
+  const int f0 = blockIdx.x * 64, m0 = blockIdx.y * 64, r = blockIdx.z;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long cols = (long long)rows * frames;
+  const float* s = sig + (long long)r * t;
+  const int m = m0 + lane;
+  for (int fl = wave; fl < 64; fl += 4) {
+    const int f = f0 + fl;
+    float e = 0.f, o = 0.f;
+    if (f < frames && m < h) {
+      int q1 = f * hop + h + m - pad, q2 = f * hop + h - m - pad;
+      q1 = q1 < 0 ? -q1 : q1; q1 = q1 >= t ? 2 * (t - 1) - q1 : q1;
+      q2 = q2 < 0 ? -q2 : q2; q2 = q2 >= t ? 2 * (t - 1) - q2 : q2;
+      const float a = s[q1], b = s[q2];
+      e = m ? a + b : a;
+      o = m ? a - b : 0.f;
+    }
+    te[lane][fl] = e;
+    to[lane][fl] = o;
+  }
+  __syncthreads();
+  const int f = f0 + lane;
+  if (f >= frames) return;
+  float* oe = out + (long long)r * frames + f;
+  float* oo = oe + (long long)h * cols;
+  for (int ml = wave; ml < 64 && m0 + ml < h; ml += 4) {
+    oe[(long long)(m0 + ml) * cols] = te[ml][lane];
+    oo[(long long)(m0 + ml) * cols] = to[ml][lane];
+  }
+}
 extern "C" int eben_stft_frames_folded(const float* sig, float* out, int rows, int t, int win, int hop, int pad, int frames, int split,
                                        void* stream) {
   EBEN_REQUIRE(sig && out && rows > 0 && t > 1 && win > 1 && (win & 1) == 0 && hop > 0 && pad >= 0 && pad < t && frames > 0,
                "bad stft_frames_folded arguments");
   EBEN_REQUIRE((frames - 1) * hop + win - 1 - pad <= 2 * (t - 1), "stft_frames_folded: frames reach past the reflected signal");
+  static const bool transposed = !(getenv("EBEN_STFT_FRAMES_T") && atoi(getenv("EBEN_STFT_FRAMES_T")) == 0);
+  if (!split && transposed && rows <= 65535 && ceil_div(win / 2, 64) <= 65535) {
+    hipLaunchKernelGGL(stft_frames_folded_t_kernel, dim3(ceil_div(frames, 64), ceil_div(win / 2, 64), rows), dim3(256), 0, as_stream(stream), sig,
+                       out, rows, t, win, hop, pad, frames);
+    EBEN_CHECK_LAUNCH("stft_frames_folded_t_kernel");
+    return EBEN_OK;
+  }
   hipLaunchKernelGGL(stft_frames_folded_kernel, dim3(grid_for((size_t)rows * frames, 64), win / 2), dim3(256), 0, as_stream(stream), sig,
                      out, rows, t, win, hop, pad, frames, split);
   EBEN_CHECK_LAUNCH("stft_frames_folded_kernel");

@@ -185,7 +185,11 @@ static PwPlan pw_plan(int math, int G, int M, int K) {
   if (!p.NP || G <= 0 || M <= 0 || K <= 0) return p;
   // 64-row tiles: two blocks per CU by registers with three pieces per operand, and the least padding of M = 257 / 513 / 1025 (or 120 / 300 / 600)
   static const int force = getenv("EBEN_PWGEMM_FM") ? atoi(getenv("EBEN_PWGEMM_FM")) : 0;
-  p.FM = force >= 1 && force <= 2 ? force : (M <= 32 ? 1 : 2);
+  p.FM = force >= 1 && force <= 4 ? force : (M <= 32 ? 1 : 2);
+  // hi + lo operands: 96-row tiles where they pad M no more than 64-row ones (+6 %) -- every row tile's block loads and splits the x columns
+  // again, so fewer, taller tiles do less of that ([MI355X] forward M = 257 / 513 / 1025: 45 / 66 / 102 -> 38 / 58 / 91 us; the transposes
+  // M = 120 / 300 keep 64 rows: 23 / 36 us against 27 / 42)
+  if (!force && p.NP == 2 && M > 64 && ceil_div(M, 96) * 3 * 100 <= ceil_div(M, 64) * 2 * 106) p.FM = 3;
   p.nmt = ceil_div(M, 32 * p.FM);
   p.nch = ceil_div(ceil_div(K, 16), PG_KSC);
   p.units = (long long)G * p.nmt * p.nch * PG_KSC * p.NP * p.FM * 64;
@@ -235,5 +239,8 @@ extern "C" int eben_gemm_fwd(int math, int groups, int m, int k, long long n, co
   if (p.FM == 1) {
     switch (p.NP) { case 1: return pw_launch<1, 1>(a, nb, st); case 2: return pw_launch<1, 2>(a, nb, st); default: return pw_launch<1, 3>(a, nb, st); }
   }
+  if (p.FM == 3 && p.NP == 2) return pw_launch<3, 2>(a, nb, st);
+  if (p.FM == 4 && p.NP == 2) return pw_launch<4, 2>(a, nb, st);
+  if (p.FM > 2) return fail(EBEN_EUNSUPPORTED, "gemm_fwd: 96 / 128-row tiles are built for hi + lo operands only");
   switch (p.NP) { case 1: return pw_launch<2, 1>(a, nb, st); case 2: return pw_launch<2, 2>(a, nb, st); default: return pw_launch<2, 3>(a, nb, st); }
 }

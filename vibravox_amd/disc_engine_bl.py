@@ -276,6 +276,74 @@ class _ChainBL:
         return grads
 
     @staticmethod
+    def weight_grads_group(chains, jobs_list, x_fulls, g0s, half: int, sink=None):
+        """``weight_grads`` of several chains of ONE structure (the three PQMF-band discriminators: same channels and taps per layer, their
+        own dilation and lengths) in one launch sequence: the mid layers of one index as ONE ``eben_bl_conv1d_bwd_dw_multi`` launch (a
+        thin layer's weight gradient is mostly fixed cost: [MI355X] 64 rows 37-40 us, 192 rows 66-87 us), one slab reduction / weight-norm
+        pass for all of them.  Same slabs, same results as chain by chain.  Returns the chains' gradient lists."""
+        lib = load()
+        st = _stream()
+        n = len(chains[0].layers)
+        assert all(len(ch.layers) == n for ch in chains)
+        grads = [[None] * n for _ in chains]
+        wn_jobs, logits, by_layer = [], [], {}
+        for ci, (ch, jobs) in enumerate(zip(chains, jobs_list)):
+            for i, g, x_in in jobs:
+                if i == n - 1:
+                    gf, gr = ch._tail_dw(ch.layers[i], g, x_in, half, st, wn_jobs)
+                    logits.append((ci, i, gf, gr))
+                else:
+                    by_layer.setdefault(i, []).append((ci, g, x_in))
+        for i in sorted(by_layer, reverse=True):
+            items = by_layer[i]
+            outs = _ChainBL._mid_dw_multi([(chains[ci].layers[i], g, x_in) for ci, g, x_in in items], half, st, wn_jobs, sink)
+            for (ci, _, _), o in zip(items, outs):
+                grads[ci][i] = o
+        for ci, ch in enumerate(chains):
+            if g0s[ci] is not None:
+                grads[ci][0] = ch._head_dw(g0s[ci], x_fulls[ci], half, st, wn_jobs, sink)
+        ops.wn_bwd_multi(wn_jobs)
+        for ci, i, gf, gr in logits:
+            outs = [None if sink is None or p is None else sink.grad_buffer(p) for p in chains[ci].layers[i].params()]
+            grads[ci][i] = tuple(None if a is None else (a + b if o is None else torch.add(a, b, out=o)) for a, b, o in zip(gf, gr, outs))
+        return grads
+
+    @staticmethod
+    def _mid_dw_multi(items, half: int, st: int, wn_jobs: list, sink=None):
+        """items: (layer, gradient planes rows [fake | real], input planes) of the SAME layer index of several chains."""
+        lib = load()
+        k = len(items)
+        descs = (ctypes.POINTER(ops.EbenConv1dDesc) * k)()
+        dys, xs, slabs_p = (ctypes.c_void_p * k)(), (ctypes.c_void_p * k)(), (ctypes.c_void_p * k)()
+        nbs = (ctypes.c_size_t * k)()
+        keep, outs = [], []
+        has_bias = None
+        for j, (lay, g, x_in) in enumerate(items):
+            v, gain, bias = lay.params()
+            hb = 1 if bias is not None else 0
+            assert has_bias in (None, hb)
+            has_bias = hb
+            d = ops.conv_desc(lay.spec_lin, 2 * half, x_in.length, lay.math_dw)
+            ws = getattr(d, "_bl_dw_ws", None)
+            if ws is None:
+                nslab, row_stride, perm = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+                nbytes = lib.eben_bl_conv1d_bwd_dw_workspace(ctypes.byref(d), ctypes.byref(nslab), ctypes.byref(row_stride), ctypes.byref(perm))
+                if nbytes == 0:
+                    raise ops._lib.EbenError(f"bundle-layout weight gradient does not cover {lay.spec}")
+                ws = d._bl_dw_ws = (nbytes, nslab.value, row_stride.value, perm.value)
+            nbytes, nslab, row_stride, perm = ws
+            slabs = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=g.hi.device)
+            descs[j] = ctypes.pointer(d)
+            dys[j], xs[j], slabs_p[j], nbs[j] = _addr(g.hi), _addr(x_in.hi), slabs.data_ptr(), nbytes
+            keep.append((d, slabs))
+            dv, dg, dbias = _ChainBL._outputs(lay, sink, g.hi.device)
+            rows = v.shape[0]
+            wn_jobs.append((slabs, nslab, rows * row_stride, rows, v.numel() // rows, row_stride, gain.detach(), v.detach(), lay.norm, dg, dv, dbias, perm))
+            outs.append((dv, dg, dbias))
+        check(lib.eben_bl_conv1d_bwd_dw_multi(descs, dys, xs, has_bias, slabs_p, nbs, k, st), "bl_conv1d_bwd_dw_multi")
+        return outs
+
+    @staticmethod
     def _outputs(lay: _Layer, sink, device):
         v, gain, bias = lay.params()
         dv = dg = dbias = None
@@ -654,6 +722,29 @@ class DiscriminatorEngineBL(DiscriminatorEngine):
             sink.mark_ready([p for lay in self.chains[i].layers for p in lay.params() if p is not None and p.requires_grad])
         return out
 
+    #: weight gradients of the three PQMF-band chains as one launch sequence (``_ChainBL.weight_grads_group``); 0: chain by chain
+    group_weight_grads: bool = __import__("os").environ.get("EBEN_DW_GROUP", "0") != "0"
+
+    def _launch_weight_grads_group(self, s, group, keep, half):
+        """``_launch_weight_grads`` for the chains ``group`` (one stream, one structure) as ONE replayed sequence."""
+        sink = self._sink
+        chains = [self.chains[i] for i in group]
+        params = [p for ch in chains for lay in ch.layers for p in lay.params() if p is not None]
+        sink_sig = None if sink is None else tuple(0 if (b := sink.grad_buffer(p)) is None else b.data_ptr() for p in params)
+        jobs_sig = tuple(tuple((k, (g.hi.data_ptr() if isinstance(g, Planes) else g.data_ptr()), x.hi.data_ptr(), x.lo.data_ptr()) for k, g, x in keep[i][1])
+                         for i in group)
+        sig = (half, tuple(s["inputs"][i].data_ptr() for i in group), tuple(keep[i][2].hi.data_ptr() for i in group), jobs_sig,
+               tuple(self._chain_sig(ch, -1) for ch in chains), sink_sig)
+        body = lambda: _ChainBL.weight_grads_group(chains, [keep[i][1] for i in group], [s["inputs"][i] for i in group], [keep[i][2] for i in group],
+                                                   half, sink)
+        held = sink is None and any(p.grad is not None for p in params)
+        if "dw_group" not in self._graphs:
+            self._graphs["dw_group"] = [ops.ReplayedChain()]
+        out = body() if held else self._graphs["dw_group"][0].run(sig, body, torch.cuda.current_stream())
+        if sink is not None:
+            sink.mark_ready([p for p in params if p.requires_grad])
+        return out
+
     @torch.no_grad()
     def backward_launch(self, want_param_grads: bool = True, sink=None):
         self._sink = sink
@@ -701,12 +792,19 @@ class DiscriminatorEngineBL(DiscriminatorEngine):
                 g, jobs, g0 = self.chains[i].backward_body(s["acts"][i], seeds[2 * half:], half, True, sums_ptr + 8 * s["fm_first"][i], s["fm_inv"], "disc")
                 return g, jobs, g0
 
+            group = list(range(n - 1)) if (self.group_weight_grads and n >= 3 and len({self._second_pass_stream(i, res[i][4]) for i in range(n - 1)}) == 1) else []
             for i in [n - 1] + list(range(n - 1)):
                 with torch.cuda.stream(self._second_pass_stream(i, res[i][4])):
                     sig = sig_of(i, "disc") + (res[i][3].data_ptr(),)
                     out = self._graphs["bwd_d"][i].run(sig, lambda i=i: body_d(i), torch.cuda.current_stream())
                     keep[i] = out
-                    pend[i] = self._launch_weight_grads(s, i, out[1], out[2], half)
+                    if i not in group:
+                        pend[i] = self._launch_weight_grads(s, i, out[1], out[2], half)
+            if group:
+                # the PQMF-band chains share a stream and a structure: their weight gradients layer index by layer index
+                with torch.cuda.stream(self._second_pass_stream(group[0], res[group[0]][4])):
+                    for i, grads in zip(group, self._launch_weight_grads_group(s, group, keep, half)):
+                        pend[i] = grads
             self._pending = (pend, s, res, keep)   # keeps the saved activations and the stacked gradients alive until the kernels have run
         self._bwd = (res, want_param_grads, (one,))
 
