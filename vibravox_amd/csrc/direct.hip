@@ -557,15 +557,31 @@ __global__ __launch_bounds__(256) void overlap_add_folded_t_kernel(const float* 
   if (nf > fcap) nf = fcap;   // never (fcap is sized for the worst tile)
   const float* bb = buf + (long long)b * row_stride;
   // unfold: entry (frame fl, m) of the two row blocks -> window samples h + m and h - m of that frame
-  const int per = nf * h;
-  for (int i = tid; i < per; i += 256) {
-    const int m = i / nf, fl = i - m * nf;
-    const float e = bb[(long long)m * j_stride + f_lo + fl];
-    const float o = m ? bb[(long long)(h + m) * j_stride + f_lo + fl] : 0.f;
+  // thread = (frame fl = tid % nfp, rows m = tid / nfp, + 256 / nfp, ...), nfp = the power of two >= nf: no division, the loads of four
+  // rows in flight together
+  int nfp = 1;
+  while (nfp < nf) nfp <<= 1;
+  const int fl = tid & (nfp - 1), mstep = 256 / nfp;
+  if (fl < nf) {
+    const float* col = bb + f_lo + fl;
     float* row = ola_tile + fl * win;
-    row[h + m] = e + o;
-    if (m) row[h - m] = e - o;
-    else row[0] = 0.f;   // window sample 0 carries no weight
+    for (int m0 = tid / nfp; m0 < h; m0 += 4 * mstep) {
+      float e[4], o[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int m = m0 + k * mstep;
+        const int mc = m < h ? m : 0;
+        e[k] = col[(long long)mc * j_stride];
+        o[k] = col[(long long)(h + mc) * j_stride];
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int m = m0 + k * mstep;
+        if (m >= h) continue;
+        if (m) { row[h + m] = e[k] + o[k]; row[h - m] = e[k] - o[k]; }
+        else { row[h] = e[k] + 0.f; row[0] = 0.f; }   // the centre sample has no odd part; window sample 0 carries no weight
+      }
+    }
   }
   __syncthreads();
   for (int u = u0 + tid; u <= qhi; u += 256) {
@@ -1434,19 +1450,22 @@ __global__ __launch_bounds__(256) void stft_frames_folded_t_kernel(const float* 
   const long long cols = (long long)rows * frames;
   const float* s = sig + (long long)r * t;
   const int m = m0 + lane;
-  for (int fl = wave; fl < 64; fl += 4) {
-    const int f = f0 + fl;
-    float e = 0.f, o = 0.f;
-    if (f < frames && m < h) {
-      int q1 = f * hop + h + m - pad, q2 = f * hop + h - m - pad;
-      q1 = q1 < 0 ? -q1 : q1; q1 = q1 >= t ? 2 * (t - 1) - q1 : q1;
-      q2 = q2 < 0 ? -q2 : q2; q2 = q2 >= t ? 2 * (t - 1) - q2 : q2;
-      const float a = s[q1], b = s[q2];
-      e = m ? a + b : a;
-      o = m ? a - b : 0.f;
-    }
-    te[lane][fl] = e;
-    to[lane][fl] = o;
+  float av[16], bv[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {   // the 32 loads of this thread first: all in flight together
+    const int f = f0 + wave + 4 * k;
+    const bool ok = f < frames && m < h;
+    int q1 = f * hop + h + m - pad, q2 = f * hop + h - m - pad;
+    q1 = q1 < 0 ? -q1 : q1; q1 = q1 >= t ? 2 * (t - 1) - q1 : q1;
+    q2 = q2 < 0 ? -q2 : q2; q2 = q2 >= t ? 2 * (t - 1) - q2 : q2;
+    av[k] = ok ? s[q1] : 0.f;
+    bv[k] = ok ? s[q2] : 0.f;
+  }
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int fl = wave + 4 * k;
+    te[lane][fl] = m ? av[k] + bv[k] : av[k];
+    to[lane][fl] = m ? av[k] - bv[k] : 0.f;
   }
   __syncthreads();
   const int f = f0 + lane;
