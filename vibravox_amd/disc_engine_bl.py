@@ -31,11 +31,14 @@ from ._lib import stream as _stream
 from .disc_engine import DiscriminatorEngine, _Layer
 
 BL = 0x100   # EBEN_LAYOUT_BL
-#: split forward (forward_reference): also run MelGAN's reference half underneath the generator forward (0: MelGAN whole, behind it -- the
-#: default of rounds 4-5, when its heavy layers lost more as two 32-row launches than the overlap gave back; with the two-pass backward
-#: [MI355X, same box, 3 x alternated, 100 steps] 9.03 / 9.08 / 8.99 -> 8.96 / 9.03 / 8.94 ms per step, and 8.90 / 8.92 / 8.88 together
-#: with EBEN_D_BWD_SPREAD=0)
-SPLIT_MELGAN = __import__("os").environ.get("EBEN_SPLIT_MELGAN", "1") != "0"
+#: split forward (forward_reference): how much of MelGAN's reference half runs underneath the generator forward.  "0": none (MelGAN whole,
+#: behind the generator: rounds 4-5); "1": all of it ([MI355X, same box, 3 x alternated, 100 steps] 9.03 / 9.08 / 8.99 -> 8.96 / 9.03 /
+#: 8.94 ms per step, 8.90 / 8.92 / 8.88 together with EBEN_D_BWD_SPREAD=0 -- but layers 3-5 then run as two 32-row launches at 0.26 of
+#: the MFMA peak instead of one at 0.47); "thin" (default): its head and thin layers only
+SPLIT_MELGAN = __import__("os").environ.get("EBEN_SPLIT_MELGAN", "thin")
+#: "thin": MelGAN's head and layers 1 .. MELGAN_SPLIT_DEPTH - 1 (the HBM-bound ones) run per half like the PQMF-band chains; the MFMA-bound
+#: layers behind them keep ONE 2B-row launch (the persistent tile kernel fills the machine exactly once at 64 rows)
+MELGAN_SPLIT_DEPTH = int(__import__("os").environ.get("EBEN_SPLIT_MELGAN_DEPTH", "3"))
 #: the four stacked seed blocks of a chain's backward from one launch (eben_hinge_bwd_stacked); 0: a memset + three launches
 STACKED_SEEDS = __import__("os").environ.get("EBEN_STACKED_SEEDS", "1") != "0"
 #: the feature-matching rows of the stacked input gradients read a one-byte code plane of each embedding (signs of a - r and of a, written by
@@ -165,15 +168,17 @@ class _ChainBL:
         sp = self.layers[-1].spec
         return shapes, cur + sp.pad_l + sp.pad_r - (sp.ksize - 1)
 
-    def forward_body(self, act0: Planes, outs: Optional[List[Planes]] = None, logits_out: Optional[torch.Tensor] = None):
+    def forward_body(self, act0: Planes, outs: Optional[List[Planes]] = None, logits_out: Optional[torch.Tensor] = None, start: int = 1,
+                     stop: Optional[int] = None):
         """The layers behind the head on the rows of ``act0``; ``outs`` / ``logits_out``: write into these (row views of the full batch's
-        planes: the two halves of the batch run as two launches sequences) instead of allocating."""
+        planes: the two halves of the batch run as two launches sequences) instead of allocating.  ``start`` / ``stop``: layers
+        [start, stop) only (``outs`` required; layer ``start`` reads ``outs[start - 2]``; the logits layer runs when stop is None)."""
         lib = load()
         acts = [act0]
         rows = act0.rows
-        cur = act0
+        cur = act0 if start == 1 else outs[start - 2]
         n = len(self.layers)
-        for i in range(1, n - 1):
+        for i in range(start, n - 1 if stop is None else stop):
             lay = self.layers[i]
             d = ops.conv_desc(lay.spec, rows, cur.length, lay.math_fwd)
             y = outs[i - 1] if outs is not None else Planes(rows, lay.spec.c_out, d.l_out, act0.hi.device)
@@ -188,6 +193,8 @@ class _ChainBL:
                 tm.stop(e0, rows)
             acts.append(y)
             cur = y
+        if stop is not None:
+            return acts, None
         tail = self.layers[-1]
         sp = tail.spec
         v, _, bias = tail.params()
@@ -520,7 +527,10 @@ class DiscriminatorEngineBL(DiscriminatorEngine):
         # MelGAN (the last chain) keeps ONE 2B-row launch per layer, behind the generator: its heavy layers fill the machine exactly once at
         # 64 rows (512 blocks = two per CU) and lose a third of their rate as two 32-row launches ([MI355X] L4 forward alone 0.35 -> 0.29 of
         # the bf16 peak); the thin PQMF-band chains are what gains from running beside the generator forward
-        whole_last = not SPLIT_MELGAN
+        whole_last = SPLIT_MELGAN == "0"
+        depth = MELGAN_SPLIT_DEPTH if SPLIT_MELGAN == "thin" else None   # layers [1, depth) of the last chain per half, the rest on 2B rows
+        if depth is not None and not (1 < depth < len(self.chains[n - 1].layers) - 1):
+            depth = None
 
         def rng(i):
             if whole_last and i == n - 1:
@@ -530,7 +540,12 @@ class DiscriminatorEngineBL(DiscriminatorEngine):
         def body(i):
             q0, q1 = rng(i)
             a0 = act0[i].rows_slice(q0, q1)
-            self.chains[i].forward_body(a0, [p.rows_slice(q0, q1) for p in planes[i]], logits[i][q0:q1])
+            if i == n - 1 and depth is not None:
+                self.chains[i].forward_body(a0, [p.rows_slice(q0, q1) for p in planes[i]], None, stop=depth)
+                if fm:   # both halves of layer depth - 1 are there: the heavy layers once, on all 2B rows
+                    self.chains[i].forward_body(act0[i], planes[i], logits[i], start=depth)
+            else:
+                self.chains[i].forward_body(a0, [p.rows_slice(q0, q1) for p in planes[i]], logits[i][q0:q1])
             if fm:
                 _fm_sums(lib, [act0[i]] + planes[i], half, fm_sums[2 * fm_first[i]:])
             return True
