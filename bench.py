@@ -71,6 +71,25 @@ def profile_average(fragment):
     return None
 
 
+def named_launch(name):
+    """In-step duration of ONE named launch from the latest committed kernel trace with dispatch order (tools/step_trace.py under
+    rocprofv3 --kernel-trace, tools/step_trace_report.py --named -> profiles/rNN_instep_layers.json): that launch, not the average over every
+    launch of its template instantiation."""
+    path = next((q for q in (os.path.join(ROOT, "profiles", f"r{n:02d}_instep_layers.json") for n in range(9, 5, -1)) if os.path.exists(q)), None)
+    if path is None:
+        return None
+    try:
+        with open(path) as f:
+            rec = json.load(f)
+        r = rec.get(name)
+        if not r:
+            return None
+        return {"file": os.path.relpath(path, ROOT), "launch": name, "launches": r["launches"], "avg_ms": round(r["avg_us"] / 1e3, 4),
+                "min_ms": round(r["min_us"] / 1e3, 4), "note": rec.get("_note")}
+    except Exception:
+        return None
+
+
 def pmc_family(math):
     """Roofline records with HBM traffic from this round's rocprofv3 PMC passes (tools/pmc_family_bl.sh -> profiles/rNN_pmc_family.json, the latest round's:
     FETCH_SIZE / WRITE_SIZE / TCC hit + miss in separate passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950): the
@@ -460,15 +479,24 @@ def main():
         roof["traffic_source"] = next((r.get("source") for r in family if r["name"] == "melgan_l4_fwd"), None)
         roof["launch_ms_note"] = ("HIP events around the launch on its stream, over a second run of the timed steps with the chains launched kernel by "
                                   "kernel (events cannot sit between the nodes of a replayed graph); `isolated` = the same launch alone; "
-                                  "`profile` = rocprofv3 --kernel-trace average of the graph-replayed step from the committed file")
-        prof = profile_average("tap4_kernel<2, 2, 4, 2, 1" if args.disc_math == "bf16_bl" else "tap3_kernel<4")
+                                  "`profile` = THAT launch's duration inside the graph-replayed step, from the committed rocprofv3 --kernel-trace with "
+                                  "dispatch order (named by its position on MelGAN's queue; the tracer stretches the step)")
+        prof = (named_launch("melgan_l4_fwd") if args.disc_math == "bf16_bl" else None) or profile_average("tap4_kernel<2, 2, 4, 2, 1" if args.disc_math == "bf16_bl" else "tap3_kernel<4")
         if prof:
             roof["profile"] = prof
+            if prof.get("launch") and prof.get("avg_ms"):
+                roof["profile"]["achieved"] = round(flops / (prof["avg_ms"] * 1e-3) / 1e12, 2)
+                roof["profile"]["frac"] = round(flops / (prof["avg_ms"] * 1e-3) / 1e12 / peak, 4)
         if iso_ms:
             roof["isolated"] = {"launch_ms": round(iso_ms, 4), "achieved": round(flops / (iso_ms * 1e-3) / 1e12, 2),
                                 "frac": round(flops / (iso_ms * 1e-3) / 1e12 / peak, 4),
                                 "note": "same launch alone on the device, 20 back-to-back launches after the timed region"}
-        roof_t, _ = launch_record(timer_t, "input gradient, rows [fm | adv | fake | real]", kn)
+        roof_t, flops_t = launch_record(timer_t, "input gradient (two 2B-row passes per step: rows [fm | adv], then rows [fake | real])", kn)
+        prof_t = named_launch("melgan_l3_dx") if args.disc_math == "bf16_bl" else None
+        if prof_t and prof_t.get("avg_ms"):
+            prof_t["achieved"] = round(flops_t / (prof_t["avg_ms"] * 1e-3) / 1e12, 2)
+            prof_t["frac"] = round(flops_t / (prof_t["avg_ms"] * 1e-3) / 1e12 / peak, 4)
+            roof_t["profile"] = prof_t
         ideal = step_roofline_ms("f32" if not bf16 else "bf16", scale)
         line = {
             "metric": "EBEN train-step audio-seconds/sec (gen+disc)", "value": round(value, 2), "unit": "audio-seconds/sec",

@@ -116,11 +116,13 @@ def main():
             wp = lay.packed(0, r2, cur.length)
             t_f = time_ms(lambda: check(lib.eben_bl_conv1d_fwd(ctypes.byref(d), xin.hi.data_ptr(), xin.lo.data_ptr() if split else None, ptr(wp), ptr(bias),
                                                                y.hi.data_ptr(), y.lo.data_ptr(), st)), a.iters)
-            d4 = ops.conv_desc(lay.spec_lin, r4, cur.length, lay.math_dx)
+            # the stacked input gradients as the engine launches them since round 6: two passes of 2B rows (rows [fm | adv] with the
+            # feature-matching term, then rows [fake | real]); the column is their sum (rounds 1-5: one 4B-row launch)
+            d4 = ops.conv_desc(lay.spec_lin, r2, cur.length, lay.math_dx)
             g = Planes.from_f32(torch.randn(r4, sp.c_out, d.l_out, device=dev), lo=False)
             gp = Planes(r4, sp.c_in, cur.length, dev, lo=False)
-            pr = lay.pr_desc(r4, cur.length) is not None   # strided MelGAN layers: the phases-as-rows form (as the engine launches it)
-            wpb = lay.packed(2 if pr else 1, r4, cur.length)
+            pr = lay.pr_desc(r2, cur.length) is not None   # strided MelGAN layers: the phases-as-rows form (as the engine launches it)
+            wpb = lay.packed(2 if pr else 1, r2, cur.length)
             dx_fn = lib.eben_bl_conv1d_bwd_dx_pr if pr else lib.eben_bl_conv1d_bwd_dx
             fm_rows = 0 if a.no_fm_rows else half
             # as the engine launches it: the feature-matching code plane of the embedding (written by its sums pass) instead of three operand planes
@@ -129,8 +131,14 @@ def main():
                 _fm_sums(lib, [xin], half, torch.empty(2, device=dev))
                 codes = xin.codes.data_ptr()
             dx_fn = lib.eben_bl_conv1d_bwd_dx_pr_c if pr else lib.eben_bl_conv1d_bwd_dx_c
-            t_b = time_ms(lambda: check(dx_fn(ctypes.byref(d4), g.hi.data_ptr(), ptr(wpb), xin.hi.data_ptr(), xin.lo.data_ptr(), codes, 0.2, half, seg_map,
-                                              fm_rows, half, ptr(sums), 0.1, gp.hi.data_ptr(), None, st)), a.iters)
+            seg_gen, seg_disc = (ctypes.c_int * 2)(0, 0), (ctypes.c_int * 2)(0, 1)
+
+            def two_passes():
+                check(dx_fn(ctypes.byref(d4), g.hi.data_ptr(), ptr(wpb), xin.hi.data_ptr(), xin.lo.data_ptr(), codes, 0.2, half, seg_gen,
+                            fm_rows, half, ptr(sums), 0.1, gp.hi.data_ptr(), None, st))
+                check(dx_fn(ctypes.byref(d4), g.hi[r2:].data_ptr(), ptr(wpb), xin.hi.data_ptr(), xin.lo.data_ptr(), None, 0.2, half, seg_disc,
+                            0, half, ptr(sums), 0.1, gp.hi[r2:].data_ptr(), None, st))
+            t_b = time_ms(two_passes, a.iters)
             t_w = time_ms(lambda: ch.weight_grads([(i, g.rows_slice(r2, r4), xin)], x_in, None, half), a.iters)
             wshape = sp.weight_shape()
             wel = wshape[0] * wshape[1] * wshape[2]
@@ -159,8 +167,14 @@ def main():
         gt = Planes(r4, cur.channels, cur.length, dev, lo=False)
         t_f = time_ms(lambda: check(lib.eben_bl_tail_fwd(xin.hi.data_ptr(), xin.lo.data_ptr(), r2, cur.channels, cur.length, sp.ksize, sp.pad_l, ptr(v.detach()),
                                                          ptr(tail.scale), ptr(bias.detach()), 1.0, ptr(logits), st)), a.iters)
-        t_b = time_ms(lambda: check(lib.eben_bl_tail_dx(ptr(seeds), r4, cur.channels, cur.length, sp.ksize, sp.pad_l, ptr(v.detach()), ptr(tail.scale), xin.hi.data_ptr(),
-                                                        xin.lo.data_ptr(), 0.2, half, seg_map, half, half, ptr(sums), 0.1, gt.hi.data_ptr(), None, st)), a.iters)
+        seg_gen, seg_disc = (ctypes.c_int * 2)(0, 0), (ctypes.c_int * 2)(0, 1)
+
+        def tail_two_passes():
+            check(lib.eben_bl_tail_dx(ptr(seeds), r2, cur.channels, cur.length, sp.ksize, sp.pad_l, ptr(v.detach()), ptr(tail.scale), xin.hi.data_ptr(),
+                                      xin.lo.data_ptr(), 0.2, half, seg_gen, half, half, ptr(sums), 0.1, gt.hi.data_ptr(), None, st))
+            check(lib.eben_bl_tail_dx(ptr(seeds[r2:]), r2, cur.channels, cur.length, sp.ksize, sp.pad_l, ptr(v.detach()), ptr(tail.scale), xin.hi.data_ptr(),
+                                      xin.lo.data_ptr(), 0.2, half, seg_disc, 0, half, ptr(sums), 0.1, gt.hi[r2:].data_ptr(), None, st))
+        t_b = time_ms(tail_two_passes, a.iters)
         t_w = time_ms(lambda: ch.weight_grads([(n - 1, seeds[r2:], xin)], x_in, None, half), a.iters)
         nin = cur.channels * cur.length
         macs1 = nin * sp.ksize

@@ -6,6 +6,7 @@ run the discriminators' mid layers (tap3 / tap4 / bl_dw) of ONE step in dispatch
 by its position in its chain.  Usage: step_trace_report.py p_results.db [--layers] [--top N]"""
 import argparse, re, sqlite3
 ap = argparse.ArgumentParser(); ap.add_argument("db"); ap.add_argument("--layers", action="store_true"); ap.add_argument("--top", type=int, default=70)
+ap.add_argument("--named", help="write the per-launch in-step durations of MelGAN's MFMA-bound layers (named by their position in the chain) to this JSON file")
 a = ap.parse_args()
 con = sqlite3.connect(a.db)
 suf = [r[0] for r in con.execute("select name from sqlite_master where type='table'") if r[0].startswith("rocpd_metadata")][0][len("rocpd_metadata"):]
@@ -55,3 +56,31 @@ if a.layers:
         if not any(t in n for t in ("tap3_kernel", "tap4_kernel", "bl_dw_kernel", "bl_head", "bl_tail", "bl_fm")): continue
         qs.setdefault(q, len(qs))
         print(f"{(s - marks[i]) / 1e6:8.3f} {(e - s) / 1e3:8.1f}  q{qs[q]}  grid {g:>8}  {short(n)}")
+
+if a.named:
+    # MelGAN's chain runs on the queue of its head (bl_head_fwd_kernel<1, 16, 15>).  On that queue the persistent tile kernel tap4<2,2,4,...>
+    # runs layers 3, 4, 5 forward right before the logits layer (bl_tail_fwd) and layers 5, 4, 3 of the input gradients right behind its
+    # gradient (bl_tail_dx) -- once per pass of the two-pass backward.  Every such launch inside the marked steps is listed.
+    import json
+    mq = next((q for n, s, e, q, g in rows if "bl_head_fwd_kernel" in n and ("ILi1ELi16ELi15E" in n or "<1, 16, 15>" in n)), None)
+    assert mq is not None, "no MelGAN head launch in the trace"
+    seq = [(n, s, e) for n, s, e, q, g in rows if q == mq and t0 <= s < t1]
+    is_t4 = lambda n: "tap4_kernel" in n and ("ILi2ELi2ELi4E" in n or "<2, 2, 4," in n)
+    named = {}
+    for i, (n, s, e) in enumerate(seq):
+        if "bl_tail_fwd" in n:
+            back = [x for x in seq[max(0, i - 8):i] if is_t4(x[0])][-3:]
+            if len(back) == 3:
+                for name, x in zip(("melgan_l3_fwd", "melgan_l4_fwd", "melgan_l5_fwd"), back):
+                    named.setdefault(name, []).append((x[2] - x[1]) / 1e3)
+        if "bl_tail_dx" in n:
+            fwd = [x for x in seq[i + 1:i + 9] if is_t4(x[0])][:3]
+            if len(fwd) == 3:
+                for name, x in zip(("melgan_l5_dx", "melgan_l4_dx", "melgan_l3_dx"), fwd):
+                    named.setdefault(name, []).append((x[2] - x[1]) / 1e3)
+    out = {k: {"launches": len(v), "avg_us": round(sum(v) / len(v), 2), "min_us": round(min(v), 2), "max_us": round(max(v), 2)} for k, v in named.items()}
+    out["_note"] = (f"rocprofv3 --kernel-trace of tools/step_trace.py, {nsteps} marked steps of the graph-replayed train step ({(t1 - t0) / 1e6 / nsteps:.2f} ms per step under "
+                    "the tracer); launches named by their position on MelGAN's queue; the input-gradient launches are 2B-row passes (rows [fm | adv], then "
+                    "[fake | real])")
+    json.dump(out, open(a.named, "w"), indent=1)
+    print("\n# named launches (us): " + ", ".join(f"{k} {v['avg_us']} (min {v['min_us']}, {v['launches']}x)" for k, v in out.items() if not k.startswith("_")))
