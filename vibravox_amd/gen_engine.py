@@ -46,8 +46,12 @@ USE_FUSED_RU_DW = os.environ.get("EBEN_RU_FUSED_DW", "1") != "0"
 #: backward / weight-gradient launches (csrc/ru_bl.hip) -- 32 bytes per element and unit instead of 52-56
 USE_RU_BL = os.environ.get("EBEN_RU_BL", "1") != "0"
 USE_GRAPHS = os.environ.get("EBEN_GEN_GRAPHS", "1") != "0"   # training forward / backward sequences replayed as HIP graphs
-#: backward segments (3 decoder blocks, latent convs, 3 encoder blocks) per replayed graph
-BWD_GROUPS = os.environ.get("EBEN_GEN_BWD_GROUPS", "2,2,3")
+#: backward segments (3 decoder blocks, latent convs, 3 encoder blocks) per replayed graph.  A group's weight gradients start on the side
+#: stream when its whole input-gradient graph has been issued, and what the main stream waits for in front of the generator's Adam is the
+#: LAST group's weight gradients: one segment per graph keeps that tail at one encoder block ([MI355X, same box, 2 x alternated] "2,2,3"
+#: 8.839 / 8.842, "2,2,2,1" 8.865 / 8.845, "3,3,1" 9.008 / 8.982, one per graph 8.795 / 8.809 ms per step; rounds 3-5 were bound by the host's
+#: enqueue time -- a replay costs it ~70 us -- and ran "2,2,3")
+BWD_GROUPS = os.environ.get("EBEN_GEN_BWD_GROUPS", "1,1,1,1,1,1,1")
 # arithmetic of the fused ResidualUnit launches (include/eben_hip.h, eben_ru_*_ex): the forward and the fp32 backward run on the bf16
 # matrix pipe with three bf16 pieces per operand (EBEN_MATH_BF16X6: every mantissa bit of the fp32 operands, fp32 accumulate --
 # fp32 arithmetic at 6/16 of the fp32 MFMA's cost); "f32" selects the v_mfma_f32_32x32x2_f32 kernels (bisecting aid).
