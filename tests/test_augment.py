@@ -135,7 +135,7 @@ def test_device_speed_matches_oracle(factor, shape):
     assert float(np.abs(got.double().numpy() - ref).max()) < 2e-6 * max(1.0, float(np.abs(ref).max()))
 
 
-@pytest.mark.parametrize("steps", [-2, -1, 1, 2, 5])
+@pytest.mark.parametrize("steps", [-2, 1, 5])   # (the float64 oracle is a per-bin Python walk: ~1 min of CPU per case; five cases were 4 of the suite's 6.5 minutes)
 def test_oracle_pitch_shift_on_a_sine(steps):
     """pitch_shift keeps the duration and moves a 440 Hz sine to 440 * 2^(steps/12) Hz."""
     sr, t = 16000, 8000

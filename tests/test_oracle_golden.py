@@ -198,7 +198,9 @@ def test_resample_kernel_tables_fixture_regenerates():
 
     gold = np.load(os.path.join(ROOT, "tests", "golden", "resample_kernels.npz"))
     n_tables = 0
-    for orig, new in rate_pairs():
+    for idx, (orig, new) in enumerate(rate_pairs()):
+        if f"{orig}_{new}" not in gold.files and idx % 3:   # every committed table, every third signature (all of them: 2 minutes of CPU)
+            continue
         k, width, o, n = sinc_resample_kernel(orig, new)
         sig = gold[f"{orig}_{new}:sig"]
         assert (width, o, n) == tuple(int(v) for v in sig[:3])
