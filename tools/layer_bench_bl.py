@@ -131,7 +131,7 @@ def main():
                 _fm_sums(lib, [xin], half, torch.empty(2, device=dev))
                 codes = xin.codes.data_ptr()
             dx_fn = lib.eben_bl_conv1d_bwd_dx_pr_c if pr else lib.eben_bl_conv1d_bwd_dx_c
-            seg_gen, seg_disc = (ctypes.c_int * 2)(0, 0), (ctypes.c_int * 2)(0, 1)
+            seg_gen, seg_disc = (ctypes.c_int * 4)(0, 0, 0, 0), (ctypes.c_int * 4)(0, 1, 0, 1)
 
             def two_passes():
                 check(dx_fn(ctypes.byref(d4), g.hi.data_ptr(), ptr(wpb), xin.hi.data_ptr(), xin.lo.data_ptr(), codes, 0.2, half, seg_gen,
@@ -167,7 +167,7 @@ def main():
         gt = Planes(r4, cur.channels, cur.length, dev, lo=False)
         t_f = time_ms(lambda: check(lib.eben_bl_tail_fwd(xin.hi.data_ptr(), xin.lo.data_ptr(), r2, cur.channels, cur.length, sp.ksize, sp.pad_l, ptr(v.detach()),
                                                          ptr(tail.scale), ptr(bias.detach()), 1.0, ptr(logits), st)), a.iters)
-        seg_gen, seg_disc = (ctypes.c_int * 2)(0, 0), (ctypes.c_int * 2)(0, 1)
+        seg_gen, seg_disc = (ctypes.c_int * 4)(0, 0, 0, 0), (ctypes.c_int * 4)(0, 1, 0, 1)
 
         def tail_two_passes():
             check(lib.eben_bl_tail_dx(ptr(seeds), r2, cur.channels, cur.length, sp.ksize, sp.pad_l, ptr(v.detach()), ptr(tail.scale), xin.hi.data_ptr(),

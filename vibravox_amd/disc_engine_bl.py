@@ -219,9 +219,9 @@ class _ChainBL:
         if part == "all":
             rows, seg_map, fm_rows, d0 = 4 * half, (ctypes.c_int * 4)(0, 0, 0, 1), half, 2 * half
         elif part == "gen":
-            rows, seg_map, fm_rows, d0 = 2 * half, (ctypes.c_int * 2)(0, 0), half, None
+            rows, seg_map, fm_rows, d0 = 2 * half, (ctypes.c_int * 4)(0, 0, 0, 0), half, None
         else:
-            rows, seg_map, fm_rows, d0 = 2 * half, (ctypes.c_int * 2)(0, 1), 0, 0
+            rows, seg_map, fm_rows, d0 = 2 * half, (ctypes.c_int * 4)(0, 1, 0, 1), 0, 0
         assert seeds.shape[0] == rows
         want_param_grads = want_param_grads and d0 is not None
         jobs = []
