@@ -3,8 +3,24 @@ import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
+FORCE_DDP = os.environ.get("FORCE_DDP", "0") == "1"   # the single-rank RCCL path of bench.py --force-ddp: where its extra time goes
+if FORCE_DDP:
+    from vibravox_amd._env import configure_hw_queues
+    configure_hw_queues(True)
 dev = torch.device("cuda", 0)
+if FORCE_DDP:
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29577")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
 mod = bench.build_module(dev, 1234)
+if FORCE_DDP:
+    from vibravox_amd.ddp import BucketedZeroGrad, GradSync
+    g_opt, d_opt = mod.optimizers()
+    gs, ds = GradSync(mod.generator.parameters(), bucket_bytes=2 << 20), GradSync(mod.discriminator.parameters())
+    g_w, d_w = BucketedZeroGrad(g_opt, gs), BucketedZeroGrad(d_opt, ds)
+    mod._optimizers = [g_w, d_w]
+    mod.grad_sync = {id(g_w): gs, id(d_w): ds}
 mod.disc_math = os.environ.get("EBEN_DISC_MATH", "bf16_bl"); mod.gen_backward_math = os.environ.get("EBEN_GEN_BWD_MATH", "f32" if mod.disc_math == "f32" else "bf16")
 mod.stft_math = "folded" if mod.disc_math == "f32" else "folded_x3"
 if os.environ.get("NO_RECON", "0") == "1":   # the discriminator phases alone: how long the chains take with nothing beside them

@@ -734,8 +734,31 @@ class DiscriminatorEngineBL(DiscriminatorEngine):
         held = sink is None and any(p.grad is not None for lay in self.chains[i].layers for p in lay.params() if p is not None)
         out = dw_body() if held else self._graphs["dw"][i].run(sig, dw_body, torch.cuda.current_stream())
         if sink is not None:
-            sink.mark_ready([p for lay in self.chains[i].layers for p in lay.params() if p is not None and p.requires_grad])
+            ready = [p for lay in self.chains[i].layers for p in lay.params() if p is not None and p.requires_grad]
+            if self.defer_mark_ready:
+                self._deferred_ready = (getattr(self, "_deferred_ready", None) or []) + ready
+            else:
+                sink.mark_ready(ready)
         return out
+
+    #: data-parallel runs: report the discriminator's gradients to the bucket exchange when the main stream joins the weight gradients
+    #: (``collect_param_grads``) instead of from each chain's stream right behind its launches.  Reported early, a bucket's collective sits
+    #: on the communication stream WAITING for the chain's events for ~3 ms (second backward pass + weight gradients), and a waiting stream
+    #: stalls whatever shares its hardware queue: [MI355X, single-rank RCCL, 7 queues] the main stream did not start the generator's seeds
+    #: until the discriminator's last weight gradient had run -- 10.07 ms per step against 9.18 deferred (9.06 with the generator's deferred
+    #: too, 8.7 without the exchange).  The price at N > 1 is the discriminator's exchange (92.6 MB) exposed in front of its Adam instead
+    #: of under the tail of its weight gradients.  EBEN_D_DEFER_READY=0: the early form.
+    defer_mark_ready: bool = __import__("os").environ.get("EBEN_D_DEFER_READY", "1") != "0"
+
+    def collect_param_grads(self):
+        sink = getattr(self, "_sink", None)
+        ready, self._deferred_ready = getattr(self, "_deferred_ready", None), None
+        if ready and sink is not None and getattr(self, "_pending", None) is not None:
+            main = torch.cuda.current_stream()
+            for st in set(self._streams) | set(getattr(self, "_used_streams", None) or ()):
+                main.wait_stream(st)
+            sink.mark_ready(ready)
+        return super().collect_param_grads()
 
     #: weight gradients of the three PQMF-band chains as one launch sequence (``_ChainBL.weight_grads_group``); 0: chain by chain
     group_weight_grads: bool = __import__("os").environ.get("EBEN_DW_GROUP", "0") != "0"
