@@ -780,7 +780,8 @@ def test_generator_graphs_match_eager_launches(hip, golden):
             gen_engine.USE_GRAPHS = prev
 
     (a, cap_a), (b, cap_b) = run(True), run(False)
-    assert cap_a == [7, 7] and cap_b == [0, 0], (cap_a, cap_b)   # forward + 3 segment groups x (input gradients, weight gradients)
+    groups = len([t for t in gen_engine.BWD_GROUPS.split(",") if t.strip()])   # backward segment groups (default: one segment each, 7)
+    assert cap_a == [1 + 2 * groups] * 2 and cap_b == [0, 0], (cap_a, cap_b)   # forward + groups x (input gradients, weight gradients)
     assert [k for k in a if not torch.equal(a[k], b[k])] == []
 
 
