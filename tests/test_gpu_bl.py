@@ -565,3 +565,38 @@ def test_weight_gradients_of_three_chains_in_one_launch(hip, shape):
     for one, (_, _, _, many) in zip(single, keep):
         # the slabs hold every weight's partial sums; columns no weight owns stay what they were (NaN here, both ways)
         assert torch.equal(torch.nan_to_num(one, nan=-7.0), torch.nan_to_num(many, nan=-7.0))
+
+
+@pytest.mark.parametrize("kw,length", [(dict(c_in=16, c_out=32, ksize=5, stride=1, pad_l=2, pad_r=2), 300),       # 64-row tile, 128 columns
+                                       (dict(c_in=8, c_out=16, ksize=3, stride=1, pad_l=1, pad_r=1), 257),        # 64-row tile, 64 columns
+                                       (dict(c_in=16, c_out=128, ksize=5, stride=2, pad_l=2, pad_r=2), 301),      # 128-row tile, 128 columns
+                                       (dict(c_in=8, c_out=128, ksize=3, stride=1, dilation=2, pad_l=2, pad_r=2), 190)])   # 128-row tile, 64 columns
+def test_bundle_conv_weight_gradient_small_tiles(hip, kw, length):
+    """The 64- and 128-column tiles of bl_dw.hip (layers with few column bundles: none of EBEN's, which take the 192- / 256-column ones)
+    against float64 on the bf16 operands."""
+    from vibravox_amd import ops
+    from vibravox_amd._lib import check
+
+    spec = ops.ConvSpec(**kw)
+    rows = 4
+    l_out = spec.out_len(length)
+    tag = f"bldw_small/{spec.c_in}_{spec.c_out}_{spec.ksize}"
+    dy = formula_tensor(tag + "/dy", (rows, spec.c_out, l_out)).to(DEV)
+    x = formula_tensor(tag + "/x", (rows, spec.c_in, length)).to(DEV)
+    dyp, xp = planes_of(dy, lo=False), planes_of(x, lo=False)
+    d = ops.conv_desc(spec, rows, length, ops.MATH_BF16 | BL)
+    nslab, rs, perm = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+    nbytes = hip.eben_bl_conv1d_bwd_dw_workspace(ctypes.byref(d), ctypes.byref(nslab), ctypes.byref(rs), ctypes.byref(perm))
+    assert nbytes > 0
+    slabs = torch.empty(nbytes // 4, dtype=torch.float32, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    check(hip.eben_bl_conv1d_bwd_dw(ctypes.byref(d), dyp.hi.data_ptr(), xp.hi.data_ptr(), 1, slabs.data_ptr(), nbytes, st), "bl_conv1d_bwd_dw")
+    wshape = spec.weight_shape()
+    dv, dbias = torch.empty(wshape, dtype=torch.float32, device=DEV), torch.empty(wshape[0], dtype=torch.float32, device=DEV)
+    ops.wn_bwd_multi([(slabs, nslab.value, wshape[0] * rs.value, wshape[0], wshape[1] * wshape[2], rs.value, None, dv, None, None, dv, dbias, perm.value)])
+    wr = torch.zeros(wshape, dtype=torch.float64, device=DEV).requires_grad_(True)
+    br = torch.zeros(wshape[0], dtype=torch.float64, device=DEV).requires_grad_(True)
+    out = F.conv1d(bf16_hi(x).double(), wr, br, stride=spec.stride, padding=spec.pad_l, dilation=spec.dilation, groups=spec.groups)
+    (out * bf16_hi(dy).double()).sum().backward()
+    assert rel_err(dv, wr.grad) < 3e-5, rel_err(dv, wr.grad)
+    assert rel_err(dbias, br.grad) < 3e-5
