@@ -24,3 +24,5 @@ pr.disable()
 torch.cuda.synchronize()
 st = pstats.Stats(pr, stream=sys.stdout)
 st.strip_dirs().sort_stats(a.sort).print_stats(a.top)
+if os.environ.get("CALLERS"):
+    st.print_callers(os.environ["CALLERS"])

@@ -64,6 +64,7 @@ class _Layer:
         self.keep_scale = False   # the layer's kernels take (v, scale) directly (bundle-layout heads / tails): prepack refreshes the scale
         self.pr_weights: Dict[tuple, torch.Tensor] = {}   # slot -> primed weights of the phases-as-rows input gradient
         self._pr_descs: Dict[tuple, object] = {}
+        self._params = None
 
     def ensure_scale(self) -> None:
         """Weight-norm scale g / ||v|| and norm ||v|| of the current weights (what ``packed`` computes on the way)."""
@@ -78,8 +79,14 @@ class _Layer:
             self.scale_key = wkey
 
     def params(self):
-        prm = self.conv.parametrizations["weight"]
-        return prm.original1, prm.original0, self.conv.bias   # v, g, bias
+        """(v, g, bias).  Looked up ~440 times a step: the Parameter objects are kept until ``ops.bump_weights_epoch()`` (no arguments)
+        announces replaced parameters (three module ``__getattr__`` walks per call otherwise)."""
+        epoch = ops._storage_epoch.get(-1, 0)
+        hit = self._params
+        if hit is None or hit[0] != epoch:
+            prm = self.conv.parametrizations["weight"]
+            hit = self._params = (epoch, (prm.original1, prm.original0, self.conv.bias))
+        return hit[1]
 
     def _weights_key(self):
         v, g, _ = self.params()
@@ -709,4 +716,4 @@ class DiscriminatorEngine:
                     if t is not None:
                         t.record_stream(main)
         self._pending = None
-        return [by_param.get(id(p)) for p in self.disc.parameters()]
+        return [by_param.get(id(p)) for p in ops.parameters_of(self.disc)]

@@ -795,10 +795,14 @@ class DiscriminatorEngineBL(DiscriminatorEngine):
         split = self.split_backward
         n = len(self.chains)
 
+        chain_sigs = {}   # both passes of a chain see the same weights and images: one walk of its layers per step
+
         def sig_of(i, tag):
+            if i not in chain_sigs:
+                chain_sigs[i] = self._chain_sig(self.chains[i], 1)
             return (half, tag, tuple(self.seed_weights), s["fm_inv"], sums_ptr, s["logits"][i].data_ptr(),
                     tuple((a.hi.data_ptr(), a.lo.data_ptr(), a.length, None if a.codes is None else a.codes.data_ptr()) for a in s["acts"][i]),
-                    self._chain_sig(self.chains[i], 1))
+                    chain_sigs[i])
 
         def body(i):
             seeds = self._seeds(lib, s, i, dev)

@@ -110,10 +110,7 @@ S2D_MIN_STRIDE = int(os.environ.get("EBEN_GEN_S2D_MIN_STRIDE", "8"))
 
 
 def _params(m):
-    if m.weight_norm:
-        prm = m.parametrizations["weight"]
-        return prm.original1, prm.original0
-    return m.weight, None
+    return ops.conv_params(m)
 
 
 class _ConvRec:
@@ -830,7 +827,7 @@ def core(gen, cut_audio: torch.Tensor):
         object.__setattr__(gen, "_engine", engine)   # not a submodule / buffer: invisible to state_dict
     # the parameters the core owns: NOT last_conv's -- the balancing passes differentiate the losses w.r.t. last_conv.weight alone
     # (eben.py:223-227) and must not reach into the core
-    params = [p for m in (gen.first_conv, gen.encoder_blocks, gen.latent_conv, gen.decoder_blocks) for p in m.parameters() if p.requires_grad]
+    params = [p for m in (gen.first_conv, gen.encoder_blocks, gen.latent_conv, gen.decoder_blocks) for p in ops.parameters_of(m) if p.requires_grad]
     if torch.is_grad_enabled() and params:
         return _CoreFn.apply(cut_audio.contiguous(), engine, *params)
     pre, first_bands, _ = engine.forward(cut_audio.contiguous(), False)

@@ -250,7 +250,7 @@ class EBENLightningModule(BaseSELightningModule):
         corrupted_speech = self.generator.cut_to_valid_length(batch["audio_body_conducted"])
         reference_speech = self.generator.cut_to_valid_length(batch["audio_airborne"])
         generator_optimizer, discriminator_optimizer = self.optimizers(use_pl_optimizer=True)
-        g_params = [p for p in self.generator.parameters() if p.requires_grad]
+        g_params = [p for p in ops.parameters_of(self.generator) if p.requires_grad]
         math = DISC_MATH_PLANS[self.disc_math] if isinstance(self.disc_math, str) else self.disc_math
         if getattr(self, "_disc_engine", None) is None or self._disc_engine.disc is not self.discriminator or self._disc_engine.math != math:
             self._disc_engine = DiscriminatorEngine(self.discriminator, math)
@@ -359,7 +359,7 @@ class EBENLightningModule(BaseSELightningModule):
             self.log("train/discriminator/backprop_loss", real_loss + fake_loss, sync_dist=True)
             d_grads = engine.collect_param_grads()   # None when they went straight into the data-parallel buckets
             if d_grads is not None:
-                inject_grads(list(self.discriminator.parameters()), d_grads)
+                inject_grads(ops.parameters_of(self.discriminator), d_grads)
             self._mark("discriminator weight gradients joined")
             self._step(discriminator_optimizer, self._sync_grads(discriminator_optimizer))
             discriminator_optimizer.zero_grad()
@@ -394,8 +394,8 @@ class EBENLightningModule(BaseSELightningModule):
         corrupted_speech = self.generator.cut_to_valid_length(batch["audio_body_conducted"])
         reference_speech = self.generator.cut_to_valid_length(batch["audio_airborne"])
         generator_optimizer, discriminator_optimizer = self.optimizers(use_pl_optimizer=True)
-        g_params = [p for p in self.generator.parameters() if p.requires_grad]
-        d_params = [p for p in self.discriminator.parameters() if p.requires_grad]
+        g_params = [p for p in ops.parameters_of(self.generator) if p.requires_grad]
+        d_params = [p for p in ops.parameters_of(self.discriminator) if p.requires_grad]
 
         # ---- generator phase: every forward of the step happens here
         enhanced_speech, bands = self.generator(corrupted_speech)
