@@ -6,6 +6,7 @@ run the discriminators' mid layers (tap3 / tap4 / bl_dw) of ONE step in dispatch
 by its position in its chain.  Usage: step_trace_report.py p_results.db [--layers] [--top N]"""
 import argparse, re, sqlite3
 ap = argparse.ArgumentParser(); ap.add_argument("db"); ap.add_argument("--layers", action="store_true"); ap.add_argument("--top", type=int, default=70)
+ap.add_argument("--main", action="store_true", help="every dispatch on the main stream's queue of one step, with the idle time of that queue before it")
 ap.add_argument("--named", help="write the per-launch in-step durations of MelGAN's MFMA-bound layers (named by their position in the chain) to this JSON file")
 a = ap.parse_args()
 con = sqlite3.connect(a.db)
@@ -56,6 +57,21 @@ if a.layers:
         if not any(t in n for t in ("tap3_kernel", "tap4_kernel", "bl_dw_kernel", "bl_head", "bl_tail", "bl_fm")): continue
         qs.setdefault(q, len(qs))
         print(f"{(s - marks[i]) / 1e6:8.3f} {(e - s) / 1e3:8.1f}  q{qs[q]}  grid {g:>8}  {short(n)}")
+
+if a.main:
+    i = nsteps // 2
+    mq = next(q for n, s, e, q, g in rows if "spin_kernel" in n)
+    print(f"\n# step {i}: the main stream's queue (ms from the step mark, us, idle us before, kernel); other queues' dispatches counted only")
+    last = marks[i]
+    idle_tot = busy_tot = 0.0
+    small = {}
+    for n, s, e, q, g in rows:
+        if not (marks[i] <= s < marks[i + 1]) or q != mq or "spin_kernel" in n: continue
+        gap = max(0.0, (s - last) / 1e3)
+        idle_tot += gap; busy_tot += (e - s) / 1e3
+        print(f"{(s - marks[i]) / 1e6:8.3f} {(e - s) / 1e3:8.1f} {gap:8.1f}  {short(n)}")
+        last = max(last, e)
+    print(f"# main queue: busy {busy_tot / 1e3:.3f} ms, idle {idle_tot / 1e3:.3f} ms")
 
 if a.named:
     # MelGAN's chain runs on the queue of its head (bl_head_fwd_kernel<1, 16, 15>).  On that queue the persistent tile kernel tap4<2,2,4,...>
