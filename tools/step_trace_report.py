@@ -7,6 +7,7 @@ by its position in its chain.  Usage: step_trace_report.py p_results.db [--layer
 import argparse, re, sqlite3
 ap = argparse.ArgumentParser(); ap.add_argument("db"); ap.add_argument("--layers", action="store_true"); ap.add_argument("--top", type=int, default=70)
 ap.add_argument("--main", action="store_true", help="every dispatch on the main stream's queue of one step, with the idle time of that queue before it")
+ap.add_argument("--window", help="a,b: every dispatch of one step that starts between a and b ms after the step mark, all queues")
 ap.add_argument("--named", help="write the per-launch in-step durations of MelGAN's MFMA-bound layers (named by their position in the chain) to this JSON file")
 a = ap.parse_args()
 con = sqlite3.connect(a.db)
@@ -72,6 +73,16 @@ if a.main:
         print(f"{(s - marks[i]) / 1e6:8.3f} {(e - s) / 1e3:8.1f} {gap:8.1f}  {short(n)}")
         last = max(last, e)
     print(f"# main queue: busy {busy_tot / 1e3:.3f} ms, idle {idle_tot / 1e3:.3f} ms")
+
+if a.window:
+    w0, w1 = (float(v) for v in a.window.split(","))
+    i = nsteps // 2
+    qs = {}
+    print(f"\n# step {i}: dispatches starting {w0} .. {w1} ms after the step mark (ms, us, queue, grid, kernel)")
+    for n, s, e, q, g in rows:
+        qs.setdefault(q, len(qs))
+        if not (marks[i] + w0 * 1e6 <= s < marks[i] + w1 * 1e6) or "spin_kernel" in n: continue
+        print(f"{(s - marks[i]) / 1e6:8.3f} {(e - s) / 1e3:8.1f}  q{qs[q]}  grid {g:>8}  {short(n)}")
 
 if a.named:
     # MelGAN's chain runs on the queue of its head (bl_head_fwd_kernel<1, 16, 15>).  On that queue the persistent tile kernel tap4<2,2,4,...>
