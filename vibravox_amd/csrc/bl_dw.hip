@@ -34,6 +34,9 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #ifndef EBEN_BLDW_DBG
 #define EBEN_BLDW_DBG 0   // scratch-build ablations (wrong results): 1 no A-tile DMA, 2 no X-row DMA, 4 no MFMA, 8 no slab stores
 #endif
+#ifndef EBEN_BLDW_PIPE_FENCE
+#define EBEN_BLDW_PIPE_FENCE 1
+#endif
 constexpr int BLDW_BKT = 64;    // time steps per K chunk
 constexpr int BLDW_TS = 68;     // A row stride in units (64 + 4: = 4 mod 16)
 constexpr int BLDW_RS_MAX = 132;   // largest X row stride in units (two whole 64-unit LDS-DMA pieces + 4)
@@ -156,26 +159,59 @@ __device__ __forceinline__ void bl_dw_body(const BlDwArgs& P, unsigned bid, unsi
     if (bundle > P.CBa - 1) bundle = P.CBa - 1;
     arow[i] = mt * BMB + wave + 4 * i < P.MgB ? (long long)bundle * P.La : -1;   // rows past the group's last: zeros (no traffic), never stored
   }
-  auto issue = [&](int q, int bsel) {
-    const int b = q / P.nct;
-    const int t0 = (q - b * P.nct) * BKT;
+  // what a chunk's pieces need besides (item, first time step): fixed for the launch (the divisions and 64-bit products of the row
+  // addresses were ~240 mostly scalar instructions per chunk and wave, in front of the chunk's 16-32 MFMAs)
+  constexpr int XW = 4;                                  // X rows per wave held in registers (XR <= 16); wider tiles walk the rows
+  const bool x_regs = P.XR <= 4 * XW;
+  long long xoff[XW];
+  int xlane[XW];
+  unsigned xdst[XW];
+#pragma unroll
+  for (int i = 0; i < XW; ++i) {
+    const int xr = wave + 4 * i;
+    const int cbl = xr / P.S, p = xr - cbl * P.S;
+    int cb = cb_lo + cbl;
+    if (cb > P.CgB - 1) cb = P.CgB - 1;
+    xoff[i] = ((long long)g * P.CgB + cb) * P.Lx;
+    xlane[i] = (P.amin + lane) * P.S + p;              // unit u of the row = position (t0 + amin + u) S + p
+    xdst[i] = (unsigned)((a_units + xr * RS) * 16);
+  }
+  const long long a_item = (long long)P.CBa * P.La, x_item = (long long)P.CBx * P.Lx;
+  auto issue = [&](int b, int t0, int bsel) {
     const unsigned dst = buf_addr + (unsigned)(bsel * buf_units * 16);
-    const u32x4* ab = P.ah + (long long)b * P.CBa * P.La;
+    const u32x4* ab = P.ah + (long long)b * a_item + t0 + lane;
     const bool a_ok = t0 + lane < P.La;
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
       const int r = wave + 4 * i;
-      if (r < BMB && !(EBEN_BLDW_DBG & 1)) bl_dma_piece((a_ok && arow[i] >= 0) ? ab + arow[i] + t0 + lane : zero, __builtin_amdgcn_readfirstlane(dst + (unsigned)(r * TS * 16)));
+      if (r < BMB && !(EBEN_BLDW_DBG & 1)) bl_dma_piece((a_ok && arow[i] >= 0) ? ab + arow[i] : zero, __builtin_amdgcn_readfirstlane(dst + (unsigned)(r * TS * 16)));
     }
-    const u32x4* xb = P.xh + ((long long)b * P.CBx + (long long)g * P.CgB) * P.Lx;
-    for (int xr = wave; xr < ((EBEN_BLDW_DBG & 2) ? 0 : xrows); xr += 4) {
+    const u32x4* xb = P.xh + (long long)b * x_item;
+    if (EBEN_BLDW_DBG & 2) return;
+    // outside [0, Lx): the zero unit.  The second piece covers the taps' reach behind the 64 time steps: its lanes past xneed are
+    // switched off (the row's stride is RS < 128 units)
+    if (x_regs) {
+      const int ts = t0 * P.S;
+#pragma unroll
+      for (int i = 0; i < XW; ++i)
+        if (wave + 4 * i < xrows) {
+          const u32x4* row = xb + xoff[i];
+          const int pos0 = ts + xlane[i];
+          const unsigned rdst = dst + xdst[i];
+          bl_dma_piece((unsigned)pos0 < (unsigned)P.Lx ? row + pos0 : zero, __builtin_amdgcn_readfirstlane(rdst));
+          if (64 + lane < P.xneed) {
+            const int pos1 = pos0 + 64 * P.S;
+            bl_dma_piece((unsigned)pos1 < (unsigned)P.Lx ? row + pos1 : zero, __builtin_amdgcn_readfirstlane(rdst + (unsigned)(64 * 16)));
+          }
+        }
+      return;
+    }
+    for (int xr = wave; xr < xrows; xr += 4) {
       const int cbl = xr / P.S, p = xr - cbl * P.S;
       int cb = cb_lo + cbl;
       if (cb > P.CgB - 1) cb = P.CgB - 1;
-      const u32x4* row = xb + (long long)cb * P.Lx;
+      const u32x4* row = xb + ((long long)g * P.CgB + cb) * P.Lx;
       const unsigned rdst = dst + (unsigned)((a_units + xr * RS) * 16);
-      // unit u of the row = position (t0 + amin + u) S + p; outside [0, Lx): the zero unit.  The second piece covers the taps' reach
-      // behind the 64 time steps: its lanes past xneed are switched off (the row's stride is RS < 128 units)
       const int pos0 = (t0 + P.amin + lane) * P.S + p;
       bl_dma_piece((pos0 >= 0 && pos0 < P.Lx) ? row + pos0 : zero, __builtin_amdgcn_readfirstlane(rdst));
       if (64 + lane < P.xneed) {
@@ -184,29 +220,47 @@ __device__ __forceinline__ void bl_dw_body(const BlDwArgs& P, unsigned bid, unsi
       }
     }
   };
+  // chunk q = (item q / nct, time steps 64 (q mod nct) ..): walked without divisions
+  const int dq_b = P.nsplit / P.nct, dq_t = P.nsplit - dq_b * P.nct;
+  int qb = z / P.nct, qt = z - qb * P.nct;             // the chunk whose pieces are issued next
 
   int bsel = 0;
-  if (z < P.nchunks) issue(z, 0);
+  auto advance = [&]() {
+    qb += dq_b; qt += dq_t;
+    if (qt >= P.nct) { qt -= P.nct; ++qb; }
+  };
+  if (z < P.nchunks) { issue(qb, qt * BKT, 0); advance(); }
   for (int q = z; q < P.nchunks; q += P.nsplit) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of chunk q have landed ...
     __syncthreads();                                   // ... and everybody's; buffer bsel ^ 1 (read during the previous chunk) is free
-    const int qn = q + P.nsplit;
-    if (qn < P.nchunks) issue(qn, bsel ^ 1);
+    if (q + P.nsplit < P.nchunks) { issue(qb, qt * BKT, bsel ^ 1); advance(); }
     const unsigned base = buf_addr + (unsigned)(bsel * buf_units * 16);
+    // fragments of k-step ks + 1 are read while k-step ks is multiplied (two register sets: left to itself hipcc reads a k-step's
+    // fragments into ONE set right in front of its MFMAs -- two exposed LDS round trips per 6-8 MFMAs)
+    bf16x8 av[2][FM], bv[2][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i) av[0][i] = bl_tr_frag(base + aoff[i]);
+#pragma unroll
+    for (int f = 0; f < FN; ++f) bv[0][f] = bl_tr_frag((bconst[f] ? ones_addr : base) + boff[f]);
 #pragma unroll
     for (int ks = 0; ks < BKT / 16; ++ks) {
-      bf16x8 av[FM], bv[FN];
+      const int cur = ks & 1, nxt = cur ^ 1;
+      if (ks + 1 < BKT / 16) {
 #pragma unroll
-      for (int i = 0; i < FM; ++i) av[i] = bl_tr_frag(base + aoff[i] + (unsigned)(ks * 256));
+        for (int i = 0; i < FM; ++i) av[nxt][i] = bl_tr_frag(base + aoff[i] + (unsigned)((ks + 1) * 256));
 #pragma unroll
-      for (int f = 0; f < FN; ++f) bv[f] = bl_tr_frag((bconst[f] ? ones_addr : base) + boff[f] + (unsigned)(ks * 256));
+        for (int f = 0; f < FN; ++f) bv[nxt][f] = bl_tr_frag((bconst[f] ? ones_addr : base) + boff[f] + (unsigned)((ks + 1) * 256));
+      }
 #pragma unroll
       for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int f = 0; f < FN; ++f) {
-          if (EBEN_BLDW_DBG & 4) acc[i][f][0] += __builtin_bit_cast(float, __builtin_bit_cast(u32x4, av[i])[0] ^ __builtin_bit_cast(u32x4, bv[f])[1]);
-          else acc[i][f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[f], acc[i][f], 0, 0, 0);
+          if (EBEN_BLDW_DBG & 4) acc[i][f][0] += __builtin_bit_cast(float, __builtin_bit_cast(u32x4, av[cur][i])[0] ^ __builtin_bit_cast(u32x4, bv[cur][f])[1]);
+          else acc[i][f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[cur][i], bv[cur][f], acc[i][f], 0, 0, 0);
         }
+#if EBEN_BLDW_PIPE_FENCE
+      __builtin_amdgcn_sched_barrier(0);   // k-step ks's MFMAs and k-step ks + 1's reads stay in front of k-step ks + 1's MFMAs
+#endif
     }
     bsel ^= 1;
   }
