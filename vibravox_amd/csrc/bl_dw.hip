@@ -54,13 +54,15 @@ struct BlDwArgs {
   int has_bias, nnt, nmt, nsplit, nct, nchunks, XR, xneed;   // xneed: units of an X row a chunk reads (64 time steps + the taps' reach)
   int dense, c_in_g, c_out_g, row_stride;
   int RS;                        // X row stride in LDS units (bldw_row_stride)
+  int xw;                        // XC: units of an X row a chunk reads (xneed time steps x stride)
   long long slab_stride;
 };
 
+template <unsigned STEP4 = 64u>
 __device__ __forceinline__ bf16x8 bl_tr_frag(unsigned addr) {
   typedef __attribute__((address_space(3))) s16x4* lds4_t;
   const s16x4 r0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(size_t)(addr));
-  const s16x4 r1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(size_t)(addr + 64u));   // + 4 units: k = 4..7 of the lane's eight
+  const s16x4 r1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_t)(size_t)(addr + STEP4));   // + 4 time steps: k = 4..7 of the lane's eight
   const s16x8 v = {r0[0], r0[1], r0[2], r0[3], r1[0], r1[1], r1[2], r1[3]};
   return __builtin_bit_cast(bf16x8, v);
 }
@@ -79,7 +81,13 @@ __device__ __forceinline__ void bl_dma_piece(const u32x4* src, unsigned dst) {
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(src), "s"(dst) : "memory");
 }
 
-template <int FM, int FN>
+// XC (stride 4, dilation 1: MelGAN L1-L4): an X row is ONE channel bundle at consecutive positions, copied as whole 1 KB pieces (the
+// phase rows' lanes gather their units 64 bytes apart: 32 cache lines per piece for 8, and a CU's vector-memory path is what a launch waits
+// for -- DESIGN_LOG 13.8); the phases are de-interleaved by the fragment addresses instead: time step t of tap j sits at unit
+// (t - t0) S + (j - pad - amin S), a lane's four column bundles (consecutive taps) 16 bytes apart and its four time steps 64 bytes apart --
+// 32 distinct banks per half-wave.
+constexpr int BLDW_XC_S = 4;
+template <int FM, int FN, bool XC = false>
 __device__ __forceinline__ void bl_dw_body(const BlDwArgs& P, unsigned bid, unsigned nblk) {
   constexpr int BM = 64 * FM, BMB = BM / 8, BNQ = 8 * FN, BKT = BLDW_BKT, TS = BLDW_TS;
   const int RS = P.RS;
@@ -101,11 +109,11 @@ __device__ __forceinline__ void bl_dw_body(const BlDwArgs& P, unsigned bid, unsi
   int qlast = q0 + BNQ < P.NQW ? q0 + BNQ : P.NQW;
   int cb_hi = (qlast - 1) / P.k;
   if (cb_hi < cb_lo) cb_hi = cb_lo;
-  const int xrows = (cb_hi - cb_lo + 1) * P.S;        // X rows of this tile: (channel bundle, stride phase)
+  const int xrows = (cb_hi - cb_lo + 1) * (XC ? 1 : P.S);   // X rows of this tile: (channel bundle, stride phase); XC: channel bundles
 
   const int a_units = BMB * TS, buf_units = a_units + P.XR * RS;
   // LDS: [ones row: TS units of (1, 0, 0, 0 | 0, 0, 0, 0)] [buffer 0: A rows, X rows] [buffer 1]
-  for (int i = tid; i < BLDW_TS; i += 256) smem_bldw[i] = u32x4{0x00003f80u, 0u, 0u, 0u};   // read at units koff .. koff + 3 + 16 ks < 64
+  for (int i = tid; i < BLDW_TS; i += 256) smem_bldw[i] = u32x4{0x00003f80u, 0u, 0u, 0u};   // read at units koff .. koff + 3 (+ 4 time steps of an X row) < 64
   const unsigned lds0 = (unsigned)(unsigned long long)(lds_t)smem_bldw;
   const unsigned ones_addr = lds0, buf_addr = lds0 + BLDW_TS * 16;
 
@@ -127,11 +135,15 @@ __device__ __forceinline__ void bl_dw_body(const BlDwArgs& P, unsigned bid, unsi
     if (q < P.NQW) {
       const int cb = q / P.k, j = q - cb * P.k;
       const int off = j * P.d - P.pad;
-      int a = off / P.S;
-      if (off < 0 && a * P.S != off) --a;                // floor
-      const int p = off - a * P.S;
-      const int row = (cb - cb_lo) * P.S + p;
-      boff[f] = (unsigned)(a_units * 16 + (row * RS + (a - P.amin) + koff) * 16 + 8 * (qs & 1));
+      if (XC) {
+        boff[f] = (unsigned)(a_units * 16 + ((cb - cb_lo) * RS + (off - P.amin * BLDW_XC_S) + koff * BLDW_XC_S) * 16 + 8 * (qs & 1));
+      } else {
+        int a = off / P.S;
+        if (off < 0 && a * P.S != off) --a;                // floor
+        const int p = off - a * P.S;
+        const int row = (cb - cb_lo) * P.S + p;
+        boff[f] = (unsigned)(a_units * 16 + (row * RS + (a - P.amin) + koff) * 16 + 8 * (qs & 1));
+      }
       bconst[f] = false;
     } else {                                             // the bias column bundle (and the padding behind it): constant rows
       boff[f] = (unsigned)(koff * 16 + 8 * (qs & 1));
@@ -162,19 +174,32 @@ __device__ __forceinline__ void bl_dw_body(const BlDwArgs& P, unsigned bid, unsi
   // what a chunk's pieces need besides (item, first time step): fixed for the launch (the divisions and 64-bit products of the row
   // addresses were ~240 mostly scalar instructions per chunk and wave, in front of the chunk's 16-32 MFMAs)
   constexpr int XW = 4;                                  // X rows per wave held in registers (XR <= 16); wider tiles walk the rows
-  const bool x_regs = P.XR <= 4 * XW;
+  const bool x_regs = XC || P.XR <= 4 * XW;
   long long xoff[XW];
   int xlane[XW];
   unsigned xdst[XW];
+  bool xact[XW];                                         // XC: this lane of piece i is inside the row's xw units
+  const int npr = XC ? (P.xw + 63) / 64 : 1;             // XC: pieces per row; piece wave + 4 i = (row, 64-unit run)
 #pragma unroll
   for (int i = 0; i < XW; ++i) {
     const int xr = wave + 4 * i;
-    const int cbl = xr / P.S, p = xr - cbl * P.S;
-    int cb = cb_lo + cbl;
-    if (cb > P.CgB - 1) cb = P.CgB - 1;
-    xoff[i] = ((long long)g * P.CgB + cb) * P.Lx;
-    xlane[i] = (P.amin + lane) * P.S + p;              // unit u of the row = position (t0 + amin + u) S + p
-    xdst[i] = (unsigned)((a_units + xr * RS) * 16);
+    if (XC) {
+      const int row = xr / npr, pc = xr - row * npr;
+      int cb = cb_lo + row;
+      if (cb > P.CgB - 1) cb = P.CgB - 1;
+      xoff[i] = ((long long)g * P.CgB + cb) * P.Lx;
+      xlane[i] = P.amin * BLDW_XC_S + 64 * pc + lane;    // unit u of the row = position (t0 + amin) S + u
+      xdst[i] = (unsigned)((a_units + row * RS + 64 * pc) * 16);
+      xact[i] = xr < xrows * npr && 64 * pc + lane < P.xw;
+    } else {
+      const int cbl = xr / P.S, p = xr - cbl * P.S;
+      int cb = cb_lo + cbl;
+      if (cb > P.CgB - 1) cb = P.CgB - 1;
+      xoff[i] = ((long long)g * P.CgB + cb) * P.Lx;
+      xlane[i] = (P.amin + lane) * P.S + p;              // unit u of the row = position (t0 + amin + u) S + p
+      xdst[i] = (unsigned)((a_units + xr * RS) * 16);
+      xact[i] = true;
+    }
   }
   const long long a_item = (long long)P.CBa * P.La, x_item = (long long)P.CBx * P.Lx;
   auto issue = [&](int b, int t0, int bsel) {
@@ -190,6 +215,16 @@ __device__ __forceinline__ void bl_dw_body(const BlDwArgs& P, unsigned bid, unsi
     if (EBEN_BLDW_DBG & 2) return;
     // outside [0, Lx): the zero unit.  The second piece covers the taps' reach behind the 64 time steps: its lanes past xneed are
     // switched off (the row's stride is RS < 128 units)
+    if (XC) {
+      const int ts = t0 * BLDW_XC_S;
+#pragma unroll
+      for (int i = 0; i < XW; ++i)
+        if (wave + 4 * i < xrows * npr) {                // wave-uniform
+          const int pos0 = ts + xlane[i];
+          if (xact[i]) bl_dma_piece((unsigned)pos0 < (unsigned)P.Lx ? xb + xoff[i] + pos0 : zero, __builtin_amdgcn_readfirstlane(dst + xdst[i]));
+        }
+      return;
+    }
     if (x_regs) {
       const int ts = t0 * P.S;
 #pragma unroll
@@ -237,11 +272,14 @@ __device__ __forceinline__ void bl_dw_body(const BlDwArgs& P, unsigned bid, unsi
     const unsigned base = buf_addr + (unsigned)(bsel * buf_units * 16);
     // fragments of k-step ks + 1 are read while k-step ks is multiplied (two register sets: left to itself hipcc reads a k-step's
     // fragments into ONE set right in front of its MFMAs -- two exposed LDS round trips per 6-8 MFMAs)
+    // ONE transposing read per fragment half for all lanes (the read exchanges rows inside 16-lane groups: a lane of the bias column
+    // bundle only reads another address -- every unit of the ones row is the same, so it needs no k-step advance)
+    constexpr unsigned BSTEP4 = XC ? 64u * BLDW_XC_S : 64u;   // bytes between time steps t and t + 4 of an X row
     bf16x8 av[2][FM], bv[2][FN];
 #pragma unroll
     for (int i = 0; i < FM; ++i) av[0][i] = bl_tr_frag(base + aoff[i]);
 #pragma unroll
-    for (int f = 0; f < FN; ++f) bv[0][f] = bl_tr_frag((bconst[f] ? ones_addr : base) + boff[f]);
+    for (int f = 0; f < FN; ++f) bv[0][f] = bl_tr_frag<BSTEP4>(bconst[f] ? ones_addr + boff[f] : base + boff[f]);
 #pragma unroll
     for (int ks = 0; ks < BKT / 16; ++ks) {
       const int cur = ks & 1, nxt = cur ^ 1;
@@ -249,7 +287,8 @@ __device__ __forceinline__ void bl_dw_body(const BlDwArgs& P, unsigned bid, unsi
 #pragma unroll
         for (int i = 0; i < FM; ++i) av[nxt][i] = bl_tr_frag(base + aoff[i] + (unsigned)((ks + 1) * 256));
 #pragma unroll
-        for (int f = 0; f < FN; ++f) bv[nxt][f] = bl_tr_frag((bconst[f] ? ones_addr : base) + boff[f] + (unsigned)((ks + 1) * 256));
+        for (int f = 0; f < FN; ++f)
+          bv[nxt][f] = bl_tr_frag<BSTEP4>(bconst[f] ? ones_addr + boff[f] : base + boff[f] + (unsigned)((ks + 1) * 4 * BSTEP4));
       }
 #pragma unroll
       for (int i = 0; i < FM; ++i)
@@ -297,8 +336,8 @@ __device__ __forceinline__ void bl_dw_body(const BlDwArgs& P, unsigned bid, unsi
   }
 }
 
-template <int FM, int FN>
-__global__ __launch_bounds__(256, 2) void bl_dw_kernel(const BlDwArgs P) { bl_dw_body<FM, FN>(P, blockIdx.x, gridDim.x); }
+template <int FM, int FN, bool XC = false>
+__global__ __launch_bounds__(256, 2) void bl_dw_kernel(const BlDwArgs P) { bl_dw_body<FM, FN, XC>(P, blockIdx.x, gridDim.x); }
 
 // Several layers of ONE tile shape in one launch (the same layer index of the three PQMF-band discriminators: same channels and taps,
 // their own dilation, length, operands and slabs): block -> problem by the prefix sums of the problems' block counts.  [MI355X] a thin
@@ -320,7 +359,7 @@ __global__ __launch_bounds__(256, 2) void bl_dw_multi_kernel(const BlDwTable T) 
 
 // ---------------------------------------------------------------------------------------------------------------------------------
 struct BlDwPlan {
-  int ok, G, Mg, Cg, MgB, CgB, dense, FM, FN, nmt, nnt, NQW, nct, nchunks, nsplit, XR, amin, row_stride, perm_k, xneed, RS;
+  int ok, G, Mg, Cg, MgB, CgB, dense, FM, FN, nmt, nnt, NQW, nct, nchunks, nsplit, XR, amin, row_stride, perm_k, xneed, RS, xc, xw;
   size_t lds_bytes;
   long long slab_stride;
 };
@@ -366,6 +405,16 @@ static void make_bldw_plan(const Canon& c, BlDwPlan* p) {
   p->XR = ncb * c.s;
   p->xneed = BLDW_BKT + amax - p->amin + 1;
   p->RS = bldw_row_stride(p->xneed);
+  // contiguous X rows (bl_dw_body<.., XC>): stride 4, dilation 1, the wide tiles, at most 16 pieces per chunk (4 per wave)
+  static const int xc_on = getenv("EBEN_BLDW_XC") ? atoi(getenv("EBEN_BLDW_XC")) : 1;
+  p->xc = 0; p->xw = 0;
+  if (xc_on && c.s == BLDW_XC_S && c.d == 1 && p->FN >= 3) {
+    const int xw = p->xneed * c.s;
+    if (ncb * ceil_div(xw, 64) <= 16) {
+      p->xc = 1; p->xw = xw; p->XR = ncb;
+      p->RS = xw + 1;                                      // any stride: rows only meet at a tile's channel-bundle boundary
+    }
+  }
   p->lds_bytes = 16ull * (BLDW_TS + 2ull * ((64 * p->FM / 8) * BLDW_TS + (unsigned long long)p->XR * p->RS));
   if (p->lds_bytes > 160 * 1024) return;
   p->nct = ceil_div(c.Lout, BLDW_BKT);
@@ -399,10 +448,10 @@ static void make_bldw_plan(const Canon& c, BlDwPlan* p) {
   p->ok = 1;
 }
 
-template <int FM, int FN>
+template <int FM, int FN, bool XC = false>
 static int launch_bldw(const BlDwArgs& a, const BlDwPlan& p, hipStream_t st) {
   static LdsAttrOnce attr_once;
-  auto kern = bl_dw_kernel<FM, FN>;
+  auto kern = bl_dw_kernel<FM, FN, XC>;
   {
     const hipError_t e = lds_attr_once(attr_once, reinterpret_cast<const void*>(kern));
     if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(bl_dw)");
@@ -446,7 +495,7 @@ static int bldw_args(const EbenConv1dDesc* d, const void* dy_hi, const void* x_h
   a.S = c.s; a.d = c.d; a.k = c.k; a.pad = c.pl; a.amin = p.amin; a.NQW = p.NQW; a.has_bias = has_bias ? 1 : 0;
   a.nnt = p.nnt; a.nmt = p.nmt; a.nsplit = p.nsplit; a.nct = p.nct; a.nchunks = p.nchunks; a.XR = p.XR;
   a.dense = p.dense; a.c_in_g = c.Cin / c.g; a.c_out_g = c.Cout / c.g; a.row_stride = p.row_stride; a.slab_stride = p.slab_stride;
-  a.xneed = p.xneed; a.RS = p.RS;
+  a.xneed = p.xneed; a.RS = p.RS; a.xw = p.xw;
   *out = a; *plan = p;
   return EBEN_OK;
 }
@@ -458,6 +507,8 @@ extern "C" int eben_bl_conv1d_bwd_dw(const EbenConv1dDesc* d, const void* dy_hi,
   const int rc = bldw_args(d, dy_hi, x_hi, has_bias, slabs, ws_bytes, &a, &p);
   if (rc) return rc;
   hipStream_t st = as_stream(stream);
+  if (p.xc) return p.FM == 2 ? (p.FN == 4 ? launch_bldw<2, 4, true>(a, p, st) : launch_bldw<2, 3, true>(a, p, st))
+                             : (p.FN == 4 ? launch_bldw<1, 4, true>(a, p, st) : launch_bldw<1, 3, true>(a, p, st));
   if (p.FM == 2) return p.FN == 4 ? launch_bldw<2, 4>(a, p, st) : p.FN == 3 ? launch_bldw<2, 3>(a, p, st) : p.FN == 2 ? launch_bldw<2, 2>(a, p, st) : launch_bldw<2, 1>(a, p, st);
   return p.FN == 4 ? launch_bldw<1, 4>(a, p, st) : p.FN == 3 ? launch_bldw<1, 3>(a, p, st) : p.FN == 2 ? launch_bldw<1, 2>(a, p, st) : launch_bldw<1, 1>(a, p, st);
 }
@@ -493,6 +544,13 @@ extern "C" int eben_bl_conv1d_bwd_dw_multi(const EbenConv1dDesc* const* descs, c
       BlDwPlan p;
       const int rc = bldw_args(descs[i], dy_hi[i], x_hi[i], has_bias, slabs[i], ws_bytes[i], &a, &p);
       if (rc) return rc;
+      if (p.xc) {   // contiguous-X layers (stride 4) are not grouped: their own launch
+        if (T.n > 0) break;
+        const int rc1 = eben_bl_conv1d_bwd_dw(descs[i], dy_hi[i], x_hi[i], has_bias, slabs[i], ws_bytes[i], stream);
+        if (rc1) return rc1;
+        ++i;
+        continue;
+      }
       if (T.n > 0 && (p.FM != p0.FM || p.FN != p0.FN)) break;
       const long long nb = (long long)p.nnt * p.nmt * p.G * p.nsplit;
       if (nb <= 0 || nb > 0x3fffffffLL - (long long)T.first[T.n]) return fail(EBEN_EINVAL, "bl bwd_dw_multi grid too large");
@@ -502,6 +560,7 @@ extern "C" int eben_bl_conv1d_bwd_dw_multi(const EbenConv1dDesc* const* descs, c
       if (p.lds_bytes > lds) lds = p.lds_bytes;
       ++T.n; ++i;
     }
+    if (T.n == 0) continue;
     int rc;
     if (p0.FM == 2) rc = p0.FN == 4 ? launch_bldw_multi<2, 4>(T, lds, st) : p0.FN == 3 ? launch_bldw_multi<2, 3>(T, lds, st) : p0.FN == 2 ? launch_bldw_multi<2, 2>(T, lds, st) : launch_bldw_multi<2, 1>(T, lds, st);
     else rc = p0.FN == 4 ? launch_bldw_multi<1, 4>(T, lds, st) : p0.FN == 3 ? launch_bldw_multi<1, 3>(T, lds, st) : p0.FN == 2 ? launch_bldw_multi<1, 2>(T, lds, st) : launch_bldw_multi<1, 1>(T, lds, st);
