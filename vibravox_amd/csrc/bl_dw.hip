@@ -37,6 +37,12 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #ifndef EBEN_BLDW_PIPE_FENCE
 #define EBEN_BLDW_PIPE_FENCE 1
 #endif
+#ifdef EBEN_BLDW_STAMP
+// scratch build: wave 0 of every block sums the cycles (s_memtime) its chunks spend waiting for their pieces, at the barrier, issuing the
+// next chunk's pieces and in the MFMA loop: row = block, columns = the four sums + chunks + total
+__device__ unsigned long long bldw_stamp[8192 * 8];
+#define BLDW_T(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
+#endif
 constexpr int BLDW_BKT = 64;    // time steps per K chunk
 constexpr int BLDW_TS = 68;     // A row stride in units (64 + 4: = 4 mod 16)
 constexpr int BLDW_RS_MAX = 132;   // largest X row stride in units (two whole 64-unit LDS-DMA pieces + 4)
@@ -87,15 +93,20 @@ __device__ __forceinline__ void bl_dma_piece(const u32x4* src, unsigned dst) {
 // (t - t0) S + (j - pad - amin S), a lane's four column bundles (consecutive taps) 16 bytes apart and its four time steps 64 bytes apart --
 // 32 distinct banks per half-wave.
 constexpr int BLDW_XC_S = 4;
-template <int FM, int FN, bool XC = false>
+// WN: wave columns of a block (2 x WN waves, 64 FM x 32 WN FN outputs).  [MI355X] cycle stamps of the 2 x 2 form (MelGAN L4, per chunk):
+// waiting for the pieces 9, barrier 90, ISSUING the next chunk's ~7 pieces 1 470, fragment reads + MFMAs 1 150 -- a CU takes its blocks'
+// pieces at the rate L2 delivers them (28 bytes / clock here, 35-40 at best: tools/ubench/dma_rate.hip), waves that only issue
+// (producers) change nothing, and two 128 x 192 blocks per CU ask for 51 KB per 1 536 MFMA cycles.  2 x 4 waves on ONE A tile
+// (128 x 384 outputs) ask for 30 KB.
+template <int FM, int FN, bool XC = false, int WN = 2>
 __device__ __forceinline__ void bl_dw_body(const BlDwArgs& P, unsigned bid, unsigned nblk) {
-  constexpr int BM = 64 * FM, BMB = BM / 8, BNQ = 8 * FN, BKT = BLDW_BKT, TS = BLDW_TS;
+  constexpr int BM = 64 * FM, BMB = BM / 8, BNQ = 4 * WN * FN, BKT = BLDW_BKT, TS = BLDW_TS, NW = 2 * WN;
   const int RS = P.RS;
   extern __shared__ __attribute__((aligned(16))) u32x4 smem_bldw[];
   typedef __attribute__((address_space(3))) void* lds_t;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
 
   unsigned id = xcd_remap(bid, nblk);
   const int z = __builtin_amdgcn_readfirstlane(id % P.nsplit); id /= P.nsplit;
@@ -113,7 +124,7 @@ __device__ __forceinline__ void bl_dw_body(const BlDwArgs& P, unsigned bid, unsi
 
   const int a_units = BMB * TS, buf_units = a_units + P.XR * RS;
   // LDS: [ones row: TS units of (1, 0, 0, 0 | 0, 0, 0, 0)] [buffer 0: A rows, X rows] [buffer 1]
-  for (int i = tid; i < BLDW_TS; i += 256) smem_bldw[i] = u32x4{0x00003f80u, 0u, 0u, 0u};   // read at units koff .. koff + 3 (+ 4 time steps of an X row) < 64
+  for (int i = tid; i < BLDW_TS; i += 64 * NW) smem_bldw[i] = u32x4{0x00003f80u, 0u, 0u, 0u};   // read at units koff .. koff + 3 (+ 4 time steps of an X row) < 64
   const unsigned lds0 = (unsigned)(unsigned long long)(lds_t)smem_bldw;
   const unsigned ones_addr = lds0, buf_addr = lds0 + BLDW_TS * 16;
 
@@ -163,18 +174,18 @@ __device__ __forceinline__ void bl_dw_body(const BlDwArgs& P, unsigned bid, unsi
   // rows of this wave (fixed for the launch): A rows r = wave, wave + 4, ... (bundle clamped into the tensor: rows past it are
   // computed and not stored), X rows xr = wave, wave + 4, ... = (channel bundle, stride phase)
   const u32x4* zero = &bl_zero_unit;
-  constexpr int AR = (BMB + 3) / 4;
+  constexpr int AR = (BMB + NW - 1) / NW;
   long long arow[AR];
 #pragma unroll
   for (int i = 0; i < AR; ++i) {
-    int bundle = g * P.MgB + mt * BMB + wave + 4 * i;
+    int bundle = g * P.MgB + mt * BMB + wave + NW * i;
     if (bundle > P.CBa - 1) bundle = P.CBa - 1;
-    arow[i] = mt * BMB + wave + 4 * i < P.MgB ? (long long)bundle * P.La : -1;   // rows past the group's last: zeros (no traffic), never stored
+    arow[i] = mt * BMB + wave + NW * i < P.MgB ? (long long)bundle * P.La : -1;   // rows past the group's last: zeros (no traffic), never stored
   }
   // what a chunk's pieces need besides (item, first time step): fixed for the launch (the divisions and 64-bit products of the row
   // addresses were ~240 mostly scalar instructions per chunk and wave, in front of the chunk's 16-32 MFMAs)
   constexpr int XW = 4;                                  // X rows per wave held in registers (XR <= 16); wider tiles walk the rows
-  const bool x_regs = XC || P.XR <= 4 * XW;
+  const bool x_regs = XC || P.XR <= NW * XW;
   long long xoff[XW];
   int xlane[XW];
   unsigned xdst[XW];
@@ -182,7 +193,7 @@ __device__ __forceinline__ void bl_dw_body(const BlDwArgs& P, unsigned bid, unsi
   const int npr = XC ? (P.xw + 63) / 64 : 1;             // XC: pieces per row; piece wave + 4 i = (row, 64-unit run)
 #pragma unroll
   for (int i = 0; i < XW; ++i) {
-    const int xr = wave + 4 * i;
+    const int xr = wave + NW * i;
     if (XC) {
       const int row = xr / npr, pc = xr - row * npr;
       int cb = cb_lo + row;
@@ -208,7 +219,7 @@ __device__ __forceinline__ void bl_dw_body(const BlDwArgs& P, unsigned bid, unsi
     const bool a_ok = t0 + lane < P.La;
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
-      const int r = wave + 4 * i;
+      const int r = wave + NW * i;
       if (r < BMB && !(EBEN_BLDW_DBG & 1)) bl_dma_piece((a_ok && arow[i] >= 0) ? ab + arow[i] : zero, __builtin_amdgcn_readfirstlane(dst + (unsigned)(r * TS * 16)));
     }
     const u32x4* xb = P.xh + (long long)b * x_item;
@@ -219,7 +230,7 @@ __device__ __forceinline__ void bl_dw_body(const BlDwArgs& P, unsigned bid, unsi
       const int ts = t0 * BLDW_XC_S;
 #pragma unroll
       for (int i = 0; i < XW; ++i)
-        if (wave + 4 * i < xrows * npr) {                // wave-uniform
+        if (wave + NW * i < xrows * npr) {                // wave-uniform
           const int pos0 = ts + xlane[i];
           if (xact[i]) bl_dma_piece((unsigned)pos0 < (unsigned)P.Lx ? xb + xoff[i] + pos0 : zero, __builtin_amdgcn_readfirstlane(dst + xdst[i]));
         }
@@ -229,7 +240,7 @@ __device__ __forceinline__ void bl_dw_body(const BlDwArgs& P, unsigned bid, unsi
       const int ts = t0 * P.S;
 #pragma unroll
       for (int i = 0; i < XW; ++i)
-        if (wave + 4 * i < xrows) {
+        if (wave + NW * i < xrows) {
           const u32x4* row = xb + xoff[i];
           const int pos0 = ts + xlane[i];
           const unsigned rdst = dst + xdst[i];
@@ -241,7 +252,7 @@ __device__ __forceinline__ void bl_dw_body(const BlDwArgs& P, unsigned bid, unsi
         }
       return;
     }
-    for (int xr = wave; xr < xrows; xr += 4) {
+    for (int xr = wave; xr < xrows; xr += NW) {
       const int cbl = xr / P.S, p = xr - cbl * P.S;
       int cb = cb_lo + cbl;
       if (cb > P.CgB - 1) cb = P.CgB - 1;
@@ -265,10 +276,26 @@ __device__ __forceinline__ void bl_dw_body(const BlDwArgs& P, unsigned bid, unsi
     if (qt >= P.nct) { qt -= P.nct; ++qb; }
   };
   if (z < P.nchunks) { issue(qb, qt * BKT, 0); advance(); }
+#ifdef EBEN_BLDW_STAMP
+  unsigned long long st_wait = 0, st_bar = 0, st_issue = 0, st_mma = 0, st_n = 0;
+  const unsigned long long st_begin = __builtin_amdgcn_s_memtime();
+#endif
   for (int q = z; q < P.nchunks; q += P.nsplit) {
+#ifdef EBEN_BLDW_STAMP
+    BLDW_T(ta);
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of chunk q have landed ...
+#ifdef EBEN_BLDW_STAMP
+    BLDW_T(tb);
+#endif
     __syncthreads();                                   // ... and everybody's; buffer bsel ^ 1 (read during the previous chunk) is free
+#ifdef EBEN_BLDW_STAMP
+    BLDW_T(tc);
+#endif
     if (q + P.nsplit < P.nchunks) { issue(qb, qt * BKT, bsel ^ 1); advance(); }
+#ifdef EBEN_BLDW_STAMP
+    BLDW_T(td);
+#endif
     const unsigned base = buf_addr + (unsigned)(bsel * buf_units * 16);
     // fragments of k-step ks + 1 are read while k-step ks is multiplied (two register sets: left to itself hipcc reads a k-step's
     // fragments into ONE set right in front of its MFMAs -- two exposed LDS round trips per 6-8 MFMAs)
@@ -302,7 +329,16 @@ __device__ __forceinline__ void bl_dw_body(const BlDwArgs& P, unsigned bid, unsi
 #endif
     }
     bsel ^= 1;
+#ifdef EBEN_BLDW_STAMP
+    { BLDW_T(te); st_wait += tb - ta; st_bar += tc - tb; st_issue += td - tc; st_mma += te - td; ++st_n; }
+#endif
   }
+#ifdef EBEN_BLDW_STAMP
+  if (tid == 0 && bid < 8192u) {
+    unsigned long long* o = bldw_stamp + bid * 8;
+    o[0] = st_wait; o[1] = st_bar; o[2] = st_issue; o[3] = st_mma; o[4] = st_n; o[5] = __builtin_amdgcn_s_memtime() - st_begin;
+  }
+#endif
 
   // ---- epilogue: slab[z][row][column] ------------------------------------------------------------------------------------------------
   float* slab = P.slabs + (long long)z * P.slab_stride;
@@ -336,8 +372,8 @@ __device__ __forceinline__ void bl_dw_body(const BlDwArgs& P, unsigned bid, unsi
   }
 }
 
-template <int FM, int FN, bool XC = false>
-__global__ __launch_bounds__(256, 2) void bl_dw_kernel(const BlDwArgs P) { bl_dw_body<FM, FN, XC>(P, blockIdx.x, gridDim.x); }
+template <int FM, int FN, bool XC = false, int WN = 2>
+__global__ __launch_bounds__(128 * WN, 2) void bl_dw_kernel(const BlDwArgs P) { bl_dw_body<FM, FN, XC, WN>(P, blockIdx.x, gridDim.x); }
 
 // Several layers of ONE tile shape in one launch (the same layer index of the three PQMF-band discriminators: same channels and taps,
 // their own dilation, length, operands and slabs): block -> problem by the prefix sums of the problems' block counts.  [MI355X] a thin
@@ -359,7 +395,7 @@ __global__ __launch_bounds__(256, 2) void bl_dw_multi_kernel(const BlDwTable T) 
 
 // ---------------------------------------------------------------------------------------------------------------------------------
 struct BlDwPlan {
-  int ok, G, Mg, Cg, MgB, CgB, dense, FM, FN, nmt, nnt, NQW, nct, nchunks, nsplit, XR, amin, row_stride, perm_k, xneed, RS, xc, xw;
+  int ok, G, Mg, Cg, MgB, CgB, dense, FM, FN, nmt, nnt, NQW, nct, nchunks, nsplit, XR, amin, row_stride, perm_k, xneed, RS, xc, xw, wide;
   size_t lds_bytes;
   long long slab_stride;
 };
@@ -397,7 +433,13 @@ static void make_bldw_plan(const Canon& c, BlDwPlan* p) {
     const int t4 = ceil_div(p->NQW + 1, 32) * ceil_div(p->Mg, 64 * p->FM) * p->G, t3 = ceil_div(p->NQW + 1, 24) * ceil_div(p->Mg, 64 * p->FM) * p->G;
     if (fn3 == 2 || (t4 <= 512 && t4 > 256 && t3 <= 512)) p->FN = 3;
   }
-  const int BNQ = 8 * p->FN;
+  // eight waves on one A tile (bl_dw_body<2, 3, .., 4>: 128 x 384 outputs, one block per CU): the 128-row layers with at least one full
+  // tile of columns -- half the A bytes per MFMA through the CU's vector-memory path, which is what these launches wait for
+  static const int wide_on = getenv("EBEN_BLDW_WIDE") ? atoi(getenv("EBEN_BLDW_WIDE")) : 1;
+  // [MI355X] MelGAN L3 / L4 (stride 4) 196 / 205 -> 185 / 186 us; L5 (stride 1, eleven X rows per tile) 103 -> 112: stride-4 layers only
+  p->wide = (wide_on && p->FM == 2 && p->FN >= 3 && p->NQW + 1 >= 48 && c.s == BLDW_XC_S && c.d == 1) ? 1 : 0;
+  if (p->wide) p->FN = 3;
+  const int BNQ = (p->wide ? 16 : 8) * p->FN;
   p->nmt = ceil_div(p->Mg, 64 * p->FM);
   p->nnt = ceil_div(p->NQW + 1, BNQ);
   int ncb = (BNQ - 1) / c.k + 2;
@@ -410,7 +452,7 @@ static void make_bldw_plan(const Canon& c, BlDwPlan* p) {
   p->xc = 0; p->xw = 0;
   if (xc_on && c.s == BLDW_XC_S && c.d == 1 && p->FN >= 3) {
     const int xw = p->xneed * c.s;
-    if (ncb * ceil_div(xw, 64) <= 16) {
+    if (ncb * ceil_div(xw, 64) <= (p->wide ? 32 : 16)) {
       p->xc = 1; p->xw = xw; p->XR = ncb;
       p->RS = xw + 1;                                      // any stride: rows only meet at a tile's channel-bundle boundary
     }
@@ -425,7 +467,7 @@ static void make_bldw_plan(const Canon& c, BlDwPlan* p) {
   // gradient by the epilogue and one more read by the reduction.  Pick the factor with the least estimated time: rounds x the work of
   // one block + slab traffic at ~4 TB/s.
   static const int cus = getenv("EBEN_BLDW_CUS") ? atoi(getenv("EBEN_BLDW_CUS")) : 256;
-  const int per_cu = (int)(160 * 1024 / p->lds_bytes) < 1 ? 1 : (int)(160 * 1024 / p->lds_bytes);
+  const int per_cu = p->wide ? 1 : (int)(160 * 1024 / p->lds_bytes) < 1 ? 1 : (int)(160 * 1024 / p->lds_bytes);   // wide: 8 waves x ~150 registers
   const int slots = cus * (per_cu > 4 ? 4 : per_cu);
   const double macs = (double)c.B * c.Lout * (double)c.Cout * (c.Cin / c.g) * c.k;
   const double t_all = 2.0 * macs / 1.0e15;                                   // the whole contraction at ~1 PFLOP/s
@@ -448,16 +490,16 @@ static void make_bldw_plan(const Canon& c, BlDwPlan* p) {
   p->ok = 1;
 }
 
-template <int FM, int FN, bool XC = false>
+template <int FM, int FN, bool XC = false, int WN = 2>
 static int launch_bldw(const BlDwArgs& a, const BlDwPlan& p, hipStream_t st) {
   static LdsAttrOnce attr_once;
-  auto kern = bl_dw_kernel<FM, FN, XC>;
+  auto kern = bl_dw_kernel<FM, FN, XC, WN>;
   {
     const hipError_t e = lds_attr_once(attr_once, reinterpret_cast<const void*>(kern));
     if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(bl_dw)");
   }
   const long long nb = (long long)p.nnt * p.nmt * p.G * p.nsplit;
-  hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(256), p.lds_bytes, st, a);
+  hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(128 * WN), p.lds_bytes, st, a);
   EBEN_CHECK_LAUNCH("bl_dw_kernel");
   return EBEN_OK;
 }
@@ -507,6 +549,7 @@ extern "C" int eben_bl_conv1d_bwd_dw(const EbenConv1dDesc* d, const void* dy_hi,
   const int rc = bldw_args(d, dy_hi, x_hi, has_bias, slabs, ws_bytes, &a, &p);
   if (rc) return rc;
   hipStream_t st = as_stream(stream);
+  if (p.wide) return p.xc ? launch_bldw<2, 3, true, 4>(a, p, st) : launch_bldw<2, 3, false, 4>(a, p, st);
   if (p.xc) return p.FM == 2 ? (p.FN == 4 ? launch_bldw<2, 4, true>(a, p, st) : launch_bldw<2, 3, true>(a, p, st))
                              : (p.FN == 4 ? launch_bldw<1, 4, true>(a, p, st) : launch_bldw<1, 3, true>(a, p, st));
   if (p.FM == 2) return p.FN == 4 ? launch_bldw<2, 4>(a, p, st) : p.FN == 3 ? launch_bldw<2, 3>(a, p, st) : p.FN == 2 ? launch_bldw<2, 2>(a, p, st) : launch_bldw<2, 1>(a, p, st);
@@ -544,7 +587,7 @@ extern "C" int eben_bl_conv1d_bwd_dw_multi(const EbenConv1dDesc* const* descs, c
       BlDwPlan p;
       const int rc = bldw_args(descs[i], dy_hi[i], x_hi[i], has_bias, slabs[i], ws_bytes[i], &a, &p);
       if (rc) return rc;
-      if (p.xc) {   // contiguous-X layers (stride 4) are not grouped: their own launch
+      if (p.xc || p.wide) {   // contiguous-X (stride 4) and eight-wave layers are not grouped: their own launch
         if (T.n > 0) break;
         const int rc1 = eben_bl_conv1d_bwd_dw(descs[i], dy_hi[i], x_hi[i], has_bias, slabs[i], ws_bytes[i], stream);
         if (rc1) return rc1;
@@ -568,3 +611,9 @@ extern "C" int eben_bl_conv1d_bwd_dw_multi(const EbenConv1dDesc* const* descs, c
   }
   return EBEN_OK;
 }
+
+#ifdef EBEN_BLDW_STAMP
+extern "C" __attribute__((visibility("default"))) int eben_debug_bldw_stamps(unsigned long long* out, size_t n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(eben::bldw_stamp), n * sizeof(unsigned long long));
+}
+#endif
