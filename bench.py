@@ -491,6 +491,9 @@ def main():
             roof["isolated"] = {"launch_ms": round(iso_ms, 4), "achieved": round(flops / (iso_ms * 1e-3) / 1e12, 2),
                                 "frac": round(flops / (iso_ms * 1e-3) / 1e12 / peak, 4),
                                 "note": "same launch alone on the device, 20 back-to-back launches after the timed region"}
+        if roof.get("bound") == "mfma":
+            roof["peak_note"] = ("`peak` is the dense bf16 MFMA figure at 2.4 GHz (MI355X_MICROARCH.md); tools/ubench/clock_probe.hip on this pool: the shader clock is "
+                                 "2.38 GHz idle and 1.82-1.89 GHz with MFMA streams on every SIMD, 1.83-1.94 PFLOP/s of pure MFMA issue")
         roof_t, flops_t = launch_record(timer_t, "input gradient (two 2B-row passes per step: rows [fm | adv], then rows [fake | real])", kn)
         prof_t = named_launch("melgan_l3_dx") if args.disc_math == "bf16_bl" else None
         if prof_t and prof_t.get("avg_ms"):
