@@ -600,3 +600,46 @@ def test_bundle_conv_weight_gradient_small_tiles(hip, kw, length):
     (out * bf16_hi(dy).double()).sum().backward()
     assert rel_err(dv, wr.grad) < 3e-5, rel_err(dv, wr.grad)
     assert rel_err(dbias, br.grad) < 3e-5
+
+
+@pytest.mark.parametrize("kw,rows,length,same_split", [
+    (dict(c_in=64, c_out=256, ksize=41, stride=4, pad_l=20, pad_r=20, groups=4), 8, 1203, True),      # 64-row tiles: contiguous X rows only
+    (dict(c_in=256, c_out=512, ksize=41, stride=4, pad_l=20, pad_r=20, groups=2), 6, 610, False),     # 128-row tiles: + the eight-wave tile
+])
+def test_stride4_weight_gradient_forms_agree(hip, kw, rows, length, same_split):
+    """bl_dw.hip's stride-4 forms (X rows copied contiguously and de-interleaved by the fragment addresses; 2 x 4 waves on one A tile)
+    against the phase-row 2 x 2 form (EBEN_BLDW_XC=0 EBEN_BLDW_WIDE=0 in a second process): the same products in the same order -- bit for
+    bit where the split-K factor is the same, to the slab sum's rounding where the wider tile changes it."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, ctypes, torch; sys.path.insert(0, %r)\n"
+            "from vibravox_amd import ops\n"
+            "from vibravox_amd._lib import check, load\n"
+            "lib = load(); d = torch.device('cuda'); rows, length = %d, %d\n"
+            "spec = ops.ConvSpec(**%r); lo = spec.out_len(length)\n"
+            "g = torch.Generator().manual_seed(11)\n"
+            "dy = torch.randn(rows, spec.c_out // 8, lo, 8, generator=g).bfloat16().to(d)\n"
+            "x = torch.randn(rows, spec.c_in // 8, length, 8, generator=g).bfloat16().to(d)\n"
+            "desc = ops.conv_desc(spec, rows, length, ops.MATH_BF16 | 0x100)\n"
+            "ns, rs, pk = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)\n"
+            "nb = lib.eben_bl_conv1d_bwd_dw_workspace(ctypes.byref(desc), ctypes.byref(ns), ctypes.byref(rs), ctypes.byref(pk))\n"
+            "slabs = torch.zeros(nb // 4, dtype=torch.float32, device=d)\n"
+            "check(lib.eben_bl_conv1d_bwd_dw(ctypes.byref(desc), dy.data_ptr(), x.data_ptr(), 1, slabs.data_ptr(), nb, torch.cuda.current_stream().cuda_stream), 'dw')\n"
+            "torch.cuda.synchronize(); torch.save((slabs.view(ns.value, -1).cpu(), ns.value), sys.argv[1])\n" % (root, rows, length, kw))
+    outs = []
+    with tempfile.TemporaryDirectory() as td:
+        for k, env in enumerate(({}, {"EBEN_BLDW_XC": "0", "EBEN_BLDW_WIDE": "0"})):
+            path = os.path.join(td, f"o{k}.pt")
+            subprocess.run([sys.executable, "-c", code, path], check=True, env={**os.environ, **env}, timeout=300)
+            outs.append(torch.load(path))
+    (a, na), (b, nb_) = outs
+    assert torch.isfinite(a).all() and float(a.abs().max()) > 0
+    if same_split:
+        assert na == nb_ and torch.equal(a, b)
+    else:
+        sa, sb = a.double().sum(0), b.double().sum(0)
+        assert float((sa - sb).abs().max()) <= 1e-5 * float(sb.abs().max())

@@ -439,23 +439,27 @@ static void make_bldw_plan(const Canon& c, BlDwPlan* p) {
   // [MI355X] MelGAN L3 / L4 (stride 4) 196 / 205 -> 185 / 186 us; L5 (stride 1, eleven X rows per tile) 103 -> 112: stride-4 layers only
   p->wide = (wide_on && p->FM == 2 && p->FN >= 3 && p->NQW + 1 >= 48 && c.s == BLDW_XC_S && c.d == 1) ? 1 : 0;
   if (p->wide) p->FN = 3;
-  const int BNQ = (p->wide ? 16 : 8) * p->FN;
-  p->nmt = ceil_div(p->Mg, 64 * p->FM);
-  p->nnt = ceil_div(p->NQW + 1, BNQ);
-  int ncb = (BNQ - 1) / c.k + 2;
-  if (ncb > p->CgB) ncb = p->CgB;
-  p->XR = ncb * c.s;
-  p->xneed = BLDW_BKT + amax - p->amin + 1;
-  p->RS = bldw_row_stride(p->xneed);
-  // contiguous X rows (bl_dw_body<.., XC>): stride 4, dilation 1, the wide tiles, at most 16 pieces per chunk (4 per wave)
+  // contiguous X rows (bl_dw_body<.., XC>): stride 4, dilation 1, the wide tiles, at most four pieces per wave and chunk
   static const int xc_on = getenv("EBEN_BLDW_XC") ? atoi(getenv("EBEN_BLDW_XC")) : 1;
-  p->xc = 0; p->xw = 0;
-  if (xc_on && c.s == BLDW_XC_S && c.d == 1 && p->FN >= 3) {
-    const int xw = p->xneed * c.s;
-    if (ncb * ceil_div(xw, 64) <= (p->wide ? 32 : 16)) {
-      p->xc = 1; p->xw = xw; p->XR = ncb;
-      p->RS = xw + 1;                                      // any stride: rows only meet at a tile's channel-bundle boundary
+  p->nmt = ceil_div(p->Mg, 64 * p->FM);
+  p->xneed = BLDW_BKT + amax - p->amin + 1;
+  for (;;) {
+    const int BNQ = (p->wide ? 16 : 8) * p->FN;
+    p->nnt = ceil_div(p->NQW + 1, BNQ);
+    int ncb = (BNQ - 1) / c.k + 2;
+    if (ncb > p->CgB) ncb = p->CgB;
+    p->XR = ncb * c.s;
+    p->RS = bldw_row_stride(p->xneed);
+    p->xc = 0; p->xw = 0;
+    if (xc_on && c.s == BLDW_XC_S && c.d == 1 && p->FN >= 3) {
+      const int xw = p->xneed * c.s;
+      if (ncb * ceil_div(xw, 64) <= (p->wide ? 32 : 16)) {
+        p->xc = 1; p->xw = xw; p->XR = ncb;
+        p->RS = xw + 1;                                      // any stride: rows only meet at a tile's channel-bundle boundary
+      }
     }
+    if (!p->wide || p->xc) break;
+    p->wide = 0;                                           // the eight-wave form exists with contiguous X rows only
   }
   p->lds_bytes = 16ull * (BLDW_TS + 2ull * ((64 * p->FM / 8) * BLDW_TS + (unsigned long long)p->XR * p->RS));
   if (p->lds_bytes > 160 * 1024) return;
@@ -549,7 +553,7 @@ extern "C" int eben_bl_conv1d_bwd_dw(const EbenConv1dDesc* d, const void* dy_hi,
   const int rc = bldw_args(d, dy_hi, x_hi, has_bias, slabs, ws_bytes, &a, &p);
   if (rc) return rc;
   hipStream_t st = as_stream(stream);
-  if (p.wide) return p.xc ? launch_bldw<2, 3, true, 4>(a, p, st) : launch_bldw<2, 3, false, 4>(a, p, st);
+  if (p.wide) return launch_bldw<2, 3, true, 4>(a, p, st);
   if (p.xc) return p.FM == 2 ? (p.FN == 4 ? launch_bldw<2, 4, true>(a, p, st) : launch_bldw<2, 3, true>(a, p, st))
                              : (p.FN == 4 ? launch_bldw<1, 4, true>(a, p, st) : launch_bldw<1, 3, true>(a, p, st));
   if (p.FM == 2) return p.FN == 4 ? launch_bldw<2, 4>(a, p, st) : p.FN == 3 ? launch_bldw<2, 3>(a, p, st) : p.FN == 2 ? launch_bldw<2, 2>(a, p, st) : launch_bldw<2, 1>(a, p, st);
